@@ -1,0 +1,1246 @@
+/*
+ * pgo_oracle.c -- CPU oracle (TEST INFRASTRUCTURE, see pgo_oracle.h).
+ *
+ * Scalar fp64 restatement of the reference's pose-graph path, in reference
+ * order of operations.  Citations are to /root/reference/src/mapping/.
+ *
+ * Third-party arithmetic restated from published semantics (source not under
+ * /root/reference):
+ *   nalgebra 0.32.3 (Cargo.lock:1100-1103): Isometry2 = (translation, UnitComplex)
+ *     inverse  : (R^-1 * (-t), R^-1)            compose : (t1 + R1*t2, R1*R2)
+ *     UnitComplex::from_angle(a) = (cos a, sin a); angle() = atan2(im, re)
+ *     UnitComplex * v = (re*x - im*y, im*x + re*y); product = complex multiply,
+ *     no renormalisation.
+ *   russell_sparse 0.7.1 + SuiteSparse UMFPACK (Cargo.lock:1569-1590): COO with
+ *     duplicate entries that the solver sums, then a direct sparse LU solve.
+ *     Restated here as: sum duplicates -> CSC -> fill-reducing ordering ->
+ *     sparse Cholesky (H is SPD once the prior is on) -> two triangular solves,
+ *     ALL redone every call, like the reference redoes them every iteration
+ *     (pose_graph_optimization.rs:130-141).
+ */
+#include "pgo_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ types */
+
+typedef struct {
+  int kind;       /* OG_NODE_* */
+  int offset;     /* g2o.rs:60-61,67-68,76-77 */
+  unsigned id;    /* g2o vertex id */
+  double s[7];    /* SE2: tx,ty,re,im | XY: x,y | SE3: x,y,z,qx,qy,qz,qw */
+} og_node;
+
+typedef struct {
+  int kind;       /* OG_EDGE_* */
+  int from, to;   /* dense node indices (the reference keeps u32 ids + hash maps) */
+  double z[7];    /* SE2: tx,ty,re,im | XY: x,y | SE3: x,y,z,qx,qy,qz,qw */
+  double info[36];/* symmetric, row-major d x d (g2o.rs:89-93,107-110,126-133) */
+} og_edge;
+
+struct og_graph {
+  int n_nodes, n_edges, len;
+  og_node *nodes;
+  og_edge *edges;
+  long last_nnz_l;
+};
+
+static void set_err(char *err, int errlen, const char *msg) {
+  if (err && errlen > 0) {
+    strncpy(err, msg, (size_t)errlen - 1);
+    err[errlen - 1] = 0;
+  }
+}
+
+static int node_dim(int kind) {
+  return kind == OG_NODE_SE2 ? 3 : kind == OG_NODE_XY ? 2 : 6;
+}
+static int edge_dim(int kind) {
+  return kind == OG_EDGE_SE2 ? 3 : kind == OG_EDGE_SE2_XY ? 2 : 6;
+}
+
+/* ------------------------------------------------------------ g2o loader */
+
+/* id -> dense index: open addressing hash (the reference uses FxHashMap). */
+typedef struct {
+  unsigned *keys;
+  int *vals;
+  int cap;
+} idmap;
+
+static int idmap_init(idmap *m, int n) {
+  int cap = 16;
+  while (cap < 2 * n + 2) cap *= 2;
+  m->cap = cap;
+  m->keys = (unsigned *)malloc(sizeof(unsigned) * (size_t)cap);
+  m->vals = (int *)malloc(sizeof(int) * (size_t)cap);
+  if (!m->keys || !m->vals) return -1;
+  for (int i = 0; i < cap; i++) m->vals[i] = -1;
+  return 0;
+}
+static void idmap_free(idmap *m) {
+  free(m->keys);
+  free(m->vals);
+}
+static unsigned hash_u32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+static int idmap_get(const idmap *m, unsigned key) {
+  unsigned h = hash_u32(key) & (unsigned)(m->cap - 1);
+  while (m->vals[h] != -1) {
+    if (m->keys[h] == key) return m->vals[h];
+    h = (h + 1) & (unsigned)(m->cap - 1);
+  }
+  return -1;
+}
+static void idmap_put(idmap *m, unsigned key, int val) {
+  unsigned h = hash_u32(key) & (unsigned)(m->cap - 1);
+  while (m->vals[h] != -1 && m->keys[h] != key) h = (h + 1) & (unsigned)(m->cap - 1);
+  m->keys[h] = key;
+  m->vals[h] = val;
+}
+
+/* split on ' ' only, drop empty tokens (g2o.rs:52) */
+static int split_spaces(char *line, char **tok, int maxtok) {
+  int n = 0;
+  char *p = line;
+  while (*p) {
+    while (*p == ' ') p++;
+    if (!*p) break;
+    if (n < maxtok) tok[n] = p;
+    n++;
+    while (*p && *p != ' ') p++;
+    if (*p) *p++ = 0;
+  }
+  return n;
+}
+
+static int parse_u32(const char *s, unsigned *out) {
+  if (!*s) return -1;
+  const char *p = s;
+  if (*p == '+') p++;
+  if (!*p) return -1;
+  unsigned long long v = 0;
+  for (; *p; p++) {
+    if (*p < '0' || *p > '9') return -1;
+    v = v * 10 + (unsigned)(*p - '0');
+    if (v > 0xffffffffULL) return -1;
+  }
+  *out = (unsigned)v;
+  return 0;
+}
+static int parse_f64(const char *s, double *out) {
+  char *end = NULL;
+  if (!*s) return -1;
+  /* Rust's f64::from_str has no hex floats and no leading whitespace */
+  if (s[0] == '0' && (s[1] == 'x' || s[1] == 'X')) return -1;
+  *out = strtod(s, &end);
+  if (end == s || *end) return -1;
+  return 0;
+}
+
+static void sym_from_upper(int d, const double *up, double *full) {
+  int k = 0;
+  for (int i = 0; i < d; i++)
+    for (int j = i; j < d; j++) {
+      full[i * d + j] = up[k];
+      full[j * d + i] = up[k];
+      k++;
+    }
+}
+
+og_graph *og_load_g2o(const char *path, char *err, int errlen) {
+  FILE *f = fopen(path, "rb");
+  if (!f) {
+    set_err(err, errlen, "cannot open file");
+    return NULL;
+  }
+  fseek(f, 0, SEEK_END);
+  long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  char *buf = (char *)malloc((size_t)sz + 1);
+  if (!buf || fread(buf, 1, (size_t)sz, f) != (size_t)sz) {
+    fclose(f);
+    free(buf);
+    set_err(err, errlen, "read failed");
+    return NULL;
+  }
+  fclose(f);
+  buf[sz] = 0;
+
+  /* count lines to size arrays */
+  long nl = 1;
+  for (long i = 0; i < sz; i++) nl += buf[i] == '\n';
+  og_graph *g = (og_graph *)calloc(1, sizeof(og_graph));
+  g->nodes = (og_node *)calloc((size_t)nl, sizeof(og_node));
+  g->edges = (og_edge *)calloc((size_t)nl, sizeof(og_edge));
+  unsigned *efrom = (unsigned *)malloc(sizeof(unsigned) * (size_t)nl);
+  unsigned *eto = (unsigned *)malloc(sizeof(unsigned) * (size_t)nl);
+  idmap map;
+  idmap_init(&map, (int)nl);
+  int offset = 0, ok = 1;
+  char msg[160];
+
+  char *p = buf;
+  long lineno = 0;
+  while (ok && p < buf + sz) {
+    char *eol = memchr(p, '\n', (size_t)(buf + sz - p));
+    char *next = eol ? eol + 1 : buf + sz;
+    if (eol) *eol = 0;
+    size_t L = strlen(p);
+    if (L && p[L - 1] == '\r') p[L - 1] = 0; /* str::lines() strips \r\n */
+    lineno++;
+    char *tok[40];
+    int nt = split_spaces(p, tok, 40);
+    p = next;
+    if (nt == 0) { /* line[0] on an empty Vec panics, g2o.rs:53 */
+      snprintf(msg, sizeof msg, "line %ld: empty line", lineno);
+      ok = 0;
+      break;
+    }
+    double v[32];
+    int nv_expected = -1, first = 0, is_edge = 0, kind = 0;
+    if (!strcmp(tok[0], "VERTEX_SE2")) { nv_expected = 3; first = 2; kind = OG_NODE_SE2; }
+    else if (!strcmp(tok[0], "VERTEX_XY")) { nv_expected = 2; first = 2; kind = OG_NODE_XY; }
+    else if (!strcmp(tok[0], "VERTEX_SE3:QUAT")) { nv_expected = 7; first = 2; kind = OG_NODE_SE3; }
+    else if (!strcmp(tok[0], "EDGE_SE2")) { nv_expected = 9; first = 3; is_edge = 1; kind = OG_EDGE_SE2; }
+    else if (!strcmp(tok[0], "EDGE_SE2_XY")) { nv_expected = 5; first = 3; is_edge = 1; kind = OG_EDGE_SE2_XY; }
+    else if (!strcmp(tok[0], "EDGE_SE3:QUAT")) { nv_expected = 28; first = 3; is_edge = 1; kind = OG_EDGE_SE3; }
+    else { /* unimplemented!(), g2o.rs:138 */
+      snprintf(msg, sizeof msg, "line %ld: unsupported tag '%.40s'", lineno, tok[0]);
+      ok = 0;
+      break;
+    }
+    if (nt != first + nv_expected) { /* slice pattern mismatch -> todo!() */
+      snprintf(msg, sizeof msg, "line %ld: expected %d values", lineno, nv_expected);
+      ok = 0;
+      break;
+    }
+    unsigned id0 = 0, id1 = 0;
+    if (parse_u32(tok[1], &id0) || (is_edge && parse_u32(tok[2], &id1))) {
+      snprintf(msg, sizeof msg, "line %ld: bad id", lineno);
+      ok = 0;
+      break;
+    }
+    for (int i = 0; i < nv_expected; i++)
+      if (parse_f64(tok[first + i], &v[i])) {
+        snprintf(msg, sizeof msg, "line %ld: bad number '%.40s'", lineno, tok[first + i]);
+        ok = 0;
+        break;
+      }
+    if (!ok) break;
+    if (!is_edge) {
+      if (idmap_get(&map, id0) >= 0) {
+        /* The reference would overwrite the hash-map entry and leave the old
+         * rows structurally empty (singular system).  Treated as an error. */
+        snprintf(msg, sizeof msg, "line %ld: duplicate vertex id %u", lineno, id0);
+        ok = 0;
+        break;
+      }
+      og_node *n = &g->nodes[g->n_nodes];
+      n->kind = kind;
+      n->id = id0;
+      n->offset = offset;
+      if (kind == OG_NODE_SE2) { /* iso2, g2o.rs:14-16 */
+        n->s[0] = v[0]; n->s[1] = v[1]; n->s[2] = cos(v[2]); n->s[3] = sin(v[2]);
+      } else if (kind == OG_NODE_XY) {
+        n->s[0] = v[0]; n->s[1] = v[1];
+      } else {
+        /* g2o text order x y z qx qy qz qw (the reference passes qx as w,
+         * g2o.rs:20, SURVEY F9 -- never executed there); normalised like
+         * UnitQuaternion::from_quaternion */
+        double q = sqrt(v[3] * v[3] + v[4] * v[4] + v[5] * v[5] + v[6] * v[6]);
+        for (int i = 0; i < 3; i++) n->s[i] = v[i];
+        for (int i = 3; i < 7; i++) n->s[i] = v[i] / q;
+      }
+      idmap_put(&map, id0, g->n_nodes);
+      g->n_nodes++;
+      offset += node_dim(kind);
+    } else {
+      og_edge *e = &g->edges[g->n_edges];
+      e->kind = kind;
+      efrom[g->n_edges] = id0;
+      eto[g->n_edges] = id1;
+      if (kind == OG_EDGE_SE2) {
+        e->z[0] = v[0]; e->z[1] = v[1]; e->z[2] = cos(v[2]); e->z[3] = sin(v[2]);
+        sym_from_upper(3, v + 3, e->info);
+      } else if (kind == OG_EDGE_SE2_XY) {
+        e->z[0] = v[0]; e->z[1] = v[1];
+        sym_from_upper(2, v + 2, e->info);
+      } else {
+        double q = sqrt(v[3] * v[3] + v[4] * v[4] + v[5] * v[5] + v[6] * v[6]);
+        for (int i = 0; i < 3; i++) e->z[i] = v[i];
+        for (int i = 3; i < 7; i++) e->z[i] = v[i] / q;
+        sym_from_upper(6, v + 7, e->info);
+      }
+      g->n_edges++;
+    }
+  }
+  /* resolve edge endpoints (the reference resolves lazily through the hash
+   * maps and panics on a missing id, pose_graph_optimization.rs:312-320) */
+  for (int k = 0; ok && k < g->n_edges; k++) {
+    int a = idmap_get(&map, efrom[k]), b = idmap_get(&map, eto[k]);
+    if (a < 0 || b < 0) {
+      snprintf(msg, sizeof msg, "edge %d references unknown vertex", k);
+      ok = 0;
+      break;
+    }
+    og_edge *e = &g->edges[k];
+    int ka = g->nodes[a].kind, kb = g->nodes[b].kind;
+    int good = (e->kind == OG_EDGE_SE2 && ka == OG_NODE_SE2 && kb == OG_NODE_SE2) ||
+               (e->kind == OG_EDGE_SE2_XY && ka == OG_NODE_SE2 && kb == OG_NODE_XY) ||
+               (e->kind == OG_EDGE_SE3 && ka == OG_NODE_SE3 && kb == OG_NODE_SE3);
+    if (!good) { /* unreachable!() in the reference, :315-320,342-347 */
+      snprintf(msg, sizeof msg, "edge %d: endpoint kinds do not match edge kind", k);
+      ok = 0;
+      break;
+    }
+    e->from = a;
+    e->to = b;
+  }
+  g->len = offset;
+  idmap_free(&map);
+  free(efrom);
+  free(eto);
+  free(buf);
+  if (!ok) {
+    set_err(err, errlen, msg);
+    og_free(g);
+    return NULL;
+  }
+  return g;
+}
+
+og_graph *og_create(int n_nodes, const int *node_kind, const double *node_state,
+                    int n_edges, const int *edge_kind, const int *edge_from,
+                    const int *edge_to, const double *edge_meas,
+                    const double *edge_info, char *err, int errlen) {
+  og_graph *g = (og_graph *)calloc(1, sizeof(og_graph));
+  g->nodes = (og_node *)calloc((size_t)(n_nodes > 0 ? n_nodes : 1), sizeof(og_node));
+  g->edges = (og_edge *)calloc((size_t)(n_edges > 0 ? n_edges : 1), sizeof(og_edge));
+  g->n_nodes = n_nodes;
+  g->n_edges = n_edges;
+  int offset = 0;
+  const double *s = node_state;
+  for (int i = 0; i < n_nodes; i++) {
+    og_node *n = &g->nodes[i];
+    n->kind = node_kind[i];
+    n->id = (unsigned)i;
+    n->offset = offset;
+    if (n->kind == OG_NODE_SE2) {
+      n->s[0] = s[0]; n->s[1] = s[1]; n->s[2] = cos(s[2]); n->s[3] = sin(s[2]);
+      s += 3;
+    } else if (n->kind == OG_NODE_XY) {
+      n->s[0] = s[0]; n->s[1] = s[1];
+      s += 2;
+    } else if (n->kind == OG_NODE_SE3) {
+      double q = sqrt(s[3] * s[3] + s[4] * s[4] + s[5] * s[5] + s[6] * s[6]);
+      for (int k = 0; k < 3; k++) n->s[k] = s[k];
+      for (int k = 3; k < 7; k++) n->s[k] = s[k] / q;
+      s += 7;
+    } else {
+      set_err(err, errlen, "bad node kind");
+      og_free(g);
+      return NULL;
+    }
+    offset += node_dim(n->kind);
+  }
+  g->len = offset;
+  const double *m = edge_meas, *w = edge_info;
+  for (int k = 0; k < n_edges; k++) {
+    og_edge *e = &g->edges[k];
+    e->kind = edge_kind[k];
+    e->from = edge_from[k];
+    e->to = edge_to[k];
+    if (e->from < 0 || e->from >= n_nodes || e->to < 0 || e->to >= n_nodes) {
+      set_err(err, errlen, "edge endpoint out of range");
+      og_free(g);
+      return NULL;
+    }
+    if (e->kind == OG_EDGE_SE2) {
+      e->z[0] = m[0]; e->z[1] = m[1]; e->z[2] = cos(m[2]); e->z[3] = sin(m[2]);
+      sym_from_upper(3, w, e->info);
+      m += 3; w += 6;
+    } else if (e->kind == OG_EDGE_SE2_XY) {
+      e->z[0] = m[0]; e->z[1] = m[1];
+      sym_from_upper(2, w, e->info);
+      m += 2; w += 3;
+    } else if (e->kind == OG_EDGE_SE3) {
+      double q = sqrt(m[3] * m[3] + m[4] * m[4] + m[5] * m[5] + m[6] * m[6]);
+      for (int i = 0; i < 3; i++) e->z[i] = m[i];
+      for (int i = 3; i < 7; i++) e->z[i] = m[i] / q;
+      sym_from_upper(6, w, e->info);
+      m += 7; w += 21;
+    } else {
+      set_err(err, errlen, "bad edge kind");
+      og_free(g);
+      return NULL;
+    }
+  }
+  return g;
+}
+
+void og_free(og_graph *g) {
+  if (!g) return;
+  free(g->nodes);
+  free(g->edges);
+  free(g);
+}
+
+int og_num_nodes(const og_graph *g) { return g->n_nodes; }
+int og_num_edges(const og_graph *g) { return g->n_edges; }
+int og_dim(const og_graph *g) { return g->len; }
+int og_node_kind(const og_graph *g, int i) { return g->nodes[i].kind; }
+int og_node_offset(const og_graph *g, int i) { return g->nodes[i].offset; }
+unsigned og_node_id(const og_graph *g, int i) { return g->nodes[i].id; }
+int og_edge_kind(const og_graph *g, int k) { return g->edges[k].kind; }
+int og_edge_from(const og_graph *g, int k) { return g->edges[k].from; }
+int og_edge_to(const og_graph *g, int k) { return g->edges[k].to; }
+long og_last_nnz_l(const og_graph *g) { return g->last_nnz_l; }
+
+void og_get_edge_meas(const og_graph *g, int k, double *out) {
+  const og_edge *e = &g->edges[k];
+  if (e->kind == OG_EDGE_SE2) {
+    out[0] = e->z[0]; out[1] = e->z[1]; out[2] = atan2(e->z[3], e->z[2]);
+  } else if (e->kind == OG_EDGE_SE2_XY) {
+    out[0] = e->z[0]; out[1] = e->z[1];
+  } else {
+    for (int i = 0; i < 7; i++) out[i] = e->z[i];
+  }
+}
+void og_get_edge_info_full(const og_graph *g, int k, double *out) {
+  const og_edge *e = &g->edges[k];
+  int d = edge_dim(e->kind);
+  memcpy(out, e->info, sizeof(double) * (size_t)(d * d));
+}
+
+/* ----------------------------------------------------- SE(2) factor maths */
+
+typedef struct { double tx, ty, re, im; } iso2;
+
+static iso2 iso2_of(const double *s) {
+  iso2 r = { s[0], s[1], s[2], s[3] };
+  return r;
+}
+static iso2 iso2_inverse(iso2 a) { /* nalgebra Isometry::inverse */
+  iso2 r;
+  r.re = a.re;
+  r.im = -a.im;
+  double nx = -a.tx, ny = -a.ty;
+  r.tx = r.re * nx - r.im * ny;
+  r.ty = r.im * nx + r.re * ny;
+  return r;
+}
+static iso2 iso2_mul(iso2 a, iso2 b) { /* (t1 + R1 t2, R1 R2) */
+  iso2 r;
+  r.tx = a.tx + (a.re * b.tx - a.im * b.ty);
+  r.ty = a.ty + (a.im * b.tx + a.re * b.ty);
+  r.re = a.re * b.re - a.im * b.im;
+  r.im = a.re * b.im + a.im * b.re;
+  return r;
+}
+
+/* v3(pose2D_pose2D_constraint(x1,x2,z)), :434-447 : z^-1 * x1^-1 * x2 (left assoc) */
+static void se2_error(const double *x1, const double *x2, const double *z, double e[3]) {
+  iso2 E = iso2_mul(iso2_mul(iso2_inverse(iso2_of(z)), iso2_inverse(iso2_of(x1))), iso2_of(x2));
+  e[0] = E.tx;
+  e[1] = E.ty;
+  e[2] = atan2(E.im, E.re);
+}
+
+/* linearize_pose2D_pose2D_constraint, :457-486.  Row-major 3x3 A and B. */
+static void se2_jacobians(const double *x1, const double *x2, const double *z,
+                          double A[9], double B[9]) {
+  /* to_rotation_matrix(): [[re,-im],[im,re]] ; inverse == transpose */
+  double zr = z[2], zi = z[3], r = x1[2], i = x1[3];
+  /* M = Rz^T * R1^T  (z_rot.inverse() * x1_rot.inverse()), :466,478 */
+  double zt[4] = { zr, zi, -zi, zr };
+  double r1t[4] = { r, i, -i, r };
+  double M[4] = { zt[0] * r1t[0] + zt[1] * r1t[2], zt[0] * r1t[1] + zt[1] * r1t[3],
+                  zt[2] * r1t[0] + zt[3] * r1t[2], zt[2] * r1t[1] + zt[3] * r1t[3] };
+  /* xr1d = deriv * R1, deriv = [[0,-1],[1,0]]  -> [[-im,-re],[re,-im]], :462,467 */
+  double xr1d[4] = { -i, -r, r, -i };
+  /* a_12 = (Rz^T * xr1d^T) * (t2 - t1), :468-469 */
+  double xt[4] = { xr1d[0], xr1d[2], xr1d[1], xr1d[3] };
+  double P[4] = { zt[0] * xt[0] + zt[1] * xt[2], zt[0] * xt[1] + zt[1] * xt[3],
+                  zt[2] * xt[0] + zt[3] * xt[2], zt[2] * xt[1] + zt[3] * xt[3] };
+  double dx = x2[0] - x1[0], dy = x2[1] - x1[1];
+  double a12x = P[0] * dx + P[1] * dy, a12y = P[2] * dx + P[3] * dy;
+  A[0] = -M[0]; A[1] = -M[1]; A[2] = a12x;
+  A[3] = -M[2]; A[4] = -M[3]; A[5] = a12y;
+  A[6] = 0.0;   A[7] = 0.0;   A[8] = -1.0;
+  B[0] = M[0];  B[1] = M[1];  B[2] = 0.0;
+  B[3] = M[2];  B[4] = M[3];  B[5] = 0.0;
+  B[6] = 0.0;   B[7] = 0.0;   B[8] = 1.0;
+}
+
+/* pose2D_landmark2D_constraint, :449-455 : R^T (l - t) - z */
+static void se2xy_error(const double *x, const double *l, const double *z, double e[2]) {
+  double dx = l[0] - x[0], dy = l[1] - x[1];
+  double r = x[2], i = x[3];
+  e[0] = (r * dx + i * dy) - z[0];
+  e[1] = (-i * dx + r * dy) - z[1];
+}
+
+/* linearize_pose_landmark_constraint, :516-535.  A 2x3 row-major, B 2x2. */
+static void se2xy_jacobians(const double *x, const double *l, double A[6], double B[4]) {
+  double r = x[2], i = x[3];
+  double dx = l[0] - x[0], dy = l[1] - x[1];
+  /* a_1 = -R^T ; xrd = deriv*R = [[-im,-re],[re,-im]] ; a_2 = xrd^T (l - t) */
+  double a2x = -i * dx + r * dy;
+  double a2y = -r * dx - i * dy;
+  A[0] = -r; A[1] = -i; A[2] = a2x;
+  A[3] = i;  A[4] = -r; A[5] = a2y;
+  B[0] = r;  B[1] = i;
+  B[2] = -i; B[3] = r;
+}
+
+/* ------------------------------------------------------------- SE(3) maths
+ * NOT reference behaviour (the reference's SE(3) path is todo!()).
+ * Build-defined, g2o file convention: E = Z^-1 * Xi^-1 * Xj,
+ * e = [t_E ; 2*vec(q_E) with w>=0]... see se3_error below; Jacobians are taken
+ * w.r.t. the update  X <- X * Exp([dt ; dw])  by central differences in the
+ * oracle (it is the checker, speed is irrelevant). */
+
+typedef struct { double t[3]; double q[4]; /* x y z w */ } iso3;
+
+static iso3 iso3_of(const double *s) {
+  iso3 r;
+  for (int i = 0; i < 3; i++) r.t[i] = s[i];
+  for (int i = 0; i < 4; i++) r.q[i] = s[3 + i];
+  return r;
+}
+static void quat_mul(const double a[4], const double b[4], double r[4]) {
+  double ax = a[0], ay = a[1], az = a[2], aw = a[3];
+  double bx = b[0], by = b[1], bz = b[2], bw = b[3];
+  r[0] = aw * bx + ax * bw + ay * bz - az * by;
+  r[1] = aw * by - ax * bz + ay * bw + az * bx;
+  r[2] = aw * bz + ax * by - ay * bx + az * bw;
+  r[3] = aw * bw - ax * bx - ay * by - az * bz;
+}
+static void quat_rot(const double q[4], const double v[3], double r[3]) {
+  /* r = v + 2 w (u x v) + 2 u x (u x v) */
+  double ux = q[0], uy = q[1], uz = q[2], w = q[3];
+  double cx = uy * v[2] - uz * v[1], cy = uz * v[0] - ux * v[2], cz = ux * v[1] - uy * v[0];
+  double dx = uy * cz - uz * cy, dy = uz * cx - ux * cz, dz = ux * cy - uy * cx;
+  r[0] = v[0] + 2.0 * (w * cx + dx);
+  r[1] = v[1] + 2.0 * (w * cy + dy);
+  r[2] = v[2] + 2.0 * (w * cz + dz);
+}
+static iso3 iso3_inverse(iso3 a) {
+  iso3 r;
+  r.q[0] = -a.q[0]; r.q[1] = -a.q[1]; r.q[2] = -a.q[2]; r.q[3] = a.q[3];
+  double nt[3] = { -a.t[0], -a.t[1], -a.t[2] };
+  quat_rot(r.q, nt, r.t);
+  return r;
+}
+static iso3 iso3_mul(iso3 a, iso3 b) {
+  iso3 r;
+  double rt[3];
+  quat_rot(a.q, b.t, rt);
+  for (int i = 0; i < 3; i++) r.t[i] = a.t[i] + rt[i];
+  quat_mul(a.q, b.q, r.q);
+  return r;
+}
+/* e = [t_E ; vec(q_E)] with q_E.w >= 0  (g2o EdgeSE3 / toVectorMQT convention) */
+static void se3_error(const double *x1, const double *x2, const double *z, double e[6]) {
+  iso3 E = iso3_mul(iso3_mul(iso3_inverse(iso3_of(z)), iso3_inverse(iso3_of(x1))), iso3_of(x2));
+  double s = E.q[3] < 0 ? -1.0 : 1.0;
+  e[0] = E.t[0]; e[1] = E.t[1]; e[2] = E.t[2];
+  e[3] = s * E.q[0]; e[4] = s * E.q[1]; e[5] = s * E.q[2];
+}
+/* X <- X * [dt ; Exp(dw)] : t += R dt ; q = q * exp(dw)  (exp: axis-angle, |dw| = angle) */
+static void se3_retract(const double *x, const double d[6], double out[7]) {
+  iso3 X = iso3_of(x);
+  double rt[3];
+  quat_rot(X.q, d, rt);
+  for (int i = 0; i < 3; i++) out[i] = X.t[i] + rt[i];
+  double th = sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+  double dq[4];
+  if (th < 1e-12) {
+    dq[0] = 0.5 * d[3]; dq[1] = 0.5 * d[4]; dq[2] = 0.5 * d[5]; dq[3] = 1.0;
+  } else {
+    double s = sin(0.5 * th) / th;
+    dq[0] = s * d[3]; dq[1] = s * d[4]; dq[2] = s * d[5]; dq[3] = cos(0.5 * th);
+  }
+  double q[4];
+  quat_mul(X.q, dq, q);
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int i = 0; i < 4; i++) out[3 + i] = q[i] / n;
+}
+static void se3_jacobians(const double *x1, const double *x2, const double *z,
+                          double A[36], double B[36]) {
+  const double h = 1e-6;
+  for (int c = 0; c < 6; c++) {
+    double d[6] = { 0, 0, 0, 0, 0, 0 }, xp[7], xm[7], ep[6], em[6];
+    d[c] = h;  se3_retract(x1, d, xp);
+    d[c] = -h; se3_retract(x1, d, xm);
+    se3_error(xp, x2, z, ep);
+    se3_error(xm, x2, z, em);
+    for (int r = 0; r < 6; r++) A[r * 6 + c] = (ep[r] - em[r]) / (2 * h);
+    d[c] = h;  se3_retract(x2, d, xp);
+    d[c] = -h; se3_retract(x2, d, xm);
+    se3_error(x1, xp, z, ep);
+    se3_error(x1, xm, z, em);
+    for (int r = 0; r < 6; r++) B[r * 6 + c] = (ep[r] - em[r]) / (2 * h);
+  }
+}
+
+/* ----------------------------------------------------------- global error */
+
+static double edge_chi2(const og_graph *g, const og_edge *ed) {
+  const double *x1 = g->nodes[ed->from].s, *x2 = g->nodes[ed->to].s;
+  double e[6];
+  int d = edge_dim(ed->kind);
+  if (ed->kind == OG_EDGE_SE2) se2_error(x1, x2, ed->z, e);
+  else if (ed->kind == OG_EDGE_SE2_XY) se2xy_error(x1, x2, ed->z, e);
+  else se3_error(x1, x2, ed->z, e);
+  /* (e^T * omega) * e, :555,568 */
+  double acc = 0.0;
+  for (int j = 0; j < d; j++) {
+    double t = 0.0;
+    for (int i = 0; i < d; i++) t += e[i] * ed->info[i * d + j];
+    acc += t * e[j];
+  }
+  return acc;
+}
+
+double og_global_error(const og_graph *g) {
+  double sum = 0.0; /* sequential, file order, :538-573 */
+  for (int k = 0; k < g->n_edges; k++) sum += edge_chi2(g, &g->edges[k]);
+  return sum;
+}
+
+int og_linearize_edge(const og_graph *g, int k, double *A, double *B, double *e) {
+  if (k < 0 || k >= g->n_edges) return -1;
+  const og_edge *ed = &g->edges[k];
+  const double *x1 = g->nodes[ed->from].s, *x2 = g->nodes[ed->to].s;
+  if (ed->kind == OG_EDGE_SE2) {
+    se2_error(x1, x2, ed->z, e);
+    se2_jacobians(x1, x2, ed->z, A, B);
+  } else if (ed->kind == OG_EDGE_SE2_XY) {
+    se2xy_error(x1, x2, ed->z, e);
+    se2xy_jacobians(x1, x2, A, B);
+  } else {
+    se3_error(x1, x2, ed->z, e);
+    se3_jacobians(x1, x2, ed->z, A, B);
+  }
+  return 0;
+}
+
+/* ------------------------------------------------ COO assembly (:165-212) */
+
+typedef struct {
+  int *ri, *ci;
+  double *v;
+  long n, cap;
+} coo;
+
+static void coo_put(coo *c, int i, int j, double v) {
+  if (c->n == c->cap) {
+    c->cap = c->cap ? c->cap * 2 : 1024;
+    c->ri = (int *)realloc(c->ri, sizeof(int) * (size_t)c->cap);
+    c->ci = (int *)realloc(c->ci, sizeof(int) * (size_t)c->cap);
+    c->v = (double *)realloc(c->v, sizeof(double) * (size_t)c->cap);
+  }
+  c->ri[c->n] = i;
+  c->ci[c->n] = j;
+  c->v[c->n] = v;
+  c->n++;
+}
+
+/* C(d1 x d2) = A^T(d1 x de) * W(de x de) * B(de x d2), as (A^T W) B */
+static void atwb(int de, int d1, int d2, const double *A, const double *W,
+                 const double *B, double *C) {
+  double T[36];
+  for (int i = 0; i < d1; i++)
+    for (int j = 0; j < de; j++) {
+      double s = 0.0;
+      for (int k = 0; k < de; k++) s += A[k * d1 + i] * W[k * de + j];
+      T[i * de + j] = s;
+    }
+  for (int i = 0; i < d1; i++)
+    for (int j = 0; j < d2; j++) {
+      double s = 0.0;
+      for (int k = 0; k < de; k++) s += T[i * de + k] * B[k * d2 + j];
+      C[i * d2 + j] = s;
+    }
+}
+
+/* build_linear_system, :305-369 -> COO (all four blocks, structural zeros
+ * included, exactly the reference's 36 / 25 puts per edge) + b (negated). */
+static void build_coo(const og_graph *g, double lambda, int lm, coo *H, double *b) {
+  int need_prior = 1;
+  memset(b, 0, sizeof(double) * (size_t)g->len);
+  for (int k = 0; k < g->n_edges; k++) {
+    const og_edge *ed = &g->edges[k];
+    const og_node *n1 = &g->nodes[ed->from], *n2 = &g->nodes[ed->to];
+    int de = edge_dim(ed->kind), d1 = node_dim(n1->kind), d2 = node_dim(n2->kind);
+    int fi = n1->offset, ti = n2->offset;
+    double A[36], B[36], e[6];
+    og_linearize_edge(g, k, A, B, e);
+    double Hii[36], Hij[36], Hjj[36], we[6], bi[6], bj[6];
+    atwb(de, d1, d1, A, ed->info, A, Hii);
+    atwb(de, d1, d2, A, ed->info, B, Hij);
+    atwb(de, d2, d2, B, ed->info, B, Hjj);
+    /* b_i = (A^T W) e */
+    double T[36];
+    for (int i = 0; i < d1; i++) {
+      double s = 0.0;
+      for (int j = 0; j < de; j++) {
+        double t = 0.0;
+        for (int q = 0; q < de; q++) t += A[q * d1 + i] * ed->info[q * de + j];
+        T[i * de + j] = t;
+        s += t * e[j];
+      }
+      bi[i] = s;
+    }
+    for (int i = 0; i < d2; i++) {
+      double s = 0.0;
+      for (int j = 0; j < de; j++) {
+        double t = 0.0;
+        for (int q = 0; q < de; q++) t += B[q * d2 + i] * ed->info[q * de + j];
+        s += t * e[j];
+      }
+      bj[i] = s;
+    }
+    (void)we;
+    /* set_matrix x4, :184-187 */
+    for (int i = 0; i < d1; i++)
+      for (int j = 0; j < d1; j++) coo_put(H, fi + i, fi + j, Hii[i * d1 + j]);
+    for (int i = 0; i < d1; i++)
+      for (int j = 0; j < d2; j++) coo_put(H, fi + i, ti + j, Hij[i * d2 + j]);
+    for (int i = 0; i < d2; i++)
+      for (int j = 0; j < d1; j++) coo_put(H, ti + i, fi + j, Hij[j * d2 + i]);
+    for (int i = 0; i < d2; i++)
+      for (int j = 0; j < d2; j++) coo_put(H, ti + i, ti + j, Hjj[i * d2 + j]);
+    /* set_vector x2, :189-190 */
+    for (int i = 0; i < d1; i++) b[fi + i] += bi[i];
+    for (int i = 0; i < d2; i++) b[ti + i] += bj[i];
+    /* prior on the from-node of the first EDGE_SE2 in file order, :330-336.
+     * SE(3) (build-defined): same rule applied to the first SE3 edge. */
+    if (need_prior && (ed->kind == OG_EDGE_SE2 || ed->kind == OG_EDGE_SE3)) {
+      for (int i = 0; i < d1; i++) coo_put(H, fi + i, fi + i, 10000000.0);
+      need_prior = 0;
+    }
+  }
+  for (int i = 0; i < g->len; i++) b[i] = -b[i]; /* :361 */
+  if (lm) /* :362-366 : + lambda * I */
+    for (int i = 0; i < g->len; i++) coo_put(H, i, i, lambda);
+}
+
+/* COO (full) -> lower-triangular CSC with duplicates summed in put order. */
+static int coo_to_csc_lower(int n, const coo *H, int **colptr_out, int **rowidx_out,
+                            double **vals_out) {
+  int *cnt = (int *)calloc((size_t)n + 1, sizeof(int));
+  for (long t = 0; t < H->n; t++)
+    if (H->ri[t] >= H->ci[t]) cnt[H->ci[t] + 1]++;
+  for (int j = 0; j < n; j++) cnt[j + 1] += cnt[j];
+  int nz = cnt[n];
+  int *ri = (int *)malloc(sizeof(int) * (size_t)(nz > 0 ? nz : 1));
+  double *vv = (double *)malloc(sizeof(double) * (size_t)(nz > 0 ? nz : 1));
+  int *pos = (int *)malloc(sizeof(int) * (size_t)n + 4);
+  memcpy(pos, cnt, sizeof(int) * (size_t)n);
+  for (long t = 0; t < H->n; t++)
+    if (H->ri[t] >= H->ci[t]) {
+      int p = pos[H->ci[t]]++;
+      ri[p] = H->ri[t];
+      vv[p] = H->v[t];
+    }
+  /* per column: stable sort by row then merge duplicates */
+  int *colptr = (int *)malloc(sizeof(int) * ((size_t)n + 1));
+  int w = 0;
+  int *tmpi = NULL;
+  double *tmpv = NULL;
+  int tmpcap = 0;
+  for (int j = 0; j < n; j++) {
+    int a = cnt[j], bnd = cnt[j + 1], m = bnd - a;
+    colptr[j] = w;
+    if (m > tmpcap) {
+      tmpcap = m * 2;
+      tmpi = (int *)realloc(tmpi, sizeof(int) * (size_t)tmpcap);
+      tmpv = (double *)realloc(tmpv, sizeof(double) * (size_t)tmpcap);
+    }
+    /* insertion sort (stable; columns are short) */
+    for (int q = 0; q < m; q++) {
+      int r = ri[a + q];
+      double v = vv[a + q];
+      int s = q;
+      while (s > 0 && tmpi[s - 1] > r) {
+        tmpi[s] = tmpi[s - 1];
+        tmpv[s] = tmpv[s - 1];
+        s--;
+      }
+      tmpi[s] = r;
+      tmpv[s] = v;
+    }
+    for (int q = 0; q < m; q++) {
+      if (w > colptr[j] && ri[w - 1] == tmpi[q]) vv[w - 1] += tmpv[q];
+      else {
+        ri[w] = tmpi[q];
+        vv[w] = tmpv[q];
+        w++;
+      }
+    }
+  }
+  colptr[n] = w;
+  free(tmpi);
+  free(tmpv);
+  free(pos);
+  free(cnt);
+  *colptr_out = colptr;
+  *rowidx_out = ri;
+  *vals_out = vv;
+  return w;
+}
+
+int og_build_system(const og_graph *g, double lambda, int lm, int *colptr,
+                    int *rowidx, double *vals, double *b) {
+  coo H = { 0 };
+  double *bb = (double *)malloc(sizeof(double) * (size_t)(g->len + 1));
+  build_coo(g, lambda, lm, &H, bb);
+  int *cp, *ri;
+  double *vv;
+  int nz = coo_to_csc_lower(g->len, &H, &cp, &ri, &vv);
+  if (vals) {
+    memcpy(colptr, cp, sizeof(int) * ((size_t)g->len + 1));
+    memcpy(rowidx, ri, sizeof(int) * (size_t)nz);
+    memcpy(vals, vv, sizeof(double) * (size_t)nz);
+    if (b) memcpy(b, bb, sizeof(double) * (size_t)g->len);
+  }
+  free(cp); free(ri); free(vv); free(bb);
+  free(H.ri); free(H.ci); free(H.v);
+  return nz;
+}
+
+/* ------------------------------------------- sparse direct solve (SPD) ---
+ * Stand-in for UMFPACK (see header comment).  Steps, all redone per call:
+ *  1. minimum-degree ordering on the node (block) graph, quotient-graph form;
+ *  2. permuted upper-triangular CSC;
+ *  3. elimination tree + column counts;
+ *  4. up-looking sparse Cholesky (row-by-row, Liu / Davis "Direct Methods for
+ *     Sparse Linear Systems" ch. 4);
+ *  5. forward + backward substitution. */
+
+typedef struct { int deg, node; } hent;
+typedef struct { hent *a; int n, cap; } heap;
+static void heap_push(heap *h, int deg, int node) {
+  if (h->n == h->cap) {
+    h->cap = h->cap ? 2 * h->cap : 1024;
+    h->a = (hent *)realloc(h->a, sizeof(hent) * (size_t)h->cap);
+  }
+  int i = h->n++;
+  while (i > 0) {
+    int p = (i - 1) / 2;
+    if (h->a[p].deg < deg || (h->a[p].deg == deg && h->a[p].node < node)) break;
+    h->a[i] = h->a[p];
+    i = p;
+  }
+  h->a[i].deg = deg;
+  h->a[i].node = node;
+}
+static hent heap_pop(heap *h) {
+  hent top = h->a[0], last = h->a[--h->n];
+  int i = 0;
+  for (;;) {
+    int c = 2 * i + 1;
+    if (c >= h->n) break;
+    if (c + 1 < h->n && (h->a[c + 1].deg < h->a[c].deg ||
+                         (h->a[c + 1].deg == h->a[c].deg && h->a[c + 1].node < h->a[c].node)))
+      c++;
+    if (last.deg < h->a[c].deg || (last.deg == h->a[c].deg && last.node < h->a[c].node)) break;
+    h->a[i] = h->a[c];
+    i = c;
+  }
+  h->a[i] = last;
+  return top;
+}
+
+typedef struct { int *v; int n, cap; } ivec;
+static void ivec_push(ivec *a, int x) {
+  if (a->n == a->cap) {
+    a->cap = a->cap ? 2 * a->cap : 8;
+    a->v = (int *)realloc(a->v, sizeof(int) * (size_t)a->cap);
+  }
+  a->v[a->n++] = x;
+}
+
+/* Minimum (external, weighted by node dimension) degree on the node graph.
+ * order[k] = k-th node to eliminate. */
+static void min_degree_order(int N, const int *xadj, const int *adj, const int *w, int *order) {
+  ivec *A = (ivec *)calloc((size_t)N, sizeof(ivec)); /* variable neighbours */
+  ivec *E = (ivec *)calloc((size_t)N, sizeof(ivec)); /* adjacent elements   */
+  ivec *Lst = (ivec *)calloc((size_t)N, sizeof(ivec)); /* element -> variables */
+  int *deg = (int *)malloc(sizeof(int) * (size_t)N);
+  char *done = (char *)calloc((size_t)N, 1);
+  char *absorbed = (char *)calloc((size_t)N, 1);
+  int *mark = (int *)calloc((size_t)N, sizeof(int));
+  int stamp = 0;
+  heap hp = { 0 };
+  for (int i = 0; i < N; i++) {
+    int d = 0;
+    for (int p = xadj[i]; p < xadj[i + 1]; p++) {
+      ivec_push(&A[i], adj[p]);
+      d += w[adj[p]];
+    }
+    deg[i] = d;
+    heap_push(&hp, d, i);
+  }
+  ivec Lp = { 0 };
+  for (int k = 0; k < N; k++) {
+    hent t;
+    do { t = heap_pop(&hp); } while (done[t.node] || t.deg != deg[t.node]);
+    int p = t.node;
+    order[k] = p;
+    done[p] = 1;
+    /* Lp = (A_p U union of L_e, e in E_p) \ {eliminated} */
+    Lp.n = 0;
+    stamp++;
+    mark[p] = stamp;
+    for (int q = 0; q < A[p].n; q++) {
+      int v = A[p].v[q];
+      if (!done[v] && mark[v] != stamp) { mark[v] = stamp; ivec_push(&Lp, v); }
+    }
+    for (int q = 0; q < E[p].n; q++) {
+      int e = E[p].v[q];
+      if (absorbed[e]) continue;
+      for (int s = 0; s < Lst[e].n; s++) {
+        int v = Lst[e].v[s];
+        if (!done[v] && mark[v] != stamp) { mark[v] = stamp; ivec_push(&Lp, v); }
+      }
+      absorbed[e] = 1; /* element absorption */
+      free(Lst[e].v);
+      Lst[e].v = NULL; Lst[e].n = Lst[e].cap = 0;
+    }
+    Lst[p].v = (int *)malloc(sizeof(int) * (size_t)(Lp.n > 0 ? Lp.n : 1));
+    memcpy(Lst[p].v, Lp.v, sizeof(int) * (size_t)Lp.n);
+    Lst[p].n = Lst[p].cap = Lp.n;
+    int lpstamp = stamp;
+    /* update every variable in Lp */
+    for (int q = 0; q < Lp.n; q++) {
+      int i = Lp.v[q];
+      /* prune A_i: drop eliminated vars and vars now covered by element p */
+      int wq = 0;
+      for (int s = 0; s < A[i].n; s++) {
+        int v = A[i].v[s];
+        if (!done[v] && mark[v] != lpstamp) A[i].v[wq++] = v;
+      }
+      A[i].n = wq;
+      /* prune E_i: drop absorbed, add p */
+      wq = 0;
+      for (int s = 0; s < E[i].n; s++)
+        if (!absorbed[E[i].v[s]]) E[i].v[wq++] = E[i].v[s];
+      E[i].n = wq;
+      ivec_push(&E[i], p);
+    }
+    for (int q = 0; q < Lp.n; q++) {
+      int i = Lp.v[q];
+      /* exact external degree */
+      stamp++;
+      mark[i] = stamp;
+      int d = 0;
+      for (int s = 0; s < A[i].n; s++) {
+        int v = A[i].v[s];
+        if (mark[v] != stamp) { mark[v] = stamp; d += w[v]; }
+      }
+      for (int s = 0; s < E[i].n; s++) {
+        int e = E[i].v[s];
+        for (int r = 0; r < Lst[e].n; r++) {
+          int v = Lst[e].v[r];
+          if (!done[v] && mark[v] != stamp) { mark[v] = stamp; d += w[v]; }
+        }
+      }
+      deg[i] = d;
+      heap_push(&hp, d, i);
+    }
+    /* the marks used for "in Lp" were overwritten; that is fine because the
+     * pruning loop above ran before any degree recomputation. */
+    free(A[p].v); A[p].v = NULL; A[p].n = A[p].cap = 0;
+    free(E[p].v); E[p].v = NULL; E[p].n = E[p].cap = 0;
+  }
+  for (int i = 0; i < N; i++) { free(A[i].v); free(E[i].v); free(Lst[i].v); }
+  free(A); free(E); free(Lst); free(deg); free(done); free(absorbed); free(mark);
+  free(hp.a); free(Lp.v);
+}
+
+/* Solve H x = b, H given as lower-tri CSC (n x n, SPD).  node_* describe the
+ * block structure used by the ordering.  Returns 0, or -1 if not SPD. */
+static int spd_solve(const og_graph *g, int n, const int *Hp, const int *Hi,
+                     const double *Hx, const double *b, double *x, long *nnz_l_out) {
+  int N = g->n_nodes;
+  /* 1. node graph from the edge list */
+  int *xadj = (int *)calloc((size_t)N + 1, sizeof(int));
+  for (int k = 0; k < g->n_edges; k++) {
+    if (g->edges[k].from == g->edges[k].to) continue;
+    xadj[g->edges[k].from + 1]++;
+    xadj[g->edges[k].to + 1]++;
+  }
+  for (int i = 0; i < N; i++) xadj[i + 1] += xadj[i];
+  int *adj = (int *)malloc(sizeof(int) * (size_t)(xadj[N] > 0 ? xadj[N] : 1));
+  int *fill = (int *)malloc(sizeof(int) * (size_t)N + 4);
+  memcpy(fill, xadj, sizeof(int) * (size_t)N);
+  for (int k = 0; k < g->n_edges; k++) {
+    int a = g->edges[k].from, c = g->edges[k].to;
+    if (a == c) continue;
+    adj[fill[a]++] = c;
+    adj[fill[c]++] = a;
+  }
+  /* dedupe neighbours */
+  {
+    int *mark = (int *)malloc(sizeof(int) * (size_t)N + 4);
+    for (int i = 0; i < N; i++) mark[i] = -1;
+    int *nx = (int *)calloc((size_t)N + 1, sizeof(int));
+    int wq = 0;
+    for (int i = 0; i < N; i++) {
+      nx[i] = wq;
+      for (int p = xadj[i]; p < xadj[i + 1]; p++)
+        if (mark[adj[p]] != i) { mark[adj[p]] = i; adj[wq++] = adj[p]; }
+    }
+    nx[N] = wq;
+    memcpy(xadj, nx, sizeof(int) * ((size_t)N + 1));
+    free(nx);
+    free(mark);
+  }
+  int *wdim = (int *)malloc(sizeof(int) * (size_t)N + 4);
+  for (int i = 0; i < N; i++) wdim[i] = node_dim(g->nodes[i].kind);
+  int *norder = (int *)malloc(sizeof(int) * (size_t)N + 4);
+  min_degree_order(N, xadj, adj, wdim, norder);
+  /* scalar permutation: perm[new] = old ; pinv[old] = new */
+  int *perm = (int *)malloc(sizeof(int) * (size_t)n + 4);
+  int *pinv = (int *)malloc(sizeof(int) * (size_t)n + 4);
+  {
+    int q = 0;
+    for (int k = 0; k < N; k++) {
+      const og_node *nd = &g->nodes[norder[k]];
+      for (int d = 0; d < node_dim(nd->kind); d++) perm[q++] = nd->offset + d;
+    }
+    for (int i = 0; i < n; i++) pinv[perm[i]] = i;
+  }
+  free(xadj); free(adj); free(fill); free(wdim); free(norder);
+
+  /* 2. C = upper triangle of P H P^T in CSC (column k holds rows <= k) */
+  int nzH = Hp[n];
+  int *Cp = (int *)calloc((size_t)n + 1, sizeof(int));
+  for (int j = 0; j < n; j++)
+    for (int p = Hp[j]; p < Hp[j + 1]; p++) {
+      int i2 = pinv[Hi[p]], j2 = pinv[j];
+      Cp[(i2 > j2 ? i2 : j2) + 1]++;
+    }
+  for (int j = 0; j < n; j++) Cp[j + 1] += Cp[j];
+  int *Ci = (int *)malloc(sizeof(int) * (size_t)(nzH > 0 ? nzH : 1));
+  double *Cx = (double *)malloc(sizeof(double) * (size_t)(nzH > 0 ? nzH : 1));
+  int *cw = (int *)malloc(sizeof(int) * (size_t)n + 4);
+  memcpy(cw, Cp, sizeof(int) * (size_t)n);
+  for (int j = 0; j < n; j++)
+    for (int p = Hp[j]; p < Hp[j + 1]; p++) {
+      int i2 = pinv[Hi[p]], j2 = pinv[j];
+      int c = i2 > j2 ? i2 : j2, r = i2 > j2 ? j2 : i2;
+      int q = cw[c]++;
+      Ci[q] = r;
+      Cx[q] = Hx[p];
+    }
+
+  /* 3. elimination tree (Liu, path compression) */
+  int *parent = (int *)malloc(sizeof(int) * (size_t)n + 4);
+  int *anc = (int *)malloc(sizeof(int) * (size_t)n + 4);
+  for (int k = 0; k < n; k++) {
+    parent[k] = -1;
+    anc[k] = -1;
+    for (int p = Cp[k]; p < Cp[k + 1]; p++) {
+      int i = Ci[p];
+      while (i != -1 && i < k) {
+        int nxt = anc[i];
+        anc[i] = k;
+        if (nxt == -1) parent[i] = k;
+        i = nxt;
+      }
+    }
+  }
+  /* column counts by walking every row subtree once */
+  int *flag = (int *)malloc(sizeof(int) * (size_t)n + 4);
+  int *Lp = (int *)calloc((size_t)n + 1, sizeof(int));
+  for (int k = 0; k < n; k++) flag[k] = -1;
+  for (int k = 0; k < n; k++) {
+    flag[k] = k;
+    Lp[k + 1]++; /* diagonal */
+    for (int p = Cp[k]; p < Cp[k + 1]; p++) {
+      int i = Ci[p];
+      while (i < k && flag[i] != k) {
+        flag[i] = k;
+        Lp[i + 1]++;
+        i = parent[i];
+      }
+    }
+  }
+  for (int k = 0; k < n; k++) Lp[k + 1] += Lp[k];
+  long nnzL = Lp[n];
+  if (nnz_l_out) *nnz_l_out = nnzL;
+  int *Li = (int *)malloc(sizeof(int) * (size_t)(nnzL > 0 ? nnzL : 1));
+  double *Lx = (double *)malloc(sizeof(double) * (size_t)(nnzL > 0 ? nnzL : 1));
+  int *c = (int *)malloc(sizeof(int) * (size_t)n + 4);
+  memcpy(c, Lp, sizeof(int) * (size_t)n);
+  double *xw = (double *)calloc((size_t)n + 1, sizeof(double));
+  int *stack = (int *)malloc(sizeof(int) * (size_t)n + 4);
+  int *path = (int *)malloc(sizeof(int) * (size_t)n + 4);
+  int rc = 0;
+  for (int k = 0; k < n; k++) flag[k] = -1;
+
+  /* 4. up-looking Cholesky */
+  for (int k = 0; k < n && rc == 0; k++) {
+    int top = n;
+    flag[k] = k;
+    for (int p = Cp[k]; p < Cp[k + 1]; p++) {
+      int i = Ci[p];
+      xw[i] = Cx[p];
+      int len = 0;
+      while (i < k && flag[i] != k) {
+        path[len++] = i;
+        flag[i] = k;
+        i = parent[i];
+      }
+      while (len > 0) stack[--top] = path[--len];
+    }
+    double d = xw[k];
+    xw[k] = 0.0;
+    for (; top < n; top++) {
+      int i = stack[top];
+      double lki = xw[i] / Lx[Lp[i]];
+      xw[i] = 0.0;
+      for (int p = Lp[i] + 1; p < c[i]; p++) xw[Li[p]] -= Lx[p] * lki;
+      d -= lki * lki;
+      int q = c[i]++;
+      Li[q] = k;
+      Lx[q] = lki;
+    }
+    if (!(d > 0.0)) { rc = -1; break; }
+    int q = c[k]++;
+    Li[q] = k;
+    Lx[q] = sqrt(d);
+  }
+
+  /* 5. solve */
+  if (rc == 0) {
+    double *y = xw; /* reuse (all zeros again) */
+    for (int i = 0; i < n; i++) y[i] = b[perm[i]];
+    for (int j = 0; j < n; j++) {
+      y[j] /= Lx[Lp[j]];
+      for (int p = Lp[j] + 1; p < Lp[j + 1]; p++) y[Li[p]] -= Lx[p] * y[j];
+    }
+    for (int j = n - 1; j >= 0; j--) {
+      for (int p = Lp[j] + 1; p < Lp[j + 1]; p++) y[j] -= Lx[p] * y[Li[p]];
+      y[j] /= Lx[Lp[j]];
+    }
+    for (int i = 0; i < n; i++) x[perm[i]] = y[i];
+  }
+  free(perm); free(pinv); free(Cp); free(Ci); free(Cx); free(cw); free(parent);
+  free(anc); free(flag); free(Lp); free(Li); free(Lx); free(c); free(xw);
+  free(stack); free(path);
+  return rc;
+}
+
+int og_linearize_and_solve(const og_graph *g, double lambda, int lm, double *dx) {
+  coo H = { 0 };
+  double *b = (double *)malloc(sizeof(double) * (size_t)(g->len + 1));
+  build_coo(g, lambda, lm, &H, b);
+  int *cp, *ri;
+  double *vv;
+  coo_to_csc_lower(g->len, &H, &cp, &ri, &vv);
+  free(H.ri); free(H.ci); free(H.v);
+  long nnzl = 0;
+  int rc = spd_solve(g, g->len, cp, ri, vv, b, dx, &nnzl);
+  ((og_graph *)g)->last_nnz_l = nnzl;
+  free(cp); free(ri); free(vv); free(b);
+  return rc;
+}
+
+/* -------------------------------------------------- update_nodes (:229-245) */
+
+void og_update_nodes(og_graph *g, const double *dx, double sign) {
+  for (int i = 0; i < g->n_nodes; i++) {
+    og_node *n = &g->nodes[i];
+    const double *d = dx + n->offset;
+    if (n->kind == OG_NODE_SE2) {
+      n->s[0] += sign * d[0];
+      n->s[1] += sign * d[1];
+      /* rotation *= UnitComplex::from_angle(dtheta): complex product, :236 */
+      double c = cos(sign * d[2]), s = sin(sign * d[2]);
+      double re = n->s[2] * c - n->s[3] * s;
+      double im = n->s[2] * s + n->s[3] * c;
+      n->s[2] = re;
+      n->s[3] = im;
+    } else if (n->kind == OG_NODE_XY) {
+      n->s[0] += sign * d[0];
+      n->s[1] += sign * d[1];
+    } else { /* build-defined SE(3) retraction, see se3_retract */
+      double dd[6], out[7];
+      for (int q = 0; q < 6; q++) dd[q] = sign * d[q];
+      se3_retract(n->s, dd, out);
+      memcpy(n->s, out, sizeof out);
+    }
+  }
+}
+
+/* ------------------------------------------------------ optimize (:247-303) */
+
+int og_optimize(og_graph *g, int num_iterations, int solver, double *errors,
+                double *norms) {
+  const double tolerance = 1e-4; /* :253 */
+  double lambda = 0.01;          /* :254 */
+  double last_error = og_global_error(g);
+  int ne = 0;
+  errors[ne++] = last_error;
+  double *dx = (double *)malloc(sizeof(double) * (size_t)(g->len + 1));
+  for (int i = 0; i < num_iterations; i++) {
+    if (og_linearize_and_solve(g, lambda, solver == OG_LEVENBERG_MARQUARDT, dx)) {
+      free(dx);
+      return -1;
+    }
+    og_update_nodes(g, dx, 1.0);
+    double nrm = 0.0;
+    for (int q = 0; q < g->len; q++) nrm += dx[q] * dx[q];
+    nrm = sqrt(nrm);
+    double error = og_global_error(g);
+    if (solver == OG_LEVENBERG_MARQUARDT) {
+      if (last_error < error) {
+        og_update_nodes(g, dx, -1.0); /* :277 */
+        lambda *= 2.0;
+      } else {
+        lambda /= 2.0;
+      }
+    }
+    last_error = error; /* :284, also when the step was rejected */
+    if (norms) norms[i] = nrm;
+    errors[ne++] = error;
+    if (nrm < tolerance) break;
+  }
+  free(dx);
+  return ne;
+}
+
+int og_state_len(const og_graph *g) {
+  int n = 0;
+  for (int i = 0; i < g->n_nodes; i++)
+    n += g->nodes[i].kind == OG_NODE_SE2 ? 3 : g->nodes[i].kind == OG_NODE_XY ? 2 : 7;
+  return n;
+}
+
+void og_get_state(const og_graph *g, double *out) {
+  for (int i = 0; i < g->n_nodes; i++) {
+    const og_node *n = &g->nodes[i];
+    if (n->kind == OG_NODE_SE2) {
+      *out++ = n->s[0]; *out++ = n->s[1]; *out++ = atan2(n->s[3], n->s[2]);
+    } else if (n->kind == OG_NODE_XY) {
+      *out++ = n->s[0]; *out++ = n->s[1];
+    } else {
+      for (int q = 0; q < 7; q++) *out++ = n->s[q];
+    }
+  }
+}
+
+void og_get_se2_raw(const og_graph *g, int node, double *out4) {
+  memcpy(out4, g->nodes[node].s, sizeof(double) * 4);
+}
