@@ -1,0 +1,206 @@
+/*
+ * rr_pgo.h -- C ABI of librr_pgo.so, the MI355X (gfx950) pose-graph-optimization
+ * backend for RustRobotics' `robotics::mapping::PoseGraph`.
+ *
+ * The reference crate has no FFI seam of its own for this path;
+ * the one it has one level down is russell_sparse -> UMFPACK, an opaque handle
+ * with new/factorize/solve/drop returning i32 status codes
+ * (reference src/mapping/pose_graph_optimization.rs:130,138,141).  This header
+ * follows that model: opaque handle, plain pointers + sizes, int status.
+ * Each entry point names the reference interface it replaces (file:line is
+ * relative to the reference repository root).  INTEGRATION.md shows the Rust
+ * `extern "C"` block + `PoseGraph` wrapper a maintainer would add.
+ *
+ * Threading: one handle = one caller thread at a time; handles are independent.
+ * All functions return RR_PGO_OK (0) or a negative RR_PGO_E* code;
+ * rr_pgo_last_error() returns the message of the calling thread's last failure.
+ * Nothing here falls back to the CPU: without a HIP device every compute entry
+ * point fails with RR_PGO_ENODEVICE.
+ */
+#ifndef RR_PGO_H
+#define RR_PGO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rr_pgo rr_pgo; /* opaque: replaces `struct PoseGraph`, pose_graph_optimization.rs:155-163 */
+
+enum {
+  RR_PGO_OK = 0,
+  RR_PGO_EINVAL = -1,   /* bad argument / malformed description */
+  RR_PGO_EIO = -2,      /* file could not be read                         (Err(io) at g2o.rs:51) */
+  RR_PGO_EPARSE = -3,   /* malformed g2o text                             (Err/panic at g2o.rs:53-139) */
+  RR_PGO_ENODEVICE = -4,/* no usable HIP device / HIP runtime error */
+  RR_PGO_ENOTSPD = -5,  /* factorisation hit a non-positive pivot         (Err from umfpack.factorize, :138) */
+  RR_PGO_ENOMEM = -6,
+  RR_PGO_EUNSUPPORTED = -7
+};
+
+/* enum PoseGraphSolver, pose_graph_optimization.rs:28-32 */
+enum { RR_PGO_GAUSS_NEWTON = 0, RR_PGO_LEVENBERG_MARQUARDT = 1 };
+/* enum Node variants, :147-154 ; enum Edge variants, :20-26 */
+enum { RR_PGO_NODE_SE2 = 0, RR_PGO_NODE_XY = 1, RR_PGO_NODE_SE3 = 2 };
+enum { RR_PGO_EDGE_SE2 = 0, RR_PGO_EDGE_SE2_XY = 1, RR_PGO_EDGE_SE3 = 2 };
+/* arithmetic type of the device path (the reference is f64 throughout) */
+enum { RR_PGO_F64 = 0, RR_PGO_F32 = 1 };
+
+/* What parse_g2o returns (g2o.rs:35-45: len, edges, lut, nodes), flattened.
+ * All arrays are borrowed for the duration of the call only. */
+typedef struct rr_pgo_graph_desc {
+  int32_t n_nodes;
+  const int32_t *node_kind;   /* [n_nodes] RR_PGO_NODE_*; scalar offsets follow this order (g2o.rs:60-77) */
+  const uint32_t *node_id;    /* [n_nodes] g2o ids, may be NULL (then id = index) */
+  const double *node_state;   /* packed in node order: SE2 x,y,theta | XY x,y | SE3 x,y,z,qx,qy,qz,qw */
+  int32_t n_edges;
+  const int32_t *edge_kind;   /* [n_edges] RR_PGO_EDGE_*, file order (order defines the prior, :330-336) */
+  const int32_t *edge_from;   /* [n_edges] dense node index (lut/nodes lookups of :312-320 done by the caller) */
+  const int32_t *edge_to;
+  const double *edge_meas;    /* packed in edge order: SE2 x,y,theta | SE2_XY x,y | SE3 x,y,z,qx,qy,qz,qw */
+  const double *edge_info;    /* packed upper triangles, row-major: 6 | 3 | 21 values (g2o.rs:82,100,117) */
+} rr_pgo_graph_desc;
+
+typedef struct rr_pgo_options {
+  int32_t precision;      /* RR_PGO_F64 (default) or RR_PGO_F32 */
+  int32_t device;         /* HIP device ordinal, -1 = current device */
+  int32_t solver;         /* RR_PGO_GAUSS_NEWTON / RR_PGO_LEVENBERG_MARQUARDT (PoseGraph::new's 2nd arg, :215) */
+  /* Multi-GPU sharding of ONE graph.  world_size <= 1: single GPU. */
+  int32_t rank, world_size;
+  int32_t reserved[11];   /* zero */
+} rr_pgo_options;
+
+void rr_pgo_default_options(rr_pgo_options *opt);
+
+/* ---- lifecycle ---------------------------------------------------------- */
+
+/* PoseGraph::new(file_path, solver)  (:215-227) = parse_g2o (g2o.rs:35-143) +
+ * upload + one-off symbolic analysis.  Same tag set and failure cases as the
+ * reference loader; a panic there is RR_PGO_EPARSE here. */
+int rr_pgo_load_g2o(const char *path, const rr_pgo_options *opt, rr_pgo **out);
+
+/* PoseGraph::new for an already parsed graph (what a Rust caller holding the
+ * output of its own parse_g2o passes down). */
+int rr_pgo_create(const rr_pgo_graph_desc *desc, const rr_pgo_options *opt, rr_pgo **out);
+
+/* Drop for PoseGraph */
+void rr_pgo_destroy(rr_pgo *h);
+
+/* message for the last failing call on this thread (Box<dyn Error> text) */
+const char *rr_pgo_last_error(void);
+
+/* ---- sizes / fields ------------------------------------------------------ */
+int32_t rr_pgo_num_nodes(const rr_pgo *h);  /* nodes.len()  */
+int32_t rr_pgo_num_edges(const rr_pgo *h);  /* edges.len()  */
+int32_t rr_pgo_dim(const rr_pgo *h);        /* len, :156    */
+int32_t rr_pgo_state_len(const rr_pgo *h);  /* entries rr_pgo_get_state writes */
+int32_t rr_pgo_anchor_node(const rr_pgo *h);/* from-node of the first pose-pose edge (prior target, :330-336), -1 if none */
+
+/* host copy of the parsed graph in rr_pgo_graph_desc packing (so a caller or a
+ * test can hand the identical graph to another implementation).  Pointers stay
+ * valid until rr_pgo_destroy. */
+int rr_pgo_get_graph(const rr_pgo *h, rr_pgo_graph_desc *out);
+
+/* ---- the hot path -------------------------------------------------------- */
+
+/* global_error(graph)  (:537-574): sum_e e^T Omega e at the current state.
+ * f64 result also in f32 mode. */
+int rr_pgo_chi2(rr_pgo *h, double *out);
+
+/* build_linear_system(lambda)?.solve()?  (:271 ; linearize_and_solve :371-373
+ * is lambda = 0, lm = 0).  Includes the 1e7 prior (:330-336), b = -b (:361) and,
+ * when lm != 0, + lambda*I (:362-366).  dx_out: rr_pgo_dim entries, reference
+ * scalar order (node offsets). */
+int rr_pgo_linearize_solve(rr_pgo *h, double lambda, int lm, double *dx_out);
+
+/* update_nodes(sign * dx)  (:229-245) */
+int rr_pgo_update(rr_pgo *h, const double *dx, double sign);
+
+/* optimize(num_iterations, log=false, plot=false)  (:247-303), exact control
+ * flow incl. the LM accept/reject quirks (:275-286) and the |dx| < 1e-4 break
+ * (:298-300).  errors_out needs num_iterations+1 slots; *n_errors = 1 +
+ * iterations executed (the length of the reference's returned Vec<f64>).
+ * norms_out (may be NULL): |dx| per executed iteration. */
+int rr_pgo_optimize(rr_pgo *h, int32_t num_iterations, double *errors_out,
+                    int32_t *n_errors, double *norms_out);
+
+/* State read-back: SE2 -> x, y, atan2(im,re) ; XY -> x, y ; SE3 -> x,y,z,qx,qy,qz,qw,
+ * node order.  (Field access on PoseGraph.nodes in the reference.) */
+int rr_pgo_get_state(rr_pgo *h, double *out);
+/* Overwrite the state (same packing); used to restart a benchmark run. */
+int rr_pgo_set_state(rr_pgo *h, const double *state);
+
+/* ---- inspection of the assembled system (parity tests) ------------------- */
+
+/* Runs the linearisation kernels only and returns the assembled normal matrix
+ * as a dense-block list: for every stored block s, (row_node, col_node) and
+ * d_row x d_col row-major values; plus b (negated).  Call with all output
+ * pointers NULL to get the counts.  Values are converted to f64. */
+int rr_pgo_assemble(rr_pgo *h, double lambda, int lm, int32_t *n_blocks,
+                    int32_t *block_row_node, int32_t *block_col_node,
+                    int64_t *block_val_offset, double *block_vals,
+                    int64_t *n_vals, double *b_out);
+
+/* ---- measurement --------------------------------------------------------- */
+
+/* Enqueue `iters` Gauss-Newton iterations (linearise, factor, solve, update,
+ * chi2) back to back on the handle's stream WITHOUT the convergence break and
+ * without host round trips; returns immediately.  rr_pgo_sync waits. */
+int rr_pgo_iterate_async(rr_pgo *h, int32_t iters);
+int rr_pgo_sync(rr_pgo *h);
+
+typedef struct rr_pgo_stats {
+  /* symbolic analysis (done once in create) */
+  int64_t nnz_h_blocks;      /* stored blocks of H (diag + lower off-diag)      */
+  int64_t nnz_l_scalars;     /* scalars in the supernodal factor incl. padding  */
+  int64_t factor_flops;      /* flops of one numeric factorisation               */
+  int32_t n_supernodes, n_levels, n_launches_per_iter;
+  int32_t max_front, max_pivot_cols;
+  int32_t n_big_fronts;      /* fronts taken by the tiled multi-workgroup path   */
+  double analyze_ms, parse_ms;
+  /* algorithmic bytes of one GN iteration by phase */
+  double bytes_linearize, bytes_factor, bytes_solve, bytes_update, bytes_chi2;
+  int32_t reserved[8];
+} rr_pgo_stats;
+int rr_pgo_get_stats(const rr_pgo *h, rr_pgo_stats *out);
+
+/* Per-kernel timing measured with HIP events on the handle's own stream.
+ * Runs `iters` eager (non-graph) GN iterations with an event pair around every
+ * launch and accumulates per kernel class.  Arrays have RR_PGO_NUM_KCLASS slots. */
+enum {
+  RR_PGO_K_LINEARIZE = 0, RR_PGO_K_FACTOR = 1, RR_PGO_K_SOLVE = 2,
+  RR_PGO_K_UPDATE = 3, RR_PGO_K_REDUCE = 4, RR_PGO_K_BIGFRONT = 5,
+  RR_PGO_NUM_KCLASS = 6
+};
+int rr_pgo_profile(rr_pgo *h, int32_t iters, double *ms_total /*[NUM_KCLASS]*/,
+                   int64_t *launches /*[NUM_KCLASS]*/);
+
+/* ---- synthetic workload (BASELINE config 4) -------------------- */
+
+/* Deterministic SE(2) lattice graph: W x H poses in boustrophedon order, the
+ * 10-offset stencil (+ part of an 11th) described in SURVEY.md 8(d), trimmed or
+ * capped to n_edges_target (<=0: all stencil edges).  Fills a graph description
+ * whose arrays are owned by the returned object; free with rr_pgo_synth_free. */
+typedef struct rr_pgo_synth rr_pgo_synth;
+int rr_pgo_synth_grid(int32_t width, int32_t height, int64_t n_edges_target,
+                      uint64_t seed_meas, uint64_t seed_init, rr_pgo_synth **out,
+                      rr_pgo_graph_desc *desc);
+void rr_pgo_synth_free(rr_pgo_synth *s);
+
+/* ---- multi-GPU exchange hooks --------------------------------- */
+
+/* When opt.world_size > 1 the handle owns the edges/fronts of its rank and
+ * exposes ONE contiguous device buffer holding the separator contributions that
+ * must be summed over ranks once per iteration.  The host side all-reduces it
+ * (RCCL, sum) between rr_pgo_stage_local and rr_pgo_stage_top. */
+int rr_pgo_exchange_buffer(rr_pgo *h, void **dev_ptr, int64_t *n_elems, int32_t *elem_size);
+int rr_pgo_stage_local(rr_pgo *h, double lambda, int lm); /* linearise + factor the rank's subtrees */
+int rr_pgo_stage_top(rr_pgo *h);                          /* after the all-reduce: top fronts, back-solve, update */
+void *rr_pgo_stream(rr_pgo *h);                           /* hipStream_t the handle launches on */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,193 @@
+// g2o_loader.cpp -- g2o text loader with the reference's semantics
+// (reference src/mapping/g2o.rs:35-143):
+//   * whole file read, split into lines (a trailing '\r' is stripped like
+//     str::lines() does), tokens split on ' ' ONLY, empty tokens dropped (:52);
+//   * tags VERTEX_SE2 / VERTEX_XY / VERTEX_SE3:QUAT / EDGE_SE2 / EDGE_SE2_XY /
+//     EDGE_SE3:QUAT, anything else is an error (unimplemented!() at :138);
+//   * scalar offsets grow by 3 / 2 / 6 in vertex FILE order (:60-77);
+//   * edges keep FILE order (:94-95,111-112,135-136);
+//   * information matrices are given as row-major upper triangles (:82,100,117).
+// A condition that panics in the reference (empty line, wrong value count, edge
+// to an unknown vertex) is reported as an error string here.
+// SE(3) quaternions are read in the g2o text order qx qy qz qw; the reference's
+// iso3 passes them to nalgebra as (w,i,j,k) (g2o.rs:20) but never
+// executes SE(3), so there is no behaviour to match.
+#include <charconv>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string_view>
+#include <unordered_map>
+
+#include "host_graph.h"
+
+namespace rrpgo {
+
+namespace {
+
+bool read_file(const char *path, std::string &out) {
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return false;
+  std::fseek(f, 0, SEEK_END);
+  long n = std::ftell(f);
+  std::fseek(f, 0, SEEK_SET);
+  if (n < 0) { std::fclose(f); return false; }
+  out.resize((size_t)n);
+  size_t got = n ? std::fread(out.data(), 1, (size_t)n, f) : 0;
+  std::fclose(f);
+  return got == (size_t)n;
+}
+
+bool to_u32(std::string_view s, uint32_t &v) {
+  if (!s.empty() && s[0] == '+') s.remove_prefix(1);
+  if (s.empty()) return false;
+  auto r = std::from_chars(s.data(), s.data() + s.size(), v, 10);
+  return r.ec == std::errc() && r.ptr == s.data() + s.size();
+}
+
+bool to_f64(std::string_view s, double &v) {
+  // Rust's f64::from_str: optional sign, decimal / exponent, inf / nan; no hex.
+  if (s.empty() || s.size() > 63) return false;
+  char buf[64];
+  std::memcpy(buf, s.data(), s.size());
+  buf[s.size()] = 0;
+  const char *p = buf;
+  if (*p == '+' || *p == '-') p++;
+  if (p[0] == '0' && (p[1] == 'x' || p[1] == 'X')) return false;
+  char *end = nullptr;
+  v = std::strtod(buf, &end);
+  return end != buf && *end == 0;
+}
+
+}  // namespace
+
+std::string HostGraph::finalize() {
+  const int N = n_nodes(), E = n_edges();
+  node_offset.assign(N, 0);
+  node_state_off.assign(N, 0);
+  int off = 0;
+  int64_t soff = 0;
+  has_se3 = has_2d = false;
+  for (int i = 0; i < N; i++) {
+    int k = node_kind[i];
+    if (k < NODE_SE2 || k > NODE_SE3) return "bad node kind";
+    node_offset[i] = off;
+    node_state_off[i] = soff;
+    off += node_dim(k);
+    soff += node_state_len(k);
+    (k == NODE_SE3 ? has_se3 : has_2d) = true;
+  }
+  dim = off;
+  if ((int64_t)node_state.size() != soff) return "node_state length does not match node kinds";
+  if (has_se3 && has_2d) return "mixed 2D / 3D graphs are not supported";
+  edge_meas_off.assign(E, 0);
+  edge_info_off.assign(E, 0);
+  int64_t mo = 0, io = 0;
+  anchor_node = -1;
+  for (int k = 0; k < E; k++) {
+    int ek = edge_kind[k];
+    if (ek < EDGE_SE2 || ek > EDGE_SE3) return "bad edge kind";
+    int a = edge_from[k], b = edge_to[k];
+    if (a < 0 || a >= N || b < 0 || b >= N)
+      return "edge " + std::to_string(k) + " references an unknown vertex";
+    int ka = node_kind[a], kb = node_kind[b];
+    bool ok = (ek == EDGE_SE2 && ka == NODE_SE2 && kb == NODE_SE2) ||
+              (ek == EDGE_SE2_XY && ka == NODE_SE2 && kb == NODE_XY) ||
+              (ek == EDGE_SE3 && ka == NODE_SE3 && kb == NODE_SE3);
+    if (!ok)  // unreachable!() in the reference, pose_graph_optimization.rs:315-320,342-347
+      return "edge " + std::to_string(k) + ": endpoint kinds do not match the edge kind";
+    if (a == b) return "edge " + std::to_string(k) + " is a self loop";
+    edge_meas_off[k] = mo;
+    edge_info_off[k] = io;
+    mo += edge_meas_len(ek);
+    io += edge_info_len(ek);
+    // prior goes on the from-node of the first pose-pose edge in file order (:330-336)
+    if (anchor_node < 0 && (ek == EDGE_SE2 || ek == EDGE_SE3)) anchor_node = a;
+  }
+  if ((int64_t)edge_meas.size() != mo) return "edge_meas length does not match edge kinds";
+  if ((int64_t)edge_info.size() != io) return "edge_info length does not match edge kinds";
+  return "";
+}
+
+std::string load_g2o(const char *path, HostGraph &g, bool &io_error) {
+  io_error = false;
+  std::string text;
+  if (!read_file(path, text)) {
+    io_error = true;
+    return std::string("cannot read '") + path + "'";
+  }
+  g = HostGraph();
+  std::unordered_map<uint32_t, int32_t> index_of;  // id -> dense index (lut + nodes maps of the reference)
+  std::vector<uint32_t> from_id, to_id;
+  std::vector<std::string_view> tok;
+  size_t pos = 0;
+  long lineno = 0;
+  auto fail = [&](const std::string &m) { return "line " + std::to_string(lineno) + ": " + m; };
+
+  while (pos < text.size()) {
+    size_t eol = text.find('\n', pos);
+    if (eol == std::string::npos) eol = text.size();
+    std::string_view line(text.data() + pos, eol - pos);
+    pos = eol + 1;
+    lineno++;
+    if (!line.empty() && line.back() == '\r') line.remove_suffix(1);
+    tok.clear();
+    for (size_t i = 0; i < line.size();) {
+      while (i < line.size() && line[i] == ' ') i++;
+      size_t j = i;
+      while (j < line.size() && line[j] != ' ') j++;
+      if (j > i) tok.push_back(line.substr(i, j - i));
+      i = j;
+    }
+    if (tok.empty()) return fail("empty line");  // line[0] panics in the reference (:53)
+
+    int kind = -1, nvals = 0;
+    bool is_edge = false;
+    if (tok[0] == "VERTEX_SE2") { kind = NODE_SE2; nvals = 3; }
+    else if (tok[0] == "VERTEX_XY") { kind = NODE_XY; nvals = 2; }
+    else if (tok[0] == "VERTEX_SE3:QUAT") { kind = NODE_SE3; nvals = 7; }
+    else if (tok[0] == "EDGE_SE2") { kind = EDGE_SE2; nvals = 9; is_edge = true; }
+    else if (tok[0] == "EDGE_SE2_XY") { kind = EDGE_SE2_XY; nvals = 5; is_edge = true; }
+    else if (tok[0] == "EDGE_SE3:QUAT") { kind = EDGE_SE3; nvals = 28; is_edge = true; }
+    else return fail("unsupported tag '" + std::string(tok[0]) + "'");
+
+    const size_t first = is_edge ? 3 : 2;
+    if (tok.size() != first + (size_t)nvals)
+      return fail("expected " + std::to_string(nvals) + " values after the ids");
+    uint32_t id0 = 0, id1 = 0;
+    if (!to_u32(tok[1], id0) || (is_edge && !to_u32(tok[2], id1))) return fail("bad vertex id");
+    double v[28];
+    for (int i = 0; i < nvals; i++)
+      if (!to_f64(tok[first + i], v[i])) return fail("bad number '" + std::string(tok[first + i]) + "'");
+
+    if (!is_edge) {
+      // The reference would silently overwrite the hash-map entry and leave the
+      // previous offset's rows empty (a singular system): rejected here.
+      if (!index_of.emplace(id0, (int32_t)g.node_kind.size()).second)
+        return fail("duplicate vertex id " + std::to_string(id0));
+      g.node_kind.push_back(kind);
+      g.node_id.push_back(id0);
+      g.node_state.insert(g.node_state.end(), v, v + nvals);
+    } else {
+      g.edge_kind.push_back(kind);
+      from_id.push_back(id0);
+      to_id.push_back(id1);
+      const int nm = edge_meas_len(kind);
+      g.edge_meas.insert(g.edge_meas.end(), v, v + nm);
+      g.edge_info.insert(g.edge_info.end(), v + nm, v + nvals);
+    }
+  }
+  const size_t E = g.edge_kind.size();
+  g.edge_from.resize(E);
+  g.edge_to.resize(E);
+  for (size_t k = 0; k < E; k++) {
+    auto a = index_of.find(from_id[k]), b = index_of.find(to_id[k]);
+    if (a == index_of.end() || b == index_of.end())
+      return "edge " + std::to_string(k) + " references an unknown vertex";
+    g.edge_from[k] = a->second;
+    g.edge_to[k] = b->second;
+  }
+  return g.finalize();
+}
+
+}  // namespace rrpgo

@@ -1,0 +1,895 @@
+// pgo_api.hip -- librr_pgo.so: C ABI (include/rr_pgo.h) over the HIP engine.
+//
+// Host side of the hot path, mirroring the reference's PoseGraph
+// (src/mapping/pose_graph_optimization.rs:214-373): create = parse + upload +
+// one-off symbolic analysis; optimize = the GN / LM loop with every kernel of an
+// iteration replayed from one hipGraph on the handle's own stream; the host
+// reads two scalars (chi2, |dx|) per iteration.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rr_pgo.h"
+#include "host_graph.h"
+#include "kernels.hip.h"
+#include "symbolic.h"
+
+namespace rrpgo {
+
+static_assert(sizeof(AsmItem) == sizeof(AsmItemDev), "host/device assembly item layouts differ");
+
+struct ApiError : std::runtime_error {
+  int code;
+  ApiError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+static thread_local std::string g_last_error;
+
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      throw ApiError(RR_PGO_ENODEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+  } while (0)
+
+template <typename U> struct DevBuf {
+  U *p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  void alloc(size_t count) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    n = count;
+    if (count) HIPCHK(hipMalloc((void **)&p, count * sizeof(U)));
+  }
+  void upload(const std::vector<U> &v) {
+    alloc(v.size());
+    if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(U), hipMemcpyHostToDevice));
+  }
+  void zero() { if (n) HIPCHK(hipMemset(p, 0, n * sizeof(U))); }
+};
+
+static double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+struct EngineBase {
+  virtual ~EngineBase() = default;
+  virtual void chi2(double *out) = 0;
+  virtual void linearize_solve(double lambda, int lm, double *dx_out) = 0;
+  virtual void update(const double *dx, double sign) = 0;
+  virtual void optimize(int solver, int iters, double *errors, int *n_errors, double *norms) = 0;
+  virtual void get_state(double *out) = 0;
+  virtual void set_state(const double *st) = 0;
+  virtual void assemble(double lambda, int lm, std::vector<double> &hvals, std::vector<double> &b) = 0;
+  virtual void iterate_async(int iters) = 0;
+  virtual void sync() = 0;
+  virtual void profile(int iters, double *ms, int64_t *launches) = 0;
+  virtual hipStream_t stream() = 0;
+  int n_launches_per_iter = 0;
+};
+
+constexpr int HIST = 4096;  // ring of (chi2, |dx|) pairs written by k_finalize
+
+__global__ void k_finalize_slot(const double *chi_partial, int n_chi, const double *norm_partial,
+                                int n_norm, double *hist, int *counter, int advance) {
+  __shared__ double red[4];
+  double c = 0.0, n = 0.0;
+  for (int i = threadIdx.x; i < n_chi; i += 256) c += chi_partial[i];
+  for (int i = threadIdx.x; i < n_norm; i += 256) n += norm_partial[i];
+  double ct = block_sum<double, 256>(c, red);
+  double nt = block_sum<double, 256>(n, red);
+  if (threadIdx.x == 0) {
+    int slot = *counter % HIST;
+    if (n_chi > 0) hist[2 * slot] = ct;
+    if (n_norm > 0) hist[2 * slot + 1] = sqrt(nt);
+    if (advance) *counter = *counter + 1;
+  }
+}
+
+template <typename T> __global__ void k_permute_out(int n, const int32_t *perm, const T *x, T *dx_ref) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dx_ref[perm[i]] = x[i];
+}
+
+template <typename T> class Engine final : public EngineBase {
+  using V4 = typename VecT<T>::V4;
+  using V2 = typename VecT<T>::V2;
+  const HostGraph &g_;
+  const Symbolic &sym_;
+  hipStream_t stream_ = nullptr;
+  hipGraphExec_t gn_exec_ = nullptr;
+  // graph data
+  DevBuf<V4> pose_, e_meas_, e_info_a_;
+  DevBuf<V2> e_info_b_;
+  DevBuf<int2> e_idx_;
+  DevBuf<int64_t> e_slot_, diag_off_;
+  DevBuf<int32_t> inc_ptr_, inc_list_, node_offset_, node_pcol_;
+  DevBuf<uint8_t> node_dim_;
+  // numeric
+  DevBuf<T> hvals_, b_, x_, dx_ref_, lvals_, uvals_;
+  DevBuf<double> chi_partial_, norm_partial_, hist_;
+  DevBuf<int> counter_, err_;
+  // symbolic tables
+  DevBuf<int32_t> task_ptr_, task_sn_, sn_ncols_, sn_nrows_, sn_col0_, sn_uld_, child_ptr_, child_list_,
+      rel_, perm_, sn_rows_;
+  DevBuf<int64_t> sn_loff_, sn_uoff_, asm_ptr_, rel_ptr_, sn_rows_ptr_;
+  DevBuf<AsmItemDev> asm_items_;
+  std::vector<int> step_solve_lds_;  // scalars of LDS the back-solve of each step needs
+  double *host_pair_ = nullptr;      // pinned, 2 doubles
+  int n_lin_blocks_ = 0, n_upd_blocks_ = 0;
+  int host_counter_ = 0;             // mirrors the device slot counter
+
+ public:
+  Engine(const HostGraph &g, const Symbolic &sym) : g_(g), sym_(sym) {
+    HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    HIPCHK(hipHostMalloc((void **)&host_pair_, 2 * sizeof(double)));
+    const int N = g.n_nodes(), E = g.n_edges();
+    // ---- graph arrays
+    std::vector<V4> pose(N);
+    std::vector<uint8_t> ndim(N);
+    for (int i = 0; i < N; i++) {
+      const double *s = &g.node_state[g.node_state_off[i]];
+      ndim[i] = (uint8_t)node_dim(g.node_kind[i]);
+      if (g.node_kind[i] == NODE_SE2) pose[i] = V4{(T)s[0], (T)s[1], (T)std::cos(s[2]), (T)std::sin(s[2])};
+      else pose[i] = V4{(T)s[0], (T)s[1], (T)0, (T)0};
+    }
+    pose_.upload(pose);
+    node_dim_.upload(ndim);
+    std::vector<int2> eidx(E);
+    std::vector<V4> emeas(E), einfa(E);
+    std::vector<V2> einfb(E);
+    std::vector<int64_t> eslot(E);
+    for (int k = 0; k < E; k++) {
+      eidx[k] = int2{g.edge_from[k], g.edge_to[k]};
+      const double *m = &g.edge_meas[g.edge_meas_off[k]];
+      const double *w = &g.edge_info[g.edge_info_off[k]];
+      if (g.edge_kind[k] == EDGE_SE2) {
+        emeas[k] = V4{(T)m[0], (T)m[1], (T)std::cos(m[2]), (T)std::sin(m[2])};
+        einfa[k] = V4{(T)w[0], (T)w[1], (T)w[2], (T)w[3]};
+        einfb[k] = V2{(T)w[4], (T)w[5]};
+      } else {
+        emeas[k] = V4{(T)m[0], (T)m[1], (T)0, (T)0};
+        einfa[k] = V4{(T)w[0], (T)w[1], (T)0, (T)w[2]};
+        einfb[k] = V2{(T)0, (T)0};
+      }
+      eslot[k] = (sym.blk_off[sym.edge_slot[k]] << 1) | (sym.edge_transposed[k] ? 1 : 0);
+    }
+    e_idx_.upload(eidx);
+    e_meas_.upload(emeas);
+    e_info_a_.upload(einfa);
+    e_info_b_.upload(einfb);
+    e_slot_.upload(eslot);
+    std::vector<int32_t> inc(sym.inc_list.size());
+    for (size_t q = 0; q < inc.size(); q++) {
+      int k = sym.inc_list[q] >> 1, role = sym.inc_list[q] & 1;
+      inc[q] = (k << 2) | ((g.edge_kind[k] == EDGE_SE2_XY ? 1 : 0) << 1) | role;
+    }
+    inc_ptr_.upload(sym.inc_ptr);
+    inc_list_.upload(inc);
+    node_offset_.upload(g.node_offset);
+    node_pcol_.upload(sym.node_pcol);
+    diag_off_.upload(sym.diag_off);
+    // ---- numeric buffers
+    hvals_.alloc((size_t)sym.n_hvals);
+    hvals_.zero();
+    b_.alloc((size_t)g.dim);
+    x_.alloc((size_t)g.dim);
+    dx_ref_.alloc((size_t)g.dim);
+    b_.zero(); x_.zero(); dx_ref_.zero();
+    lvals_.alloc((size_t)sym.l_elems + 4);
+    uvals_.alloc((size_t)sym.u_elems + 4);
+    lvals_.zero(); uvals_.zero();
+    n_lin_blocks_ = (int)(((int64_t)N * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
+    n_upd_blocks_ = (N + UPD_THREADS - 1) / UPD_THREADS;
+    chi_partial_.alloc((size_t)n_lin_blocks_);
+    norm_partial_.alloc((size_t)n_upd_blocks_);
+    hist_.alloc(2 * HIST);
+    hist_.zero();
+    counter_.alloc(1);
+    counter_.zero();
+    err_.alloc(1);
+    err_.zero();
+    // ---- symbolic tables
+    task_ptr_.upload(sym.task_ptr);
+    task_sn_.upload(sym.task_sn);
+    sn_ncols_.upload(sym.sn_ncols);
+    sn_nrows_.upload(sym.sn_nrows);
+    sn_col0_.upload(sym.sn_col0);
+    sn_uld_.upload(sym.sn_uld);
+    sn_loff_.upload(sym.sn_loff);
+    sn_uoff_.upload(sym.sn_uoff);
+    asm_ptr_.upload(sym.asm_ptr);
+    {
+      std::vector<AsmItemDev> items(sym.asm_items.size());
+      if (!items.empty()) std::memcpy(items.data(), sym.asm_items.data(), items.size() * sizeof(AsmItemDev));
+      asm_items_.upload(items);
+    }
+    child_ptr_.upload(sym.child_ptr);
+    child_list_.upload(sym.child_list);
+    rel_ptr_.upload(sym.rel_ptr);
+    rel_.upload(sym.rel);
+    perm_.upload(sym.perm);
+    sn_rows_ptr_.upload(sym.sn_rows_ptr);
+    sn_rows_.upload(sym.sn_rows);
+    for (const Step &st : sym.steps) {
+      int need = 0;
+      if (st.kind == STEP_TASKS) {
+        for (int t = st.task_begin; t < st.task_end; t++)
+          for (int q = sym.task_ptr[t]; q < sym.task_ptr[t + 1]; q++) {
+            int s = sym.task_sn[q], nc = sym.sn_ncols[s], nr = sym.sn_nrows[s];
+            if (nc > 256) throw ApiError(RR_PGO_EUNSUPPORTED, "internal: LDS-path supernode wider than 256 columns");
+            need = std::max(need, nr + nc + nc * nc);
+          }
+      } else {
+        need = sym.sn_ncols[st.sn] + sym.sn_nrows[st.sn];
+      }
+      step_solve_lds_.push_back(need);
+    }
+    configure_kernels();
+    n_launches_per_iter = 3 + 2 * (int)sym.steps.size();
+  }
+
+  ~Engine() override {
+    if (gn_exec_) (void)hipGraphExecDestroy(gn_exec_);
+    if (host_pair_) (void)hipHostFree(host_pair_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+  }
+
+  hipStream_t stream() override { return stream_; }
+
+ private:
+  static constexpr int MAXD2 = 9;
+  static constexpr int kMaxLds = 160 * 1024;
+
+  void configure_kernels() {
+    // opt in to > 64 KiB of dynamic LDS
+    HIPCHK(hipFuncSetAttribute((const void *)k_factor_tasks<T, 64, MAXD2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void *)k_factor_tasks<T, 128, MAXD2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void *)k_factor_tasks<T, 256, MAXD2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void *)k_solve_tasks<T, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void *)k_solve_tasks<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void *)k_solve_tasks<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void *)k_solve_big_single<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+  }
+
+  LinArgs<T> lin_args(double lambda, int lm, int write_system) {
+    LinArgs<T> a;
+    a.n_nodes = g_.n_nodes();
+    a.pose = pose_.p;
+    a.e_idx = e_idx_.p;
+    a.e_meas = e_meas_.p;
+    a.e_info_a = e_info_a_.p;
+    a.e_info_b = e_info_b_.p;
+    a.e_slot = e_slot_.p;
+    a.inc_ptr = inc_ptr_.p;
+    a.inc_list = inc_list_.p;
+    a.node_dim = node_dim_.p;
+    a.node_offset = node_offset_.p;
+    a.diag_off = diag_off_.p;
+    a.hvals = hvals_.p;
+    a.b = b_.p;
+    a.chi2_partial = chi_partial_.p;
+    a.anchor = g_.anchor_node;
+    a.lambda = lm ? (T)lambda : (T)0;
+    a.write_system = write_system;
+    return a;
+  }
+
+  FactorArgs<T> factor_args(int task_begin) {
+    FactorArgs<T> a;
+    a.task_ptr = task_ptr_.p;
+    a.task_sn = task_sn_.p;
+    a.task_begin = task_begin;
+    a.sn_ncols = sn_ncols_.p;
+    a.sn_nrows = sn_nrows_.p;
+    a.sn_col0 = sn_col0_.p;
+    a.sn_loff = sn_loff_.p;
+    a.sn_uoff = sn_uoff_.p;
+    a.sn_uld = sn_uld_.p;
+    a.asm_ptr = asm_ptr_.p;
+    a.asm_items = asm_items_.p;
+    a.child_ptr = child_ptr_.p;
+    a.child_list = child_list_.p;
+    a.rel_ptr = rel_ptr_.p;
+    a.rel = rel_.p;
+    a.perm = perm_.p;
+    a.sn_rows_ptr = sn_rows_ptr_.p;
+    a.sn_rows = sn_rows_.p;
+    a.hvals = hvals_.p;
+    a.b = b_.p;
+    a.lvals = lvals_.p;
+    a.uvals = uvals_.p;
+    a.x = x_.p;
+    a.err = err_.p;
+    return a;
+  }
+
+  // Optional per-launch event timing (rr_pgo_profile).
+  struct Prof {
+    bool on = false;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    double ms[RR_PGO_NUM_KCLASS] = {0};
+    int64_t n[RR_PGO_NUM_KCLASS] = {0};
+  } prof_;
+  void pbegin() { if (prof_.on) HIPCHK(hipEventRecord(prof_.e0, stream_)); }
+  void pend(int k) {
+    if (!prof_.on) return;
+    HIPCHK(hipEventRecord(prof_.e1, stream_));
+    HIPCHK(hipEventSynchronize(prof_.e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, prof_.e0, prof_.e1));
+    prof_.ms[k] += ms;
+    prof_.n[k]++;
+  }
+
+  void launch_linearize(double lambda, int lm, int write_system) {
+    pbegin();
+    hipLaunchKernelGGL(k_linearize<T>, dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_,
+                       lin_args(lambda, lm, write_system));
+    pend(RR_PGO_K_LINEARIZE);
+  }
+
+  void launch_factor() {
+    for (const Step &st : sym_.steps) {
+      pbegin();
+      if (st.kind == STEP_TASKS) {
+        const int nt = st.task_end - st.task_begin;
+        const size_t lds = (size_t)st.max_lds_elems * sizeof(T);
+        FactorArgs<T> a = factor_args(st.task_begin);
+        if (st.threads == 64) hipLaunchKernelGGL((k_factor_tasks<T, 64, MAXD2>), dim3(nt), dim3(64), lds, stream_, a);
+        else if (st.threads == 128) hipLaunchKernelGGL((k_factor_tasks<T, 128, MAXD2>), dim3(nt), dim3(128), lds, stream_, a);
+        else hipLaunchKernelGGL((k_factor_tasks<T, 256, MAXD2>), dim3(nt), dim3(256), lds, stream_, a);
+        pend(RR_PGO_K_FACTOR);
+      } else {
+        hipLaunchKernelGGL((k_factor_big_single<T, 1024, MAXD2>), dim3(1), dim3(1024), 0, stream_, factor_args(0), st.sn);
+        pend(RR_PGO_K_BIGFRONT);
+      }
+    }
+  }
+
+  void launch_solve() {
+    for (int i = (int)sym_.steps.size() - 1; i >= 0; i--) {
+      const Step &st = sym_.steps[i];
+      const size_t lds = (size_t)step_solve_lds_[i] * sizeof(T);
+      pbegin();
+      if (st.kind == STEP_TASKS) {
+        const int nt = st.task_end - st.task_begin;
+        FactorArgs<T> a = factor_args(st.task_begin);
+        if (st.threads == 64) hipLaunchKernelGGL((k_solve_tasks<T, 64>), dim3(nt), dim3(64), lds, stream_, a);
+        else if (st.threads == 128) hipLaunchKernelGGL((k_solve_tasks<T, 128>), dim3(nt), dim3(128), lds, stream_, a);
+        else hipLaunchKernelGGL((k_solve_tasks<T, 256>), dim3(nt), dim3(256), lds, stream_, a);
+        pend(RR_PGO_K_SOLVE);
+      } else {
+        hipLaunchKernelGGL((k_solve_big_single<T, 1024>), dim3(1), dim3(1024), lds, stream_, factor_args(0), st.sn);
+        pend(RR_PGO_K_BIGFRONT);
+      }
+    }
+  }
+
+  void launch_update(const T *dx_ref_in, double sign, bool write_ref) {
+    UpdArgs<T> u;
+    u.n_nodes = g_.n_nodes();
+    u.pose = pose_.p;
+    u.node_dim = node_dim_.p;
+    u.node_pcol = node_pcol_.p;
+    u.node_offset = node_offset_.p;
+    u.x = x_.p;
+    u.dx_ref_in = dx_ref_in;
+    u.dx_ref_out = write_ref ? dx_ref_.p : nullptr;
+    u.sign = (T)sign;
+    u.norm_partial = norm_partial_.p;
+    pbegin();
+    hipLaunchKernelGGL(k_update<T>, dim3(n_upd_blocks_), dim3(UPD_THREADS), 0, stream_, u);
+    pend(RR_PGO_K_UPDATE);
+  }
+
+  void launch_finalize(bool chi, bool norm, bool advance) {
+    pbegin();
+    hipLaunchKernelGGL(k_finalize_slot, dim3(1), dim3(256), 0, stream_, chi_partial_.p, chi ? n_lin_blocks_ : 0,
+                       norm_partial_.p, norm ? n_upd_blocks_ : 0, hist_.p, counter_.p, advance ? 1 : 0);
+    pend(RR_PGO_K_REDUCE);
+  }
+
+  // one Gauss-Newton iteration: chi2(state) -> slot.chi, |dx| -> slot.norm, slot++
+  void enqueue_gn_iteration() {
+    launch_linearize(0.0, 0, 1);
+    launch_factor();
+    launch_solve();
+    launch_update(nullptr, 1.0, true);
+    launch_finalize(true, true, true);
+  }
+
+  void ensure_gn_graph() {
+    if (gn_exec_) return;
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+    enqueue_gn_iteration();
+    HIPCHK(hipStreamEndCapture(stream_, &graph));
+    HIPCHK(hipGraphInstantiate(&gn_exec_, graph, nullptr, nullptr, 0));
+    HIPCHK(hipGraphDestroy(graph));
+  }
+
+  void read_slot(int slot, double *chi, double *norm) {
+    HIPCHK(hipMemcpyAsync(host_pair_, hist_.p + 2 * (slot % HIST), 2 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    if (chi) *chi = host_pair_[0];
+    if (norm) *norm = host_pair_[1];
+  }
+
+  void check_device_error() {
+    int e = 0;
+    HIPCHK(hipMemcpyAsync(&e, err_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    if (e) {
+      HIPCHK(hipMemsetAsync(err_.p, 0, sizeof(int), stream_));
+      if (e & DEVERR_NOT_SPD) throw ApiError(RR_PGO_ENOTSPD, "normal matrix is not positive definite (non-positive pivot)");
+      throw ApiError(RR_PGO_ENODEVICE, "device-side error flag " + std::to_string(e));
+    }
+  }
+
+  void reset_counter() {
+    HIPCHK(hipMemsetAsync(counter_.p, 0, sizeof(int), stream_));
+    host_counter_ = 0;
+  }
+
+  double chi2_now() {
+    reset_counter();
+    launch_linearize(0.0, 0, 0);
+    launch_finalize(true, false, false);
+    double c = 0;
+    read_slot(0, &c, nullptr);
+    return c;
+  }
+
+ public:
+  void chi2(double *out) override { *out = chi2_now(); }
+
+  void linearize_solve(double lambda, int lm, double *dx_out) override {
+    launch_linearize(lambda, lm, 1);
+    launch_factor();
+    launch_solve();
+    hipLaunchKernelGGL(k_permute_out<T>, dim3((g_.dim + 255) / 256), dim3(256), 0, stream_, g_.dim, perm_.p, x_.p, dx_ref_.p);
+    std::vector<T> tmp((size_t)g_.dim);
+    HIPCHK(hipMemcpyAsync(tmp.data(), dx_ref_.p, tmp.size() * sizeof(T), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    check_device_error();
+    for (int i = 0; i < g_.dim; i++) dx_out[i] = (double)tmp[i];
+  }
+
+  void update(const double *dx, double sign) override {
+    std::vector<T> tmp((size_t)g_.dim);
+    for (int i = 0; i < g_.dim; i++) tmp[i] = (T)dx[i];
+    HIPCHK(hipMemcpyAsync(dx_ref_.p, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, stream_));
+    launch_update(dx_ref_.p, sign, false);
+    HIPCHK(hipStreamSynchronize(stream_));
+  }
+
+  // optimize(), pose_graph_optimization.rs:247-303
+  void optimize(int solver, int iters, double *errors, int *n_errors, double *norms) override {
+    const double tolerance = 1e-4;  // :253
+    int ne = 0;
+    if (solver == RR_PGO_GAUSS_NEWTON) {
+      // chi2 of the state BEFORE an update comes out of that iteration's own
+      // linearisation pass, so errors[i] is known once iteration i has run and
+      // one chi2-only pass after the loop supplies the last entry.
+      ensure_gn_graph();
+      reset_counter();
+      int done = 0;
+      for (int i = 0; i < iters; i++) {
+        HIPCHK(hipGraphLaunch(gn_exec_, stream_));
+        double chi, nrm;
+        read_slot(i, &chi, &nrm);
+        check_device_error();
+        errors[ne++] = chi;
+        if (norms) norms[i] = nrm;
+        done = i + 1;
+        if (nrm < tolerance) break;  // :298-300
+      }
+      (void)done;
+      errors[ne++] = chi2_now();
+    } else {
+      double lambda = 0.01;  // :254
+      double last_error = chi2_now();
+      errors[ne++] = last_error;
+      for (int i = 0; i < iters; i++) {
+        reset_counter();
+        launch_linearize(lambda, 1, 1);
+        launch_factor();
+        launch_solve();
+        launch_update(nullptr, 1.0, true);
+        launch_finalize(false, true, false);
+        launch_linearize(0.0, 0, 0);
+        launch_finalize(true, false, false);
+        double error, nrm;
+        read_slot(0, &error, &nrm);
+        check_device_error();
+        if (last_error < error) {  // :276-281
+          launch_update(dx_ref_.p, -1.0, false);
+          lambda *= 2.0;
+        } else {
+          lambda /= 2.0;
+        }
+        last_error = error;  // :284
+        if (norms) norms[i] = nrm;
+        errors[ne++] = error;
+        if (nrm < tolerance) break;
+      }
+      HIPCHK(hipStreamSynchronize(stream_));
+    }
+    *n_errors = ne;
+  }
+
+  void get_state(double *out) override {
+    const int N = g_.n_nodes();
+    std::vector<V4> pose((size_t)N);
+    HIPCHK(hipMemcpyAsync(pose.data(), pose_.p, pose.size() * sizeof(V4), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    for (int i = 0; i < N; i++) {
+      *out++ = (double)pose[i].x;
+      *out++ = (double)pose[i].y;
+      if (g_.node_kind[i] == NODE_SE2) *out++ = std::atan2((double)pose[i].w, (double)pose[i].z);
+    }
+  }
+
+  void set_state(const double *st) override {
+    const int N = g_.n_nodes();
+    std::vector<V4> pose((size_t)N);
+    for (int i = 0; i < N; i++) {
+      if (g_.node_kind[i] == NODE_SE2) {
+        pose[i] = V4{(T)st[0], (T)st[1], (T)std::cos(st[2]), (T)std::sin(st[2])};
+        st += 3;
+      } else {
+        pose[i] = V4{(T)st[0], (T)st[1], (T)0, (T)0};
+        st += 2;
+      }
+    }
+    HIPCHK(hipMemcpyAsync(pose_.p, pose.data(), pose.size() * sizeof(V4), hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+  }
+
+  void assemble(double lambda, int lm, std::vector<double> &hv, std::vector<double> &b) override {
+    launch_linearize(lambda, lm, 1);
+    std::vector<T> th((size_t)sym_.n_hvals), tb((size_t)g_.dim);
+    HIPCHK(hipMemcpyAsync(th.data(), hvals_.p, th.size() * sizeof(T), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipMemcpyAsync(tb.data(), b_.p, tb.size() * sizeof(T), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    hv.assign(th.begin(), th.end());
+    b.assign(tb.begin(), tb.end());
+  }
+
+  void iterate_async(int iters) override {
+    ensure_gn_graph();
+    for (int i = 0; i < iters; i++) HIPCHK(hipGraphLaunch(gn_exec_, stream_));
+  }
+
+  void sync() override {
+    HIPCHK(hipStreamSynchronize(stream_));
+    check_device_error();
+  }
+
+  void profile(int iters, double *ms, int64_t *launches) override {
+    HIPCHK(hipEventCreate(&prof_.e0));
+    HIPCHK(hipEventCreate(&prof_.e1));
+    for (int k = 0; k < RR_PGO_NUM_KCLASS; k++) { prof_.ms[k] = 0; prof_.n[k] = 0; }
+    prof_.on = true;
+    try {
+      for (int i = 0; i < iters; i++) enqueue_gn_iteration();
+      HIPCHK(hipStreamSynchronize(stream_));
+    } catch (...) {
+      prof_.on = false;
+      throw;
+    }
+    prof_.on = false;
+    (void)hipEventDestroy(prof_.e0);
+    (void)hipEventDestroy(prof_.e1);
+    for (int k = 0; k < RR_PGO_NUM_KCLASS; k++) { ms[k] = prof_.ms[k]; launches[k] = prof_.n[k]; }
+  }
+};
+
+}  // namespace rrpgo
+
+// ============================================================== C ABI
+
+using namespace rrpgo;
+
+struct rr_pgo {
+  HostGraph g;
+  Symbolic sym;
+  rr_pgo_options opt;
+  std::unique_ptr<EngineBase> engine;
+  rr_pgo_stats stats;
+  std::vector<int32_t> blk_rows, blk_cols;   // assemble() block list
+  std::vector<int64_t> blk_offs;
+};
+
+struct rr_pgo_synth {
+  HostGraph g;
+};
+
+namespace {
+
+template <typename F> int guarded(F &&f) {
+  try {
+    f();
+    return RR_PGO_OK;
+  } catch (const ApiError &e) {
+    g_last_error = e.what();
+    return e.code;
+  } catch (const std::bad_alloc &) {
+    g_last_error = "out of host memory";
+    return RR_PGO_ENOMEM;
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    return RR_PGO_EINVAL;
+  }
+}
+
+void fill_desc(const HostGraph &g, rr_pgo_graph_desc *d) {
+  d->n_nodes = g.n_nodes();
+  d->node_kind = g.node_kind.data();
+  d->node_id = g.node_id.data();
+  d->node_state = g.node_state.data();
+  d->n_edges = g.n_edges();
+  d->edge_kind = g.edge_kind.data();
+  d->edge_from = g.edge_from.data();
+  d->edge_to = g.edge_to.data();
+  d->edge_meas = g.edge_meas.data();
+  d->edge_info = g.edge_info.data();
+}
+
+void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, double parse_ms) {
+  rr_pgo_options opt;
+  if (opt_in) opt = *opt_in; else rr_pgo_default_options(&opt);
+  h->opt = opt;
+  if (h->g.has_se3) throw ApiError(RR_PGO_EUNSUPPORTED, "SE(3) graphs: not implemented yet (the reference's SE(3) path is todo!())");
+  if (opt.precision != RR_PGO_F64 && opt.precision != RR_PGO_F32) throw ApiError(RR_PGO_EINVAL, "bad precision");
+  if (opt.world_size > 1) throw ApiError(RR_PGO_EUNSUPPORTED, "multi-GPU sharding of one graph is not implemented yet");
+  // symbolic analysis (host only)
+  SymbolicOptions so;
+  so.lds_budget_elems = opt.precision == RR_PGO_F64 ? 19000 : 38000;
+  so.nd_leaf = h->g.n_nodes() <= 6000 ? (1 << 30) : 64;
+  double t0 = now_ms();
+  std::string err = analyze(h->g, so, h->sym);
+  if (!err.empty()) throw ApiError(RR_PGO_EINVAL, err);
+  double t1 = now_ms();
+  // device
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    throw ApiError(RR_PGO_ENODEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (opt.device >= 0) {
+    if (opt.device >= ndev) throw ApiError(RR_PGO_EINVAL, "device ordinal out of range");
+    HIPCHK(hipSetDevice(opt.device));
+  }
+  if (opt.precision == RR_PGO_F64) h->engine = std::make_unique<Engine<double>>(h->g, h->sym);
+  else h->engine = std::make_unique<Engine<float>>(h->g, h->sym);
+  // stats
+  rr_pgo_stats &s = h->stats;
+  std::memset(&s, 0, sizeof s);
+  const Symbolic &y = h->sym;
+  const double sz = opt.precision == RR_PGO_F64 ? 8.0 : 4.0;
+  int64_t diag_elems = 0, off_elems = 0;
+  for (int i = 0; i < y.N; i++) { int d = node_dim(h->g.node_kind[i]); diag_elems += d * d; }
+  off_elems = y.n_hvals - diag_elems;
+  s.nnz_h_blocks = y.N + y.n_offblocks;
+  s.nnz_l_scalars = y.l_elems;
+  s.factor_flops = y.factor_flops;
+  s.n_supernodes = y.S;
+  s.n_levels = (int)y.steps.size();
+  s.n_launches_per_iter = h->engine->n_launches_per_iter;
+  s.max_front = y.max_front;
+  s.max_pivot_cols = y.max_pivot_cols;
+  s.n_big_fronts = y.n_big;
+  s.analyze_ms = t1 - t0;
+  s.parse_ms = parse_ms;
+  // algorithmic bytes per GN iteration, SURVEY.md 8(d): every datum moved once
+  const double E = h->g.n_edges(), N = y.N, dim = y.dim;
+  double edge_stream = 0;
+  for (int k = 0; k < h->g.n_edges(); k++)
+    edge_stream += 8.0 + sz * (edge_meas_len(h->g.edge_kind[k]) + edge_info_len(h->g.edge_kind[k]));
+  (void)E;
+  s.bytes_linearize = edge_stream + dim * sz /*poses*/ + (diag_elems + off_elems) * sz + dim * sz;
+  s.bytes_chi2 = 0;  // fused into the linearisation pass
+  s.bytes_factor = (diag_elems + off_elems) * sz + (double)y.l_elems * sz;
+  s.bytes_solve = (double)y.l_elems * sz + 2.0 * dim * sz;
+  s.bytes_update = 3.0 * dim * sz;
+  (void)N;
+}
+
+}  // namespace
+
+extern "C" {
+
+void rr_pgo_default_options(rr_pgo_options *opt) {
+  std::memset(opt, 0, sizeof *opt);
+  opt->precision = RR_PGO_F64;
+  opt->device = -1;
+  opt->solver = RR_PGO_GAUSS_NEWTON;
+  opt->rank = 0;
+  opt->world_size = 1;
+}
+
+const char *rr_pgo_last_error(void) { return g_last_error.c_str(); }
+
+int rr_pgo_load_g2o(const char *path, const rr_pgo_options *opt, rr_pgo **out) {
+  if (!path || !out) { g_last_error = "null argument"; return RR_PGO_EINVAL; }
+  *out = nullptr;
+  return guarded([&] {
+    auto h = std::make_unique<rr_pgo>();
+    bool io = false;
+    double t0 = now_ms();
+    std::string err = load_g2o(path, h->g, io);
+    if (!err.empty()) throw ApiError(io ? RR_PGO_EIO : RR_PGO_EPARSE, err);
+    build_handle(h, opt, now_ms() - t0);
+    *out = h.release();
+  });
+}
+
+int rr_pgo_create(const rr_pgo_graph_desc *d, const rr_pgo_options *opt, rr_pgo **out) {
+  if (!d || !out) { g_last_error = "null argument"; return RR_PGO_EINVAL; }
+  *out = nullptr;
+  return guarded([&] {
+    auto h = std::make_unique<rr_pgo>();
+    HostGraph &g = h->g;
+    if (d->n_nodes < 0 || d->n_edges < 0) throw ApiError(RR_PGO_EINVAL, "negative counts");
+    g.node_kind.assign(d->node_kind, d->node_kind + d->n_nodes);
+    g.node_id.resize(d->n_nodes);
+    for (int i = 0; i < d->n_nodes; i++) g.node_id[i] = d->node_id ? d->node_id[i] : (uint32_t)i;
+    size_t ns = 0;
+    for (int i = 0; i < d->n_nodes; i++) {
+      if (g.node_kind[i] < 0 || g.node_kind[i] > 2) throw ApiError(RR_PGO_EINVAL, "bad node kind");
+      ns += node_state_len(g.node_kind[i]);
+    }
+    g.node_state.assign(d->node_state, d->node_state + ns);
+    g.edge_kind.assign(d->edge_kind, d->edge_kind + d->n_edges);
+    g.edge_from.assign(d->edge_from, d->edge_from + d->n_edges);
+    g.edge_to.assign(d->edge_to, d->edge_to + d->n_edges);
+    size_t nm = 0, ni = 0;
+    for (int k = 0; k < d->n_edges; k++) {
+      if (g.edge_kind[k] < 0 || g.edge_kind[k] > 2) throw ApiError(RR_PGO_EINVAL, "bad edge kind");
+      nm += edge_meas_len(g.edge_kind[k]);
+      ni += edge_info_len(g.edge_kind[k]);
+    }
+    g.edge_meas.assign(d->edge_meas, d->edge_meas + nm);
+    g.edge_info.assign(d->edge_info, d->edge_info + ni);
+    std::string err = g.finalize();
+    if (!err.empty()) throw ApiError(RR_PGO_EINVAL, err);
+    build_handle(h, opt, 0.0);
+    *out = h.release();
+  });
+}
+
+void rr_pgo_destroy(rr_pgo *h) { delete h; }
+
+int32_t rr_pgo_num_nodes(const rr_pgo *h) { return h ? h->g.n_nodes() : 0; }
+int32_t rr_pgo_num_edges(const rr_pgo *h) { return h ? h->g.n_edges() : 0; }
+int32_t rr_pgo_dim(const rr_pgo *h) { return h ? h->g.dim : 0; }
+int32_t rr_pgo_state_len(const rr_pgo *h) { return h ? (int32_t)h->g.node_state.size() : 0; }
+int32_t rr_pgo_anchor_node(const rr_pgo *h) { return h ? h->g.anchor_node : -1; }
+
+int rr_pgo_get_graph(const rr_pgo *h, rr_pgo_graph_desc *out) {
+  if (!h || !out) { g_last_error = "null argument"; return RR_PGO_EINVAL; }
+  fill_desc(h->g, out);
+  return RR_PGO_OK;
+}
+
+int rr_pgo_chi2(rr_pgo *h, double *out) {
+  if (!h || !out) { g_last_error = "null argument"; return RR_PGO_EINVAL; }
+  return guarded([&] { h->engine->chi2(out); });
+}
+
+int rr_pgo_linearize_solve(rr_pgo *h, double lambda, int lm, double *dx_out) {
+  if (!h || !dx_out) { g_last_error = "null argument"; return RR_PGO_EINVAL; }
+  return guarded([&] { h->engine->linearize_solve(lambda, lm, dx_out); });
+}
+
+int rr_pgo_update(rr_pgo *h, const double *dx, double sign) {
+  if (!h || !dx) { g_last_error = "null argument"; return RR_PGO_EINVAL; }
+  return guarded([&] { h->engine->update(dx, sign); });
+}
+
+int rr_pgo_optimize(rr_pgo *h, int32_t iters, double *errors, int32_t *n_errors, double *norms) {
+  if (!h || !errors || !n_errors || iters < 0) { g_last_error = "bad argument"; return RR_PGO_EINVAL; }
+  *n_errors = 0;
+  return guarded([&] {
+    int ne = 0;
+    h->engine->optimize(h->opt.solver, iters, errors, &ne, norms);
+    *n_errors = ne;
+  });
+}
+
+int rr_pgo_get_state(rr_pgo *h, double *out) {
+  if (!h || !out) { g_last_error = "null argument"; return RR_PGO_EINVAL; }
+  return guarded([&] { h->engine->get_state(out); });
+}
+
+int rr_pgo_set_state(rr_pgo *h, const double *st) {
+  if (!h || !st) { g_last_error = "null argument"; return RR_PGO_EINVAL; }
+  return guarded([&] { h->engine->set_state(st); });
+}
+
+int rr_pgo_assemble(rr_pgo *h, double lambda, int lm, int32_t *n_blocks, int32_t *brow, int32_t *bcol,
+                    int64_t *boff, double *bvals, int64_t *n_vals, double *b_out) {
+  if (!h) { g_last_error = "null argument"; return RR_PGO_EINVAL; }
+  const Symbolic &y = h->sym;
+  const int64_t nb = y.N + y.n_offblocks;
+  if (n_blocks) *n_blocks = (int32_t)nb;
+  if (n_vals) *n_vals = y.n_hvals;
+  if (!bvals) return RR_PGO_OK;
+  return guarded([&] {
+    std::vector<double> hv, b;
+    h->engine->assemble(lambda, lm, hv, b);
+    for (int i = 0; i < y.N; i++) {
+      int v = y.order[i];
+      if (brow) brow[i] = v;
+      if (bcol) bcol[i] = v;
+      if (boff) boff[i] = y.diag_off[v];
+    }
+    for (int64_t s = 0; s < y.n_offblocks; s++) {
+      if (brow) brow[y.N + s] = y.blk_row[s];
+      if (bcol) bcol[y.N + s] = y.blk_col[s];
+      if (boff) boff[y.N + s] = y.blk_off[s];
+    }
+    std::memcpy(bvals, hv.data(), hv.size() * sizeof(double));
+    if (b_out) std::memcpy(b_out, b.data(), b.size() * sizeof(double));
+  });
+}
+
+int rr_pgo_iterate_async(rr_pgo *h, int32_t iters) {
+  if (!h || iters < 0) { g_last_error = "bad argument"; return RR_PGO_EINVAL; }
+  return guarded([&] { h->engine->iterate_async(iters); });
+}
+
+int rr_pgo_sync(rr_pgo *h) {
+  if (!h) { g_last_error = "null argument"; return RR_PGO_EINVAL; }
+  return guarded([&] { h->engine->sync(); });
+}
+
+int rr_pgo_get_stats(const rr_pgo *h, rr_pgo_stats *out) {
+  if (!h || !out) { g_last_error = "null argument"; return RR_PGO_EINVAL; }
+  *out = h->stats;
+  return RR_PGO_OK;
+}
+
+int rr_pgo_profile(rr_pgo *h, int32_t iters, double *ms_total, int64_t *launches) {
+  if (!h || !ms_total || !launches || iters < 0) { g_last_error = "bad argument"; return RR_PGO_EINVAL; }
+  return guarded([&] { h->engine->profile(iters, ms_total, launches); });
+}
+
+int rr_pgo_synth_grid(int32_t width, int32_t height, int64_t n_edges_target, uint64_t seed_meas,
+                      uint64_t seed_init, rr_pgo_synth **out, rr_pgo_graph_desc *desc) {
+  if (!out || !desc || width < 2 || height < 2) { g_last_error = "bad argument"; return RR_PGO_EINVAL; }
+  return guarded([&] {
+    auto s = std::make_unique<rr_pgo_synth>();
+    synth_grid(width, height, n_edges_target, seed_meas, seed_init, s->g);
+    fill_desc(s->g, desc);
+    *out = s.release();
+  });
+}
+
+void rr_pgo_synth_free(rr_pgo_synth *s) { delete s; }
+
+int rr_pgo_exchange_buffer(rr_pgo *, void **, int64_t *, int32_t *) {
+  g_last_error = "multi-GPU sharding of one graph is not implemented yet";
+  return RR_PGO_EUNSUPPORTED;
+}
+int rr_pgo_stage_local(rr_pgo *, double, int) {
+  g_last_error = "multi-GPU sharding of one graph is not implemented yet";
+  return RR_PGO_EUNSUPPORTED;
+}
+int rr_pgo_stage_top(rr_pgo *) {
+  g_last_error = "multi-GPU sharding of one graph is not implemented yet";
+  return RR_PGO_EUNSUPPORTED;
+}
+void *rr_pgo_stream(rr_pgo *h) { return h && h->engine ? (void *)h->engine->stream() : nullptr; }
+
+}  // extern "C"

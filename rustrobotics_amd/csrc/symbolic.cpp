@@ -1,0 +1,851 @@
+// symbolic.cpp -- see symbolic.h.  Host only, runs once per graph.
+#include "symbolic.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <numeric>
+#include <queue>
+
+namespace rrpgo {
+
+namespace {
+
+struct Adj {
+  std::vector<int32_t> ptr, idx;
+  int deg(int v) const { return ptr[v + 1] - ptr[v]; }
+};
+
+Adj build_adjacency(const HostGraph &g) {
+  const int N = g.n_nodes(), E = g.n_edges();
+  Adj a;
+  a.ptr.assign(N + 1, 0);
+  for (int k = 0; k < E; k++) {
+    a.ptr[g.edge_from[k] + 1]++;
+    a.ptr[g.edge_to[k] + 1]++;
+  }
+  for (int i = 0; i < N; i++) a.ptr[i + 1] += a.ptr[i];
+  std::vector<int32_t> raw(a.ptr[N]), fill(a.ptr.begin(), a.ptr.end() - 1);
+  for (int k = 0; k < E; k++) {
+    raw[fill[g.edge_from[k]]++] = g.edge_to[k];
+    raw[fill[g.edge_to[k]]++] = g.edge_from[k];
+  }
+  // sort + dedupe each list
+  std::vector<int32_t> nptr(N + 1, 0);
+  a.idx.reserve(raw.size());
+  for (int i = 0; i < N; i++) {
+    auto b = raw.begin() + a.ptr[i], e = raw.begin() + a.ptr[i + 1];
+    std::sort(b, e);
+    e = std::unique(b, e);
+    nptr[i] = (int32_t)a.idx.size();
+    a.idx.insert(a.idx.end(), b, e);
+  }
+  nptr[N] = (int32_t)a.idx.size();
+  a.ptr.swap(nptr);
+  return a;
+}
+
+// ---------------------------------------------------------------------------
+// Constrained minimum degree on a small local graph: vertices [0, ne) are
+// eliminated, vertices [ne, nt) (not yet eliminated separator nodes) only take
+// part in the degrees.  Quotient-graph formulation, exact external degree
+// weighted by the scalar dimension of every node.
+void constrained_min_degree(int ne, int nt, std::vector<std::vector<int32_t>> &A,
+                            const std::vector<int32_t> &w, std::vector<int32_t> &out) {
+  std::vector<std::vector<int32_t>> E(nt), members(nt);
+  std::vector<char> gone(nt, 0), absorbed(nt, 0);
+  std::vector<int32_t> deg(nt, 0), mark(nt, 0);
+  int stamp = 0;
+  using Ent = std::pair<int32_t, int32_t>;
+  std::priority_queue<Ent, std::vector<Ent>, std::greater<Ent>> pq;
+  for (int v = 0; v < ne; v++) {
+    int d = 0;
+    for (int u : A[v]) d += w[u];
+    deg[v] = d;
+    pq.emplace(d, v);
+  }
+  out.clear();
+  out.reserve(ne);
+  std::vector<int32_t> reach;
+  for (int k = 0; k < ne; k++) {
+    int p;
+    for (;;) {
+      auto [d, v] = pq.top();
+      pq.pop();
+      if (!gone[v] && d == deg[v]) { p = v; break; }
+    }
+    out.push_back(p);
+    gone[p] = 1;
+    reach.clear();
+    const int sp = ++stamp;
+    mark[p] = sp;
+    for (int u : A[p])
+      if (!gone[u] && mark[u] != sp) { mark[u] = sp; reach.push_back(u); }
+    for (int e : E[p]) {
+      if (absorbed[e]) continue;
+      for (int u : members[e])
+        if (!gone[u] && mark[u] != sp) { mark[u] = sp; reach.push_back(u); }
+      absorbed[e] = 1;
+      std::vector<int32_t>().swap(members[e]);
+    }
+    members[p] = reach;
+    for (int i : reach) {
+      auto &ai = A[i];
+      size_t wq = 0;
+      for (int u : ai)
+        if (!gone[u] && mark[u] != sp) ai[wq++] = u;
+      ai.resize(wq);
+      auto &ei = E[i];
+      wq = 0;
+      for (int e : ei)
+        if (!absorbed[e]) ei[wq++] = e;
+      ei.resize(wq);
+      ei.push_back(p);
+    }
+    for (int i : reach) {
+      if (i >= ne) continue;  // constrained vertices never enter the queue
+      const int si = ++stamp;
+      mark[i] = si;
+      int d = 0;
+      for (int u : A[i])
+        if (mark[u] != si) { mark[u] = si; d += w[u]; }
+      for (int e : E[i])
+        for (int u : members[e])
+          if (!gone[u] && mark[u] != si) { mark[u] = si; d += w[u]; }
+      deg[i] = d;
+      pq.emplace(d, i);
+    }
+    std::vector<int32_t>().swap(A[p]);
+    std::vector<int32_t>().swap(E[p]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Nested dissection with breadth-first level-set separators.
+struct NestedDissection {
+  const Adj &adj;
+  const std::vector<int32_t> &w;
+  const SymbolicOptions &opt;
+  int N;
+  std::vector<int32_t> set_id;   // which recursion set a node currently belongs to
+  std::vector<char> ordered;
+  std::vector<int32_t> order;    // output: order[pos] = node
+  std::vector<int32_t> part;     // owner partition, -1 shared
+  std::vector<int32_t> level, queue, local_id;
+  int next_set = 1, part_depth = 0;
+
+  NestedDissection(const Adj &a, const std::vector<int32_t> &ww, const SymbolicOptions &o)
+      : adj(a), w(ww), opt(o), N((int)ww.size()), set_id(N, 0), ordered(N, 0), part(N, -1),
+        level(N, -1), local_id(N, -1) {
+    order.reserve(N);
+    queue.reserve(N);
+    while ((1 << part_depth) < opt.n_parts) part_depth++;
+  }
+
+  // BFS inside set `sid` from `root`; fills queue (visit order) and level[].
+  // Returns the number of levels.  level[] of visited nodes must be reset by caller.
+  int bfs(int root, int sid, std::vector<int32_t> &visit) {
+    visit.clear();
+    visit.push_back(root);
+    level[root] = 0;
+    int nlev = 1;
+    for (size_t h = 0; h < visit.size(); h++) {
+      int v = visit[h];
+      for (int p = adj.ptr[v]; p < adj.ptr[v + 1]; p++) {
+        int u = adj.idx[p];
+        if (set_id[u] == sid && level[u] < 0) {
+          level[u] = level[v] + 1;
+          nlev = level[u] + 1;
+          visit.push_back(u);
+        }
+      }
+    }
+    return nlev;
+  }
+
+  void order_leaf(const std::vector<int32_t> &S) {
+    // local graph: S first, then not-yet-ordered outside neighbours (ancestor separators)
+    const int ne = (int)S.size();
+    std::vector<int32_t> verts(S);
+    for (int i = 0; i < ne; i++) local_id[S[i]] = i;
+    for (int i = 0; i < ne; i++)
+      for (int p = adj.ptr[S[i]]; p < adj.ptr[S[i] + 1]; p++) {
+        int u = adj.idx[p];
+        if (local_id[u] < 0 && !ordered[u]) {
+          local_id[u] = (int)verts.size();
+          verts.push_back(u);
+        }
+      }
+    const int nt = (int)verts.size();
+    std::vector<std::vector<int32_t>> A(nt);
+    std::vector<int32_t> lw(nt);
+    for (int i = 0; i < nt; i++) lw[i] = w[verts[i]];
+    for (int i = 0; i < ne; i++)
+      for (int p = adj.ptr[S[i]]; p < adj.ptr[S[i] + 1]; p++) {
+        int lu = local_id[adj.idx[p]];
+        if (lu >= 0) {
+          A[i].push_back(lu);
+          if (lu >= ne) A[lu].push_back(i);
+        }
+      }
+    std::vector<int32_t> lo;
+    constrained_min_degree(ne, nt, A, lw, lo);
+    for (int l : lo) {
+      order.push_back(verts[l]);
+      ordered[verts[l]] = 1;
+    }
+    for (int v : verts) local_id[v] = -1;
+  }
+
+  void assign_part(const std::vector<int32_t> &S, int depth, int path) {
+    int p = depth >= part_depth ? (path >> (depth - part_depth)) : (path << (part_depth - depth));
+    for (int v : S) part[v] = p;
+  }
+
+  void dissect(std::vector<int32_t> &S, int depth, int path) {
+    const int n = (int)S.size();
+    if (n == 0) return;
+    if (depth == part_depth || (depth < part_depth && n <= opt.nd_leaf)) assign_part(S, depth, path);
+    if (n <= opt.nd_leaf) {
+      order_leaf(S);
+      return;
+    }
+    const int sid = set_id[S[0]];
+    // connected components
+    std::vector<int32_t> visit, comp_of_start, comp_sizes;
+    std::vector<std::vector<int32_t>> comps;
+    for (int v : S)
+      if (level[v] < 0) {
+        bfs(v, sid, visit);
+        comps.emplace_back(visit);
+      }
+    for (int v : S) level[v] = -1;
+    std::vector<int32_t> left, right, sep;
+    if (comps.size() > 1) {
+      std::sort(comps.begin(), comps.end(),
+                [](const auto &a, const auto &b) { return a.size() > b.size(); });
+      size_t nl = 0, nr = 0;
+      for (auto &c : comps) {
+        auto &dst = nl <= nr ? left : right;
+        (nl <= nr ? nl : nr) += c.size();
+        dst.insert(dst.end(), c.begin(), c.end());
+      }
+    } else {
+      // pseudo-peripheral root
+      int root = S[0], nlev = 0;
+      for (int it = 0; it < 6; it++) {
+        int nl = bfs(root, sid, visit);
+        int far = visit.back(), best_deg = 1 << 30;
+        for (size_t i = visit.size(); i-- > 0 && level[visit[i]] == nl - 1;) {
+          int d = adj.deg(visit[i]);
+          if (d < best_deg) { best_deg = d; far = visit[i]; }
+        }
+        bool grew = nl > nlev;
+        nlev = nl;
+        if (!grew && it > 0) break;
+        if (it < 5) {
+          for (int v : visit) level[v] = -1;
+          root = far;
+        }
+      }
+      // make sure levels correspond to `root`
+      for (int v : S) level[v] = -1;
+      nlev = bfs(root, sid, visit);
+      if (nlev < 3) {  // no usable level separator: treat as a leaf
+        for (int v : S) level[v] = -1;
+        if (depth < part_depth) assign_part(S, depth, path);
+        order_leaf(S);
+        return;
+      }
+      std::vector<int64_t> cnt(nlev, 0), wsum(nlev, 0);
+      for (int v : visit) { cnt[level[v]]++; wsum[level[v]] += w[v]; }
+      int64_t total = n, acc = 0;
+      int best = -1;
+      double best_score = 1e300;
+      for (int j = 0; j < nlev; j++) {
+        int64_t l = acc, r = total - acc - cnt[j];
+        acc += cnt[j];
+        if (j == 0 || j == nlev - 1) continue;
+        double imb = std::fabs((double)l - (double)r) / (double)total;
+        double score = (double)wsum[j] * (1.0 + 4.0 * imb * imb) + (imb > 0.6 ? 1e6 * imb : 0.0);
+        if (score < best_score) { best_score = score; best = j; }
+      }
+      for (int v : visit) {
+        int lv = level[v];
+        if (lv < best) left.push_back(v);
+        else if (lv > best) right.push_back(v);
+        else {
+          bool touches_right = false;
+          for (int p = adj.ptr[v]; p < adj.ptr[v + 1] && !touches_right; p++) {
+            int u = adj.idx[p];
+            touches_right = set_id[u] == sid && level[u] == best + 1;
+          }
+          (touches_right ? sep : left).push_back(v);
+        }
+      }
+      for (int v : S) level[v] = -1;
+    }
+    if (depth < part_depth)
+      for (int v : sep) part[v] = -1;
+    const int lid = next_set++, rid = next_set++, zid = next_set++;
+    for (int v : left) set_id[v] = lid;
+    for (int v : right) set_id[v] = rid;
+    for (int v : sep) set_id[v] = zid;
+    std::vector<int32_t>().swap(S);
+    dissect(left, depth + 1, path * 2);
+    dissect(right, depth + 1, path * 2 + 1);
+    for (int v : sep) {
+      order.push_back(v);
+      ordered[v] = 1;
+    }
+  }
+};
+
+// Elimination tree of the permuted node graph (Liu, with path compression).
+void elimination_tree(const Adj &adj, const std::vector<int32_t> &order,
+                      const std::vector<int32_t> &pos_of, std::vector<int32_t> &parent) {
+  const int N = (int)order.size();
+  parent.assign(N, -1);
+  std::vector<int32_t> anc(N, -1);
+  for (int j = 0; j < N; j++) {
+    int v = order[j];
+    for (int p = adj.ptr[v]; p < adj.ptr[v + 1]; p++) {
+      int i = pos_of[adj.idx[p]];
+      while (i != -1 && i < j) {
+        int nx = anc[i];
+        anc[i] = j;
+        if (nx == -1) parent[i] = j;
+        i = nx;
+      }
+    }
+  }
+}
+
+void postorder_forest(const std::vector<int32_t> &parent, std::vector<int32_t> &post) {
+  const int N = (int)parent.size();
+  std::vector<int32_t> head(N, -1), next(N, -1);
+  for (int j = N - 1; j >= 0; j--)
+    if (parent[j] >= 0) { next[j] = head[parent[j]]; head[parent[j]] = j; }
+  post.clear();
+  post.reserve(N);
+  std::vector<int32_t> stack;
+  for (int r = 0; r < N; r++) {
+    if (parent[r] != -1) continue;
+    stack.push_back(r);
+    while (!stack.empty()) {
+      int v = stack.back();
+      int c = head[v];
+      if (c != -1) {
+        head[v] = next[c];
+        stack.push_back(c);
+      } else {
+        post.push_back(v);
+        stack.pop_back();
+      }
+    }
+  }
+}
+
+double front_cost_us(int nc, int nr) {
+  const double M = nc + nr + 1;
+  return 1.2 + 6e-6 * (double)nc * M * M + 4e-5 * M * M;
+}
+
+int64_t lds_elems(int nc, int nr) {
+  return (int64_t)(nc + nr + 1) * nc + (int64_t)(nr + 1) * (nr + 2) / 2;
+}
+
+}  // namespace
+
+std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sym) {
+  sym = Symbolic();
+  const int N = g.n_nodes(), E = g.n_edges();
+  if (N == 0) return "graph has no vertices";
+  sym.N = N;
+  sym.dim = g.dim;
+  std::vector<int32_t> w(N);
+  for (int i = 0; i < N; i++) w[i] = node_dim(g.node_kind[i]);
+  const Adj adj = build_adjacency(g);
+  const int64_t lds_budget = opt.lds_budget_elems;
+
+  // ---- 1. ordering ---------------------------------------------------------
+  std::vector<int32_t> order, pos_of(N);
+  {
+    NestedDissection nd(adj, w, opt);
+    std::vector<int32_t> all(N);
+    std::iota(all.begin(), all.end(), 0);
+    nd.dissect(all, 0, 0);
+    order.swap(nd.order);
+    sym.node_part.swap(nd.part);
+    if ((int)order.size() != N) return "internal: ordering lost nodes";
+    if (opt.n_parts <= 1) std::fill(sym.node_part.begin(), sym.node_part.end(), 0);
+  }
+  for (int p = 0; p < N; p++) pos_of[order[p]] = p;
+
+  // ---- 2. etree + postorder -------------------------------------------------
+  std::vector<int32_t> parent;
+  elimination_tree(adj, order, pos_of, parent);
+  {
+    std::vector<int32_t> post;
+    postorder_forest(parent, post);
+    std::vector<int32_t> norder(N);
+    for (int p = 0; p < N; p++) norder[p] = order[post[p]];
+    order.swap(norder);
+    for (int p = 0; p < N; p++) pos_of[order[p]] = p;
+    elimination_tree(adj, order, pos_of, parent);
+  }
+
+  // ---- 3. node-level column structures -> weighted counts -------------------
+  std::vector<int64_t> cc(N, 0);  // scalar rows strictly below the diagonal block
+  {
+    std::vector<std::vector<int32_t>> st(N);
+    std::vector<int32_t> mark(N, -1), head(N, -1), next(N, -1);
+    int64_t nblk = 0;
+    for (int j = 0; j < N; j++) {
+      std::vector<int32_t> &s = st[j];
+      mark[j] = j;
+      int v = order[j];
+      for (int p = adj.ptr[v]; p < adj.ptr[v + 1]; p++) {
+        int i = pos_of[adj.idx[p]];
+        if (i > j && mark[i] != j) { mark[i] = j; s.push_back(i); }
+      }
+      for (int c = head[j]; c != -1; c = next[c]) {
+        for (int x : st[c])
+          if (x != j && mark[x] != j) { mark[x] = j; s.push_back(x); }
+        std::vector<int32_t>().swap(st[c]);
+      }
+      std::sort(s.begin(), s.end());
+      int64_t sum = 0;
+      for (int x : s) sum += w[order[x]];
+      cc[j] = sum;
+      nblk += (int64_t)s.size() + 1;
+      if (!s.empty()) {
+        int pj = s[0];
+        if (parent[j] != pj) return "internal: etree mismatch";
+        next[j] = head[pj];
+        head[pj] = j;
+      }
+    }
+    sym.nnz_l_blocks = nblk;
+  }
+
+  // ---- 4. zero-fill supernodes, then relaxed amalgamation -------------------
+  std::vector<int32_t> sn_of(N), s_first, s_last;
+  for (int j = 0; j < N; j++) {
+    bool join = j > 0 && parent[j - 1] == j && cc[j - 1] == cc[j] + w[order[j]] &&
+                sym.node_part[order[j - 1]] == sym.node_part[order[j]];
+    if (!join) {
+      s_first.push_back(j);
+      s_last.push_back(j);
+    } else {
+      s_last.back() = j;
+    }
+    sn_of[j] = (int)s_first.size() - 1;
+  }
+  const int S0 = (int)s_first.size();
+  std::vector<int32_t> sp(S0, -1);
+  std::vector<int64_t> npiv(S0, 0), nrow(S0), zeros(S0, 0);
+  for (int s = 0; s < S0; s++) {
+    for (int j = s_first[s]; j <= s_last[s]; j++) npiv[s] += w[order[j]];
+    nrow[s] = cc[s_last[s]];
+    int pj = parent[s_last[s]];
+    sp[s] = pj < 0 ? -1 : sn_of[pj];
+  }
+  std::vector<int32_t> merged_into(S0, -1);
+  std::vector<std::vector<int32_t>> pre(S0);      // merged members, elimination order
+  std::vector<std::vector<int32_t>> kids(S0);
+  for (int s = 0; s < S0; s++)
+    if (sp[s] >= 0) kids[sp[s]].push_back(s);
+  auto part_of_sn = [&](int s) { return sym.node_part[order[s_first[s]]]; };
+  for (int p = 0; p < S0; p++) {
+    auto &ch = kids[p];
+    std::sort(ch.begin(), ch.end(), [&](int a, int b) { return nrow[a] > nrow[b]; });
+    for (int c : ch) {
+      if (part_of_sn(c) != part_of_sn(p)) continue;
+      int64_t np2 = npiv[c] + npiv[p];
+      int64_t z = npiv[c] * (npiv[p] + nrow[p] - nrow[c]);
+      if (z < 0) z = 0;
+      int64_t ztot = zeros[c] + zeros[p] + z;
+      double T = 0.5 * (double)np2 * (double)(np2 + 1) + (double)np2 * (double)nrow[p];
+      double frac = (double)ztot / T;
+      bool fits_before = lds_elems((int)npiv[p], (int)nrow[p]) <= lds_budget;
+      bool fits_after = lds_elems((int)np2, (int)nrow[p]) <= lds_budget;
+      if (fits_before && !fits_after) continue;
+      bool ok = z == 0 || np2 <= 12 || (np2 <= 36 && frac <= 0.35) ||
+                (np2 <= 72 && frac <= 0.15) || frac <= 0.03;
+      if (!ok) continue;
+      merged_into[c] = p;
+      npiv[p] = np2;
+      zeros[p] = ztot;
+      auto &dst = pre[p];
+      dst.insert(dst.end(), pre[c].begin(), pre[c].end());
+      dst.push_back(c);
+      std::vector<int32_t>().swap(pre[c]);
+    }
+  }
+  // merged tree + final order (DFS postorder over representatives)
+  auto rep_of = [&](int s) {
+    while (merged_into[s] >= 0) s = merged_into[s];
+    return s;
+  };
+  std::vector<int32_t> rparent(S0, -1);
+  for (int s = 0; s < S0; s++)
+    if (merged_into[s] < 0 && sp[s] >= 0) rparent[s] = rep_of(sp[s]);
+  std::vector<int32_t> final_sn;  // representatives in final elimination order
+  {
+    std::vector<int32_t> pp(S0, -1), post;
+    // restrict to representatives by mapping non-representatives to self-roots, then filter
+    for (int s = 0; s < S0; s++) pp[s] = merged_into[s] < 0 ? rparent[s] : -2;
+    std::vector<int32_t> idx_of(S0, -1), reps;
+    for (int s = 0; s < S0; s++)
+      if (pp[s] != -2) { idx_of[s] = (int)reps.size(); reps.push_back(s); }
+    std::vector<int32_t> cpar(reps.size());
+    for (size_t i = 0; i < reps.size(); i++) cpar[i] = pp[reps[i]] < 0 ? -1 : idx_of[pp[reps[i]]];
+    postorder_forest(cpar, post);
+    for (int i : post) final_sn.push_back(reps[i]);
+  }
+  const int S = (int)final_sn.size();
+  sym.S = S;
+  std::vector<int32_t> forder;
+  forder.reserve(N);
+  sym.sn_first_pos.resize(S);
+  sym.sn_npos.resize(S);
+  for (int f = 0; f < S; f++) {
+    int r = final_sn[f];
+    sym.sn_first_pos[f] = (int)forder.size();
+    auto emit = [&](int s) {
+      for (int j = s_first[s]; j <= s_last[s]; j++) forder.push_back(order[j]);
+    };
+    for (int m : pre[r]) emit(m);
+    emit(r);
+    sym.sn_npos[f] = (int)forder.size() - sym.sn_first_pos[f];
+  }
+  if ((int)forder.size() != N) return "internal: amalgamation lost nodes";
+  order.swap(forder);
+  for (int p = 0; p < N; p++) pos_of[order[p]] = p;
+  sym.order = order;
+  sym.pos_of = pos_of;
+
+  // permuted scalar numbering
+  sym.node_pcol.assign(N, 0);
+  sym.perm.resize(g.dim);
+  {
+    int c = 0;
+    for (int p = 0; p < N; p++) {
+      int v = order[p];
+      sym.node_pcol[v] = c;
+      for (int d = 0; d < w[v]; d++) sym.perm[c++] = g.node_offset[v] + d;
+    }
+  }
+
+  // ---- 5. supernodal symbolic factorisation on the final partition ----------
+  std::vector<int32_t> sn_at_pos(N);
+  for (int f = 0; f < S; f++)
+    for (int p = sym.sn_first_pos[f]; p < sym.sn_first_pos[f] + sym.sn_npos[f]; p++) sn_at_pos[p] = f;
+  std::vector<std::vector<int32_t>> rows(S);  // node positions
+  sym.sn_parent.assign(S, -1);
+  {
+    std::vector<int32_t> mark(N, -1), head(S, -1), next(S, -1);
+    for (int f = 0; f < S; f++) {
+      const int a = sym.sn_first_pos[f], b = a + sym.sn_npos[f];
+      auto &r = rows[f];
+      for (int p = a; p < b; p++) {
+        int v = order[p];
+        for (int q = adj.ptr[v]; q < adj.ptr[v + 1]; q++) {
+          int i = pos_of[adj.idx[q]];
+          if (i >= b && mark[i] != f) { mark[i] = f; r.push_back(i); }
+        }
+      }
+      for (int c = head[f]; c != -1; c = next[c])
+        for (int x : rows[c])
+          if (x >= b && mark[x] != f) { mark[x] = f; r.push_back(x); }
+      std::sort(r.begin(), r.end());
+      if (!r.empty()) {
+        int pf = sn_at_pos[r[0]];
+        sym.sn_parent[f] = pf;
+        next[f] = head[pf];
+        head[pf] = f;
+      }
+    }
+  }
+  sym.sn_ncols.resize(S);
+  sym.sn_nrows.resize(S);
+  sym.sn_col0.resize(S);
+  sym.sn_owner.resize(S);
+  sym.sn_rows_ptr.assign(S + 1, 0);
+  for (int f = 0; f < S; f++) {
+    int nc = 0, nr = 0;
+    for (int p = sym.sn_first_pos[f]; p < sym.sn_first_pos[f] + sym.sn_npos[f]; p++) nc += w[order[p]];
+    for (int x : rows[f]) nr += w[order[x]];
+    sym.sn_ncols[f] = nc;
+    sym.sn_nrows[f] = nr;
+    sym.sn_col0[f] = sym.node_pcol[order[sym.sn_first_pos[f]]];
+    sym.sn_owner[f] = opt.n_parts > 1 ? sym.node_part[order[sym.sn_first_pos[f]]] : 0;
+    sym.sn_rows_ptr[f + 1] = sym.sn_rows_ptr[f] + nr;
+  }
+  sym.sn_rows.resize(sym.sn_rows_ptr[S]);
+  for (int f = 0; f < S; f++) {
+    int64_t o = sym.sn_rows_ptr[f];
+    for (int x : rows[f]) {
+      int v = order[x];
+      for (int d = 0; d < w[v]; d++) sym.sn_rows[o++] = sym.node_pcol[v] + d;
+    }
+  }
+
+  // ---- 6. storage layout, big-front classification --------------------------
+  sym.sn_loff.resize(S);
+  sym.sn_uoff.resize(S);
+  sym.sn_uld.resize(S);
+  sym.sn_big.resize(S);
+  {
+    int64_t lo = 0, uo = 0;
+    for (int f = 0; f < S; f++) {
+      const int nc = sym.sn_ncols[f], nr = sym.sn_nrows[f], M = nc + nr + 1;
+      const bool big = lds_elems(nc, nr) > lds_budget;
+      sym.sn_big[f] = big;
+      sym.n_big += big;
+      sym.max_front = std::max(sym.max_front, nc + nr);
+      sym.max_pivot_cols = std::max(sym.max_pivot_cols, nc);
+      for (int k = 0; k < nc; k++) sym.factor_flops += (int64_t)(M - 1 - k) * (M - 1 - k) + 2 * (M - k);
+      if (!big) {
+        sym.sn_loff[f] = lo;
+        lo += (int64_t)M * nc;
+        sym.sn_uld[f] = 0;
+        sym.sn_uoff[f] = uo;
+        uo += (int64_t)(nr + 1) * (nr + 2) / 2;
+      } else {
+        // the whole M x M front lives in L storage; the update matrix is its
+        // trailing (nr+1) square, addressed in place with ld = M
+        sym.sn_loff[f] = lo;
+        sym.sn_uld[f] = M;
+        sym.sn_uoff[f] = lo + (int64_t)nc * M + nc;  // element (nc, nc)
+        lo += (int64_t)M * M;
+      }
+      // keep 16-byte alignment for either precision
+      lo = (lo + 3) & ~(int64_t)3;
+      uo = (uo + 3) & ~(int64_t)3;
+    }
+    sym.l_elems = lo;
+    sym.u_elems = uo;
+  }
+
+  // ---- 7. H block structure + assembly lists --------------------------------
+  sym.diag_off.resize(N);
+  int64_t hv = 0;
+  for (int p = 0; p < N; p++) {
+    int v = order[p];
+    sym.diag_off[v] = hv;
+    hv += (int64_t)w[v] * w[v];
+  }
+  {
+    // unique (col_pos, row_pos) pairs
+    std::vector<std::pair<int64_t, int32_t>> keyed(E);
+    for (int k = 0; k < E; k++) {
+      int pa = pos_of[g.edge_from[k]], pb = pos_of[g.edge_to[k]];
+      int c = std::min(pa, pb), r = std::max(pa, pb);
+      keyed[k] = {(int64_t)c * N + r, k};
+    }
+    std::sort(keyed.begin(), keyed.end());
+    sym.edge_slot.resize(E);
+    sym.edge_transposed.resize(E);
+    int64_t last = -1;
+    for (auto &[key, k] : keyed) {
+      {
+        // every edge owns one block; a repeated node pair (parallel edges) gets
+        // an extra block flagged `dup`, summed in a serial pass at assembly
+        int c = (int)(key / N), r = (int)(key % N);
+        sym.blk_col.push_back(order[c]);
+        sym.blk_row.push_back(order[r]);
+        sym.blk_off.push_back(hv);
+        sym.slot_shared.push_back(key == last ? 1 : 0);
+        hv += (int64_t)w[order[c]] * w[order[r]];
+        last = key;
+      }
+      sym.edge_slot[k] = (int)sym.blk_col.size() - 1;
+      // slot holds H[row node rows, col node cols]; the edge computes H[from rows, to cols]
+      sym.edge_transposed[k] = sym.blk_row.back() == g.edge_from[k] ? 0 : 1;
+    }
+    sym.n_offblocks = (int64_t)sym.blk_col.size();
+    sym.n_hvals = hv;
+  }
+  // incidence lists
+  sym.inc_ptr.assign(N + 1, 0);
+  for (int k = 0; k < E; k++) {
+    sym.inc_ptr[g.edge_from[k] + 1]++;
+    sym.inc_ptr[g.edge_to[k] + 1]++;
+  }
+  for (int i = 0; i < N; i++) sym.inc_ptr[i + 1] += sym.inc_ptr[i];
+  sym.inc_list.resize(sym.inc_ptr[N]);
+  {
+    std::vector<int32_t> fill(sym.inc_ptr.begin(), sym.inc_ptr.end() - 1);
+    for (int k = 0; k < E; k++) {
+      sym.inc_list[fill[g.edge_from[k]]++] = k * 2;
+      sym.inc_list[fill[g.edge_to[k]]++] = k * 2 + 1;
+    }
+  }
+  // local index lookup per front, assembly items, children, rel maps
+  sym.asm_ptr.assign(S + 1, 0);
+  sym.child_ptr.assign(S + 1, 0);
+  sym.rel_ptr.assign(S + 1, 0);
+  for (int f = 0; f < S; f++)
+    if (sym.sn_parent[f] >= 0) sym.child_ptr[sym.sn_parent[f] + 1]++;
+  for (int f = 0; f < S; f++) {
+    sym.child_ptr[f + 1] += sym.child_ptr[f];
+    sym.rel_ptr[f + 1] = sym.rel_ptr[f] + (sym.sn_parent[f] >= 0 ? sym.sn_nrows[f] + 1 : 0);
+  }
+  sym.child_list.resize(sym.child_ptr[S]);
+  sym.rel.resize(sym.rel_ptr[S]);
+  {
+    std::vector<int32_t> fill(sym.child_ptr.begin(), sym.child_ptr.end() - 1);
+    for (int f = 0; f < S; f++)
+      if (sym.sn_parent[f] >= 0) sym.child_list[fill[sym.sn_parent[f]]++] = f;
+  }
+  {
+    // blocks are sorted by column position, so a supernode's blocks are contiguous
+    std::vector<int64_t> blk_begin(S + 1, 0);
+    for (int64_t s = 0; s < sym.n_offblocks; s++) blk_begin[sn_at_pos[pos_of[sym.blk_col[s]]] + 1]++;
+    for (int f = 0; f < S; f++) blk_begin[f + 1] += blk_begin[f];
+    std::vector<int32_t> loc(g.dim, -1);
+    for (int f = 0; f < S; f++) {
+      const int nc = sym.sn_ncols[f], nr = sym.sn_nrows[f], c0 = sym.sn_col0[f];
+      const int32_t *rws = sym.sn_rows.data() + sym.sn_rows_ptr[f];
+      for (int i = 0; i < nc; i++) loc[c0 + i] = i;
+      for (int i = 0; i < nr; i++) loc[rws[i]] = nc + i;
+      for (int p = sym.sn_first_pos[f]; p < sym.sn_first_pos[f] + sym.sn_npos[f]; p++) {
+        int v = order[p];
+        AsmItem it;
+        it.src = sym.diag_off[v];
+        it.lrow = it.lcol = sym.node_pcol[v] - c0;
+        it.drow = it.dcol = (int16_t)w[v];
+        it.diag = 1;
+        sym.asm_items.push_back(it);
+      }
+      for (int64_t s = blk_begin[f]; s < blk_begin[f + 1]; s++) {
+        int rn = sym.blk_row[s], cn = sym.blk_col[s];
+        AsmItem it;
+        it.src = sym.blk_off[s];
+        it.lcol = sym.node_pcol[cn] - c0;
+        it.lrow = loc[sym.node_pcol[rn]];
+        if (it.lrow < 0) return "internal: H block outside its front";
+        it.drow = (int16_t)w[rn];
+        it.dcol = (int16_t)w[cn];
+        it.diag = sym.slot_shared[s] ? 2 : 0;
+        sym.asm_items.push_back(it);
+      }
+      sym.asm_ptr[f + 1] = (int64_t)sym.asm_items.size();
+      for (int q = sym.child_ptr[f]; q < sym.child_ptr[f + 1]; q++) {
+        int c = sym.child_list[q];
+        const int32_t *crows = sym.sn_rows.data() + sym.sn_rows_ptr[c];
+        int32_t *rel = sym.rel.data() + sym.rel_ptr[c];
+        for (int i = 0; i < sym.sn_nrows[c]; i++) {
+          rel[i] = loc[crows[i]];
+          if (rel[i] < 0) return "internal: child row missing from parent front";
+        }
+        rel[sym.sn_nrows[c]] = nc + nr;  // rhs row
+      }
+      for (int i = 0; i < nc; i++) loc[c0 + i] = -1;
+      for (int i = 0; i < nr; i++) loc[rws[i]] = -1;
+    }
+  }
+
+  // ---- 8. schedule ----------------------------------------------------------
+  {
+    std::vector<double> cost(S), sub(S, 0.0);
+    for (int f = 0; f < S; f++) {
+      cost[f] = front_cost_us(sym.sn_ncols[f], sym.sn_nrows[f]);
+      sub[f] += cost[f];
+      if (sym.sn_parent[f] >= 0) sub[sym.sn_parent[f]] += sub[f];
+    }
+    std::vector<char> top(S, 0);
+    for (int f = 0; f < S; f++) {
+      if (sym.sn_big[f] || sub[f] > opt.task_us || (opt.n_parts > 1 && sym.sn_owner[f] < 0)) top[f] = 1;
+      if (top[f] && sym.sn_parent[f] >= 0) top[sym.sn_parent[f]] = 1;  // parents come later in order
+    }
+    // note: a parent has a larger index than all of its descendants, so one
+    // ascending pass propagates `top` all the way up.
+    std::vector<int32_t> task_of(S, -1), lvl(S, 0);
+    std::vector<std::vector<int32_t>> tasks;
+    std::vector<int32_t> task_level;
+    // leaf tasks: maximal non-top subtrees
+    for (int f = 0; f < S; f++) {
+      if (top[f]) continue;
+      int p = sym.sn_parent[f];
+      if (p >= 0 && !top[p]) continue;  // not a subtree root
+      task_of[f] = (int)tasks.size();
+      tasks.emplace_back();
+      task_level.push_back(0);
+    }
+    for (int f = S - 1; f >= 0; f--)  // push task ids down to descendants
+      if (!top[f] && task_of[f] < 0) task_of[f] = task_of[sym.sn_parent[f]];
+    for (int f = 0; f < S; f++)
+      if (!top[f]) tasks[task_of[f]].push_back(f);
+    // top part: levels with chain merging
+    for (int f = 0; f < S; f++) {
+      if (!top[f]) continue;
+      int L = 0, nmax = 0, cmax = -1;
+      for (int q = sym.child_ptr[f]; q < sym.child_ptr[f + 1]; q++) {
+        int c = sym.child_list[q];
+        if (!top[c]) continue;
+        if (lvl[c] > L) { L = lvl[c]; nmax = 1; cmax = c; }
+        else if (lvl[c] == L) nmax++;
+      }
+      bool chain = L >= 1 && nmax == 1 && !sym.sn_big[f] && !sym.sn_big[cmax] &&
+                   tasks[task_of[cmax]].back() == cmax && sym.sn_owner[f] == sym.sn_owner[cmax];
+      if (chain) {
+        lvl[f] = L;
+        task_of[f] = task_of[cmax];
+        tasks[task_of[f]].push_back(f);
+      } else {
+        lvl[f] = L + 1;
+        if (!sym.sn_big[f]) {
+          task_of[f] = (int)tasks.size();
+          tasks.emplace_back(1, f);
+          task_level.push_back(lvl[f]);
+        }
+      }
+    }
+    int maxlvl = 0;
+    for (int f = 0; f < S; f++) maxlvl = std::max(maxlvl, (int)lvl[f]);
+    // emit steps
+    sym.task_ptr.assign(1, 0);
+    double crit = 0.0;
+    for (int L = 0; L <= maxlvl; L++) {
+      Step st{};
+      st.kind = STEP_TASKS;
+      st.task_begin = (int)sym.task_ptr.size() - 1;
+      double worst = 0.0;
+      for (size_t t = 0; t < tasks.size(); t++) {
+        if (task_level[t] != L || tasks[t].empty()) continue;
+        double tc = 0.0;
+        for (int f : tasks[t]) {
+          sym.task_sn.push_back(f);
+          tc += cost[f];
+          st.max_front = std::max(st.max_front, sym.sn_ncols[f] + sym.sn_nrows[f] + 1);
+          st.max_lds_elems = std::max<int64_t>(st.max_lds_elems, lds_elems(sym.sn_ncols[f], sym.sn_nrows[f]));
+        }
+        sym.task_ptr.push_back((int)sym.task_sn.size());
+        worst = std::max(worst, tc);
+      }
+      st.task_end = (int)sym.task_ptr.size() - 1;
+      st.threads = st.max_front <= 24 ? 64 : st.max_front <= 64 ? 128 : 256;
+      if (st.task_end > st.task_begin) {
+        sym.steps.push_back(st);
+        crit += 1.5 + worst;
+      }
+      for (int f = 0; f < S; f++)
+        if (sym.sn_big[f] && lvl[f] == L) {
+          Step b{};
+          b.kind = STEP_BIG;
+          b.sn = f;
+          b.max_front = sym.sn_ncols[f] + sym.sn_nrows[f] + 1;
+          sym.steps.push_back(b);
+          crit += cost[f];
+        }
+    }
+    sym.est_critical_us = crit;
+  }
+  return "";
+}
+
+}  // namespace rrpgo

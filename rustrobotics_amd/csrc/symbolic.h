@@ -1,0 +1,95 @@
+// symbolic.h -- one-off symbolic analysis of the normal matrix H = J^T W J.
+//
+// The reference redoes ordering + symbolic + numeric factorisation inside
+// UMFPACK on every Gauss-Newton iteration (pose_graph_optimization.rs:130-141)
+// although the sparsity pattern never changes.  Here the pattern work is done
+// ONCE per graph on the host and turned into flat tables the HIP kernels walk:
+//
+//   node graph -> nested-dissection ordering (constrained minimum degree in the
+//   leaves) -> elimination tree -> relaxed supernodes -> multifrontal fronts
+//   (pivot panel + update matrix) -> a level schedule of workgroup tasks.
+//
+// Everything is at NODE (block) granularity with per-node scalar dims (3 for
+// SE2, 2 for XY landmarks, 6 for SE3), expanded to scalar indices at the end.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "host_graph.h"
+
+namespace rrpgo {
+
+struct SymbolicOptions {
+  int64_t lds_budget_elems = 19000;  // LDS scalars one workgroup may use for a front (panel + packed update)
+  int nd_leaf = 40;         // nested dissection stops below this many nodes
+  int n_parts = 1;          // >1: top ND levels are shared, subtrees owned by ranks (power of two)
+  double task_us = 6.0;     // subtrees cheaper than this become one leaf task
+};
+
+// One (block) entry of H that has to be added into a front.
+struct AsmItem {
+  int64_t src;    // offset into the H value array (row-major d_row x d_col block)
+  int32_t lrow;   // local scalar row in the front
+  int32_t lcol;   // local scalar col in the front (a pivot column)
+  int16_t drow, dcol;
+  int32_t diag;   // 1: symmetric diagonal block (only i >= j is used)
+};
+
+enum StepKind : int32_t { STEP_TASKS = 0, STEP_BIG = 1 };
+struct Step {
+  int32_t kind;
+  int32_t task_begin, task_end;  // STEP_TASKS: range in task_ptr
+  int32_t sn;                    // STEP_BIG: the supernode
+  int32_t max_front;             // largest M = ncols + nrows + 1 among the step's fronts
+  int32_t max_lds_elems;         // LDS scalars needed by the largest front of the step
+  int32_t threads;               // workgroup size chosen for the step
+};
+
+struct Symbolic {
+  int N = 0, dim = 0, S = 0;
+  // ---- ordering
+  std::vector<int32_t> order;      // order[pos] = node
+  std::vector<int32_t> pos_of;     // node -> pos
+  std::vector<int32_t> node_pcol;  // node -> first permuted scalar column
+  std::vector<int32_t> perm;       // permuted scalar -> reference scalar (node_offset + i)
+  std::vector<int32_t> node_part;  // owner rank of the node, -1 = shared top separator
+  // ---- H storage (block CSR of the permuted lower triangle)
+  std::vector<int64_t> diag_off;   // per node: offset of its d x d diagonal block
+  int64_t n_offblocks = 0;
+  std::vector<int32_t> blk_row, blk_col;  // node ids; blk_col is eliminated first
+  std::vector<int64_t> blk_off;    // offset of the d_row x d_col block (row-major)
+  int64_t n_hvals = 0;
+  std::vector<int32_t> edge_slot;  // per edge: off-diagonal block index
+  std::vector<uint8_t> edge_transposed;  // 1: slot stores (A^T W B)^T, i.e. row node = edge.to
+  std::vector<uint8_t> slot_shared;      // per block: 1 = extra block of a repeated node pair (parallel edges)
+  // incidence lists for the pull-style linearisation: entry = edge*2 + role (0 from, 1 to)
+  std::vector<int32_t> inc_ptr, inc_list;
+  // ---- supernodes (in elimination order; children precede parents)
+  std::vector<int32_t> sn_first_pos, sn_npos;  // pivot nodes = order[first .. first+npos)
+  std::vector<int32_t> sn_ncols, sn_nrows, sn_col0, sn_parent, sn_owner;
+  std::vector<int64_t> sn_rows_ptr;  // into sn_rows (nrows entries: permuted scalar indices, ascending)
+  std::vector<int32_t> sn_rows;
+  std::vector<int64_t> sn_loff;      // panel offset in L storage, (M x ncols), ld = M = ncols+nrows+1
+  std::vector<int64_t> sn_uoff;      // update matrix offset; packed lower ((nrows+1) square) when sn_uld==0
+  std::vector<int32_t> sn_uld;       // 0 = packed lower triangle, else leading dimension (big fronts)
+  std::vector<uint8_t> sn_big;
+  int64_t l_elems = 0, u_elems = 0;
+  std::vector<int64_t> asm_ptr;
+  std::vector<AsmItem> asm_items;
+  std::vector<int32_t> child_ptr, child_list;
+  std::vector<int64_t> rel_ptr;      // per supernode (as a child): into rel, nrows+1 entries
+  std::vector<int32_t> rel;          // local index in the parent's front (last entry = parent's rhs row)
+  // ---- schedule
+  std::vector<int32_t> task_ptr, task_sn;
+  std::vector<Step> steps;           // factor order; the back-solve walks it backwards
+  // ---- stats
+  int64_t nnz_l_blocks = 0;          // node-level nonzero blocks of L (no padding)
+  int64_t factor_flops = 0;
+  int32_t max_front = 0, max_pivot_cols = 0, n_big = 0;
+  double est_critical_us = 0.0;
+};
+
+// Returns "" or an error message.
+std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sym);
+
+}  // namespace rrpgo
