@@ -1,0 +1,209 @@
+// mf_host_check.cpp -- TEST HELPER (host only, never part of librr_pgo.so).
+//
+// Validates the tables produced by rustrobotics_amd/csrc/symbolic.cpp without a
+// GPU: fills the H block structure with random SPD values, walks the fronts
+// exactly as the HIP kernels do (assembly items, extend-add through the `rel`
+// maps, partial Cholesky with the rhs carried as the last row, back
+// substitution through sn_rows) in the order the level schedule prescribes,
+// and checks  || b - H x ||_inf / ||b||_inf.  Also checks that the schedule is
+// a valid topological order (children done in an earlier step, or earlier in
+// the same task).
+//
+// usage: mf_host_check <file.g2o> | grid W H [n_edges]   [env LEAF, PARTS, LDS]
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+
+#include "host_graph.h"
+#include "symbolic.h"
+using namespace rrpgo;
+
+static int64_t tri(int n, int ld, int i, int j) {
+  return ld > 0 ? (int64_t)j * ld + i : (int64_t)j * n - (int64_t)j * (j - 1) / 2 + (i - j);
+}
+
+int main(int argc, char **argv) {
+  HostGraph g;
+  if (argc >= 4 && !strcmp(argv[1], "grid")) {
+    synth_grid(atoi(argv[2]), atoi(argv[3]), argc > 4 ? atoll(argv[4]) : 0, 42, 43, g);
+  } else if (argc >= 2) {
+    bool io;
+    std::string e = load_g2o(argv[1], g, io);
+    if (!e.empty()) { printf("load error: %s\n", e.c_str()); return 2; }
+  } else {
+    return 2;
+  }
+  SymbolicOptions opt;
+  if (getenv("LEAF")) opt.nd_leaf = atoi(getenv("LEAF"));
+  if (getenv("PARTS")) opt.n_parts = atoi(getenv("PARTS"));
+  if (getenv("LDS")) opt.lds_budget_elems = atoll(getenv("LDS"));
+  Symbolic y;
+  std::string e = analyze(g, opt, y);
+  if (!e.empty()) { printf("analyze error: %s\n", e.c_str()); return 2; }
+  const int N = y.N, dim = y.dim, S = y.S;
+
+  // ---- random SPD values on the block pattern
+  std::mt19937_64 rng(7);
+  std::uniform_real_distribution<double> U(-1.0, 1.0);
+  std::vector<double> hv((size_t)y.n_hvals, 0.0), b(dim), rowsum(dim, 0.0);
+  for (int64_t s = 0; s < y.n_offblocks; s++) {
+    int rn = y.blk_row[s], cn = y.blk_col[s];
+    int dr = node_dim(g.node_kind[rn]), dc = node_dim(g.node_kind[cn]);
+    for (int i = 0; i < dr; i++)
+      for (int j = 0; j < dc; j++) {
+        double v = U(rng);
+        hv[y.blk_off[s] + i * dc + j] = v;
+        rowsum[g.node_offset[rn] + i] += std::fabs(v);
+        rowsum[g.node_offset[cn] + j] += std::fabs(v);
+      }
+  }
+  for (int v = 0; v < N; v++) {
+    int d = node_dim(g.node_kind[v]);
+    for (int i = 0; i < d; i++)
+      for (int j = 0; j <= i; j++) {
+        double x = i == j ? 0.0 : U(rng);
+        hv[y.diag_off[v] + i * d + j] = x;
+        hv[y.diag_off[v] + j * d + i] = x;
+        if (i != j) { rowsum[g.node_offset[v] + i] += std::fabs(x); rowsum[g.node_offset[v] + j] += std::fabs(x); }
+      }
+    for (int i = 0; i < d; i++) hv[y.diag_off[v] + i * d + i] = rowsum[g.node_offset[v] + i] + 1.0 + std::fabs(U(rng));
+  }
+  for (int i = 0; i < dim; i++) b[i] = U(rng);
+
+  // ---- schedule check + factor order
+  std::vector<int> done_step(S, -1), order;
+  std::vector<int> pos_in_task(S, -1);
+  int n_sched = 0;
+  for (size_t si = 0; si < y.steps.size(); si++) {
+    const Step &st = y.steps[si];
+    auto check_children = [&](int s, int task) {
+      for (int q = y.child_ptr[s]; q < y.child_ptr[s + 1]; q++) {
+        int c = y.child_list[q];
+        bool ok = done_step[c] >= 0 && (done_step[c] < (int)si || (task >= 0 && pos_in_task[c] == task));
+        if (!ok) { printf("FAIL: supernode %d scheduled before its child %d\n", s, c); exit(1); }
+      }
+    };
+    if (st.kind == STEP_TASKS) {
+      for (int t = st.task_begin; t < st.task_end; t++)
+        for (int q = y.task_ptr[t]; q < y.task_ptr[t + 1]; q++) {
+          int s = y.task_sn[q];
+          if (y.sn_big[s]) { printf("FAIL: big front %d inside a task\n", s); return 1; }
+          check_children(s, t);
+          done_step[s] = (int)si;
+          pos_in_task[s] = t;
+          order.push_back(s);
+          n_sched++;
+        }
+    } else {
+      check_children(st.sn, -1);
+      done_step[st.sn] = (int)si;
+      order.push_back(st.sn);
+      n_sched++;
+    }
+  }
+  if (n_sched != S) { printf("FAIL: schedule covers %d of %d supernodes\n", n_sched, S); return 1; }
+
+  // ---- numeric multifrontal, same data flow as the kernels
+  std::vector<double> L((size_t)y.l_elems + 4, 0.0), Uv((size_t)y.u_elems + 4, 0.0), x(dim, 0.0);
+  std::vector<double> P, Uloc;
+  for (int s : order) {
+    const int nc = y.sn_ncols[s], nr = y.sn_nrows[s], M = nc + nr + 1, nu = nr + 1;
+    P.assign((size_t)M * nc, 0.0);
+    Uloc.assign((size_t)nu * (nu + 1) / 2, 0.0);
+    for (int64_t q = y.asm_ptr[s]; q < y.asm_ptr[s + 1]; q++) {
+      const AsmItem &it = y.asm_items[q];
+      for (int i = 0; i < it.drow; i++)
+        for (int j = 0; j < it.dcol; j++) {
+          if (it.diag == 1 && i < j) continue;
+          P[(size_t)(it.lcol + j) * M + it.lrow + i] += hv[it.src + i * it.dcol + j];
+        }
+    }
+    for (int j = 0; j < nc; j++) P[(size_t)j * M + M - 1] = b[y.perm[y.sn_col0[s] + j]];
+    for (int q = y.child_ptr[s]; q < y.child_ptr[s + 1]; q++) {
+      int c = y.child_list[q];
+      int ncu = y.sn_nrows[c] + 1, cld = y.sn_uld[c];
+      const double *Uc = (cld > 0 ? L.data() : Uv.data()) + y.sn_uoff[c];
+      const int32_t *rel = y.rel.data() + y.rel_ptr[c];
+      for (int j = 0; j < ncu; j++)
+        for (int i = j; i < ncu; i++) {
+          if (i == ncu - 1 && j == ncu - 1) continue;
+          double v = Uc[tri(ncu, cld, i, j)];
+          int li = rel[i], lj = rel[j];
+          if (li < lj) { printf("FAIL: rel map not monotone\n"); return 1; }
+          if (lj < nc) P[(size_t)lj * M + li] += v;
+          else Uloc[tri(nu, 0, li - nc, lj - nc)] += v;
+        }
+    }
+    for (int k = 0; k < nc; k++) {
+      double d = P[(size_t)k * M + k];
+      if (!(d > 0)) { printf("FAIL: non-positive pivot in supernode %d\n", s); return 1; }
+      d = std::sqrt(d);
+      P[(size_t)k * M + k] = d;
+      for (int i = k + 1; i < M; i++) P[(size_t)k * M + i] /= d;
+      for (int j = k + 1; j < nc; j++)
+        for (int i = j; i < M; i++) P[(size_t)j * M + i] -= P[(size_t)k * M + i] * P[(size_t)k * M + j];
+    }
+    for (int j = 0; j < nu; j++)
+      for (int i = j; i < nu; i++) {
+        double sacc = 0;
+        for (int k = 0; k < nc; k++) sacc += P[(size_t)k * M + nc + i] * P[(size_t)k * M + nc + j];
+        Uloc[tri(nu, 0, i, j)] -= sacc;
+      }
+    if (!y.sn_big[s]) {
+      std::copy(P.begin(), P.end(), L.begin() + y.sn_loff[s]);
+      std::copy(Uloc.begin(), Uloc.end(), Uv.begin() + y.sn_uoff[s]);
+    } else {
+      double *F = L.data() + y.sn_loff[s];
+      for (int j = 0; j < nc; j++)
+        for (int i = 0; i < M; i++) F[(size_t)j * M + i] = P[(size_t)j * M + i];
+      for (int j = 0; j < nu; j++)
+        for (int i = j; i < nu; i++) L[y.sn_uoff[s] + tri(nu, M, i, j)] = Uloc[tri(nu, 0, i, j)];
+    }
+  }
+  for (size_t oi = order.size(); oi-- > 0;) {
+    int s = order[oi];
+    const int nc = y.sn_ncols[s], nr = y.sn_nrows[s], M = nc + nr + 1;
+    const double *Lg = L.data() + y.sn_loff[s];
+    const int32_t *rows = y.sn_rows.data() + y.sn_rows_ptr[s];
+    std::vector<double> t(nc);
+    for (int j = 0; j < nc; j++) {
+      double sacc = 0;
+      for (int i = 0; i < nr; i++) sacc += Lg[(size_t)j * M + nc + i] * x[rows[i]];
+      t[j] = Lg[(size_t)j * M + M - 1] - sacc;
+    }
+    for (int j = nc - 1; j >= 0; j--) {
+      double sacc = 0;
+      for (int i = j + 1; i < nc; i++) sacc += Lg[(size_t)j * M + i] * t[i];
+      t[j] = (t[j] - sacc) / Lg[(size_t)j * M + j];
+    }
+    for (int j = 0; j < nc; j++) x[y.sn_col0[s] + j] = t[j];
+  }
+  // ---- residual in reference scalar order
+  std::vector<double> xr(dim), r(b);
+  for (int i = 0; i < dim; i++) xr[y.perm[i]] = x[i];
+  for (int v = 0; v < N; v++) {
+    int d = node_dim(g.node_kind[v]), o = g.node_offset[v];
+    for (int i = 0; i < d; i++)
+      for (int j = 0; j < d; j++) r[o + i] -= hv[y.diag_off[v] + i * d + j] * xr[o + j];
+  }
+  for (int64_t s = 0; s < y.n_offblocks; s++) {
+    int rn = y.blk_row[s], cn = y.blk_col[s];
+    int dr = node_dim(g.node_kind[rn]), dc = node_dim(g.node_kind[cn]);
+    int ro = g.node_offset[rn], co = g.node_offset[cn];
+    for (int i = 0; i < dr; i++)
+      for (int j = 0; j < dc; j++) {
+        double v = hv[y.blk_off[s] + i * dc + j];
+        r[ro + i] -= v * xr[co + j];
+        r[co + j] -= v * xr[ro + i];
+      }
+  }
+  double rmax = 0, bmax = 0;
+  for (int i = 0; i < dim; i++) { rmax = std::max(rmax, std::fabs(r[i])); bmax = std::max(bmax, std::fabs(b[i])); }
+  printf("N=%d dim=%d S=%d steps=%zu big=%d maxfront=%d  rel_residual=%.3e\n", N, dim, S, y.steps.size(), y.n_big,
+         y.max_front, rmax / bmax);
+  if (!(rmax / bmax < 1e-9)) { printf("FAIL: residual too large\n"); return 1; }
+  printf("OK\n");
+  return 0;
+}
