@@ -24,15 +24,29 @@ constexpr int LIN_GROUP = 8;      // lanes cooperating on one node in k_lineariz
 constexpr int LIN_THREADS = 256;
 constexpr int UPD_THREADS = 256;
 
+// Diagnostic build only (-DRRPGO_STAMPS): thread 0 of a workgroup records the
+// 100 MHz wall clock at the phase boundaries of every front it processes.
+#ifdef RRPGO_STAMPS
+#define RRPGO_STAMP(a, s, slot)                                                     \
+  do {                                                                               \
+    if (threadIdx.x == 0 && (a).stamps) (a).stamps[(int64_t)(s) * 12 + (slot)] = wall_clock64(); \
+  } while (0)
+#define RRPGO_ACC_DECL() unsigned long long acc_t0_ = 0
+#define RRPGO_ACC_BEGIN() acc_t0_ = wall_clock64()
+#define RRPGO_ACC_END(ptr, slot)                                                     \
+  do {                                                                               \
+    if (threadIdx.x == 0 && (ptr)) (ptr)[slot] += wall_clock64() - acc_t0_;         \
+  } while (0)
+#else
+#define RRPGO_STAMP(a, s, slot) do { } while (0)
+#define RRPGO_ACC_DECL() do { } while (0)
+#define RRPGO_ACC_BEGIN() do { } while (0)
+#define RRPGO_ACC_END(ptr, slot) do { } while (0)
+#endif
+
 // device-side error flags (sticky, read by the host at sync points)
 enum : int { DEVERR_NOT_SPD = 1 };
 
-struct AsmItemDev {
-  int64_t src;
-  int32_t lrow, lcol;
-  int16_t drow, dcol;
-  int32_t diag;  // 0 off-diagonal block, 1 diagonal block (lower part used), 2 duplicate-edge block (serial pass)
-};
 
 template <typename T> struct LinArgs {
   int n_nodes;
@@ -223,29 +237,42 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<T> a) {
 
 // ------------------------------------------------------------ multifrontal
 
+// Everything a workgroup needs to know about one front, one 64-byte record
+// (fetched with a single scalar load instead of a chain of table lookups).
+struct SnMeta {
+  int32_t nc, nr, col0, uld;        // pivot columns, rows below, first permuted column, ld of U (0 = packed)
+  int32_t asm_begin, asm_count;     // flat assembly entries (fasm_src / fasm_dst)
+  int32_t dup_begin, dup_count;     // entries of parallel-edge blocks, added serially
+  int32_t child_begin, child_count; // into child_meta
+  int32_t rows_ptr, pad;            // into sn_rows
+  int64_t loff, uoff;               // panel / update-matrix offsets
+};
+static_assert(sizeof(SnMeta) == 64, "SnMeta must stay one 64-byte record");
+
+struct ChildMeta {
+  int64_t uoff;      // the child's update matrix (uvals when uld == 0, lvals otherwise)
+  int64_t scat_ptr;  // scatter map into the parent's LDS image, -1 = use rel
+  int64_t rel_ptr;
+  int32_t ncu, uld;  // nrows + 1 (rhs row), leading dimension (0 = packed)
+};
+static_assert(sizeof(ChildMeta) == 32, "ChildMeta must stay one 32-byte record");
+
 template <typename T> struct FactorArgs {
-  // schedule
   const int32_t *task_ptr, *task_sn;
   int task_begin;
-  // supernodes
-  const int32_t *sn_ncols, *sn_nrows, *sn_col0;
-  const int64_t *sn_loff, *sn_uoff;
-  const int32_t *sn_uld;
-  const int64_t *asm_ptr;
-  const AsmItemDev *asm_items;
-  const int32_t *child_ptr, *child_list;
-  const int64_t *rel_ptr;
-  const int32_t *rel;
+  const SnMeta *sn_meta;
+  const ChildMeta *child_meta;
+  const int32_t *fasm_src, *fasm_dst, *fdup_src, *fdup_dst;
+  const int32_t *scat, *rel;
   const int32_t *perm;      // permuted scalar -> reference scalar
-  const int64_t *sn_rows_ptr;
   const int32_t *sn_rows;
-  // numeric
   const T *hvals;
   const T *b;
-  T *lvals;                 // factor panels
-  T *uvals;                 // update matrices (packed)
+  T *lvals;                 // factor panels (and whole big fronts)
+  T *uvals;                 // packed update matrices
   T *x;                     // solution, permuted order
   int *err;
+  unsigned long long *stamps;  // [S][8], diagnostic builds only (else null)
 };
 
 // update-matrix element (i >= j) of an n x n lower triangle: packed columns, or
@@ -254,75 +281,183 @@ __device__ __forceinline__ int64_t tri_index(int n, int ld, int i, int j) {
   return ld > 0 ? (int64_t)j * ld + i : (int64_t)j * n - (int64_t)j * (j - 1) / 2 + (i - j);
 }
 
+// ---- MFMA 16x16x4 tiles (f64: v_mfma_f64_16x16x4_f64, f32: v_mfma_f32_16x16x4_f32).
+// A operand: lane l holds A[l & 15][l >> 4]; B operand: lane l holds B[l >> 4][l & 15];
+// result register `reg` of lane l is D[row(l, reg)][l & 15] -- the row map differs
+// between the f64 and the f32 instruction (cdna_hip_programming.md, Fragment layout).
+template <typename T> struct Mfma16;
+template <> struct Mfma16<double> {
+  typedef double Acc __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ Acc mma(double a, double b, Acc c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <> struct Mfma16<float> {
+  typedef float Acc __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ Acc mma(float a, float b, Acc c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+
+// One wave:  C(i, j) -= sum_{k in [ka, kb)} X[i][k] * X[j][k]  for the 16 x 16 tile
+// i in [i0, i0+16), j in [j0, j0+16), restricted to i < imax, j < jmax, i >= j.
+// X is column-major with leading dimension ldx.  The product is formed as
+// D = (-X_j) * X_i^T so that a lane's four results are four different columns j
+// of one row i: consecutive lanes touch consecutive i (contiguous in memory).
+// Operands of four k-steps are fetched before the four dependent MFMAs issue.
+template <typename T, typename CAddr>
+__device__ __forceinline__ void tile_rank_update(const T *X, int ldx, int i0, int j0, int imax, int jmax,
+                                                 int ka, int kb, CAddr caddr) {
+  using MM = Mfma16<T>;
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int i = i0 + li;
+  typename MM::Acc acc;
+  bool valid[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int j = j0 + MM::row(lane, r);
+    valid[r] = i < imax && j < jmax && i >= j;
+    acc[r] = valid[r] ? *caddr(i, j) : (T)0;
+  }
+  const bool iok = i < imax, jok = (j0 + li) < jmax;
+  const T *xi = X + i0 + li, *xj = X + j0 + li;
+  for (int k = ka; k < kb; k += 16) {
+    T av[4], bv[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int kk = k + 4 * q + lk;
+      const bool kok = kk < kb;
+      bv[q] = (iok && kok) ? xi[kk * ldx] : (T)0;
+      av[q] = (jok && kok) ? -xj[kk * ldx] : (T)0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (k + 4 * q < kb) acc = MM::mma(av[q], bv[q], acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+    if (valid[r]) *caddr(i, j0 + MM::row(lane, r)) = acc[r];
+}
+
+// value of `v` in lane `src` (wave-uniform src): v_readlane, no LDS crossbar trip
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+// 1/sqrt(d): hardware seed + Newton steps (the library sqrt + divide pair is a
+// ~40-instruction dependent chain and sits on the critical path of every column)
+__device__ __forceinline__ double fast_rsqrt(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  y = y * (1.5 - h * y * y);
+  y = y * (1.5 - h * y * y);
+  return y;
+}
+__device__ __forceinline__ float fast_rsqrt(float d) {
+  float y = __builtin_amdgcn_rsqf(d);
+  return y * (1.5f - 0.5f * d * y * y);
+}
+
 // Workgroup-wide partial Cholesky of the leading nc columns of the M x nc panel
 // P (column-major, ld M; rows nc.. are the off-diagonal rows and the rhs row),
-// blocked by NB columns: diagonal block in the registers of the first wave
-// (row per lane, columns exchanged with wave shuffles), triangular solve with
-// one thread per row, rank-NB update of the remaining panel columns.
-template <typename T, int THREADS, int NB>
-__device__ void panel_factor(T *P, int M, int nc, int *err) {
+// blocked by NB = 16 columns: diagonal block in the registers of the first wave
+// (row per lane, columns exchanged with v_readlane), triangular solve with one
+// thread per row, rank-16 update of the remaining panel columns on the matrix
+// cores (one 16 x 16 tile per wave at a time).
+template <typename T, int THREADS>
+__device__ void panel_factor(T *P, int M, int nc, int *err, T *dinv /* 16 scalars of LDS */,
+                             unsigned long long *acc = nullptr) {
+  constexpr int NB = 16;
   const int tid = threadIdx.x;
+  RRPGO_ACC_DECL();
   for (int k0 = 0; k0 < nc; k0 += NB) {
     const int nb = min(NB, nc - k0);
+    RRPGO_ACC_BEGIN();
     if (tid < 64) {
+      // Row `tid` of the block lives in r[0..tid]; r[j] for j > tid is scratch
+      // that is updated like everything else but never read (no predication,
+      // no per-column branches on the critical path).
       T r[NB];
       bool bad = false;
 #pragma unroll
-      for (int k = 0; k < NB; k++)
-        r[k] = (tid < nb && k <= tid) ? P[(int64_t)(k0 + k) * M + k0 + tid] : (T)0;
+      for (int k = 0; k < NB; k++) r[k] = (tid < nb && k <= tid && k < nb) ? P[(k0 + k) * M + k0 + tid] : (T)0;
+      if (nb == NB) {
 #pragma unroll
-      for (int k = 0; k < NB; k++) {
-        T d = __shfl(r[k], k);
-        if (k < nb && !(d > (T)0)) bad = true;
-        if (!(d > (T)0)) d = (T)1;
-        const T sq = sqrt(d);
-        const T lik = tid > k ? r[k] / sq : (tid == k ? sq : (T)0);
-        r[k] = lik;
+        for (int k = 0; k < NB; k++) {
+          T d = lane_bcast(r[k], k);
+          if (!(d > (T)0)) { bad = true; d = (T)1; }
+          const T inv = fast_rsqrt(d);
+          const T lik = tid >= k ? r[k] * inv : (T)0;   // lane k: d * inv = sqrt(d)
+          r[k] = lik;
+          if (tid == k) dinv[k] = inv;
 #pragma unroll
-        for (int j = k + 1; j < NB; j++) {
-          const T ljk = __shfl(lik, j);
-          if (tid >= j) r[j] -= lik * ljk;
+          for (int j = k + 1; j < NB; j++) r[j] -= lik * lane_bcast(lik, j);
+        }
+      } else {
+        // partial last block: pad with an identity so the same straight-line code runs
+#pragma unroll
+        for (int k = 0; k < NB; k++)
+          if (k >= nb && tid == k) r[k] = (T)1;
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+          T d = lane_bcast(r[k], k);
+          if (!(d > (T)0)) { bad = true; d = (T)1; }
+          const T inv = fast_rsqrt(d);
+          const T lik = tid >= k ? r[k] * inv : (T)0;
+          r[k] = lik;
+          if (tid == k) dinv[k] = inv;
+          if (k + 1 >= nb) break;  // wave-uniform
+#pragma unroll
+          for (int j = k + 1; j < NB; j++) r[j] -= lik * lane_bcast(lik, j);
         }
       }
 #pragma unroll
       for (int k = 0; k < NB; k++)
-        if (tid < nb && k <= tid) P[(int64_t)(k0 + k) * M + k0 + tid] = r[k];
+        if (tid < nb && k <= tid && k < nb) P[(k0 + k) * M + k0 + tid] = r[k];
       if (bad && tid == 0) atomicOr(err, DEVERR_NOT_SPD);
     }
     __syncthreads();
+    RRPGO_ACC_END(acc, 7);
+    if (k0 + nb >= M) break;
+    RRPGO_ACC_BEGIN();
     // rows below the diagonal block: x * L11^T = row  (forward substitution per row)
     for (int i = k0 + nb + tid; i < M; i += THREADS) {
       T xr[NB];
 #pragma unroll
       for (int k = 0; k < NB; k++) {
         if (k < nb) {
-          T s = P[(int64_t)(k0 + k) * M + i];
+          T sacc = P[(k0 + k) * M + i];
 #pragma unroll
           for (int q = 0; q < NB; q++)
-            if (q < k) s -= xr[q] * P[(int64_t)(k0 + q) * M + k0 + k];
-          xr[k] = s / P[(int64_t)(k0 + k) * M + k0 + k];
-          P[(int64_t)(k0 + k) * M + i] = xr[k];
+            if (q < k) sacc -= xr[q] * P[(k0 + q) * M + k0 + k];
+          xr[k] = sacc * dinv[k];
+          P[(k0 + k) * M + i] = xr[k];
         }
       }
     }
     __syncthreads();
-    // update the remaining pivot columns j in [k0+nb, nc), rows i >= j
-    const int j0 = k0 + nb;
-    const int ncols_left = nc - j0;
-    if (ncols_left > 0) {
-      const int rows_left = M - j0;
-      const int total = ncols_left * rows_left;
-      for (int t = tid; t < total; t += THREADS) {
-        const int jj = t / rows_left, ii = t - jj * rows_left;
-        const int j = j0 + jj, i = j0 + ii;
-        if (i < j) continue;
-        T s = 0;
-#pragma unroll
-        for (int k = 0; k < NB; k++)
-          if (k < nb) s += P[(int64_t)(k0 + k) * M + i] * P[(int64_t)(k0 + k) * M + j];
-        P[(int64_t)j * M + i] -= s;
+    RRPGO_ACC_END(acc, 8);
+    // remaining pivot columns j in [k0+nb, nc), rows i >= j: P(i,j) -= L(i, blk) L(j, blk)^T
+    const int js = k0 + nb;
+    if (js < nc) {
+      RRPGO_ACC_BEGIN();
+      const int nj = (nc - js + 15) >> 4, ni = (M - js + 15) >> 4;
+      const int wave = tid >> 6;
+      for (int t = wave; t < nj * ni; t += THREADS / 64) {
+        const int jb = t / ni, ib = t - jb * ni;
+        if (ib < jb) continue;
+        tile_rank_update<T>(P, M, js + 16 * ib, js + 16 * jb, M, nc, k0, k0 + nb,
+                            [&](int i, int j) { return P + j * M + i; });
       }
       __syncthreads();
+      RRPGO_ACC_END(acc, 9);
     }
   }
 }
@@ -330,179 +465,258 @@ __device__ void panel_factor(T *P, int M, int nc, int *err) {
 // Assemble, factor and publish one front.  P is the M x nc pivot panel
 // (column-major, ld M), U the (nr+1) x (nr+1) update matrix (packed lower when
 // uld == 0, column-major with leading dimension uld otherwise).  For fronts
-// held in LDS both are copied to global memory at the end; a front that lives
-// in global memory (IN_PLACE) is already where it has to be.
-template <typename T, int THREADS, int MAXD2, bool IN_PLACE>
-__device__ void process_front(const FactorArgs<T> &a, int s, T *P, T *U, int uld) {
+// held in LDS (P and U contiguous: U = P + M*nc) both are copied to global
+// memory at the end; a front that lives in global memory (IN_PLACE) is already
+// where it has to be.
+template <typename T, int THREADS, bool IN_PLACE>
+__device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *P, T *U, int uld, T *dinv) {
   const int tid = threadIdx.x;
-  const int nc = a.sn_ncols[s], nr = a.sn_nrows[s];
+  const int nc = m.nc, nr = m.nr;
   const int M = nc + nr + 1, nu = nr + 1;
-  const int64_t psize = (int64_t)M * nc;
+  const int psize = M * nc, usize = nu * (nu + 1) / 2;
+  RRPGO_STAMP(a, s, 0);
   if (IN_PLACE) {
     for (int64_t t = tid; t < (int64_t)M * M; t += THREADS) P[t] = 0;  // whole front, ld M
   } else {
-    const int64_t usize = (int64_t)nu * (nu + 1) / 2;
-    for (int64_t t = tid; t < psize; t += THREADS) P[t] = 0;
-    for (int64_t t = tid; t < usize; t += THREADS) U[t] = 0;
+    for (int t = tid; t < psize + usize; t += THREADS) P[t] = 0;
   }
   __syncthreads();
-  // ---- original entries of H that live in this front's pivot columns
-  const int64_t i0 = a.asm_ptr[s], i1 = a.asm_ptr[s + 1];
-  for (int64_t t = tid; t < (i1 - i0) * MAXD2; t += THREADS) {
-    const AsmItemDev it = a.asm_items[i0 + t / MAXD2];
-    const int e = (int)(t % MAXD2);
-    const int dr = it.drow, dc = it.dcol;
-    if (e >= dr * dc || it.diag == 2) continue;
-    const int i = e / dc, j = e - i * dc;
-    if (it.diag == 1 && i < j) continue;
-    P[(int64_t)(it.lcol + j) * M + it.lrow + i] = a.hvals[it.src + e];
-  }
-  const int c0 = a.sn_col0[s];
-  for (int j = tid; j < nc; j += THREADS) P[(int64_t)j * M + (M - 1)] = a.b[a.perm[c0 + j]];
-  __syncthreads();
-  if (tid == 0)  // blocks of duplicated edges (rare): serial, fixed order
-    for (int64_t q = i0; q < i1; q++) {
-      const AsmItemDev it = a.asm_items[q];
-      if (it.diag != 2) continue;
-      for (int i = 0; i < it.drow; i++)
-        for (int j = 0; j < it.dcol; j++)
-          P[(int64_t)(it.lcol + j) * M + it.lrow + i] += a.hvals[it.src + i * it.dcol + j];
-    }
-  // ---- extend-add of the children's update matrices, fixed child order
-  for (int q = a.child_ptr[s]; q < a.child_ptr[s + 1]; q++) {
-    const int c = a.child_list[q];
-    const int ncu = a.sn_nrows[c] + 1;
-    const int cld = a.sn_uld[c];
-    const T *Uc = (cld > 0 ? a.lvals : a.uvals) + a.sn_uoff[c];
-    const int32_t *rel = a.rel + a.rel_ptr[c];
-    __syncthreads();
-    for (int t = tid; t < ncu * ncu; t += THREADS) {
-      const int j = t / ncu, i = t - j * ncu;
-      if (i < j || t == ncu * ncu - 1) continue;  // lower triangle; (rhs, rhs) corner is never used
-      const T v = Uc[tri_index(ncu, cld, i, j)];
-      const int li = rel[i], lj = rel[j];
-      if (lj < nc) P[(int64_t)lj * M + li] += v;
-      else U[tri_index(nu, uld, li - nc, lj - nc)] += v;
-    }
-  }
-  __syncthreads();
-  // ---- partial factorisation + Schur complement
-  panel_factor<T, THREADS, 8>(P, M, nc, a.err);
+  RRPGO_STAMP(a, s, 1);
+  // ---- original entries of H that live in this front's pivot columns (plain stores: every
+  // destination is hit once), then the rhs row
   {
-    // U(i,j) -= sum_k P[nc+i][k] P[nc+j][k]   (i >= j); 2 x 2 register tiles
-    const int nt = (nu + 1) / 2;
-    for (int t = tid; t < nt * nt; t += THREADS) {
-      const int tj = t / nt, ti = t - tj * nt;
-      if (ti < tj) continue;
-      const int i0r = 2 * ti, j0r = 2 * tj;
-      const bool i1ok = i0r + 1 < nu, j1ok = j0r + 1 < nu;
-      T s00 = 0, s10 = 0, s01 = 0, s11 = 0;
-      const T *pi = P + nc + i0r, *pj = P + nc + j0r;
-      for (int k = 0; k < nc; k++) {
-        const T a0 = pi[(int64_t)k * M], a1 = i1ok ? pi[(int64_t)k * M + 1] : (T)0;
-        const T b0 = pj[(int64_t)k * M], b1 = j1ok ? pj[(int64_t)k * M + 1] : (T)0;
-        s00 += a0 * b0; s10 += a1 * b0; s01 += a0 * b1; s11 += a1 * b1;
+    const int32_t *src = a.fasm_src + m.asm_begin, *dst = a.fasm_dst + m.asm_begin;
+    for (int t = tid; t < m.asm_count; t += THREADS) P[dst[t]] = a.hvals[src[t]];
+    for (int j = tid; j < nc; j += THREADS) P[j * M + (M - 1)] = a.b[a.perm[m.col0 + j]];
+  }
+  if (m.dup_count > 0) {  // blocks of parallel edges (rare): serial, fixed order
+    __syncthreads();
+    if (tid == 0)
+      for (int t = 0; t < m.dup_count; t++) P[a.fdup_dst[m.dup_begin + t]] += a.hvals[a.fdup_src[m.dup_begin + t]];
+  }
+  RRPGO_STAMP(a, s, 2);
+  // ---- extend-add of the children's update matrices, fixed child order
+  for (int q = 0; q < m.child_count; q++) {
+    const ChildMeta c = a.child_meta[m.child_begin + q];
+    const T *Uc = (c.uld > 0 ? a.lvals : a.uvals) + c.uoff;
+    __syncthreads();
+    if (!IN_PLACE && c.scat_ptr >= 0) {
+      // packed child, LDS parent: one precomputed destination per element, coalesced
+      const int32_t *map = a.scat + c.scat_ptr;
+      const int cnt = c.ncu * (c.ncu + 1) / 2;
+      int t = tid;
+      for (; t + 3 * THREADS < cnt; t += 4 * THREADS) {
+        const int d0 = map[t], d1 = map[t + THREADS], d2 = map[t + 2 * THREADS], d3 = map[t + 3 * THREADS];
+        const T v0 = Uc[t], v1 = Uc[t + THREADS], v2 = Uc[t + 2 * THREADS], v3 = Uc[t + 3 * THREADS];
+        if (d0 >= 0) P[d0] += v0;
+        if (d1 >= 0) P[d1] += v1;
+        if (d2 >= 0) P[d2] += v2;
+        if (d3 >= 0) P[d3] += v3;
       }
-      U[tri_index(nu, uld, i0r, j0r)] -= s00;
-      if (i1ok) U[tri_index(nu, uld, i0r + 1, j0r)] -= s10;
-      if (j1ok && ti > tj) U[tri_index(nu, uld, i0r, j0r + 1)] -= s01;
-      if (i1ok && j1ok) U[tri_index(nu, uld, i0r + 1, j0r + 1)] -= s11;
+      for (; t < cnt; t += THREADS) {
+        const int d0 = map[t];
+        if (d0 >= 0) P[d0] += Uc[t];
+      }
+    } else {
+      const int32_t *rel = a.rel + c.rel_ptr;
+      const int ncu = c.ncu;
+      for (int t = tid; t < ncu * ncu; t += THREADS) {
+        const int j = t / ncu, i = t - j * ncu;
+        if (i < j || t == ncu * ncu - 1) continue;  // lower triangle; (rhs, rhs) corner is never used
+        const T v = Uc[tri_index(ncu, c.uld, i, j)];
+        const int li = rel[i], lj = rel[j];
+        if (lj < nc) P[(int64_t)lj * M + li] += v;
+        else U[tri_index(nu, uld, li - nc, lj - nc)] += v;
+      }
     }
   }
   __syncthreads();
+  RRPGO_STAMP(a, s, 3);
+  // ---- partial factorisation + Schur complement
+#ifdef RRPGO_STAMPS
+  if (tid == 0 && a.stamps) { a.stamps[(int64_t)s * 12 + 7] = 0; a.stamps[(int64_t)s * 12 + 8] = 0; a.stamps[(int64_t)s * 12 + 9] = 0; }
+  panel_factor<T, THREADS>(P, M, nc, a.err, dinv, a.stamps ? a.stamps + (int64_t)s * 12 : nullptr);
+#else
+  panel_factor<T, THREADS>(P, M, nc, a.err, dinv);
+#endif
+  RRPGO_STAMP(a, s, 4);
+  {
+    // U(i,j) -= sum_k L21[i][k] L21[j][k]  (i >= j), 16 x 16 tiles on the matrix cores
+    const int nt = (nu + 15) >> 4;
+    const int wave = tid >> 6;
+    for (int t = wave; t < nt * nt; t += THREADS / 64) {
+      const int jb = t / nt, ib = t - jb * nt;
+      if (ib < jb) continue;
+      tile_rank_update<T>(P + nc, M, 16 * ib, 16 * jb, nu, nu, 0, nc,
+                          [&](int i, int j) { return U + tri_index(nu, uld, i, j); });
+    }
+  }
+  __syncthreads();
+  RRPGO_STAMP(a, s, 5);
   if (!IN_PLACE) {
-    const int64_t usize = (int64_t)nu * (nu + 1) / 2;
-    T *Lg = a.lvals + a.sn_loff[s];
-    for (int64_t t = tid; t < psize; t += THREADS) Lg[t] = P[t];
-    T *Ug = a.uvals + a.sn_uoff[s];
-    for (int64_t t = tid; t < usize; t += THREADS) Ug[t] = U[t];
+    using V2 = typename VecT<T>::V2;
+    // panel -> L storage, packed update -> U storage (both offsets are multiples of 4 scalars)
+    T *Lg = a.lvals + m.loff;
+    T *Ug = a.uvals + m.uoff;
+    if ((psize & 1) == 0) {
+      const V2 *sp = reinterpret_cast<const V2 *>(P);
+      V2 *dp = reinterpret_cast<V2 *>(Lg);
+      for (int t = tid; t < (psize >> 1); t += THREADS) dp[t] = sp[t];
+    } else {
+      for (int t = tid; t < psize; t += THREADS) Lg[t] = P[t];
+    }
+    for (int t = tid; t < usize; t += THREADS) Ug[t] = U[t];
     __syncthreads();
   }
+  RRPGO_STAMP(a, s, 6);
 }
 
 // One workgroup per task; a task is a list of supernodes in elimination order
 // whose fronts are assembled, factored and pushed to global memory one after
 // the other, entirely out of LDS.
-template <typename T, int THREADS, int MAXD2>
+template <typename T, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_factor_tasks(FactorArgs<T> a) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
+  __shared__ T dinv[16];
   T *smem = reinterpret_cast<T *>(smem_raw);
   const int task = a.task_begin + blockIdx.x;
   for (int si = a.task_ptr[task]; si < a.task_ptr[task + 1]; si++) {
     const int s = a.task_sn[si];
-    const int nc = a.sn_ncols[s], nr = a.sn_nrows[s];
-    process_front<T, THREADS, MAXD2, false>(a, s, smem, smem + (int64_t)(nc + nr + 1) * nc, 0);
+    const SnMeta m = a.sn_meta[s];
+    process_front<T, THREADS, false>(a, s, m, smem, smem + (m.nc + m.nr + 1) * m.nc, 0, dinv);
   }
 }
 
 // Fallback for a front that does not fit in LDS: one workgroup works on the
 // front in place in global memory (L storage holds the whole M x M front).
-template <typename T, int THREADS, int MAXD2>
+template <typename T, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_factor_big_single(FactorArgs<T> a, int s) {
-  T *F = a.lvals + a.sn_loff[s];
-  const int M = a.sn_ncols[s] + a.sn_nrows[s] + 1;
-  process_front<T, THREADS, MAXD2, true>(a, s, F, a.lvals + a.sn_uoff[s], M);
+  __shared__ T dinv[16];
+  const SnMeta m = a.sn_meta[s];
+  process_front<T, THREADS, true>(a, s, m, a.lvals + m.loff, a.lvals + m.uoff, m.nc + m.nr + 1, dinv);
 }
 
 // Back substitution for one supernode:
 //   x1 = L11^-T ( y1 - L21^T x[rows] ),  y1 = the rhs row of the factored panel.
-// work: LDS scratch of nr + nc scalars (+ nc*nc when STAGE_L11).
-template <typename T, int THREADS, bool STAGE_L11>
+// STAGE (fronts of the LDS path): L11 is staged into LDS TRANSPOSED with an odd
+// leading dimension, so the row sweeps of the backward substitution are
+// conflict-free column reads; L21^T x is accumulated straight from global
+// memory with every thread streaming a slice of the panel (coalesced along the
+// rows), partial sums combined per column through LDS.
+// work: STAGE: nc*ldt + nr + nc*NSLICE ; else nr + nc scalars.
+template <typename T, int THREADS, bool STAGE>
 __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
   const int tid = threadIdx.x;
-  const int nc = a.sn_ncols[s], nr = a.sn_nrows[s];
+  const SnMeta m = a.sn_meta[s];
+  const int nc = m.nc, nr = m.nr;
   const int M = nc + nr + 1;
-  const T *Lg = a.lvals + a.sn_loff[s];
-  T *x2 = work;        // nr
-  T *t1 = work + nr;   // nc
-  T *L11 = t1 + nc;    // nc x nc, ld nc (STAGE_L11 only)
-  const int32_t *rows = a.sn_rows + a.sn_rows_ptr[s];
-  __syncthreads();
-  for (int i = tid; i < nr; i += THREADS) x2[i] = a.x[rows[i]];
-  if (STAGE_L11)
+  const T *Lg = a.lvals + m.loff;
+  const int32_t *rows = a.sn_rows + m.rows_ptr;
+  if (STAGE) {
+    const int ldt = nc | 1;
+    T *Lt = work;                 // Lt[i * ldt + j] = L11(j, i)  (row j of L11 is contiguous in j... see below)
+    T *x2 = work + nc * ldt;      // nr
+    T *t1 = x2 + nr;              // nc
+    __syncthreads();
+    RRPGO_STAMP(a, s, 0);
+    for (int i = tid; i < nr; i += THREADS) x2[i] = a.x[rows[i]];
+    // stage L11 transposed: element L(r, c), r >= c, goes to Lt[r * ldt + c]
+    // (the diagonal is stored as its reciprocal: the divide would otherwise sit on the
+    // critical path of every column of the substitution)
     for (int t = tid; t < nc * nc; t += THREADS) {
-      const int j = t / nc, i = t - j * nc;
-      L11[t] = Lg[(int64_t)j * M + i];
+      const int c = t / nc, r = t - c * nc;
+      if (r > c) Lt[r * ldt + c] = Lg[(int64_t)c * M + r];
+      else if (r == c) Lt[r * ldt + c] = (T)1 / Lg[(int64_t)c * M + r];
     }
-  __syncthreads();
-  // t1[j] = y1[j] - sum_i L21[i][j] x2[i] ; one wave per column, lanes over rows
-  {
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int j = wave; j < nc; j += THREADS / 64) {
-      const T *col = Lg + (int64_t)j * M + nc;
-      T sacc = 0;
-      for (int i = lane; i < nr; i += 64) sacc += col[i] * x2[i];
-      for (int o = 32; o > 0; o >>= 1) sacc += __shfl_down(sacc, o);
-      if (lane == 0) t1[j] = col[nr] - sacc;
-    }
-  }
-  __syncthreads();
-  if (STAGE_L11) {
-    // L11^T x = t, backward, in the registers of the first wave: lane l owns
-    // entries l, l+64, l+128, l+192 (nc <= 256 on this path)
-    if (tid < 64) {
-      T tt[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) tt[q] = (tid + 64 * q) < nc ? t1[tid + 64 * q] : (T)0;
-      for (int j = nc - 1; j >= 0; j--) {
-        const int owner = j & 63, slot = j >> 6;
-        T mine = slot == 0 ? tt[0] : slot == 1 ? tt[1] : slot == 2 ? tt[2] : tt[3];
-        const T xj = __shfl(mine, owner) / L11[j * nc + j];
-        if (tid == owner) {
-          if (slot == 0) tt[0] = xj; else if (slot == 1) tt[1] = xj; else if (slot == 2) tt[2] = xj; else tt[3] = xj;
+    __syncthreads();
+    RRPGO_STAMP(a, s, 1);
+    // t1[j] = y1[j] - sum_i L21[i][j] x2[i]: a wave takes four columns at a time (four
+    // independent global load streams in flight), lanes over rows (coalesced)
+    {
+      const int wave = tid >> 6, lane = tid & 63;
+      constexpr int NW = THREADS / 64;
+      for (int j = wave; j < nc; j += 4 * NW) {
+        const int j1 = j + NW, j2 = j + 2 * NW, j3 = j + 3 * NW;
+        const T *c0 = Lg + (int64_t)j * M + nc;
+        const T *c1 = Lg + (int64_t)(j1 < nc ? j1 : j) * M + nc;
+        const T *c2 = Lg + (int64_t)(j2 < nc ? j2 : j) * M + nc;
+        const T *c3 = Lg + (int64_t)(j3 < nc ? j3 : j) * M + nc;
+        T s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        for (int i = lane; i < nr; i += 64) {
+          const T xv = x2[i];
+          s0 += c0[i] * xv; s1 += c1[i] * xv; s2 += c2[i] * xv; s3 += c3[i] * xv;
         }
-        // t[i] -= L(j,i) * x_j for i < j  (row j of L11: stride nc)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int i = tid + 64 * q;
-          if (i < j) tt[q] -= L11[i * nc + j] * xj;
+        for (int o = 32; o > 0; o >>= 1) {
+          s0 += __shfl_down(s0, o); s1 += __shfl_down(s1, o);
+          s2 += __shfl_down(s2, o); s3 += __shfl_down(s3, o);
+        }
+        if (lane == 0) {
+          t1[j] = c0[nr] - s0;
+          if (j1 < nc) t1[j1] = c1[nr] - s1;
+          if (j2 < nc) t1[j2] = c2[nr] - s2;
+          if (j3 < nc) t1[j3] = c3[nr] - s3;
         }
       }
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-        if (tid + 64 * q < nc) t1[tid + 64 * q] = tt[q];
     }
+    __syncthreads();
+    RRPGO_STAMP(a, s, 2);
+    // L11^T x = t, backward, in 64-column chunks.  Inside a chunk lane l of the first wave
+    // owns entry c0+l; step j needs row j of L11 (Lt[j*ldt + c0 ..], contiguous), fetched
+    // one step ahead so that the chain between steps is readlane -> mul -> fma.  After a
+    // chunk is solved every thread folds it into the entries to its left.
+    for (int c0 = ((nc - 1) >> 6) << 6; c0 >= 0; c0 -= 64) {
+      const int cw = min(64, nc - c0);
+      if (tid < 64) {
+        T tv = tid < cw ? t1[c0 + tid] : (T)0;
+        const T *row = Lt + (c0 + cw - 1) * ldt + c0;
+        T rd = row[cw - 1];
+        T rv = tid < cw - 1 ? row[tid] : (T)0;
+        for (int jj = cw - 1; jj >= 0; jj--) {
+          T nd = 0, nv = 0;
+          if (jj > 0) {
+            const T *rn = row - ldt;
+            nd = rn[jj - 1];
+            nv = tid < jj - 1 ? rn[tid] : (T)0;
+            row = rn;
+          }
+          const T xj = lane_bcast(tv, jj) * rd;
+          const T upd = tv - rv * xj;          // rv == 0 at and right of the diagonal
+          tv = tid == jj ? xj : upd;
+          rd = nd;
+          rv = nv;
+        }
+        if (tid < cw) t1[c0 + tid] = tv;
+      }
+      __syncthreads();
+      for (int i = tid; i < c0; i += THREADS) {
+        T sacc = 0;
+        for (int jj = 0; jj < cw; jj++) sacc += Lt[(c0 + jj) * ldt + i] * t1[c0 + jj];
+        t1[i] -= sacc;
+      }
+      if (c0 > 0) __syncthreads();
+    }
+    __syncthreads();
+    RRPGO_STAMP(a, s, 3);
+    for (int j = tid; j < nc; j += THREADS) a.x[m.col0 + j] = t1[j];
+    __syncthreads();
+    RRPGO_STAMP(a, s, 4);
   } else {
+    T *x2 = work;        // nr
+    T *t1 = work + nr;   // nc
+    __syncthreads();
+    for (int i = tid; i < nr; i += THREADS) x2[i] = a.x[rows[i]];
+    __syncthreads();
+    {
+      const int wave = tid >> 6, lane = tid & 63;
+      for (int j = wave; j < nc; j += THREADS / 64) {
+        const T *col = Lg + (int64_t)j * M + nc;
+        T sacc = 0;
+        for (int i = lane; i < nr; i += 64) sacc += col[i] * x2[i];
+        for (int o = 32; o > 0; o >>= 1) sacc += __shfl_down(sacc, o);
+        if (lane == 0) t1[j] = col[nr] - sacc;
+      }
+    }
+    __syncthreads();
     // big fronts: column dot products straight from global memory, first wave
     if (tid < 64) {
       for (int j = nc - 1; j >= 0; j--) {
@@ -515,11 +729,10 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
         __builtin_amdgcn_wave_barrier();
       }
     }
+    __syncthreads();
+    for (int j = tid; j < nc; j += THREADS) a.x[m.col0 + j] = t1[j];
+    __syncthreads();
   }
-  __syncthreads();
-  const int c0 = a.sn_col0[s];
-  for (int j = tid; j < nc; j += THREADS) a.x[c0 + j] = t1[j];
-  __syncthreads();
 }
 
 template <typename T, int THREADS>

@@ -22,7 +22,6 @@
 
 namespace rrpgo {
 
-static_assert(sizeof(AsmItem) == sizeof(AsmItemDev), "host/device assembly item layouts differ");
 
 struct ApiError : std::runtime_error {
   int code;
@@ -75,6 +74,7 @@ struct EngineBase {
   virtual void sync() = 0;
   virtual void profile(int iters, double *ms, int64_t *launches) = 0;
   virtual hipStream_t stream() = 0;
+  virtual void read_stamps(std::vector<unsigned long long> &out) = 0;
   int n_launches_per_iter = 0;
 };
 
@@ -119,11 +119,11 @@ template <typename T> class Engine final : public EngineBase {
   DevBuf<T> hvals_, b_, x_, dx_ref_, lvals_, uvals_;
   DevBuf<double> chi_partial_, norm_partial_, hist_;
   DevBuf<int> counter_, err_;
+  DevBuf<unsigned long long> stamps_;  // diagnostic builds only
   // symbolic tables
-  DevBuf<int32_t> task_ptr_, task_sn_, sn_ncols_, sn_nrows_, sn_col0_, sn_uld_, child_ptr_, child_list_,
-      rel_, perm_, sn_rows_;
-  DevBuf<int64_t> sn_loff_, sn_uoff_, asm_ptr_, rel_ptr_, sn_rows_ptr_;
-  DevBuf<AsmItemDev> asm_items_;
+  DevBuf<int32_t> task_ptr_, task_sn_, fasm_src_, fasm_dst_, fdup_src_, fdup_dst_, scat_, rel_, perm_, sn_rows_;
+  DevBuf<SnMeta> sn_meta_;
+  DevBuf<ChildMeta> child_meta_;
   std::vector<int> step_solve_lds_;  // scalars of LDS the back-solve of each step needs
   double *host_pair_ = nullptr;      // pinned, 2 doubles
   int n_lin_blocks_ = 0, n_upd_blocks_ = 0;
@@ -202,24 +202,45 @@ template <typename T> class Engine final : public EngineBase {
     // ---- symbolic tables
     task_ptr_.upload(sym.task_ptr);
     task_sn_.upload(sym.task_sn);
-    sn_ncols_.upload(sym.sn_ncols);
-    sn_nrows_.upload(sym.sn_nrows);
-    sn_col0_.upload(sym.sn_col0);
-    sn_uld_.upload(sym.sn_uld);
-    sn_loff_.upload(sym.sn_loff);
-    sn_uoff_.upload(sym.sn_uoff);
-    asm_ptr_.upload(sym.asm_ptr);
     {
-      std::vector<AsmItemDev> items(sym.asm_items.size());
-      if (!items.empty()) std::memcpy(items.data(), sym.asm_items.data(), items.size() * sizeof(AsmItemDev));
-      asm_items_.upload(items);
+      std::vector<SnMeta> meta(sym.S);
+      std::vector<ChildMeta> cm(sym.child_list.size());
+      for (int f = 0; f < sym.S; f++) {
+        SnMeta &m = meta[f];
+        m.nc = sym.sn_ncols[f];
+        m.nr = sym.sn_nrows[f];
+        m.col0 = sym.sn_col0[f];
+        m.uld = sym.sn_uld[f];
+        m.asm_begin = (int32_t)sym.fasm_ptr[f];
+        m.asm_count = (int32_t)(sym.fasm_ptr[f + 1] - sym.fasm_ptr[f]);
+        m.dup_begin = (int32_t)sym.fdup_ptr[f];
+        m.dup_count = (int32_t)(sym.fdup_ptr[f + 1] - sym.fdup_ptr[f]);
+        m.child_begin = sym.child_ptr[f];
+        m.child_count = sym.child_ptr[f + 1] - sym.child_ptr[f];
+        if (sym.sn_rows_ptr[f] > 0x7fffffffLL) throw ApiError(RR_PGO_EUNSUPPORTED, "row structure exceeds 32-bit indexing");
+        m.rows_ptr = (int32_t)sym.sn_rows_ptr[f];
+        m.pad = 0;
+        m.loff = sym.sn_loff[f];
+        m.uoff = sym.sn_uoff[f];
+      }
+      for (size_t q = 0; q < cm.size(); q++) {
+        const int c = sym.child_list[q];
+        cm[q].uoff = sym.sn_uoff[c];
+        cm[q].scat_ptr = sym.scat_ptr[c];
+        cm[q].rel_ptr = sym.rel_ptr[c];
+        cm[q].ncu = sym.sn_nrows[c] + 1;
+        cm[q].uld = sym.sn_uld[c];
+      }
+      sn_meta_.upload(meta);
+      child_meta_.upload(cm);
     }
-    child_ptr_.upload(sym.child_ptr);
-    child_list_.upload(sym.child_list);
-    rel_ptr_.upload(sym.rel_ptr);
+    fasm_src_.upload(sym.fasm_src);
+    fasm_dst_.upload(sym.fasm_dst);
+    fdup_src_.upload(sym.fdup_src);
+    fdup_dst_.upload(sym.fdup_dst);
+    scat_.upload(sym.scat);
     rel_.upload(sym.rel);
     perm_.upload(sym.perm);
-    sn_rows_ptr_.upload(sym.sn_rows_ptr);
     sn_rows_.upload(sym.sn_rows);
     for (const Step &st : sym.steps) {
       int need = 0;
@@ -228,13 +249,17 @@ template <typename T> class Engine final : public EngineBase {
           for (int q = sym.task_ptr[t]; q < sym.task_ptr[t + 1]; q++) {
             int s = sym.task_sn[q], nc = sym.sn_ncols[s], nr = sym.sn_nrows[s];
             if (nc > 256) throw ApiError(RR_PGO_EUNSUPPORTED, "internal: LDS-path supernode wider than 256 columns");
-            need = std::max(need, nr + nc + nc * nc);
+            need = std::max(need, nc * (nc | 1) + nr + nc + 2);
           }
       } else {
         need = sym.sn_ncols[st.sn] + sym.sn_nrows[st.sn];
       }
       step_solve_lds_.push_back(need);
     }
+#ifdef RRPGO_STAMPS
+    stamps_.alloc((size_t)sym.S * 12);
+    stamps_.zero();
+#endif
     configure_kernels();
     n_launches_per_iter = 3 + 2 * (int)sym.steps.size();
   }
@@ -248,18 +273,26 @@ template <typename T> class Engine final : public EngineBase {
   hipStream_t stream() override { return stream_; }
 
  private:
-  static constexpr int MAXD2 = 9;
-  static constexpr int kMaxLds = 160 * 1024;
+  static constexpr int kMaxLds = 160 * 1024 - 512;  // the kernels also hold a few static __shared__ scalars
 
+  template <int TH> void set_lds_attr() {
+    HIPCHK(hipFuncSetAttribute((const void *)k_factor_tasks<T, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void *)k_solve_tasks<T, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+  }
   void configure_kernels() {
     // opt in to > 64 KiB of dynamic LDS
-    HIPCHK(hipFuncSetAttribute((const void *)k_factor_tasks<T, 64, MAXD2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-    HIPCHK(hipFuncSetAttribute((const void *)k_factor_tasks<T, 128, MAXD2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-    HIPCHK(hipFuncSetAttribute((const void *)k_factor_tasks<T, 256, MAXD2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-    HIPCHK(hipFuncSetAttribute((const void *)k_solve_tasks<T, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-    HIPCHK(hipFuncSetAttribute((const void *)k_solve_tasks<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-    HIPCHK(hipFuncSetAttribute((const void *)k_solve_tasks<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+    set_lds_attr<64>();
+    set_lds_attr<128>();
+    set_lds_attr<256>();
+    set_lds_attr<512>();
     HIPCHK(hipFuncSetAttribute((const void *)k_solve_big_single<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+  }
+
+  template <int TH> void launch_factor_tasks(int nt, size_t lds, const FactorArgs<T> &a) {
+    hipLaunchKernelGGL((k_factor_tasks<T, TH>), dim3(nt), dim3(TH), lds, stream_, a);
+  }
+  template <int TH> void launch_solve_tasks(int nt, size_t lds, const FactorArgs<T> &a) {
+    hipLaunchKernelGGL((k_solve_tasks<T, TH>), dim3(nt), dim3(TH), lds, stream_, a);
   }
 
   LinArgs<T> lin_args(double lambda, int lm, int write_system) {
@@ -290,20 +323,15 @@ template <typename T> class Engine final : public EngineBase {
     a.task_ptr = task_ptr_.p;
     a.task_sn = task_sn_.p;
     a.task_begin = task_begin;
-    a.sn_ncols = sn_ncols_.p;
-    a.sn_nrows = sn_nrows_.p;
-    a.sn_col0 = sn_col0_.p;
-    a.sn_loff = sn_loff_.p;
-    a.sn_uoff = sn_uoff_.p;
-    a.sn_uld = sn_uld_.p;
-    a.asm_ptr = asm_ptr_.p;
-    a.asm_items = asm_items_.p;
-    a.child_ptr = child_ptr_.p;
-    a.child_list = child_list_.p;
-    a.rel_ptr = rel_ptr_.p;
+    a.sn_meta = sn_meta_.p;
+    a.child_meta = child_meta_.p;
+    a.fasm_src = fasm_src_.p;
+    a.fasm_dst = fasm_dst_.p;
+    a.fdup_src = fdup_src_.p;
+    a.fdup_dst = fdup_dst_.p;
+    a.scat = scat_.p;
     a.rel = rel_.p;
     a.perm = perm_.p;
-    a.sn_rows_ptr = sn_rows_ptr_.p;
     a.sn_rows = sn_rows_.p;
     a.hvals = hvals_.p;
     a.b = b_.p;
@@ -311,6 +339,7 @@ template <typename T> class Engine final : public EngineBase {
     a.uvals = uvals_.p;
     a.x = x_.p;
     a.err = err_.p;
+    a.stamps = stamps_.p;
     return a;
   }
 
@@ -346,12 +375,13 @@ template <typename T> class Engine final : public EngineBase {
         const int nt = st.task_end - st.task_begin;
         const size_t lds = (size_t)st.max_lds_elems * sizeof(T);
         FactorArgs<T> a = factor_args(st.task_begin);
-        if (st.threads == 64) hipLaunchKernelGGL((k_factor_tasks<T, 64, MAXD2>), dim3(nt), dim3(64), lds, stream_, a);
-        else if (st.threads == 128) hipLaunchKernelGGL((k_factor_tasks<T, 128, MAXD2>), dim3(nt), dim3(128), lds, stream_, a);
-        else hipLaunchKernelGGL((k_factor_tasks<T, 256, MAXD2>), dim3(nt), dim3(256), lds, stream_, a);
+        if (st.threads == 64) launch_factor_tasks<64>(nt, lds, a);
+        else if (st.threads == 128) launch_factor_tasks<128>(nt, lds, a);
+        else if (st.threads == 256) launch_factor_tasks<256>(nt, lds, a);
+        else launch_factor_tasks<512>(nt, lds, a);
         pend(RR_PGO_K_FACTOR);
       } else {
-        hipLaunchKernelGGL((k_factor_big_single<T, 1024, MAXD2>), dim3(1), dim3(1024), 0, stream_, factor_args(0), st.sn);
+        hipLaunchKernelGGL((k_factor_big_single<T, 1024>), dim3(1), dim3(1024), 0, stream_, factor_args(0), st.sn);
         pend(RR_PGO_K_BIGFRONT);
       }
     }
@@ -365,9 +395,10 @@ template <typename T> class Engine final : public EngineBase {
       if (st.kind == STEP_TASKS) {
         const int nt = st.task_end - st.task_begin;
         FactorArgs<T> a = factor_args(st.task_begin);
-        if (st.threads == 64) hipLaunchKernelGGL((k_solve_tasks<T, 64>), dim3(nt), dim3(64), lds, stream_, a);
-        else if (st.threads == 128) hipLaunchKernelGGL((k_solve_tasks<T, 128>), dim3(nt), dim3(128), lds, stream_, a);
-        else hipLaunchKernelGGL((k_solve_tasks<T, 256>), dim3(nt), dim3(256), lds, stream_, a);
+        if (st.threads == 64) launch_solve_tasks<64>(nt, lds, a);
+        else if (st.threads == 128) launch_solve_tasks<128>(nt, lds, a);
+        else if (st.threads == 256) launch_solve_tasks<256>(nt, lds, a);
+        else launch_solve_tasks<512>(nt, lds, a);
         pend(RR_PGO_K_SOLVE);
       } else {
         hipLaunchKernelGGL((k_solve_big_single<T, 1024>), dim3(1), dim3(1024), lds, stream_, factor_args(0), st.sn);
@@ -575,6 +606,11 @@ template <typename T> class Engine final : public EngineBase {
   void sync() override {
     HIPCHK(hipStreamSynchronize(stream_));
     check_device_error();
+  }
+
+  void read_stamps(std::vector<unsigned long long> &out) override {
+    out.resize(stamps_.n);
+    if (stamps_.n) HIPCHK(hipMemcpy(out.data(), stamps_.p, stamps_.n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   }
 
   void profile(int iters, double *ms, int64_t *launches) override {
@@ -890,6 +926,35 @@ int rr_pgo_stage_top(rr_pgo *) {
   g_last_error = "multi-GPU sharding of one graph is not implemented yet";
   return RR_PGO_EUNSUPPORTED;
 }
+#ifdef RRPGO_STAMPS
+// Diagnostic build only: per-supernode phase stamps of the last factorisation
+// plus the supernode -> (step, task, ncols, nrows) map.  out: [S][16] doubles.
+int rr_pgo_debug_stamps(rr_pgo *h, double *out, int32_t *n_sn) {
+  if (!h) return RR_PGO_EINVAL;
+  return guarded([&] {
+    const Symbolic &y = h->sym;
+    *n_sn = y.S;
+    if (!out) return;
+    std::vector<unsigned long long> st;
+    h->engine->read_stamps(st);
+    std::vector<int> step_of(y.S, -1), task_of(y.S, -1);
+    for (size_t si = 0; si < y.steps.size(); si++) {
+      const Step &sp = y.steps[si];
+      if (sp.kind == STEP_TASKS) {
+        for (int t = sp.task_begin; t < sp.task_end; t++)
+          for (int q = y.task_ptr[t]; q < y.task_ptr[t + 1]; q++) { step_of[y.task_sn[q]] = (int)si; task_of[y.task_sn[q]] = t; }
+      } else { step_of[sp.sn] = (int)si; }
+    }
+    for (int s = 0; s < y.S; s++) {
+      double *o = out + (size_t)s * 16;
+      o[0] = step_of[s]; o[1] = task_of[s]; o[2] = y.sn_ncols[s]; o[3] = y.sn_nrows[s];
+      o[4] = y.child_ptr[s + 1] - y.child_ptr[s];
+      for (int q = 0; q < 10; q++) o[5 + q] = (double)st[(size_t)s * 12 + q];
+    }
+  });
+}
+#endif
+
 void *rr_pgo_stream(rr_pgo *h) { return h && h->engine ? (void *)h->engine->stream() : nullptr; }
 
 }  // extern "C"

@@ -472,7 +472,11 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
       bool fits_before = lds_elems((int)npiv[p], (int)nrow[p]) <= lds_budget;
       bool fits_after = lds_elems((int)np2, (int)nrow[p]) <= lds_budget;
       if (fits_before && !fits_after) continue;
-      bool ok = z == 0 || np2 <= 12 || (np2 <= 36 && frac <= 0.35) ||
+      // Per-front fixed cost on the GPU (zero / assemble / extend-add / store,
+      // ~3 us) dwarfs the flops of padding zeros in a small front, so small
+      // fronts merge eagerly; large ones only when it is (nearly) free.
+      const int64_t m2 = np2 + nrow[p];
+      bool ok = z == 0 || np2 <= 16 || (m2 <= 64 && frac <= 0.70) || (m2 <= 96 && np2 <= 64 && frac <= 0.50) ||
                 (np2 <= 72 && frac <= 0.15) || frac <= 0.03;
       if (!ok) continue;
       merged_into[c] = p;
@@ -505,8 +509,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     postorder_forest(cpar, post);
     for (int i : post) final_sn.push_back(reps[i]);
   }
-  const int S = (int)final_sn.size();
-  sym.S = S;
+  int S = (int)final_sn.size();
   std::vector<int32_t> forder;
   forder.reserve(N);
   sym.sn_first_pos.resize(S);
@@ -522,6 +525,47 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     sym.sn_npos[f] = (int)forder.size() - sym.sn_first_pos[f];
   }
   if ((int)forder.size() != N) return "internal: amalgamation lost nodes";
+  // A supernode whose front does not fit the LDS budget is cut into a chain of
+  // narrower supernodes when that makes every piece fit (same flops, the later
+  // pivots simply travel through the first pieces' update matrices).
+  {
+    std::vector<int32_t> nfirst, nnpos;
+    for (int f = 0; f < S; f++) {
+      const int a = sym.sn_first_pos[f], n = sym.sn_npos[f];
+      const int64_t below = nrow[final_sn[f]];
+      int64_t tot = 0;
+      for (int p = a; p < a + n; p++) tot += w[forder[p]];
+      int pieces = 1;
+      if (lds_elems((int)tot, (int)below) > lds_budget && n > 1) {
+        for (int np = 2; np <= n && pieces == 1; np++) {
+          // np pieces of (almost) equal node counts; check that all fit
+          bool ok = true;
+          int64_t done = 0;
+          int pos = a;
+          for (int q = 0; q < np && ok; q++) {
+            int cnt = n / np + (q < n % np ? 1 : 0);
+            int64_t nc = 0;
+            for (int p = pos; p < pos + cnt; p++) nc += w[forder[p]];
+            ok = lds_elems((int)nc, (int)(tot - done - nc + below)) <= lds_budget;
+            done += nc;
+            pos += cnt;
+          }
+          if (ok) pieces = np;
+        }
+      }
+      int pos = a;
+      for (int q = 0; q < pieces; q++) {
+        int cnt = n / pieces + (q < n % pieces ? 1 : 0);
+        nfirst.push_back(pos);
+        nnpos.push_back(cnt);
+        pos += cnt;
+      }
+    }
+    sym.sn_first_pos.swap(nfirst);
+    sym.sn_npos.swap(nnpos);
+  }
+  S = (int)sym.sn_first_pos.size();
+  sym.S = S;
   order.swap(forder);
   for (int p = 0; p < N; p++) pos_of[order[p]] = p;
   sym.order = order;
@@ -748,6 +792,49 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
       for (int i = 0; i < nr; i++) loc[rws[i]] = -1;
     }
   }
+  // flat lists + scatter maps
+  sym.fasm_ptr.assign(S + 1, 0);
+  sym.fdup_ptr.assign(S + 1, 0);
+  sym.scat_ptr.assign(S, -1);
+  for (int f = 0; f < S; f++) {
+    const int M = sym.sn_ncols[f] + sym.sn_nrows[f] + 1;
+    for (int64_t q = sym.asm_ptr[f]; q < sym.asm_ptr[f + 1]; q++) {
+      const AsmItem &it = sym.asm_items[q];
+      for (int i = 0; i < it.drow; i++)
+        for (int j = 0; j < it.dcol; j++) {
+          if (it.diag == 1 && i < j) continue;
+          int64_t src = it.src + i * it.dcol + j;
+          int64_t dst = (int64_t)(it.lcol + j) * M + it.lrow + i;
+          if (src > 0x7fffffffLL || dst > 0x7fffffffLL) return "graph too large for 32-bit assembly indices";
+          if (it.diag == 2) { sym.fdup_src.push_back((int32_t)src); sym.fdup_dst.push_back((int32_t)dst); }
+          else { sym.fasm_src.push_back((int32_t)src); sym.fasm_dst.push_back((int32_t)dst); }
+        }
+    }
+    sym.fasm_ptr[f + 1] = (int64_t)sym.fasm_src.size();
+    sym.fdup_ptr[f + 1] = (int64_t)sym.fdup_src.size();
+  }
+  for (int c = 0; c < S; c++) {
+    const int p = sym.sn_parent[c];
+    if (p < 0 || sym.sn_big[c] || sym.sn_big[p]) continue;
+    const int ncu = sym.sn_nrows[c] + 1;
+    const int ncp = sym.sn_ncols[p], Mp = ncp + sym.sn_nrows[p] + 1, nup = sym.sn_nrows[p] + 1;
+    const int32_t *rel = sym.rel.data() + sym.rel_ptr[c];
+    sym.scat_ptr[c] = (int64_t)sym.scat.size();
+    for (int j = 0; j < ncu; j++)
+      for (int i = j; i < ncu; i++) {
+        int32_t d;
+        if (i == ncu - 1 && j == ncu - 1) d = -1;
+        else {
+          const int li = rel[i], lj = rel[j];
+          if (lj < ncp) d = lj * Mp + li;
+          else {
+            const int a2 = li - ncp, b2 = lj - ncp;
+            d = Mp * ncp + (b2 * nup - b2 * (b2 - 1) / 2 + (a2 - b2));
+          }
+        }
+        sym.scat.push_back(d);
+      }
+  }
 
   // ---- 8. schedule ----------------------------------------------------------
   {
@@ -828,7 +915,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
         worst = std::max(worst, tc);
       }
       st.task_end = (int)sym.task_ptr.size() - 1;
-      st.threads = st.max_front <= 24 ? 64 : st.max_front <= 64 ? 128 : 256;
+      st.threads = st.max_front <= 20 ? 64 : st.max_front <= 48 ? 128 : st.max_front <= 96 ? 256 : 512;
       if (st.task_end > st.task_begin) {
         sym.steps.push_back(st);
         crit += 1.5 + worst;

@@ -76,6 +76,16 @@ struct Symbolic {
   int64_t l_elems = 0, u_elems = 0;
   std::vector<int64_t> asm_ptr;
   std::vector<AsmItem> asm_items;
+  // flat scalar-level assembly lists (what the kernels read): H value index ->
+  // index in the front's panel (lcol*M + lrow); `dup` = blocks of parallel edges
+  // that must be ADDED serially after the plain stores
+  std::vector<int64_t> fasm_ptr, fdup_ptr;        // per supernode
+  std::vector<int32_t> fasm_src, fasm_dst, fdup_src, fdup_dst;
+  // extend-add scatter maps: for a child with a packed update matrix and a
+  // parent that lives in LDS, one destination per packed element: index into
+  // the parent's [panel | packed update] LDS image, -1 = skip
+  std::vector<int64_t> scat_ptr;                  // per supernode (as a child), -1 = no map
+  std::vector<int32_t> scat;
   std::vector<int32_t> child_ptr, child_list;
   std::vector<int64_t> rel_ptr;      // per supernode (as a child): into rel, nrows+1 entries
   std::vector<int32_t> rel;          // local index in the parent's front (last entry = parent's rhs row)
