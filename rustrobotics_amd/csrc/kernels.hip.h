@@ -587,13 +587,170 @@ __global__ void __launch_bounds__(THREADS) k_factor_tasks(FactorArgs<T> a) {
   }
 }
 
-// Fallback for a front that does not fit in LDS: one workgroup works on the
-// front in place in global memory (L storage holds the whole M x M front).
+// Mid-size fronts (beyond LDS, small enough for one workgroup): the same front code working in
+// place in HBM (L storage holds the whole M x M front), one workgroup per front, batched per level.
 template <typename T, int THREADS>
-__global__ void __launch_bounds__(THREADS) k_factor_big_single(FactorArgs<T> a, int s) {
+__global__ void __launch_bounds__(THREADS) k_factor_mid(FactorArgs<T> a) {
   __shared__ T dinv[16];
+  const int task = a.task_begin + blockIdx.x;
+  const int s = a.task_sn[a.task_ptr[task]];
   const SnMeta m = a.sn_meta[s];
   process_front<T, THREADS, true>(a, s, m, a.lvals + m.loff, a.lvals + m.uoff, m.nc + m.nr + 1, dinv);
+}
+
+// ---- huge fronts: many workgroups per front, one launch per phase, the huge fronts of one
+// level batched in the launch (grid y or z = front slot; the level's fronts are the single-front
+// tasks task_begin, task_begin+1, ...).  Each M x M front lies in L storage (column-major, ld M).
+//   k_big_zero / k_big_assemble / k_big_extend_add (one launch per child rank: fixed order)
+//   per 128-column super-panel: 4 x { k_big_panel (32-col diagonal block + TRSM),
+//                                     k_big_update mode 0 (rest of the super-panel, K = 32) }
+//                               then  k_big_update mode 1 (everything right of it, K = 128)
+constexpr int BIG_NB = 32;           // pivot block width
+constexpr int BIG_SUPER = 128;       // super-panel width = K of the big trailing update
+constexpr int BIG_PANEL_ROWS = 224;  // rows below the diagonal block handled by one workgroup
+
+template <typename T> __device__ __forceinline__ int big_front(const FactorArgs<T> &a, int slot) {
+  return a.task_sn[a.task_ptr[a.task_begin + slot]];
+}
+
+template <typename T> __global__ void __launch_bounds__(256) k_big_zero(FactorArgs<T> a) {
+  using V4 = typename VecT<T>::V4;
+  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  const int M = m.nc + m.nr + 1;
+  const int64_t n = (int64_t)M * M;
+  T *F = a.lvals + m.loff;       // loff is a multiple of 4 scalars
+  V4 *F4 = reinterpret_cast<V4 *>(F);
+  const V4 z = {0, 0, 0, 0};
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsz = (int64_t)gridDim.x * 256;
+  for (int64_t t = gid; t < (n >> 2); t += gsz) F4[t] = z;
+  if (gid < (n & 3)) F[(n & ~(int64_t)3) + gid] = 0;
+}
+
+template <typename T> __global__ void __launch_bounds__(256) k_big_assemble(FactorArgs<T> a) {
+  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  T *F = a.lvals + m.loff;
+  const int M = m.nc + m.nr + 1;
+  const int gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+  const int32_t *src = a.fasm_src + m.asm_begin, *dst = a.fasm_dst + m.asm_begin;
+  for (int t = gid; t < m.asm_count; t += gsz) F[dst[t]] = a.hvals[src[t]];
+  for (int j = gid; j < m.nc; j += gsz) F[(int64_t)j * M + (M - 1)] = a.b[a.perm[m.col0 + j]];
+}
+
+// blocks of parallel edges (rare): serial, after the plain stores
+template <typename T> __global__ void k_big_assemble_dup(FactorArgs<T> a) {
+  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  T *F = a.lvals + m.loff;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int t = 0; t < m.dup_count; t++) F[a.fdup_dst[m.dup_begin + t]] += a.hvals[a.fdup_src[m.dup_begin + t]];
+}
+
+template <typename T> __global__ void __launch_bounds__(256) k_big_extend_add(FactorArgs<T> a, int q) {
+  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  if (q >= m.child_count) return;
+  const ChildMeta c = a.child_meta[m.child_begin + q];
+  T *F = a.lvals + m.loff;
+  const int M = m.nc + m.nr + 1;
+  const T *Uc = (c.uld > 0 ? a.lvals : a.uvals) + c.uoff;
+  const int32_t *rel = a.rel + c.rel_ptr;
+  const int ncu = c.ncu;
+  // one column of the child's update matrix per workgroup pass, threads over its rows
+  for (int j = blockIdx.x; j < ncu; j += gridDim.x) {
+    const int64_t dcol = (int64_t)rel[j] * M;
+    for (int i = j + threadIdx.x; i < ncu; i += 256) {
+      if (i == ncu - 1 && j == ncu - 1) continue;
+      // the in-place front stores panel and update matrix in one M x M array: both land at (li, lj)
+      F[dcol + rel[i]] += Uc[tri_index(ncu, c.uld, i, j)];
+    }
+  }
+}
+
+// One workgroup: the nb x nb diagonal block (factored redundantly by every workgroup, so that
+// no launch boundary separates it from the triangular solve) + BIG_PANEL_ROWS rows below it.
+template <typename T> __global__ void __launch_bounds__(256) k_big_panel(FactorArgs<T> a, int kb) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  __shared__ T dinv[16];
+  T *Pl = reinterpret_cast<T *>(smem_raw);
+  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  if (kb >= m.nc) return;
+  const int nb = min(BIG_NB, m.nc - kb);
+  T *F = a.lvals + m.loff;
+  const int M = m.nc + m.nr + 1;
+  const int tid = threadIdx.x;
+  const int r0 = kb + nb + blockIdx.x * BIG_PANEL_ROWS;
+  if (r0 >= M) return;
+  const int nrows = min(BIG_PANEL_ROWS, M - r0);
+  const int Mp = nb + nrows;
+  for (int c = 0; c < nb; c++) {
+    const T *src = F + (int64_t)(kb + c) * M;
+    if (tid < nb) Pl[c * Mp + tid] = src[kb + tid];
+    if (tid < nrows) Pl[c * Mp + nb + tid] = src[r0 + tid];
+  }
+  __syncthreads();
+  panel_factor<T, 256>(Pl, Mp, nb, a.err, dinv);
+  for (int c = 0; c < nb; c++) {
+    T *dst = F + (int64_t)(kb + c) * M;
+    if (blockIdx.x == 0 && tid < nb && tid >= c) dst[kb + tid] = Pl[c * Mp + tid];   // diagonal block once
+    if (tid < nrows) dst[r0 + tid] = Pl[c * Mp + nb + tid];
+  }
+}
+
+// Rank update  C(i,j) -= sum_{k in [ka,ke)} F(i,k) F(j,k)  over i in [t0, M), j in [t0, jmax), i >= j.
+//   mode 0: after the 32-column panel at kb: the rest of its 128-column super-panel (K = 32)
+//   mode 1: after the super-panel at kb: everything to its right, Schur complement included (K <= 128)
+// One 128 x 128 tile per workgroup, 64 x 64 per wave as 4 x 4 MFMA 16x16x4 tiles (16 independent
+// accumulators per wave); operands straight from L2 (the block column is small and shared).
+template <typename T> __global__ void __launch_bounds__(256) k_big_update(FactorArgs<T> a, int kb, int mode) {
+  using MM = Mfma16<T>;
+  if (blockIdx.x < blockIdx.y) return;   // lower triangle of tiles only
+  const SnMeta m = a.sn_meta[big_front(a, blockIdx.z)];
+  if (kb >= m.nc) return;
+  const int M = m.nc + m.nr + 1;
+  const int super_end = min((kb / BIG_SUPER) * BIG_SUPER + BIG_SUPER, m.nc);
+  const int ka = kb;
+  const int ke = mode == 0 ? min(kb + BIG_NB, m.nc) : super_end;
+  const int t0 = ke;
+  const int jmax = mode == 0 ? super_end : M;
+  T *F = a.lvals + m.loff;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i0 = t0 + blockIdx.x * 128 + (wave & 1) * 64;
+  const int j0 = t0 + blockIdx.y * 128 + (wave >> 1) * 64;
+  if (i0 >= M || j0 >= jmax || i0 + 64 <= j0) return;   // nothing of this wave tile is wanted
+  const int li = lane & 15, lk = lane >> 4;
+  typename MM::Acc acc[4][4];
+#pragma unroll
+  for (int ib = 0; ib < 4; ib++)
+#pragma unroll
+    for (int jb = 0; jb < 4; jb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int i = i0 + 16 * ib + li, j = j0 + 16 * jb + MM::row(lane, r);
+        acc[ib][jb][r] = (i < M && j < jmax && i >= j) ? F[(int64_t)j * M + i] : (T)0;
+      }
+  for (int k = ka; k < ke; k += 4) {
+    const int kk = k + lk;
+    const bool kok = kk < ke;
+    const T *colk = F + (int64_t)(kok ? kk : ka) * M;
+    T av[4], bv[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int i = i0 + 16 * q + li, j = j0 + 16 * q + li;
+      bv[q] = (kok && i < M) ? colk[i] : (T)0;
+      av[q] = (kok && j < jmax) ? -colk[j] : (T)0;
+    }
+#pragma unroll
+    for (int ib = 0; ib < 4; ib++)
+#pragma unroll
+      for (int jb = 0; jb < 4; jb++) acc[ib][jb] = MM::mma(av[jb], bv[ib], acc[ib][jb]);
+  }
+#pragma unroll
+  for (int ib = 0; ib < 4; ib++)
+#pragma unroll
+    for (int jb = 0; jb < 4; jb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int i = i0 + 16 * ib + li, j = j0 + 16 * jb + MM::row(lane, r);
+        if (i < M && j < jmax && i >= j) F[(int64_t)j * M + i] = acc[ib][jb][r];
+      }
 }
 
 // Back substitution for one supernode:
@@ -701,35 +858,85 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
     __syncthreads();
     RRPGO_STAMP(a, s, 4);
   } else {
-    T *x2 = work;        // nr
-    T *t1 = work + nr;   // nc
+    // front in place in HBM (mid / huge fronts): same algorithm, the 64 x 64 diagonal chunk of
+    // L11 is staged per chunk, everything else streams from global memory.
+    T *x2 = work;          // nr
+    T *t1 = work + nr;     // nc
+    T *Lc = t1 + nc;       // 64 x 65 chunk, transposed, reciprocal diagonal
+    constexpr int NW = THREADS / 64;
+    const int wave = tid >> 6, lane = tid & 63;
     __syncthreads();
     for (int i = tid; i < nr; i += THREADS) x2[i] = a.x[rows[i]];
     __syncthreads();
-    {
-      const int wave = tid >> 6, lane = tid & 63;
-      for (int j = wave; j < nc; j += THREADS / 64) {
-        const T *col = Lg + (int64_t)j * M + nc;
-        T sacc = 0;
-        for (int i = lane; i < nr; i += 64) sacc += col[i] * x2[i];
-        for (int o = 32; o > 0; o >>= 1) sacc += __shfl_down(sacc, o);
-        if (lane == 0) t1[j] = col[nr] - sacc;
+    for (int j = wave; j < nc; j += 4 * NW) {
+      const int j1 = j + NW, j2 = j + 2 * NW, j3 = j + 3 * NW;
+      const T *c0 = Lg + (int64_t)j * M + nc;
+      const T *c1 = Lg + (int64_t)(j1 < nc ? j1 : j) * M + nc;
+      const T *c2 = Lg + (int64_t)(j2 < nc ? j2 : j) * M + nc;
+      const T *c3 = Lg + (int64_t)(j3 < nc ? j3 : j) * M + nc;
+      T s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+      for (int i = lane; i < nr; i += 64) {
+        const T xv = x2[i];
+        s0 += c0[i] * xv; s1 += c1[i] * xv; s2 += c2[i] * xv; s3 += c3[i] * xv;
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_down(s0, o); s1 += __shfl_down(s1, o);
+        s2 += __shfl_down(s2, o); s3 += __shfl_down(s3, o);
+      }
+      if (lane == 0) {
+        t1[j] = c0[nr] - s0;
+        if (j1 < nc) t1[j1] = c1[nr] - s1;
+        if (j2 < nc) t1[j2] = c2[nr] - s2;
+        if (j3 < nc) t1[j3] = c3[nr] - s3;
       }
     }
     __syncthreads();
-    // big fronts: column dot products straight from global memory, first wave
-    if (tid < 64) {
-      for (int j = nc - 1; j >= 0; j--) {
-        const T *col = Lg + (int64_t)j * M;
-        T sacc = 0;
-        for (int i = j + 1 + tid; i < nc; i += 64) sacc += col[i] * t1[i];
-        for (int o = 32; o > 0; o >>= 1) sacc += __shfl_down(sacc, o);
-        if (tid == 0) t1[j] = (t1[j] - sacc) / col[j];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+    for (int c0 = ((nc - 1) >> 6) << 6; c0 >= 0; c0 -= 64) {
+      const int cw = min(64, nc - c0);
+      for (int t = tid; t < cw * cw; t += THREADS) {
+        const int c = t / cw, r = t - c * cw;
+        if (r > c) Lc[r * 65 + c] = Lg[(int64_t)(c0 + c) * M + c0 + r];
+        else if (r == c) Lc[r * 65 + c] = (T)1 / Lg[(int64_t)(c0 + c) * M + c0 + r];
       }
+      __syncthreads();
+      if (tid < 64) {
+        T tv = tid < cw ? t1[c0 + tid] : (T)0;
+        const T *row = Lc + (cw - 1) * 65;
+        T rd = row[cw - 1];
+        T rv = tid < cw - 1 ? row[tid] : (T)0;
+        for (int jj = cw - 1; jj >= 0; jj--) {
+          T nd = 0, nv = 0;
+          if (jj > 0) {
+            const T *rn = row - 65;
+            nd = rn[jj - 1];
+            nv = tid < jj - 1 ? rn[tid] : (T)0;
+            row = rn;
+          }
+          const T xj = lane_bcast(tv, jj) * rd;
+          const T upd = tv - rv * xj;
+          tv = tid == jj ? xj : upd;
+          rd = nd;
+          rv = nv;
+        }
+        if (tid < cw) t1[c0 + tid] = tv;
+      }
+      __syncthreads();
+      // fold the solved chunk into the entries to its left: t1[i] -= sum_jj L(c0+jj, i) x[c0+jj]
+      {
+        const T xv = lane < cw ? t1[c0 + lane] : (T)0;
+        for (int i = wave; i < c0; i += 2 * NW) {
+          const int i1 = i + NW;
+          T v0 = lane < cw ? Lg[(int64_t)i * M + c0 + lane] * xv : (T)0;
+          T v1 = (i1 < c0 && lane < cw) ? Lg[(int64_t)i1 * M + c0 + lane] * xv : (T)0;
+          for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_down(v0, o); v1 += __shfl_down(v1, o); }
+          if (lane == 0) {
+            t1[i] -= v0;
+            if (i1 < c0) t1[i1] -= v1;
+          }
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
     for (int j = tid; j < nc; j += THREADS) a.x[m.col0 + j] = t1[j];
     __syncthreads();
   }
@@ -744,9 +951,11 @@ __global__ void __launch_bounds__(THREADS) k_solve_tasks(FactorArgs<T> a) {
     solve_front<T, THREADS, true>(a, a.task_sn[si], smem);
 }
 
+// mid / huge fronts: one workgroup per front, panel streamed from HBM (task list of single fronts)
 template <typename T, int THREADS>
-__global__ void __launch_bounds__(THREADS) k_solve_big_single(FactorArgs<T> a, int s) {
+__global__ void __launch_bounds__(THREADS) k_solve_mid(FactorArgs<T> a) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int s = a.task_sn[a.task_ptr[a.task_begin + blockIdx.x]];
   solve_front<T, THREADS, false>(a, s, reinterpret_cast<T *>(smem_raw));
 }
 

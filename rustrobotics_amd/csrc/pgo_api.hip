@@ -9,6 +9,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -252,8 +253,12 @@ template <typename T> class Engine final : public EngineBase {
             need = std::max(need, nc * (nc | 1) + nr + nc + 2);
           }
       } else {
-        need = sym.sn_ncols[st.sn] + sym.sn_nrows[st.sn];
+        for (int t = st.task_begin; t < st.task_end; t++) {
+          int s = sym.task_sn[sym.task_ptr[t]];
+          need = std::max(need, sym.sn_ncols[s] + sym.sn_nrows[s] + 64 * 65 + 2);
+        }
       }
+      if ((size_t)need * sizeof(T) > (size_t)kMaxLds) throw ApiError(RR_PGO_EUNSUPPORTED, "front too large for the back-substitution scratch");
       step_solve_lds_.push_back(need);
     }
 #ifdef RRPGO_STAMPS
@@ -261,7 +266,8 @@ template <typename T> class Engine final : public EngineBase {
     stamps_.zero();
 #endif
     configure_kernels();
-    n_launches_per_iter = 3 + 2 * (int)sym.steps.size();
+    n_launches_per_iter = 3;
+    for (const Step &st : sym.steps) n_launches_per_iter += st.kind == STEP_BIG ? count_big_launches(st) + 1 : 2;
   }
 
   ~Engine() override {
@@ -285,7 +291,8 @@ template <typename T> class Engine final : public EngineBase {
     set_lds_attr<128>();
     set_lds_attr<256>();
     set_lds_attr<512>();
-    HIPCHK(hipFuncSetAttribute((const void *)k_solve_big_single<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void *)k_solve_mid<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void *)k_big_panel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
   }
 
   template <int TH> void launch_factor_tasks(int nt, size_t lds, const FactorArgs<T> &a) {
@@ -380,12 +387,78 @@ template <typename T> class Engine final : public EngineBase {
         else if (st.threads == 256) launch_factor_tasks<256>(nt, lds, a);
         else launch_factor_tasks<512>(nt, lds, a);
         pend(RR_PGO_K_FACTOR);
+      } else if (st.kind == STEP_MID) {
+        hipLaunchKernelGGL((k_factor_mid<T, 1024>), dim3(st.task_end - st.task_begin), dim3(1024), 0, stream_,
+                           factor_args(st.task_begin));
+        pend(RR_PGO_K_BIGFRONT);
       } else {
-        hipLaunchKernelGGL((k_factor_big_single<T, 1024>), dim3(1), dim3(1024), 0, stream_, factor_args(0), st.sn);
+        launch_big_level(st, true);
         pend(RR_PGO_K_BIGFRONT);
       }
     }
   }
+
+  // The huge fronts of one level, batched: zero, assemble, extend-add (one launch per child rank),
+  // then per 128-column super-panel four (panel, inner update) pairs and one K=128 trailing update.
+  // do_launch == false only counts the launches.
+  int launch_big_level(const Step &st, bool do_launch) {
+    const FactorArgs<T> a = factor_args(st.task_begin);
+    const int nf = st.task_end - st.task_begin;
+    int maxM = 0, max_nc = 0, max_kids = 0, n = 0;
+    int64_t max_asm = 0, max_ncu = 0;
+    bool any_dup = false;
+    std::vector<int> fr(nf);
+    for (int z = 0; z < nf; z++) {
+      const int s = sym_.task_sn[sym_.task_ptr[st.task_begin + z]];
+      fr[z] = s;
+      maxM = std::max(maxM, sym_.sn_ncols[s] + sym_.sn_nrows[s] + 1);
+      max_nc = std::max(max_nc, sym_.sn_ncols[s]);
+      max_kids = std::max(max_kids, sym_.child_ptr[s + 1] - sym_.child_ptr[s]);
+      max_asm = std::max<int64_t>(max_asm, std::max<int64_t>(sym_.fasm_ptr[s + 1] - sym_.fasm_ptr[s], sym_.sn_ncols[s]));
+      any_dup = any_dup || sym_.fdup_ptr[s + 1] > sym_.fdup_ptr[s];
+      for (int q = sym_.child_ptr[s]; q < sym_.child_ptr[s + 1]; q++)
+        max_ncu = std::max<int64_t>(max_ncu, sym_.sn_nrows[sym_.child_list[q]] + 1);
+    }
+    auto rows_max = [&](int from) {  // max over fronts still active at column `from` of (M - from)
+      int r = 0;
+      for (int s : fr)
+        if (sym_.sn_ncols[s] > from) r = std::max(r, sym_.sn_ncols[s] + sym_.sn_nrows[s] + 1 - from);
+      return r;
+    };
+    const unsigned znb = (unsigned)std::min<int64_t>(((int64_t)maxM * maxM / 4 + 255) / 256, 4096);
+    if (do_launch) hipLaunchKernelGGL(k_big_zero<T>, dim3(znb, nf), dim3(256), 0, stream_, a);
+    n++;
+    if (do_launch) hipLaunchKernelGGL(k_big_assemble<T>, dim3((unsigned)std::min<int64_t>((max_asm + 255) / 256, 2048), nf), dim3(256), 0, stream_, a);
+    n++;
+    if (any_dup) {
+      if (do_launch) hipLaunchKernelGGL(k_big_assemble_dup<T>, dim3(1, nf), dim3(64), 0, stream_, a);
+      n++;
+    }
+    for (int q = 0; q < max_kids; q++) {
+      if (do_launch) hipLaunchKernelGGL(k_big_extend_add<T>, dim3((unsigned)std::min<int64_t>(max_ncu, 1024), nf), dim3(256), 0, stream_, a, q);
+      n++;
+    }
+    for (int K0 = 0; K0 < max_nc; K0 += BIG_SUPER) {
+      for (int kb = K0; kb < std::min(K0 + BIG_SUPER, max_nc); kb += BIG_NB) {
+        const int rb = rows_max(kb) - 1;   // rows below a 1..32 wide block, at least the rhs row
+        const int gp = (std::max(rb, 1) + BIG_PANEL_ROWS - 1) / BIG_PANEL_ROWS;
+        const size_t lds = (size_t)(BIG_NB + BIG_PANEL_ROWS) * BIG_NB * sizeof(T);
+        if (do_launch) hipLaunchKernelGGL(k_big_panel<T>, dim3(gp, nf), dim3(256), lds, stream_, a, kb);
+        n++;
+        if (kb + BIG_NB < std::min(K0 + BIG_SUPER, max_nc)) {
+          const int nti = (std::max(rb, 1) + 127) / 128;
+          if (do_launch) hipLaunchKernelGGL(k_big_update<T>, dim3(nti, 1, nf), dim3(256), 0, stream_, a, kb, 0);
+          n++;
+        }
+      }
+      const int rt = rows_max(K0);   // rows from K0 on; the trailing part starts after the super-panel
+      const int nti = (std::max(rt, 1) + 127) / 128;
+      if (do_launch) hipLaunchKernelGGL(k_big_update<T>, dim3(nti, nti, nf), dim3(256), 0, stream_, a, K0, 1);
+      n++;
+    }
+    return n;
+  }
+  int count_big_launches(const Step &st) { return launch_big_level(st, false); }
 
   void launch_solve() {
     for (int i = (int)sym_.steps.size() - 1; i >= 0; i--) {
@@ -401,7 +474,8 @@ template <typename T> class Engine final : public EngineBase {
         else launch_solve_tasks<512>(nt, lds, a);
         pend(RR_PGO_K_SOLVE);
       } else {
-        hipLaunchKernelGGL((k_solve_big_single<T, 1024>), dim3(1), dim3(1024), lds, stream_, factor_args(0), st.sn);
+        hipLaunchKernelGGL((k_solve_mid<T, 1024>), dim3(st.task_end - st.task_begin), dim3(1024), lds, stream_,
+                           factor_args(st.task_begin));
         pend(RR_PGO_K_BIGFRONT);
       }
     }
@@ -599,6 +673,13 @@ template <typename T> class Engine final : public EngineBase {
   }
 
   void iterate_async(int iters) override {
+    // RR_PGO_NO_GRAPH=1: plain launches (rocprofv3 --kernel-trace crashes on replays of graphs
+    // with thousands of nodes; profiling runs of the large workloads use this switch)
+    static const bool no_graph = std::getenv("RR_PGO_NO_GRAPH") != nullptr;
+    if (no_graph) {
+      for (int i = 0; i < iters; i++) enqueue_gn_iteration();
+      return;
+    }
     ensure_gn_graph();
     for (int i = 0; i < iters; i++) HIPCHK(hipGraphLaunch(gn_exec_, stream_));
   }

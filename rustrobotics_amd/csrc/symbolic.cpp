@@ -642,12 +642,14 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
   sym.sn_uoff.resize(S);
   sym.sn_uld.resize(S);
   sym.sn_big.resize(S);
+  sym.sn_huge.assign(S, 0);
   {
     int64_t lo = 0, uo = 0;
     for (int f = 0; f < S; f++) {
       const int nc = sym.sn_ncols[f], nr = sym.sn_nrows[f], M = nc + nr + 1;
       const bool big = lds_elems(nc, nr) > lds_budget;
       sym.sn_big[f] = big;
+      sym.sn_huge[f] = big && M > opt.mid_max_front;
       sym.n_big += big;
       sym.max_front = std::max(sym.max_front, nc + nr);
       sym.max_pivot_cols = std::max(sym.max_pivot_cols, nc);
@@ -920,15 +922,46 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
         sym.steps.push_back(st);
         crit += 1.5 + worst;
       }
-      for (int f = 0; f < S; f++)
-        if (sym.sn_big[f] && lvl[f] == L) {
-          Step b{};
-          b.kind = STEP_BIG;
-          b.sn = f;
-          b.max_front = sym.sn_ncols[f] + sym.sn_nrows[f] + 1;
-          sym.steps.push_back(b);
-          crit += cost[f];
+      // fronts beyond LDS at this level: the mid-size ones as one batched launch ...
+      {
+        Step md{};
+        md.kind = STEP_MID;
+        md.task_begin = (int)sym.task_ptr.size() - 1;
+        double worst = 0.0;
+        for (int f = 0; f < S; f++)
+          if (sym.sn_big[f] && !sym.sn_huge[f] && lvl[f] == L) {
+            sym.task_sn.push_back(f);
+            sym.task_ptr.push_back((int)sym.task_sn.size());
+            md.max_front = std::max(md.max_front, sym.sn_ncols[f] + sym.sn_nrows[f] + 1);
+            worst = std::max(worst, cost[f]);
+          }
+        md.task_end = (int)sym.task_ptr.size() - 1;
+        md.threads = 1024;
+        if (md.task_end > md.task_begin) {
+          sym.steps.push_back(md);
+          crit += 1.5 + worst;
         }
+      }
+      // ... the huge ones as one batch of tiled launches (grid z = front)
+      {
+        Step b{};
+        b.kind = STEP_BIG;
+        b.sn = -1;
+        b.task_begin = (int)sym.task_ptr.size() - 1;
+        double worst = 0.0;
+        for (int f = 0; f < S; f++)
+          if (sym.sn_huge[f] && lvl[f] == L) {
+            sym.task_sn.push_back(f);
+            sym.task_ptr.push_back((int)sym.task_sn.size());
+            b.max_front = std::max(b.max_front, sym.sn_ncols[f] + sym.sn_nrows[f] + 1);
+            worst = std::max(worst, cost[f]);
+          }
+        b.task_end = (int)sym.task_ptr.size() - 1;
+        if (b.task_end > b.task_begin) {
+          sym.steps.push_back(b);
+          crit += worst;
+        }
+      }
     }
     sym.est_critical_us = crit;
   }

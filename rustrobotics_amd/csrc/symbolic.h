@@ -24,6 +24,7 @@ struct SymbolicOptions {
   int nd_leaf = 40;         // nested dissection stops below this many nodes
   int n_parts = 1;          // >1: top ND levels are shared, subtrees owned by ranks (power of two)
   double task_us = 6.0;     // subtrees cheaper than this become one leaf task
+  int mid_max_front = 640;  // fronts beyond LDS up to this size: one workgroup each, in place in HBM, batched per level
 };
 
 // One (block) entry of H that has to be added into a front.
@@ -35,11 +36,14 @@ struct AsmItem {
   int32_t diag;   // 1: symmetric diagonal block (only i >= j is used)
 };
 
-enum StepKind : int32_t { STEP_TASKS = 0, STEP_BIG = 1 };
+// STEP_TASKS: LDS fronts, one workgroup per task.  STEP_MID: fronts beyond LDS but small enough for one
+// workgroup working in place in HBM, batched (task list of single fronts).  STEP_BIG: the huge fronts of
+// one level (task list of single fronts), tiled over many workgroups, a sequence of batched launches.
+enum StepKind : int32_t { STEP_TASKS = 0, STEP_BIG = 1, STEP_MID = 2 };
 struct Step {
   int32_t kind;
   int32_t task_begin, task_end;  // STEP_TASKS: range in task_ptr
-  int32_t sn;                    // STEP_BIG: the supernode
+  int32_t sn;                    // unused (-1)
   int32_t max_front;             // largest M = ncols + nrows + 1 among the step's fronts
   int32_t max_lds_elems;         // LDS scalars needed by the largest front of the step
   int32_t threads;               // workgroup size chosen for the step
@@ -72,7 +76,8 @@ struct Symbolic {
   std::vector<int64_t> sn_loff;      // panel offset in L storage, (M x ncols), ld = M = ncols+nrows+1
   std::vector<int64_t> sn_uoff;      // update matrix offset; packed lower ((nrows+1) square) when sn_uld==0
   std::vector<int32_t> sn_uld;       // 0 = packed lower triangle, else leading dimension (big fronts)
-  std::vector<uint8_t> sn_big;
+  std::vector<uint8_t> sn_big;       // front does not fit LDS (mid or huge): lives in place in L storage
+  std::vector<uint8_t> sn_huge;      // ... and is too large for one workgroup
   int64_t l_elems = 0, u_elems = 0;
   std::vector<int64_t> asm_ptr;
   std::vector<AsmItem> asm_items;

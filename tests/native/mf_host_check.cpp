@@ -85,23 +85,19 @@ int main(int argc, char **argv) {
         if (!ok) { printf("FAIL: supernode %d scheduled before its child %d\n", s, c); exit(1); }
       }
     };
-    if (st.kind == STEP_TASKS) {
-      for (int t = st.task_begin; t < st.task_end; t++)
-        for (int q = y.task_ptr[t]; q < y.task_ptr[t + 1]; q++) {
-          int s = y.task_sn[q];
-          if (y.sn_big[s]) { printf("FAIL: big front %d inside a task\n", s); return 1; }
-          check_children(s, t);
-          done_step[s] = (int)si;
-          pos_in_task[s] = t;
-          order.push_back(s);
-          n_sched++;
-        }
-    } else {
-      check_children(st.sn, -1);
-      done_step[st.sn] = (int)si;
-      order.push_back(st.sn);
-      n_sched++;
-    }
+    for (int t = st.task_begin; t < st.task_end; t++)
+      for (int q = y.task_ptr[t]; q < y.task_ptr[t + 1]; q++) {
+        int s = y.task_sn[q];
+        if (st.kind == STEP_TASKS && y.sn_big[s]) { printf("FAIL: big front %d inside an LDS task\n", s); return 1; }
+        if (st.kind != STEP_TASKS && y.task_ptr[t + 1] - y.task_ptr[t] != 1) { printf("FAIL: bad batch task %d\n", t); return 1; }
+        if (st.kind == STEP_MID && (!y.sn_big[s] || y.sn_huge[s])) { printf("FAIL: bad mid front %d\n", s); return 1; }
+        if (st.kind == STEP_BIG && !y.sn_huge[s]) { printf("FAIL: STEP_BIG on a front that is not huge\n"); return 1; }
+        check_children(s, st.kind == STEP_TASKS ? t : -1);
+        done_step[s] = (int)si;
+        pos_in_task[s] = t;
+        order.push_back(s);
+        n_sched++;
+      }
   }
   if (n_sched != S) { printf("FAIL: schedule covers %d of %d supernodes\n", n_sched, S); return 1; }
 

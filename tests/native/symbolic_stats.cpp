@@ -28,9 +28,32 @@ int main(int argc, char **argv) {
   printf("N=%d E=%d dim=%d | analyze %.1f ms | S=%d Lblocks=%lld l_elems=%lld u_elems=%lld flops=%.3g | maxfront=%d maxpiv=%d big=%d | steps=%zu tasks=%zu est_crit=%.1f us\n",
          s.N, g.n_edges(), s.dim, ms, s.S, (long long)s.nnz_l_blocks, (long long)s.l_elems, (long long)s.u_elems,
          (double)s.factor_flops, s.max_front, s.max_pivot_cols, s.n_big, s.steps.size(), s.task_ptr.size() - 1, s.est_critical_us);
+  if (getenv("HIST")) {
+    // fronts by size class: count, flops share
+    const int edges[] = {64, 128, 256, 384, 512, 768, 1024, 1536, 2048, 4096, 1 << 30};
+    long long cnt[11] = {0}, big[11] = {0};
+    double fl[11] = {0};
+    for (int f = 0; f < s.S; f++) {
+      int nc = s.sn_ncols[f], M = nc + s.sn_nrows[f] + 1;
+      int b = 0;
+      while (M > edges[b]) b++;
+      cnt[b]++;
+      big[b] += s.sn_big[f];
+      fl[b] += (double)nc * M * M;
+    }
+    double tot = 0;
+    for (int b = 0; b < 11; b++) tot += fl[b];
+    for (int b = 0; b < 11; b++)
+      printf("  M<=%-10d fronts %-7lld (big %-6lld) flops %5.1f%%\n", edges[b], cnt[b], big[b], 100 * fl[b] / tot);
+    int nsteps_tasks = 0, nsteps_big = 0;
+    for (auto &st : s.steps) (st.kind == STEP_BIG ? nsteps_big : nsteps_tasks)++;
+    printf("  steps: %d task launches, %d big-front steps\n", nsteps_tasks, nsteps_big);
+    return 0;
+  }
   for (auto &st : s.steps) {
-    if (st.kind == STEP_TASKS) printf("  tasks %d (threads %d, maxM %d, lds %d)\n", st.task_end - st.task_begin, st.threads, st.max_front, st.max_lds_elems);
-    else printf("  BIG sn %d M=%d nc=%d\n", st.sn, st.max_front, s.sn_ncols[st.sn]);
+    printf("  %s %d (threads %d, maxM %d, lds %d)\n", st.kind == STEP_TASKS ? "tasks" : st.kind == STEP_MID ? "mid" : "HUGE",
+           st.task_end - st.task_begin, st.threads, st.max_front, st.max_lds_elems);
   }
   return 0;
 }
+// (histogram helper appended below main via env HIST=1 is handled in main)
