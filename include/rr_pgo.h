@@ -162,7 +162,8 @@ typedef struct rr_pgo_stats {
   double analyze_ms, parse_ms;
   /* algorithmic bytes of one GN iteration by phase */
   double bytes_linearize, bytes_factor, bytes_solve, bytes_update, bytes_chi2;
-  int32_t reserved[8];
+  double big_update_flops;   /* flops (2 per multiply-add) of one iteration's k_big_update launches */
+  int32_t reserved[6];
 } rr_pgo_stats;
 int rr_pgo_get_stats(const rr_pgo *h, rr_pgo_stats *out);
 
@@ -170,9 +171,17 @@ int rr_pgo_get_stats(const rr_pgo *h, rr_pgo_stats *out);
  * Runs `iters` eager (non-graph) GN iterations with an event pair around every
  * launch and accumulates per kernel class.  Arrays have RR_PGO_NUM_KCLASS slots. */
 enum {
-  RR_PGO_K_LINEARIZE = 0, RR_PGO_K_FACTOR = 1, RR_PGO_K_SOLVE = 2,
-  RR_PGO_K_UPDATE = 3, RR_PGO_K_REDUCE = 4, RR_PGO_K_BIGFRONT = 5,
-  RR_PGO_NUM_KCLASS = 6
+  RR_PGO_K_LINEARIZE = 0,   /* k_linearize                                             */
+  RR_PGO_K_FACTOR = 1,      /* k_factor_tasks (fronts in LDS)                          */
+  RR_PGO_K_SOLVE = 2,       /* k_solve_tasks                                           */
+  RR_PGO_K_UPDATE = 3,      /* k_update                                                */
+  RR_PGO_K_REDUCE = 4,      /* k_finalize_slot                                         */
+  RR_PGO_K_BIGFRONT = 5,    /* huge fronts: k_big_zero / k_big_assemble / k_big_extend_add */
+  RR_PGO_K_BIG_PANEL = 6,   /* k_big_panel  (huge fronts: diagonal block + TRSM)       */
+  RR_PGO_K_BIG_UPDATE = 7,  /* k_big_update (huge fronts: MFMA rank-32 / rank-128 updates) */
+  RR_PGO_K_MID_FACTOR = 8,  /* k_factor_mid (fronts beyond LDS, one workgroup each)    */
+  RR_PGO_K_BIG_SOLVE = 9,   /* k_solve_mid  (back substitution of fronts beyond LDS)   */
+  RR_PGO_NUM_KCLASS = 10
 };
 int rr_pgo_profile(rr_pgo *h, int32_t iters, double *ms_total /*[NUM_KCLASS]*/,
                    int64_t *launches /*[NUM_KCLASS]*/);

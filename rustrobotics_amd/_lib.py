@@ -12,8 +12,9 @@ LIB_PATH = os.path.join(_HERE, "librr_pgo.so")
 
 OK, EINVAL, EIO, EPARSE, ENODEVICE, ENOTSPD, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7
 F64, F32 = 0, 1
-NUM_KCLASS = 6
-KCLASS_NAMES = ("linearize", "factor", "solve", "update", "reduce", "bigfront")
+NUM_KCLASS = 10
+KCLASS_NAMES = ("linearize", "factor", "solve", "update", "reduce", "big_assembly", "big_panel", "big_update",
+                "mid_factor", "big_solve")
 
 # every symbol include/rr_pgo.h declares (tests check that the .so exports exactly these)
 EXPORTS = (
@@ -47,7 +48,8 @@ class Stats(C.Structure):
         ("max_front", C.c_int32), ("max_pivot_cols", C.c_int32), ("n_big_fronts", C.c_int32),
         ("analyze_ms", C.c_double), ("parse_ms", C.c_double),
         ("bytes_linearize", C.c_double), ("bytes_factor", C.c_double), ("bytes_solve", C.c_double),
-        ("bytes_update", C.c_double), ("bytes_chi2", C.c_double), ("reserved", C.c_int32 * 8),
+        ("bytes_update", C.c_double), ("bytes_chi2", C.c_double), ("big_update_flops", C.c_double),
+        ("reserved", C.c_int32 * 6),
     ]
 
 

@@ -680,10 +680,25 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_panel(FactorA
   if (r0 >= M) return;
   const int nrows = min(BIG_PANEL_ROWS, M - r0);
   const int Mp = nb + nrows;
-  for (int c = 0; c < nb; c++) {
-    const T *src = F + (int64_t)(kb + c) * M;
-    if (tid < nb) Pl[c * Mp + tid] = src[kb + tid];
-    if (tid < nrows) Pl[c * Mp + nb + tid] = src[r0 + tid];
+  {
+    // all loads of a thread's row issued before the first LDS store (32 + 4 loads in flight)
+    T rowv[BIG_NB], dv[4];
+    const T *src = F + (int64_t)kb * M;
+#pragma unroll
+    for (int c = 0; c < BIG_NB; c++) rowv[c] = (c < nb && tid < nrows) ? src[(int64_t)c * M + r0 + tid] : (T)0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int t = tid + 256 * q, c = t / nb, r = t - c * nb;
+      dv[q] = t < nb * nb ? src[(int64_t)c * M + kb + r] : (T)0;
+    }
+#pragma unroll
+    for (int c = 0; c < BIG_NB; c++)
+      if (c < nb && tid < nrows) Pl[c * Mp + nb + tid] = rowv[c];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int t = tid + 256 * q, c = t / nb, r = t - c * nb;
+      if (t < nb * nb) Pl[c * Mp + r] = dv[q];
+    }
   }
   __syncthreads();
   panel_factor<T, 256>(Pl, Mp, nb, a.err, dinv);

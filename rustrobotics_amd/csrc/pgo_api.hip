@@ -390,7 +390,7 @@ template <typename T> class Engine final : public EngineBase {
       } else if (st.kind == STEP_MID) {
         hipLaunchKernelGGL((k_factor_mid<T, 1024>), dim3(st.task_end - st.task_begin), dim3(1024), 0, stream_,
                            factor_args(st.task_begin));
-        pend(RR_PGO_K_BIGFRONT);
+        pend(RR_PGO_K_MID_FACTOR);
       } else {
         launch_big_level(st, true);
         pend(RR_PGO_K_BIGFRONT);
@@ -438,24 +438,26 @@ template <typename T> class Engine final : public EngineBase {
       if (do_launch) hipLaunchKernelGGL(k_big_extend_add<T>, dim3((unsigned)std::min<int64_t>(max_ncu, 1024), nf), dim3(256), 0, stream_, a, q);
       n++;
     }
+    if (do_launch) pend(RR_PGO_K_BIGFRONT);   // closes the zero / assemble / extend-add segment
     for (int K0 = 0; K0 < max_nc; K0 += BIG_SUPER) {
       for (int kb = K0; kb < std::min(K0 + BIG_SUPER, max_nc); kb += BIG_NB) {
         const int rb = rows_max(kb) - 1;   // rows below a 1..32 wide block, at least the rhs row
         const int gp = (std::max(rb, 1) + BIG_PANEL_ROWS - 1) / BIG_PANEL_ROWS;
         const size_t lds = (size_t)(BIG_NB + BIG_PANEL_ROWS) * BIG_NB * sizeof(T);
-        if (do_launch) hipLaunchKernelGGL(k_big_panel<T>, dim3(gp, nf), dim3(256), lds, stream_, a, kb);
+        if (do_launch) { pbegin(); hipLaunchKernelGGL(k_big_panel<T>, dim3(gp, nf), dim3(256), lds, stream_, a, kb); pend(RR_PGO_K_BIG_PANEL); }
         n++;
         if (kb + BIG_NB < std::min(K0 + BIG_SUPER, max_nc)) {
           const int nti = (std::max(rb, 1) + 127) / 128;
-          if (do_launch) hipLaunchKernelGGL(k_big_update<T>, dim3(nti, 1, nf), dim3(256), 0, stream_, a, kb, 0);
+          if (do_launch) { pbegin(); hipLaunchKernelGGL(k_big_update<T>, dim3(nti, 1, nf), dim3(256), 0, stream_, a, kb, 0); pend(RR_PGO_K_BIG_UPDATE); }
           n++;
         }
       }
       const int rt = rows_max(K0);   // rows from K0 on; the trailing part starts after the super-panel
       const int nti = (std::max(rt, 1) + 127) / 128;
-      if (do_launch) hipLaunchKernelGGL(k_big_update<T>, dim3(nti, nti, nf), dim3(256), 0, stream_, a, K0, 1);
+      if (do_launch) { pbegin(); hipLaunchKernelGGL(k_big_update<T>, dim3(nti, nti, nf), dim3(256), 0, stream_, a, K0, 1); pend(RR_PGO_K_BIG_UPDATE); }
       n++;
     }
+    if (do_launch) pbegin();   // re-arm: the caller closes the level with pend(BIGFRONT)
     return n;
   }
   int count_big_launches(const Step &st) { return launch_big_level(st, false); }
@@ -476,7 +478,7 @@ template <typename T> class Engine final : public EngineBase {
       } else {
         hipLaunchKernelGGL((k_solve_mid<T, 1024>), dim3(st.task_end - st.task_begin), dim3(1024), lds, stream_,
                            factor_args(st.task_begin));
-        pend(RR_PGO_K_BIGFRONT);
+        pend(RR_PGO_K_BIG_SOLVE);
       }
     }
   }
@@ -820,6 +822,15 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
   s.bytes_solve = (double)y.l_elems * sz + 2.0 * dim * sz;
   s.bytes_update = 3.0 * dim * sz;
   (void)N;
+  // rank updates of the huge fronts: column k of a front with M rows touches (M-1-k)(M-k)/2 entries
+  // of the lower triangle to its right, 2 flops each
+  double buf = 0;
+  for (int f = 0; f < y.S; f++)
+    if (y.sn_huge[f]) {
+      const double M = y.sn_ncols[f] + y.sn_nrows[f] + 1;
+      for (int k = 0; k < y.sn_ncols[f]; k++) buf += (M - 1 - k) * (M - k);
+    }
+  s.big_update_flops = buf;
 }
 
 }  // namespace

@@ -35,7 +35,7 @@ def test_struct_layouts_match_header(lib):
     from rustrobotics_amd import _lib
     assert C.sizeof(_lib.Options) == 16 * 4
     assert C.sizeof(_lib.GraphDesc) == 80
-    assert C.sizeof(_lib.Stats) == 3 * 8 + 6 * 4 + 7 * 8 + 8 * 4
+    assert C.sizeof(_lib.Stats) == 3 * 8 + 6 * 4 + 8 * 8 + 6 * 4
 
 
 def _load(lib, path):
