@@ -180,7 +180,7 @@ def main():
                        "solve": stats["bytes_solve"], "update": stats["bytes_update"]}
         kernel_of = {"linearize": "k_linearize", "factor": "k_factor_tasks", "solve": "k_solve_tasks",
                      "update": "k_update", "reduce": "k_finalize_slot", "big_assembly": "k_big_zero+k_big_assemble+k_big_extend_add",
-                     "big_panel": "k_big_panel", "big_update": "k_big_update", "mid_factor": "k_factor_mid",
+                     "big_panel": "k_big_diag+k_big_trsm", "big_update": "k_big_update", "mid_factor": "k_factor_mid",
                      "big_solve": "k_solve_mid"}
         dom = max((k for k in per_iter_us if k != "reduce"), key=lambda k: per_iter_us[k])
         n_launch = prof[dom][1] / 20

@@ -177,7 +177,7 @@ enum {
   RR_PGO_K_UPDATE = 3,      /* k_update                                                */
   RR_PGO_K_REDUCE = 4,      /* k_finalize_slot                                         */
   RR_PGO_K_BIGFRONT = 5,    /* huge fronts: k_big_zero / k_big_assemble / k_big_extend_add */
-  RR_PGO_K_BIG_PANEL = 6,   /* k_big_panel  (huge fronts: diagonal block + TRSM)       */
+  RR_PGO_K_BIG_PANEL = 6,   /* k_big_diag + k_big_trsm (huge fronts: 32-column panels)  */
   RR_PGO_K_BIG_UPDATE = 7,  /* k_big_update (huge fronts: MFMA rank-32 / rank-128 updates) */
   RR_PGO_K_MID_FACTOR = 8,  /* k_factor_mid (fronts beyond LDS, one workgroup each)    */
   RR_PGO_K_BIG_SOLVE = 9,   /* k_solve_mid  (back substitution of fronts beyond LDS)   */

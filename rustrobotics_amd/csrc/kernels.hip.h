@@ -602,7 +602,7 @@ __global__ void __launch_bounds__(THREADS) k_factor_mid(FactorArgs<T> a) {
 // level batched in the launch (grid y or z = front slot; the level's fronts are the single-front
 // tasks task_begin, task_begin+1, ...).  Each M x M front lies in L storage (column-major, ld M).
 //   k_big_zero / k_big_assemble / k_big_extend_add (one launch per child rank: fixed order)
-//   per 128-column super-panel: 4 x { k_big_panel (32-col diagonal block + TRSM),
+//   per 128-column super-panel: 4 x { k_big_diag (32-col diagonal block), k_big_trsm (rows below),
 //                                     k_big_update mode 0 (rest of the super-panel, K = 32) }
 //                               then  k_big_update mode 1 (everything right of it, K = 128)
 constexpr int BIG_NB = 32;           // pivot block width
@@ -664,12 +664,40 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_extend_add(Fa
   }
 }
 
-// One workgroup: the nb x nb diagonal block (factored redundantly by every workgroup, so that
-// no launch boundary separates it from the triangular solve) + BIG_PANEL_ROWS rows below it.
-template <typename T> __global__ void __launch_bounds__(256) k_big_panel(FactorArgs<T> a, int kb) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
+// The nb x nb diagonal block of the current 32-column panel: one workgroup per front, in LDS.
+// (A separate launch: workgroups of a big grid are not co-resident, so nobody may read the block
+// in the launch that rewrites it.)
+template <typename T> __global__ void __launch_bounds__(256) k_big_diag(FactorArgs<T> a, int kb) {
+  __shared__ T Pl[BIG_NB * BIG_NB];
   __shared__ T dinv[16];
-  T *Pl = reinterpret_cast<T *>(smem_raw);
+  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  if (kb >= m.nc) return;
+  const int nb = min(BIG_NB, m.nc - kb);
+  T *F = a.lvals + m.loff;
+  const int M = m.nc + m.nr + 1;
+  const int tid = threadIdx.x;
+  T dv[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int t = tid + 256 * q, c = t / nb, r = t - c * nb;
+    dv[q] = t < nb * nb ? F[(int64_t)(kb + c) * M + kb + r] : (T)0;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+    if (tid + 256 * q < nb * nb) Pl[tid + 256 * q] = dv[q];
+  __syncthreads();
+  panel_factor<T, 256>(Pl, nb, nb, a.err, dinv);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int t = tid + 256 * q, c = t / nb, r = t - c * nb;
+    if (t < nb * nb && r >= c) F[(int64_t)(kb + c) * M + kb + r] = Pl[t];
+  }
+}
+
+// Rows below the diagonal block:  X * L11^T = A, one thread per row (BIG_PANEL_ROWS rows per
+// workgroup), L11 broadcast from LDS with its diagonal stored as reciprocals.
+template <typename T> __global__ void __launch_bounds__(256) k_big_trsm(FactorArgs<T> a, int kb) {
+  __shared__ T L11[BIG_NB * (BIG_NB + 1)];
   const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
   if (kb >= m.nc) return;
   const int nb = min(BIG_NB, m.nc - kb);
@@ -678,35 +706,35 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_panel(FactorA
   const int tid = threadIdx.x;
   const int r0 = kb + nb + blockIdx.x * BIG_PANEL_ROWS;
   if (r0 >= M) return;
-  const int nrows = min(BIG_PANEL_ROWS, M - r0);
-  const int Mp = nb + nrows;
-  {
-    // all loads of a thread's row issued before the first LDS store (32 + 4 loads in flight)
-    T rowv[BIG_NB], dv[4];
-    const T *src = F + (int64_t)kb * M;
+  const int row = r0 + tid;
+  const bool active = tid < BIG_PANEL_ROWS && row < M;
+  T *src = F + (int64_t)kb * M;
+  T xr[BIG_NB];
 #pragma unroll
-    for (int c = 0; c < BIG_NB; c++) rowv[c] = (c < nb && tid < nrows) ? src[(int64_t)c * M + r0 + tid] : (T)0;
+  for (int c = 0; c < BIG_NB; c++) xr[c] = (c < nb && active) ? src[(int64_t)c * M + row] : (T)0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int t = tid + 256 * q, c = t / nb, r = t - c * nb;
-      dv[q] = t < nb * nb ? src[(int64_t)c * M + kb + r] : (T)0;
-    }
-#pragma unroll
-    for (int c = 0; c < BIG_NB; c++)
-      if (c < nb && tid < nrows) Pl[c * Mp + nb + tid] = rowv[c];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int t = tid + 256 * q, c = t / nb, r = t - c * nb;
-      if (t < nb * nb) Pl[c * Mp + r] = dv[q];
+  for (int q = 0; q < 4; q++) {
+    // L11(r, c), r >= c, stored at [c * (BIG_NB+1) + r]; diagonal as reciprocal
+    const int t = tid + 256 * q, c = t / nb, r = t - c * nb;
+    if (t < nb * nb && r >= c) {
+      const T v = src[(int64_t)c * M + kb + r];
+      L11[c * (BIG_NB + 1) + r] = r == c ? (T)1 / v : v;
     }
   }
   __syncthreads();
-  panel_factor<T, 256>(Pl, Mp, nb, a.err, dinv);
-  for (int c = 0; c < nb; c++) {
-    T *dst = F + (int64_t)(kb + c) * M;
-    if (blockIdx.x == 0 && tid < nb && tid >= c) dst[kb + tid] = Pl[c * Mp + tid];   // diagonal block once
-    if (tid < nrows) dst[r0 + tid] = Pl[c * Mp + nb + tid];
+#pragma unroll
+  for (int k = 0; k < BIG_NB; k++) {
+    if (k < nb) {
+      T sacc = xr[k];
+#pragma unroll
+      for (int q = 0; q < BIG_NB; q++)
+        if (q < k) sacc -= xr[q] * L11[q * (BIG_NB + 1) + k];
+      xr[k] = sacc * L11[k * (BIG_NB + 1) + k];
+    }
   }
+#pragma unroll
+  for (int c = 0; c < BIG_NB; c++)
+    if (c < nb && active) src[(int64_t)c * M + row] = xr[c];
 }
 
 // Rank update  C(i,j) -= sum_{k in [ka,ke)} F(i,k) F(j,k)  over i in [t0, M), j in [t0, jmax), i >= j.
@@ -725,6 +753,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_update(Factor
   const int ke = mode == 0 ? min(kb + BIG_NB, m.nc) : super_end;
   const int t0 = ke;
   const int jmax = mode == 0 ? super_end : M;
+  if (t0 >= jmax) return;
   T *F = a.lvals + m.loff;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i0 = t0 + blockIdx.x * 128 + (wave & 1) * 64;

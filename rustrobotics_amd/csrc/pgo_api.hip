@@ -292,7 +292,6 @@ template <typename T> class Engine final : public EngineBase {
     set_lds_attr<256>();
     set_lds_attr<512>();
     HIPCHK(hipFuncSetAttribute((const void *)k_solve_mid<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-    HIPCHK(hipFuncSetAttribute((const void *)k_big_panel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
   }
 
   template <int TH> void launch_factor_tasks(int nt, size_t lds, const FactorArgs<T> &a) {
@@ -368,6 +367,12 @@ template <typename T> class Engine final : public EngineBase {
     prof_.n[k]++;
   }
 
+  // a launch with an invalid configuration fails silently unless asked
+  void check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw ApiError(RR_PGO_ENODEVICE, std::string("kernel launch failed (") + what + "): " + hipGetErrorString(e));
+  }
+
   void launch_linearize(double lambda, int lm, int write_system) {
     pbegin();
     hipLaunchKernelGGL(k_linearize<T>, dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_,
@@ -426,9 +431,10 @@ template <typename T> class Engine final : public EngineBase {
       return r;
     };
     const unsigned znb = (unsigned)std::min<int64_t>(((int64_t)maxM * maxM / 4 + 255) / 256, 4096);
-    if (do_launch) hipLaunchKernelGGL(k_big_zero<T>, dim3(znb, nf), dim3(256), 0, stream_, a);
+    if (do_launch) { hipLaunchKernelGGL(k_big_zero<T>, dim3(znb, nf), dim3(256), 0, stream_, a); check_launch("k_big_zero"); }
     n++;
     if (do_launch) hipLaunchKernelGGL(k_big_assemble<T>, dim3((unsigned)std::min<int64_t>((max_asm + 255) / 256, 2048), nf), dim3(256), 0, stream_, a);
+    if (do_launch) check_launch("k_big_assemble");
     n++;
     if (any_dup) {
       if (do_launch) hipLaunchKernelGGL(k_big_assemble_dup<T>, dim3(1, nf), dim3(64), 0, stream_, a);
@@ -436,6 +442,7 @@ template <typename T> class Engine final : public EngineBase {
     }
     for (int q = 0; q < max_kids; q++) {
       if (do_launch) hipLaunchKernelGGL(k_big_extend_add<T>, dim3((unsigned)std::min<int64_t>(max_ncu, 1024), nf), dim3(256), 0, stream_, a, q);
+      if (do_launch) check_launch("k_big_extend_add");
       n++;
     }
     if (do_launch) pend(RR_PGO_K_BIGFRONT);   // closes the zero / assemble / extend-add segment
@@ -443,18 +450,29 @@ template <typename T> class Engine final : public EngineBase {
       for (int kb = K0; kb < std::min(K0 + BIG_SUPER, max_nc); kb += BIG_NB) {
         const int rb = rows_max(kb) - 1;   // rows below a 1..32 wide block, at least the rhs row
         const int gp = (std::max(rb, 1) + BIG_PANEL_ROWS - 1) / BIG_PANEL_ROWS;
-        const size_t lds = (size_t)(BIG_NB + BIG_PANEL_ROWS) * BIG_NB * sizeof(T);
-        if (do_launch) { pbegin(); hipLaunchKernelGGL(k_big_panel<T>, dim3(gp, nf), dim3(256), lds, stream_, a, kb); pend(RR_PGO_K_BIG_PANEL); }
-        n++;
+        if (do_launch) {
+          pbegin();
+          hipLaunchKernelGGL(k_big_diag<T>, dim3(1, nf), dim3(256), 0, stream_, a, kb);
+          check_launch("k_big_diag");
+          hipLaunchKernelGGL(k_big_trsm<T>, dim3(gp, nf), dim3(256), 0, stream_, a, kb);
+          check_launch("k_big_trsm");
+          pend(RR_PGO_K_BIG_PANEL);
+        }
+        n += 2;
         if (kb + BIG_NB < std::min(K0 + BIG_SUPER, max_nc)) {
           const int nti = (std::max(rb, 1) + 127) / 128;
-          if (do_launch) { pbegin(); hipLaunchKernelGGL(k_big_update<T>, dim3(nti, 1, nf), dim3(256), 0, stream_, a, kb, 0); pend(RR_PGO_K_BIG_UPDATE); }
+          if (do_launch) { pbegin(); hipLaunchKernelGGL(k_big_update<T>, dim3(nti, 1, nf), dim3(256), 0, stream_, a, kb, 0); check_launch("k_big_update/0"); pend(RR_PGO_K_BIG_UPDATE); }
           n++;
         }
       }
       const int rt = rows_max(K0);   // rows from K0 on; the trailing part starts after the super-panel
       const int nti = (std::max(rt, 1) + 127) / 128;
-      if (do_launch) { pbegin(); hipLaunchKernelGGL(k_big_update<T>, dim3(nti, nti, nf), dim3(256), 0, stream_, a, K0, 1); pend(RR_PGO_K_BIG_UPDATE); }
+      if (do_launch) {
+        pbegin();
+        hipLaunchKernelGGL(k_big_update<T>, dim3(nti, nti, nf), dim3(256), 0, stream_, a, K0, 1);
+        check_launch("k_big_update/1");
+        pend(RR_PGO_K_BIG_UPDATE);
+      }
       n++;
     }
     if (do_launch) pbegin();   // re-arm: the caller closes the level with pend(BIGFRONT)
@@ -777,6 +795,7 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
   SymbolicOptions so;
   so.lds_budget_elems = opt.precision == RR_PGO_F64 ? 19000 : 38000;
   so.nd_leaf = h->g.n_nodes() <= 6000 ? (1 << 30) : 64;
+  if (const char *e = std::getenv("RR_PGO_MID_MAX")) so.mid_max_front = std::atoi(e);   // tuning knob
   double t0 = now_ms();
   std::string err = analyze(h->g, so, h->sym);
   if (!err.empty()) throw ApiError(RR_PGO_EINVAL, err);

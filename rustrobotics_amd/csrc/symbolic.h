@@ -24,7 +24,8 @@ struct SymbolicOptions {
   int nd_leaf = 40;         // nested dissection stops below this many nodes
   int n_parts = 1;          // >1: top ND levels are shared, subtrees owned by ranks (power of two)
   double task_us = 6.0;     // subtrees cheaper than this become one leaf task
-  int mid_max_front = 640;  // fronts beyond LDS up to this size: one workgroup each, in place in HBM, batched per level
+  int mid_max_front = 0;    // fronts beyond LDS up to this size go to the one-workgroup in-place path (0: none,
+                            // measured slower than the batched tiled path on the 1M-edge lattice)
 };
 
 // One (block) entry of H that has to be added into a front.
