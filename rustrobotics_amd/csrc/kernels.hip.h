@@ -235,6 +235,284 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<T> a) {
   if (threadIdx.x == 0) a.chi2_partial[blockIdx.x] = tot;
 }
 
+// ------------------------------------------------------------------ SE(3)
+// NOT reference behaviour: the reference's SE(3) path is todo!() (pose_graph_optimization.rs:241,
+// 357,570).  Build-defined, g2o file convention, identical to the oracle's definition:
+//   E = Z^-1 * Xi^-1 * Xj ,  e = [ t_E ; sign(w_E) * vec(q_E) ]                (6 scalars)
+//   update  X <- X * (dt, Exp(dw)) :  t += R dt ,  q <- q (x) exp(dw)            (right increments)
+// Jacobians (cf. the structure hinted at :488-514: A = [-Ra, Ra*skew(t_b); 0, ..], B = [Re, 0; 0, ..]):
+//   B = [ R_E , 0 ; 0 , (s/2)(w_E I + [v_E]x) ]
+//   A = [ -Rz^T , Rz^T [t_C]x ; 0 , -(s/2) vec3x3( L(q_z^-1) R(q_C) ) ] ,  C = Xi^-1 Xj
+template <typename T> struct LinArgs3 {
+  int n_nodes;
+  const typename VecT<T>::V4 *pose;     // 2 per node: (tx,ty,tz,-), (qx,qy,qz,qw)
+  const int2 *e_idx;
+  const typename VecT<T>::V4 *e_meas;   // 2 per edge, same packing
+  const T *e_info;                      // 21 per edge, row-major upper triangle
+  const int64_t *e_slot;
+  const int32_t *inc_ptr, *inc_list;    // entry = edge << 2 | role
+  const int32_t *node_offset;
+  const int64_t *diag_off;
+  T *hvals;
+  T *b;
+  double *chi2_partial;
+  int anchor;
+  T lambda;
+  int write_system;
+};
+
+template <typename T> __device__ __forceinline__ void q_mul(const T a[4], const T b[4], T r[4]) {
+  r[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  r[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+  r[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+  r[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+template <typename T> __device__ __forceinline__ void q_rot(const T q[4], const T v[3], T r[3]) {
+  const T cx = q[1] * v[2] - q[2] * v[1], cy = q[2] * v[0] - q[0] * v[2], cz = q[0] * v[1] - q[1] * v[0];
+  const T dx = q[1] * cz - q[2] * cy, dy = q[2] * cx - q[0] * cz, dz = q[0] * cy - q[1] * cx;
+  r[0] = v[0] + 2 * (q[3] * cx + dx);
+  r[1] = v[1] + 2 * (q[3] * cy + dy);
+  r[2] = v[2] + 2 * (q[3] * cz + dz);
+}
+template <typename T> __device__ __forceinline__ void q_to_rot(const T q[4], T R[3][3]) {
+  const T x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0][0] = 1 - 2 * (y * y + z * z); R[0][1] = 2 * (x * y - z * w);     R[0][2] = 2 * (x * z + y * w);
+  R[1][0] = 2 * (x * y + z * w);     R[1][1] = 1 - 2 * (x * x + z * z); R[1][2] = 2 * (y * z - x * w);
+  R[2][0] = 2 * (x * z - y * w);     R[2][1] = 2 * (y * z + x * w);     R[2][2] = 1 - 2 * (x * x + y * y);
+}
+
+// error (6) and the requested Jacobian (role 0: A w.r.t. Xi, role 1: B w.r.t. Xj), 6 x 6 row-major
+template <typename T>
+__device__ void edge_linearize_3d(int role, const T ti[3], const T qi[4], const T tj[3], const T qj[4],
+                                  const T tz[3], const T qz[4], T e[6], T J[6][6]) {
+  const T qic[4] = {-qi[0], -qi[1], -qi[2], qi[3]};
+  const T qzc[4] = {-qz[0], -qz[1], -qz[2], qz[3]};
+  // C = Xi^-1 Xj
+  T d[3] = {tj[0] - ti[0], tj[1] - ti[1], tj[2] - ti[2]}, tC[3], qC[4];
+  q_rot(qic, d, tC);
+  q_mul(qic, qj, qC);
+  // E = Z^-1 C
+  T d2[3] = {tC[0] - tz[0], tC[1] - tz[1], tC[2] - tz[2]}, tE[3], qE[4];
+  q_rot(qzc, d2, tE);
+  q_mul(qzc, qC, qE);
+  const T sgn = qE[3] < 0 ? (T)-1 : (T)1;
+  e[0] = tE[0]; e[1] = tE[1]; e[2] = tE[2];
+  e[3] = sgn * qE[0]; e[4] = sgn * qE[1]; e[5] = sgn * qE[2];
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int c = 0; c < 6; c++) J[r][c] = 0;
+  if (role) {
+    T RE[3][3];
+    q_to_rot(qE, RE);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) J[r][c] = RE[r][c];
+    const T h = (T)0.5 * sgn, w = qE[3], vx = qE[0], vy = qE[1], vz = qE[2];
+    J[3][3] = h * w;   J[3][4] = -h * vz; J[3][5] = h * vy;
+    J[4][3] = h * vz;  J[4][4] = h * w;   J[4][5] = -h * vx;
+    J[5][3] = -h * vy; J[5][4] = h * vx;  J[5][5] = h * w;
+  } else {
+    T RZt[3][3];
+    q_to_rot(qzc, RZt);   // rotation of Z^-1 = Rz^T
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) J[r][c] = -RZt[r][c];
+      // Rz^T [tC]x : column k = Rz^T (tC x e_k)... [tC]x u = tC x u
+      J[r][3] = RZt[r][1] * tC[2] - RZt[r][2] * tC[1];
+      J[r][4] = RZt[r][2] * tC[0] - RZt[r][0] * tC[2];
+      J[r][5] = RZt[r][0] * tC[1] - RZt[r][1] * tC[0];
+    }
+    // d vec(q_E)/d dw_i = -(1/2) vec( qz^-1 (x) (u,0) (x) qC ), column by column
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      T u[4] = {k == 0 ? (T)1 : (T)0, k == 1 ? (T)1 : (T)0, k == 2 ? (T)1 : (T)0, (T)0}, t1[4], t2[4];
+      q_mul(qzc, u, t1);
+      q_mul(t1, qC, t2);
+      J[3][3 + k] = (T)-0.5 * sgn * t2[0];
+      J[4][3 + k] = (T)-0.5 * sgn * t2[1];
+      J[5][3 + k] = (T)-0.5 * sgn * t2[2];
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(LIN_THREADS) k_linearize_se3(LinArgs3<T> a) {
+  using V4 = typename VecT<T>::V4;
+  __shared__ double red[LIN_THREADS / 64];
+  const int gid = blockIdx.x * LIN_THREADS + threadIdx.x;
+  const int node = gid / LIN_GROUP, sub = gid % LIN_GROUP;
+  double chi = 0.0;
+  T hd[21], bv[6];   // lower triangle of the 6 x 6 diagonal block, row-major: (0,0),(1,0),(1,1),...
+#pragma unroll
+  for (int t = 0; t < 21; t++) hd[t] = 0;
+#pragma unroll
+  for (int t = 0; t < 6; t++) bv[t] = 0;
+  if (node < a.n_nodes) {
+    const V4 st = a.pose[2 * node], sq = a.pose[2 * node + 1];
+    const T ts[3] = {st.x, st.y, st.z}, qs[4] = {sq.x, sq.y, sq.z, sq.w};
+    const int q1 = a.inc_ptr[node + 1];
+    for (int q = a.inc_ptr[node] + sub; q < q1; q += LIN_GROUP) {
+      const int ent = a.inc_list[q];
+      const int k = ent >> 2, role = ent & 1;
+      const int2 ft = a.e_idx[k];
+      const int other = role ? ft.x : ft.y;
+      const V4 ot = a.pose[2 * other], oq = a.pose[2 * other + 1];
+      const T to[3] = {ot.x, ot.y, ot.z}, qo[4] = {oq.x, oq.y, oq.z, oq.w};
+      const V4 zt = a.e_meas[2 * k], zq = a.e_meas[2 * k + 1];
+      const T tz[3] = {zt.x, zt.y, zt.z}, qz[4] = {zq.x, zq.y, zq.z, zq.w};
+      T W[6][6];
+      {
+        const T *w = a.e_info + (int64_t)k * 21;
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+          for (int j = i; j < 6; j++) { W[i][j] = w[t]; W[j][i] = w[t]; t++; }
+      }
+      T e[6], J[6][6];
+      if (role) edge_linearize_3d<T>(1, to, qo, ts, qs, tz, qz, e, J);
+      else edge_linearize_3d<T>(0, ts, qs, to, qo, tz, qz, e, J);
+      T JW[6][6];   // J^T W
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          T sacc = 0;
+#pragma unroll
+          for (int r = 0; r < 6; r++) sacc += J[r][i] * W[r][j];
+          JW[i][j] = sacc;
+        }
+      if (a.write_system) {
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+          for (int j = 0; j <= i; j++) {
+            T sacc = 0;
+#pragma unroll
+            for (int r = 0; r < 6; r++) sacc += JW[i][r] * J[r][j];
+            hd[t++] += sacc;
+          }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          T sacc = 0;
+#pragma unroll
+          for (int r = 0; r < 6; r++) sacc += JW[i][r] * e[r];
+          bv[i] += sacc;
+        }
+      }
+      if (role == 0) {
+        T c2 = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          T we = 0;
+#pragma unroll
+          for (int r = 0; r < 6; r++) we += W[i][r] * e[r];
+          c2 += e[i] * we;
+        }
+        chi += (double)c2;
+        if (a.write_system) {
+          // off-diagonal block H[from rows, to cols] = A^T W B: B of the same edge
+          T e2[6], Bm[6][6];
+          edge_linearize_3d<T>(1, ts, qs, to, qo, tz, qz, e2, Bm);
+          const int64_t so = a.e_slot[k];
+          T *dst = a.hvals + (so >> 1);
+          const bool tr = so & 1;
+#pragma unroll
+          for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+              T sacc = 0;
+#pragma unroll
+              for (int r = 0; r < 6; r++) sacc += JW[i][r] * Bm[r][j];
+              dst[tr ? j * 6 + i : i * 6 + j] = sacc;
+            }
+        }
+      }
+    }
+  }
+  if (a.write_system) {
+#pragma unroll
+    for (int t = 0; t < 21; t++) hd[t] = group_sum8(hd[t]);
+#pragma unroll
+    for (int t = 0; t < 6; t++) bv[t] = group_sum8(bv[t]);
+    if (node < a.n_nodes && sub == 0) {
+      T add = a.lambda;
+      if (node == a.anchor) add += (T)10000000.0;
+      T *d = a.hvals + a.diag_off[node];
+      int t = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+          const T v = hd[t++] + (i == j ? add : (T)0);
+          d[i * 6 + j] = v;
+          d[j * 6 + i] = v;
+        }
+      T *bo = a.b + a.node_offset[node];
+#pragma unroll
+      for (int i = 0; i < 6; i++) bo[i] = -bv[i];
+    }
+  }
+  double tot = block_sum<double, LIN_THREADS>(chi, red);
+  if (threadIdx.x == 0) a.chi2_partial[blockIdx.x] = tot;
+}
+
+template <typename T> struct UpdArgs3 {
+  int n_nodes;
+  typename VecT<T>::V4 *pose;
+  const int32_t *node_pcol, *node_offset;
+  const T *x, *dx_ref_in;
+  T *dx_ref_out;
+  T sign;
+  double *norm_partial;
+};
+
+// X <- X * (dt, Exp(dw)):  t += R dt ;  q <- normalise( q (x) exp(dw) )
+template <typename T>
+__global__ void __launch_bounds__(UPD_THREADS) k_update_se3(UpdArgs3<T> a) {
+  __shared__ double red[UPD_THREADS / 64];
+  const int node = blockIdx.x * UPD_THREADS + threadIdx.x;
+  double nrm = 0.0;
+  if (node < a.n_nodes) {
+    T d[6];
+    const T *src = a.dx_ref_in ? a.dx_ref_in + a.node_offset[node] : a.x + a.node_pcol[node];
+#pragma unroll
+    for (int t = 0; t < 6; t++) d[t] = src[t];
+    if (a.dx_ref_out) {
+      T *dst = a.dx_ref_out + a.node_offset[node];
+#pragma unroll
+      for (int t = 0; t < 6; t++) dst[t] = d[t];
+    }
+#pragma unroll
+    for (int t = 0; t < 6; t++) { nrm += (double)d[t] * (double)d[t]; d[t] *= a.sign; }
+    auto pt = a.pose[2 * node], pq = a.pose[2 * node + 1];
+    const T q[4] = {pq.x, pq.y, pq.z, pq.w};
+    T rt[3];
+    q_rot(q, d, rt);
+    pt.x += rt[0]; pt.y += rt[1]; pt.z += rt[2];
+    const T th = sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+    T dq[4];
+    if (th < (T)1e-12) {
+      dq[0] = (T)0.5 * d[3]; dq[1] = (T)0.5 * d[4]; dq[2] = (T)0.5 * d[5]; dq[3] = 1;
+    } else {
+      const T sc = sin((T)0.5 * th) / th;
+      dq[0] = sc * d[3]; dq[1] = sc * d[4]; dq[2] = sc * d[5]; dq[3] = cos((T)0.5 * th);
+    }
+    T qn[4];
+    q_mul(q, dq, qn);
+    const T inv = (T)1 / sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+    pq.x = qn[0] * inv; pq.y = qn[1] * inv; pq.z = qn[2] * inv; pq.w = qn[3] * inv;
+    a.pose[2 * node] = pt;
+    a.pose[2 * node + 1] = pq;
+  }
+  double tot = block_sum<double, UPD_THREADS>(nrm, red);
+  if (threadIdx.x == 0) a.norm_partial[blockIdx.x] = tot;
+}
+
 // ------------------------------------------------------------ multifrontal
 
 // Everything a workgroup needs to know about one front, one 64-byte record

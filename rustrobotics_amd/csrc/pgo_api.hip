@@ -116,6 +116,8 @@ template <typename T> class Engine final : public EngineBase {
   DevBuf<int64_t> e_slot_, diag_off_;
   DevBuf<int32_t> inc_ptr_, inc_list_, node_offset_, node_pcol_;
   DevBuf<uint8_t> node_dim_;
+  DevBuf<T> e_info3_;   // SE(3): 21 information entries per edge
+  bool is3d_ = false;
   // numeric
   DevBuf<T> hvals_, b_, x_, dx_ref_, lvals_, uvals_;
   DevBuf<double> chi_partial_, norm_partial_, hist_;
@@ -136,40 +138,63 @@ template <typename T> class Engine final : public EngineBase {
     HIPCHK(hipHostMalloc((void **)&host_pair_, 2 * sizeof(double)));
     const int N = g.n_nodes(), E = g.n_edges();
     // ---- graph arrays
-    std::vector<V4> pose(N);
+    is3d_ = g.has_se3;
     std::vector<uint8_t> ndim(N);
-    for (int i = 0; i < N; i++) {
-      const double *s = &g.node_state[g.node_state_off[i]];
-      ndim[i] = (uint8_t)node_dim(g.node_kind[i]);
-      if (g.node_kind[i] == NODE_SE2) pose[i] = V4{(T)s[0], (T)s[1], (T)std::cos(s[2]), (T)std::sin(s[2])};
-      else pose[i] = V4{(T)s[0], (T)s[1], (T)0, (T)0};
-    }
-    pose_.upload(pose);
+    for (int i = 0; i < N; i++) ndim[i] = (uint8_t)node_dim(g.node_kind[i]);
     node_dim_.upload(ndim);
     std::vector<int2> eidx(E);
-    std::vector<V4> emeas(E), einfa(E);
-    std::vector<V2> einfb(E);
     std::vector<int64_t> eslot(E);
     for (int k = 0; k < E; k++) {
       eidx[k] = int2{g.edge_from[k], g.edge_to[k]};
-      const double *m = &g.edge_meas[g.edge_meas_off[k]];
-      const double *w = &g.edge_info[g.edge_info_off[k]];
-      if (g.edge_kind[k] == EDGE_SE2) {
-        emeas[k] = V4{(T)m[0], (T)m[1], (T)std::cos(m[2]), (T)std::sin(m[2])};
-        einfa[k] = V4{(T)w[0], (T)w[1], (T)w[2], (T)w[3]};
-        einfb[k] = V2{(T)w[4], (T)w[5]};
-      } else {
-        emeas[k] = V4{(T)m[0], (T)m[1], (T)0, (T)0};
-        einfa[k] = V4{(T)w[0], (T)w[1], (T)0, (T)w[2]};
-        einfb[k] = V2{(T)0, (T)0};
-      }
       eslot[k] = (sym.blk_off[sym.edge_slot[k]] << 1) | (sym.edge_transposed[k] ? 1 : 0);
     }
     e_idx_.upload(eidx);
-    e_meas_.upload(emeas);
-    e_info_a_.upload(einfa);
-    e_info_b_.upload(einfb);
     e_slot_.upload(eslot);
+    if (!is3d_) {
+      std::vector<V4> pose(N);
+      for (int i = 0; i < N; i++) {
+        const double *s = &g.node_state[g.node_state_off[i]];
+        if (g.node_kind[i] == NODE_SE2) pose[i] = V4{(T)s[0], (T)s[1], (T)std::cos(s[2]), (T)std::sin(s[2])};
+        else pose[i] = V4{(T)s[0], (T)s[1], (T)0, (T)0};
+      }
+      pose_.upload(pose);
+      std::vector<V4> emeas(E), einfa(E);
+      std::vector<V2> einfb(E);
+      for (int k = 0; k < E; k++) {
+        const double *m = &g.edge_meas[g.edge_meas_off[k]];
+        const double *w = &g.edge_info[g.edge_info_off[k]];
+        if (g.edge_kind[k] == EDGE_SE2) {
+          emeas[k] = V4{(T)m[0], (T)m[1], (T)std::cos(m[2]), (T)std::sin(m[2])};
+          einfa[k] = V4{(T)w[0], (T)w[1], (T)w[2], (T)w[3]};
+          einfb[k] = V2{(T)w[4], (T)w[5]};
+        } else {
+          emeas[k] = V4{(T)m[0], (T)m[1], (T)0, (T)0};
+          einfa[k] = V4{(T)w[0], (T)w[1], (T)0, (T)w[2]};
+          einfb[k] = V2{(T)0, (T)0};
+        }
+      }
+      e_meas_.upload(emeas);
+      e_info_a_.upload(einfa);
+      e_info_b_.upload(einfb);
+    } else {
+      // SE(3): (t, -), (q) pairs; quaternions normalised like UnitQuaternion::from_quaternion
+      auto pack7 = [](const double *s, V4 &a, V4 &b) {
+        const double n = std::sqrt(s[3] * s[3] + s[4] * s[4] + s[5] * s[5] + s[6] * s[6]);
+        a = V4{(T)s[0], (T)s[1], (T)s[2], (T)0};
+        b = V4{(T)(s[3] / n), (T)(s[4] / n), (T)(s[5] / n), (T)(s[6] / n)};
+      };
+      std::vector<V4> pose(2 * (size_t)N), emeas(2 * (size_t)E);
+      std::vector<T> einfo(21 * (size_t)E);
+      for (int i = 0; i < N; i++) pack7(&g.node_state[g.node_state_off[i]], pose[2 * i], pose[2 * i + 1]);
+      for (int k = 0; k < E; k++) {
+        pack7(&g.edge_meas[g.edge_meas_off[k]], emeas[2 * k], emeas[2 * k + 1]);
+        const double *w = &g.edge_info[g.edge_info_off[k]];
+        for (int t = 0; t < 21; t++) einfo[21 * (size_t)k + t] = (T)w[t];
+      }
+      pose_.upload(pose);
+      e_meas_.upload(emeas);
+      e_info3_.upload(einfo);
+    }
     std::vector<int32_t> inc(sym.inc_list.size());
     for (size_t q = 0; q < inc.size(); q++) {
       int k = sym.inc_list[q] >> 1, role = sym.inc_list[q] & 1;
@@ -375,8 +400,30 @@ template <typename T> class Engine final : public EngineBase {
 
   void launch_linearize(double lambda, int lm, int write_system) {
     pbegin();
-    hipLaunchKernelGGL(k_linearize<T>, dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_,
-                       lin_args(lambda, lm, write_system));
+    if (!is3d_) {
+      hipLaunchKernelGGL(k_linearize<T>, dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_,
+                         lin_args(lambda, lm, write_system));
+    } else {
+      LinArgs3<T> a;
+      a.n_nodes = g_.n_nodes();
+      a.pose = pose_.p;
+      a.e_idx = e_idx_.p;
+      a.e_meas = e_meas_.p;
+      a.e_info = e_info3_.p;
+      a.e_slot = e_slot_.p;
+      a.inc_ptr = inc_ptr_.p;
+      a.inc_list = inc_list_.p;
+      a.node_offset = node_offset_.p;
+      a.diag_off = diag_off_.p;
+      a.hvals = hvals_.p;
+      a.b = b_.p;
+      a.chi2_partial = chi_partial_.p;
+      a.anchor = g_.anchor_node;
+      a.lambda = lm ? (T)lambda : (T)0;
+      a.write_system = write_system;
+      hipLaunchKernelGGL(k_linearize_se3<T>, dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_, a);
+    }
+    check_launch("k_linearize");
     pend(RR_PGO_K_LINEARIZE);
   }
 
@@ -502,19 +549,34 @@ template <typename T> class Engine final : public EngineBase {
   }
 
   void launch_update(const T *dx_ref_in, double sign, bool write_ref) {
-    UpdArgs<T> u;
-    u.n_nodes = g_.n_nodes();
-    u.pose = pose_.p;
-    u.node_dim = node_dim_.p;
-    u.node_pcol = node_pcol_.p;
-    u.node_offset = node_offset_.p;
-    u.x = x_.p;
-    u.dx_ref_in = dx_ref_in;
-    u.dx_ref_out = write_ref ? dx_ref_.p : nullptr;
-    u.sign = (T)sign;
-    u.norm_partial = norm_partial_.p;
     pbegin();
-    hipLaunchKernelGGL(k_update<T>, dim3(n_upd_blocks_), dim3(UPD_THREADS), 0, stream_, u);
+    if (!is3d_) {
+      UpdArgs<T> u;
+      u.n_nodes = g_.n_nodes();
+      u.pose = pose_.p;
+      u.node_dim = node_dim_.p;
+      u.node_pcol = node_pcol_.p;
+      u.node_offset = node_offset_.p;
+      u.x = x_.p;
+      u.dx_ref_in = dx_ref_in;
+      u.dx_ref_out = write_ref ? dx_ref_.p : nullptr;
+      u.sign = (T)sign;
+      u.norm_partial = norm_partial_.p;
+      hipLaunchKernelGGL(k_update<T>, dim3(n_upd_blocks_), dim3(UPD_THREADS), 0, stream_, u);
+    } else {
+      UpdArgs3<T> u;
+      u.n_nodes = g_.n_nodes();
+      u.pose = pose_.p;
+      u.node_pcol = node_pcol_.p;
+      u.node_offset = node_offset_.p;
+      u.x = x_.p;
+      u.dx_ref_in = dx_ref_in;
+      u.dx_ref_out = write_ref ? dx_ref_.p : nullptr;
+      u.sign = (T)sign;
+      u.norm_partial = norm_partial_.p;
+      hipLaunchKernelGGL(k_update_se3<T>, dim3(n_upd_blocks_), dim3(UPD_THREADS), 0, stream_, u);
+    }
+    check_launch("k_update");
     pend(RR_PGO_K_UPDATE);
   }
 
@@ -656,10 +718,16 @@ template <typename T> class Engine final : public EngineBase {
 
   void get_state(double *out) override {
     const int N = g_.n_nodes();
-    std::vector<V4> pose((size_t)N);
+    std::vector<V4> pose(pose_.n);
     HIPCHK(hipMemcpyAsync(pose.data(), pose_.p, pose.size() * sizeof(V4), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     for (int i = 0; i < N; i++) {
+      if (is3d_) {
+        const V4 &t = pose[2 * i], &q = pose[2 * i + 1];
+        *out++ = (double)t.x; *out++ = (double)t.y; *out++ = (double)t.z;
+        *out++ = (double)q.x; *out++ = (double)q.y; *out++ = (double)q.z; *out++ = (double)q.w;
+        continue;
+      }
       *out++ = (double)pose[i].x;
       *out++ = (double)pose[i].y;
       if (g_.node_kind[i] == NODE_SE2) *out++ = std::atan2((double)pose[i].w, (double)pose[i].z);
@@ -668,9 +736,14 @@ template <typename T> class Engine final : public EngineBase {
 
   void set_state(const double *st) override {
     const int N = g_.n_nodes();
-    std::vector<V4> pose((size_t)N);
+    std::vector<V4> pose(pose_.n);
     for (int i = 0; i < N; i++) {
-      if (g_.node_kind[i] == NODE_SE2) {
+      if (is3d_) {
+        const double n = std::sqrt(st[3] * st[3] + st[4] * st[4] + st[5] * st[5] + st[6] * st[6]);
+        pose[2 * i] = V4{(T)st[0], (T)st[1], (T)st[2], (T)0};
+        pose[2 * i + 1] = V4{(T)(st[3] / n), (T)(st[4] / n), (T)(st[5] / n), (T)(st[6] / n)};
+        st += 7;
+      } else if (g_.node_kind[i] == NODE_SE2) {
         pose[i] = V4{(T)st[0], (T)st[1], (T)std::cos(st[2]), (T)std::sin(st[2])};
         st += 3;
       } else {
@@ -788,7 +861,6 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
   rr_pgo_options opt;
   if (opt_in) opt = *opt_in; else rr_pgo_default_options(&opt);
   h->opt = opt;
-  if (h->g.has_se3) throw ApiError(RR_PGO_EUNSUPPORTED, "SE(3) graphs: not implemented yet (the reference's SE(3) path is todo!())");
   if (opt.precision != RR_PGO_F64 && opt.precision != RR_PGO_F32) throw ApiError(RR_PGO_EINVAL, "bad precision");
   if (opt.world_size > 1) throw ApiError(RR_PGO_EUNSUPPORTED, "multi-GPU sharding of one graph is not implemented yet");
   // symbolic analysis (host only)
