@@ -198,15 +198,28 @@ int rr_pgo_synth_grid(int32_t width, int32_t height, int64_t n_edges_target,
                       rr_pgo_graph_desc *desc);
 void rr_pgo_synth_free(rr_pgo_synth *s);
 
-/* ---- multi-GPU exchange hooks --------------------------------- */
+/* ---- sharding ONE graph over ranks ------------------------------ */
 
-/* When opt.world_size > 1 the handle owns the edges/fronts of its rank and
- * exposes ONE contiguous device buffer holding the separator contributions that
- * must be summed over ranks once per iteration.  The host side all-reduces it
- * (RCCL, sum) between rr_pgo_stage_local and rr_pgo_stage_top. */
-int rr_pgo_exchange_buffer(rr_pgo *h, void **dev_ptr, int64_t *n_elems, int32_t *elem_size);
-int rr_pgo_stage_local(rr_pgo *h, double lambda, int lm); /* linearise + factor the rank's subtrees */
-int rr_pgo_stage_top(rr_pgo *h);                          /* after the all-reduce: top fronts, back-solve, update */
+/* A handle created with opt.world_size = P > 1 (power of two) and opt.rank = r owns the subtrees
+ * of partition r of the nested dissection; the top log2(P) separator levels are shared.  Every rank
+ * creates its handle from the SAME graph.  One Gauss-Newton iteration is three stages with two
+ * sum all-reduces (RCCL) between them, done by the caller on the two exchange buffers:
+ *
+ *   rr_pgo_stage(h, 0, lambda, lm)   linearise, factor own subtrees, publish boundary update matrices
+ *   all-reduce(sum) buffer 0         (boundary update matrices; zero where this rank owns nothing)
+ *   rr_pgo_stage(h, 1, ...)          shared top fronts (redundant), back substitution, mask the solution
+ *   all-reduce(sum) buffer 1         (the solution dx in permuted order; each entry owned by one rank)
+ *   rr_pgo_stage(h, 2, ...)          update all poses, chi2 / |dx| -> rr_pgo_stage_scalars
+ *
+ * rr_pgo_sync(h) must separate a stage from the collective that follows it (the library runs on its
+ * own stream).  Buffers are device memory of element size *elem_size (4 or 8); the caller may bind
+ * memory it allocated itself (so that its collective library can register it) with
+ * rr_pgo_set_exchange_buffer before the first stage. */
+int rr_pgo_exchange_buffer(rr_pgo *h, int32_t which, void **dev_ptr, int64_t *n_elems, int32_t *elem_size);
+int rr_pgo_set_exchange_buffer(rr_pgo *h, int32_t which, void *dev_ptr, int64_t n_elems);
+int rr_pgo_stage(rr_pgo *h, int32_t stage, double lambda, int lm);
+/* chi2 of the state BEFORE the iteration's update and |dx| of the step, valid after stage 2 */
+int rr_pgo_stage_scalars(rr_pgo *h, double *chi2, double *norm_dx);
 void *rr_pgo_stream(rr_pgo *h);                           /* hipStream_t the handle launches on */
 
 #ifdef __cplusplus

@@ -3,4 +3,5 @@
 Only what the hot path needs: `csrc/` (HIP kernels + the C ABI of librr_pgo.so)
 and `mapping` (the host-side mirror of `robotics::mapping::{PoseGraph, PoseGraphSolver}`).
 """
-from .mapping import PoseGraph, PoseGraphSolver, PoseGraphError, synthetic_grid_arrays  # noqa: F401
+from .mapping import (PoseGraph, PoseGraphSolver, PoseGraphError, synthetic_grid_arrays,  # noqa: F401
+                      sharded_gauss_newton)

@@ -23,7 +23,7 @@ EXPORTS = (
     "rr_pgo_get_graph", "rr_pgo_chi2", "rr_pgo_linearize_solve", "rr_pgo_update", "rr_pgo_optimize",
     "rr_pgo_get_state", "rr_pgo_set_state", "rr_pgo_assemble", "rr_pgo_iterate_async", "rr_pgo_sync",
     "rr_pgo_get_stats", "rr_pgo_profile", "rr_pgo_synth_grid", "rr_pgo_synth_free",
-    "rr_pgo_exchange_buffer", "rr_pgo_stage_local", "rr_pgo_stage_top", "rr_pgo_stream",
+    "rr_pgo_exchange_buffer", "rr_pgo_set_exchange_buffer", "rr_pgo_stage", "rr_pgo_stage_scalars", "rr_pgo_stream",
 )
 
 
@@ -93,9 +93,10 @@ def load():
                                     C.POINTER(GraphDesc)]
     L.rr_pgo_synth_free.argtypes = [vp]
     L.rr_pgo_synth_free.restype = None
-    L.rr_pgo_exchange_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64), ip]
-    L.rr_pgo_stage_local.argtypes = [vp, C.c_double, C.c_int]
-    L.rr_pgo_stage_top.argtypes = [vp]
+    L.rr_pgo_exchange_buffer.argtypes = [vp, C.c_int32, C.POINTER(vp), C.POINTER(C.c_int64), ip]
+    L.rr_pgo_set_exchange_buffer.argtypes = [vp, C.c_int32, vp, C.c_int64]
+    L.rr_pgo_stage.argtypes = [vp, C.c_int32, C.c_double, C.c_int]
+    L.rr_pgo_stage_scalars.argtypes = [vp, dp, dp]
     L.rr_pgo_stream.argtypes = [vp]
     L.rr_pgo_stream.restype = vp
     _lib = L

@@ -518,7 +518,8 @@ __global__ void __launch_bounds__(UPD_THREADS) k_update_se3(UpdArgs3<T> a) {
 // Everything a workgroup needs to know about one front, one 64-byte record
 // (fetched with a single scalar load instead of a chain of table lookups).
 struct SnMeta {
-  int32_t nc, nr, col0, uld;        // pivot columns, rows below, first permuted column, ld of U (0 = packed)
+  int32_t nc, nr, col0, uld;        // pivot columns, rows below, first permuted column, ld of U
+                                    // (0 = packed in uvals, > 0 = in place in lvals, < 0 = packed in xch)
   int32_t asm_begin, asm_count;     // flat assembly entries (fasm_src / fasm_dst)
   int32_t dup_begin, dup_count;     // entries of parallel-edge blocks, added serially
   int32_t child_begin, child_count; // into child_meta
@@ -528,7 +529,7 @@ struct SnMeta {
 static_assert(sizeof(SnMeta) == 64, "SnMeta must stay one 64-byte record");
 
 struct ChildMeta {
-  int64_t uoff;      // the child's update matrix (uvals when uld == 0, lvals otherwise)
+  int64_t uoff;      // the child's update matrix: uvals (uld == 0), lvals in place (uld > 0), xch (uld < 0)
   int64_t scat_ptr;  // scatter map into the parent's LDS image, -1 = use rel
   int64_t rel_ptr;
   int32_t ncu, uld;  // nrows + 1 (rhs row), leading dimension (0 = packed)
@@ -548,6 +549,7 @@ template <typename T> struct FactorArgs {
   const T *b;
   T *lvals;                 // factor panels (and whole big fronts)
   T *uvals;                 // packed update matrices
+  T *xch;                   // sharded runs: exchange buffer of the boundary fronts' packed update matrices
   T *x;                     // solution, permuted order
   int *err;
   unsigned long long *stamps;  // [S][8], diagnostic builds only (else null)
@@ -776,7 +778,7 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
   // ---- extend-add of the children's update matrices, fixed child order
   for (int q = 0; q < m.child_count; q++) {
     const ChildMeta c = a.child_meta[m.child_begin + q];
-    const T *Uc = (c.uld > 0 ? a.lvals : a.uvals) + c.uoff;
+    const T *Uc = (c.uld > 0 ? a.lvals : c.uld < 0 ? a.xch : a.uvals) + c.uoff;
     __syncthreads();
     if (!IN_PLACE && c.scat_ptr >= 0) {
       // packed child, LDS parent: one precomputed destination per element, coalesced
@@ -835,7 +837,7 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
     using V2 = typename VecT<T>::V2;
     // panel -> L storage, packed update -> U storage (both offsets are multiples of 4 scalars)
     T *Lg = a.lvals + m.loff;
-    T *Ug = a.uvals + m.uoff;
+    T *Ug = (m.uld < 0 ? a.xch : a.uvals) + m.uoff;
     if ((psize & 1) == 0) {
       const V2 *sp = reinterpret_cast<const V2 *>(P);
       V2 *dp = reinterpret_cast<V2 *>(Lg);
@@ -928,7 +930,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_extend_add(Fa
   const ChildMeta c = a.child_meta[m.child_begin + q];
   T *F = a.lvals + m.loff;
   const int M = m.nc + m.nr + 1;
-  const T *Uc = (c.uld > 0 ? a.lvals : a.uvals) + c.uoff;
+  const T *Uc = (c.uld > 0 ? a.lvals : c.uld < 0 ? a.xch : a.uvals) + c.uoff;
   const int32_t *rel = a.rel + c.rel_ptr;
   const int ncu = c.ncu;
   // one column of the child's update matrix per workgroup pass, threads over its rows
@@ -1279,6 +1281,31 @@ __global__ void __launch_bounds__(THREADS) k_solve_mid(FactorArgs<T> a) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int s = a.task_sn[a.task_ptr[a.task_begin + blockIdx.x]];
   solve_front<T, THREADS, false>(a, s, reinterpret_cast<T *>(smem_raw));
+}
+
+// ---- sharding over ranks -----------------------------------------------------------------------
+// A boundary front that lives in place in HBM publishes its update matrix by copying the lower
+// triangle of its trailing square into the exchange buffer (packed); `list` = (front, offset) pairs.
+template <typename T> __global__ void __launch_bounds__(256) k_pack_boundary(FactorArgs<T> a, const int64_t *list) {
+  const int s = (int)list[2 * blockIdx.y];
+  T *dst = a.xch + list[2 * blockIdx.y + 1];
+  const SnMeta m = a.sn_meta[s];
+  const int M = m.nc + m.nr + 1, nu = m.nr + 1;
+  const T *Usrc = a.lvals + m.uoff;   // element (nc, nc) of the front, ld M
+  for (int j = blockIdx.x; j < nu; j += gridDim.x) {
+    const int64_t o = (int64_t)j * nu - (int64_t)j * (j - 1) / 2;
+    for (int i = j + threadIdx.x; i < nu; i += 256) dst[o + (i - j)] = Usrc[(int64_t)j * M + i];
+  }
+}
+
+// Before the all-reduce of the solution: keep the columns this rank owns (rank 0 also keeps the
+// shared ones, which every rank computed identically), zero the rest.
+template <typename T> __global__ void k_mask_x(int n, T *x, const int8_t *col_owner, int rank) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const int o = col_owner[i];
+    if (!(o == rank || (o < 0 && rank == 0))) x[i] = 0;
+  }
 }
 
 // ------------------------------------------------------------------ update

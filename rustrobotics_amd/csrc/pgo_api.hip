@@ -76,6 +76,11 @@ struct EngineBase {
   virtual void profile(int iters, double *ms, int64_t *launches) = 0;
   virtual hipStream_t stream() = 0;
   virtual void read_stamps(std::vector<unsigned long long> &out) = 0;
+  // sharded runs
+  virtual void exchange_buffer(int which, void **ptr, int64_t *n, int32_t *esize) = 0;
+  virtual void set_exchange_buffer(int which, void *ptr, int64_t n) = 0;
+  virtual void stage(int stage, double lambda, int lm) = 0;
+  virtual void read_last_scalars(double *chi, double *norm) = 0;
   int n_launches_per_iter = 0;
 };
 
@@ -118,6 +123,13 @@ template <typename T> class Engine final : public EngineBase {
   DevBuf<uint8_t> node_dim_;
   DevBuf<T> e_info3_;   // SE(3): 21 information entries per edge
   bool is3d_ = false;
+  // sharding over ranks
+  int rank_ = 0, world_ = 1;
+  DevBuf<T> xch_own_;               // exchange buffer (boundary update matrices) unless the caller binds one
+  T *xch_ = nullptr, *x_ptr_ = nullptr;
+  DevBuf<int8_t> col_owner_;
+  DevBuf<int64_t> pack_list_;       // (front, exchange offset) of the in-place boundary fronts this rank owns
+  int n_pack_ = 0, pack_max_nu_ = 0;
   // numeric
   DevBuf<T> hvals_, b_, x_, dx_ref_, lvals_, uvals_;
   DevBuf<double> chi_partial_, norm_partial_, hist_;
@@ -133,7 +145,7 @@ template <typename T> class Engine final : public EngineBase {
   int host_counter_ = 0;             // mirrors the device slot counter
 
  public:
-  Engine(const HostGraph &g, const Symbolic &sym) : g_(g), sym_(sym) {
+  Engine(const HostGraph &g, const Symbolic &sym, int rank, int world) : g_(g), sym_(sym), rank_(rank), world_(world) {
     HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     HIPCHK(hipHostMalloc((void **)&host_pair_, 2 * sizeof(double)));
     const int N = g.n_nodes(), E = g.n_edges();
@@ -212,6 +224,22 @@ template <typename T> class Engine final : public EngineBase {
     x_.alloc((size_t)g.dim);
     dx_ref_.alloc((size_t)g.dim);
     b_.zero(); x_.zero(); dx_ref_.zero();
+    x_ptr_ = x_.p;
+    if (world_ > 1) {
+      xch_own_.alloc((size_t)sym.xch_elems + 4);
+      xch_own_.zero();
+      xch_ = xch_own_.p;
+      col_owner_.upload(sym.col_owner);
+      std::vector<int64_t> pl;
+      for (int f = 0; f < sym.S; f++)
+        if (sym.sn_xch_off[f] >= 0 && sym.sn_big[f] && sym.sn_owner[f] == rank_) {
+          pl.push_back(f);
+          pl.push_back(sym.sn_xch_off[f]);
+          pack_max_nu_ = std::max(pack_max_nu_, sym.sn_nrows[f] + 1);
+        }
+      n_pack_ = (int)pl.size() / 2;
+      pack_list_.upload(pl);
+    }
     lvals_.alloc((size_t)sym.l_elems + 4);
     uvals_.alloc((size_t)sym.u_elems + 4);
     lvals_.zero(); uvals_.zero();
@@ -248,6 +276,10 @@ template <typename T> class Engine final : public EngineBase {
         m.pad = 0;
         m.loff = sym.sn_loff[f];
         m.uoff = sym.sn_uoff[f];
+        if (sym.sn_xch_off[f] >= 0 && !sym.sn_big[f]) {   // LDS boundary front: writes straight into the exchange buffer
+          m.uld = -1;
+          m.uoff = sym.sn_xch_off[f];
+        }
       }
       for (size_t q = 0; q < cm.size(); q++) {
         const int c = sym.child_list[q];
@@ -256,6 +288,10 @@ template <typename T> class Engine final : public EngineBase {
         cm[q].rel_ptr = sym.rel_ptr[c];
         cm[q].ncu = sym.sn_nrows[c] + 1;
         cm[q].uld = sym.sn_uld[c];
+        if (sym.sn_xch_off[c] >= 0) {   // boundary child: every rank reads it from the (all-reduced) exchange buffer
+          cm[q].uld = -1;
+          cm[q].uoff = sym.sn_xch_off[c];
+        }
       }
       sn_meta_.upload(meta);
       child_meta_.upload(cm);
@@ -368,7 +404,8 @@ template <typename T> class Engine final : public EngineBase {
     a.b = b_.p;
     a.lvals = lvals_.p;
     a.uvals = uvals_.p;
-    a.x = x_.p;
+    a.xch = xch_;
+    a.x = x_ptr_;
     a.err = err_.p;
     a.stamps = stamps_.p;
     return a;
@@ -427,8 +464,10 @@ template <typename T> class Engine final : public EngineBase {
     pend(RR_PGO_K_LINEARIZE);
   }
 
-  void launch_factor() {
-    for (const Step &st : sym_.steps) {
+  void launch_factor() { launch_factor_range(0, sym_.steps.size()); }
+  void launch_factor_range(size_t from, size_t to) {
+    for (size_t si = from; si < to; si++) {
+      const Step &st = sym_.steps[si];
       pbegin();
       if (st.kind == STEP_TASKS) {
         const int nt = st.task_end - st.task_begin;
@@ -528,7 +567,7 @@ template <typename T> class Engine final : public EngineBase {
   int count_big_launches(const Step &st) { return launch_big_level(st, false); }
 
   void launch_solve() {
-    for (int i = (int)sym_.steps.size() - 1; i >= 0; i--) {
+    for (int i = (int)sym_.steps.size() - 1; i >= 0; i--) {   // shared top fronts first, then this rank's subtrees
       const Step &st = sym_.steps[i];
       const size_t lds = (size_t)step_solve_lds_[i] * sizeof(T);
       pbegin();
@@ -557,7 +596,7 @@ template <typename T> class Engine final : public EngineBase {
       u.node_dim = node_dim_.p;
       u.node_pcol = node_pcol_.p;
       u.node_offset = node_offset_.p;
-      u.x = x_.p;
+      u.x = x_ptr_;
       u.dx_ref_in = dx_ref_in;
       u.dx_ref_out = write_ref ? dx_ref_.p : nullptr;
       u.sign = (T)sign;
@@ -569,7 +608,7 @@ template <typename T> class Engine final : public EngineBase {
       u.pose = pose_.p;
       u.node_pcol = node_pcol_.p;
       u.node_offset = node_offset_.p;
-      u.x = x_.p;
+      u.x = x_ptr_;
       u.dx_ref_in = dx_ref_in;
       u.dx_ref_out = write_ref ? dx_ref_.p : nullptr;
       u.sign = (T)sign;
@@ -642,10 +681,11 @@ template <typename T> class Engine final : public EngineBase {
   void chi2(double *out) override { *out = chi2_now(); }
 
   void linearize_solve(double lambda, int lm, double *dx_out) override {
+    if (world_ > 1) throw ApiError(RR_PGO_EUNSUPPORTED, "sharded handle: drive it with rr_pgo_stage + all-reduces");
     launch_linearize(lambda, lm, 1);
     launch_factor();
     launch_solve();
-    hipLaunchKernelGGL(k_permute_out<T>, dim3((g_.dim + 255) / 256), dim3(256), 0, stream_, g_.dim, perm_.p, x_.p, dx_ref_.p);
+    hipLaunchKernelGGL(k_permute_out<T>, dim3((g_.dim + 255) / 256), dim3(256), 0, stream_, g_.dim, perm_.p, x_ptr_, dx_ref_.p);
     std::vector<T> tmp((size_t)g_.dim);
     HIPCHK(hipMemcpyAsync(tmp.data(), dx_ref_.p, tmp.size() * sizeof(T), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
@@ -663,6 +703,7 @@ template <typename T> class Engine final : public EngineBase {
 
   // optimize(), pose_graph_optimization.rs:247-303
   void optimize(int solver, int iters, double *errors, int *n_errors, double *norms) override {
+    if (world_ > 1) throw ApiError(RR_PGO_EUNSUPPORTED, "sharded handle: drive it with rr_pgo_stage + all-reduces");
     const double tolerance = 1e-4;  // :253
     int ne = 0;
     if (solver == RR_PGO_GAUSS_NEWTON) {
@@ -766,6 +807,7 @@ template <typename T> class Engine final : public EngineBase {
   }
 
   void iterate_async(int iters) override {
+    if (world_ > 1) throw ApiError(RR_PGO_EUNSUPPORTED, "sharded handle: drive it with rr_pgo_stage + all-reduces");
     // RR_PGO_NO_GRAPH=1: plain launches (rocprofv3 --kernel-trace crashes on replays of graphs
     // with thousands of nodes; profiling runs of the large workloads use this switch)
     static const bool no_graph = std::getenv("RR_PGO_NO_GRAPH") != nullptr;
@@ -785,6 +827,57 @@ template <typename T> class Engine final : public EngineBase {
   void read_stamps(std::vector<unsigned long long> &out) override {
     out.resize(stamps_.n);
     if (stamps_.n) HIPCHK(hipMemcpy(out.data(), stamps_.p, stamps_.n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  }
+
+  // ---- sharded execution (world_size > 1): one GN iteration in three stages, the host all-reduces
+  // (sum) buffer 0 between stage 0 and 1 and buffer 1 between stage 1 and 2.
+  void exchange_buffer(int which, void **ptr, int64_t *n, int32_t *esize) override {
+    if (world_ <= 1) throw ApiError(RR_PGO_EINVAL, "handle is not sharded (world_size <= 1)");
+    if (which == 0) { *ptr = xch_; *n = sym_.xch_elems; }
+    else if (which == 1) { *ptr = x_ptr_; *n = g_.dim; }
+    else throw ApiError(RR_PGO_EINVAL, "exchange buffer index must be 0 or 1");
+    *esize = (int32_t)sizeof(T);
+  }
+  void set_exchange_buffer(int which, void *ptr, int64_t n) override {
+    if (world_ <= 1) throw ApiError(RR_PGO_EINVAL, "handle is not sharded (world_size <= 1)");
+    if (which == 0 && n >= sym_.xch_elems) xch_ = (T *)ptr;
+    else if (which == 1 && n >= g_.dim) x_ptr_ = (T *)ptr;
+    else throw ApiError(RR_PGO_EINVAL, "exchange buffer index / size mismatch");
+  }
+  void stage(int stg, double lambda, int lm) override {
+    if (world_ <= 1) throw ApiError(RR_PGO_EINVAL, "handle is not sharded (world_size <= 1)");
+    if (stg == 0) {
+      // linearise everything (every rank holds the full state; 1M edges cost < 0.1 ms), factor this
+      // rank's subtrees, publish the boundary update matrices
+      if (sym_.xch_elems) HIPCHK(hipMemsetAsync(xch_, 0, (size_t)sym_.xch_elems * sizeof(T), stream_));
+      launch_linearize(lambda, lm, 1);
+      launch_factor_range(0, (size_t)sym_.n_local_steps);
+      if (n_pack_ > 0) {
+        hipLaunchKernelGGL(k_pack_boundary<T>, dim3(std::min(pack_max_nu_, 1024), n_pack_), dim3(256), 0, stream_,
+                           factor_args(0), pack_list_.p);
+        check_launch("k_pack_boundary");
+      }
+    } else if (stg == 1) {
+      // after the all-reduce of buffer 0: the shared top fronts (redundantly), the whole back
+      // substitution this rank can do, then mask the solution for the all-reduce of buffer 1
+      launch_factor_range((size_t)sym_.n_local_steps, sym_.steps.size());
+      launch_solve();
+      hipLaunchKernelGGL(k_mask_x<T>, dim3((g_.dim + 255) / 256), dim3(256), 0, stream_, g_.dim, x_ptr_, col_owner_.p, rank_);
+      check_launch("k_mask_x");
+    } else if (stg == 2) {
+      // after the all-reduce of buffer 1: every rank applies the full step and reduces chi2 / |dx|
+      launch_update(nullptr, 1.0, true);
+      launch_finalize(true, true, false);
+    } else {
+      throw ApiError(RR_PGO_EINVAL, "stage must be 0, 1 or 2");
+    }
+  }
+  void read_last_scalars(double *chi, double *norm) override {
+    int c = 0;
+    HIPCHK(hipMemcpyAsync(&c, counter_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    read_slot(c, chi, norm);
+    check_device_error();
   }
 
   void profile(int iters, double *ms, int64_t *launches) override {
@@ -862,11 +955,19 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
   if (opt_in) opt = *opt_in; else rr_pgo_default_options(&opt);
   h->opt = opt;
   if (opt.precision != RR_PGO_F64 && opt.precision != RR_PGO_F32) throw ApiError(RR_PGO_EINVAL, "bad precision");
-  if (opt.world_size > 1) throw ApiError(RR_PGO_EUNSUPPORTED, "multi-GPU sharding of one graph is not implemented yet");
+  if (opt.world_size > 1) {
+    if (opt.world_size & (opt.world_size - 1)) throw ApiError(RR_PGO_EINVAL, "world_size must be a power of two");
+    if (opt.rank < 0 || opt.rank >= opt.world_size) throw ApiError(RR_PGO_EINVAL, "rank out of range");
+  }
   // symbolic analysis (host only)
   SymbolicOptions so;
   so.lds_budget_elems = opt.precision == RR_PGO_F64 ? 19000 : 38000;
   so.nd_leaf = h->g.n_nodes() <= 6000 ? (1 << 30) : 64;
+  if (opt.world_size > 1) {   // sharding needs the nested-dissection top levels
+    so.n_parts = opt.world_size;
+    so.my_part = opt.rank;
+    so.nd_leaf = 64;
+  }
   if (const char *e = std::getenv("RR_PGO_MID_MAX")) so.mid_max_front = std::atoi(e);   // tuning knob
   double t0 = now_ms();
   std::string err = analyze(h->g, so, h->sym);
@@ -880,8 +981,9 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
     if (opt.device >= ndev) throw ApiError(RR_PGO_EINVAL, "device ordinal out of range");
     HIPCHK(hipSetDevice(opt.device));
   }
-  if (opt.precision == RR_PGO_F64) h->engine = std::make_unique<Engine<double>>(h->g, h->sym);
-  else h->engine = std::make_unique<Engine<float>>(h->g, h->sym);
+  const int wr = opt.world_size > 1 ? opt.rank : 0, ww = opt.world_size > 1 ? opt.world_size : 1;
+  if (opt.precision == RR_PGO_F64) h->engine = std::make_unique<Engine<double>>(h->g, h->sym, wr, ww);
+  else h->engine = std::make_unique<Engine<float>>(h->g, h->sym, wr, ww);
   // stats
   rr_pgo_stats &s = h->stats;
   std::memset(&s, 0, sizeof s);
@@ -1097,17 +1199,21 @@ int rr_pgo_synth_grid(int32_t width, int32_t height, int64_t n_edges_target, uin
 
 void rr_pgo_synth_free(rr_pgo_synth *s) { delete s; }
 
-int rr_pgo_exchange_buffer(rr_pgo *, void **, int64_t *, int32_t *) {
-  g_last_error = "multi-GPU sharding of one graph is not implemented yet";
-  return RR_PGO_EUNSUPPORTED;
+int rr_pgo_exchange_buffer(rr_pgo *h, int32_t which, void **dev_ptr, int64_t *n_elems, int32_t *elem_size) {
+  if (!h || !dev_ptr || !n_elems || !elem_size) { g_last_error = "null argument"; return RR_PGO_EINVAL; }
+  return guarded([&] { h->engine->exchange_buffer(which, dev_ptr, n_elems, elem_size); });
 }
-int rr_pgo_stage_local(rr_pgo *, double, int) {
-  g_last_error = "multi-GPU sharding of one graph is not implemented yet";
-  return RR_PGO_EUNSUPPORTED;
+int rr_pgo_set_exchange_buffer(rr_pgo *h, int32_t which, void *dev_ptr, int64_t n_elems) {
+  if (!h || !dev_ptr) { g_last_error = "null argument"; return RR_PGO_EINVAL; }
+  return guarded([&] { h->engine->set_exchange_buffer(which, dev_ptr, n_elems); });
 }
-int rr_pgo_stage_top(rr_pgo *) {
-  g_last_error = "multi-GPU sharding of one graph is not implemented yet";
-  return RR_PGO_EUNSUPPORTED;
+int rr_pgo_stage(rr_pgo *h, int32_t stage, double lambda, int lm) {
+  if (!h) { g_last_error = "null argument"; return RR_PGO_EINVAL; }
+  return guarded([&] { h->engine->stage(stage, lambda, lm); });
+}
+int rr_pgo_stage_scalars(rr_pgo *h, double *chi2, double *norm_dx) {
+  if (!h || !chi2 || !norm_dx) { g_last_error = "null argument"; return RR_PGO_EINVAL; }
+  return guarded([&] { h->engine->read_last_scalars(chi2, norm_dx); });
 }
 #ifdef RRPGO_STAMPS
 // Diagnostic build only: per-supernode phase stamps of the last factorisation

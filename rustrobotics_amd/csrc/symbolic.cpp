@@ -676,6 +676,26 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     sym.u_elems = uo;
   }
 
+  // ---- 6b. sharding: boundary fronts and column owners
+  sym.sn_xch_off.assign(S, -1);
+  sym.col_owner.assign(g.dim, 0);
+  if (opt.n_parts > 1) {
+    int64_t xo = 0;
+    for (int f = 0; f < S; f++) {
+      for (int c = 0; c < sym.sn_ncols[f]; c++) sym.col_owner[sym.sn_col0[f] + c] = (int8_t)sym.sn_owner[f];
+      const int p = sym.sn_parent[f];
+      if (sym.sn_owner[f] >= 0 && p >= 0 && sym.sn_owner[p] < 0) {
+        sym.sn_xch_off[f] = xo;
+        xo += (int64_t)(sym.sn_nrows[f] + 1) * (sym.sn_nrows[f] + 2) / 2;
+        xo = (xo + 3) & ~(int64_t)3;
+      }
+      if (sym.sn_owner[f] >= 0 && p >= 0 && sym.sn_owner[p] >= 0 && sym.sn_owner[p] != sym.sn_owner[f])
+        return "internal: a front's parent belongs to another rank";
+      if (sym.sn_owner[f] < 0 && p >= 0 && sym.sn_owner[p] >= 0) return "internal: shared front below an owned one";
+    }
+    sym.xch_elems = xo;
+  }
+
   // ---- 7. H block structure + assembly lists --------------------------------
   sym.diag_off.resize(N);
   int64_t hv = 0;
@@ -896,72 +916,61 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     }
     int maxlvl = 0;
     for (int f = 0; f < S; f++) maxlvl = std::max(maxlvl, (int)lvl[f]);
-    // emit steps
+    // emit steps.  Sharded: two passes -- this rank's own fronts (all levels), then the shared ones.
     sym.task_ptr.assign(1, 0);
     double crit = 0.0;
-    for (int L = 0; L <= maxlvl; L++) {
-      Step st{};
-      st.kind = STEP_TASKS;
-      st.task_begin = (int)sym.task_ptr.size() - 1;
-      double worst = 0.0;
-      for (size_t t = 0; t < tasks.size(); t++) {
-        if (task_level[t] != L || tasks[t].empty()) continue;
-        double tc = 0.0;
-        for (int f : tasks[t]) {
-          sym.task_sn.push_back(f);
-          tc += cost[f];
-          st.max_front = std::max(st.max_front, sym.sn_ncols[f] + sym.sn_nrows[f] + 1);
-          st.max_lds_elems = std::max<int64_t>(st.max_lds_elems, lds_elems(sym.sn_ncols[f], sym.sn_nrows[f]));
-        }
-        sym.task_ptr.push_back((int)sym.task_sn.size());
-        worst = std::max(worst, tc);
-      }
-      st.task_end = (int)sym.task_ptr.size() - 1;
-      st.threads = st.max_front <= 20 ? 64 : st.max_front <= 48 ? 128 : st.max_front <= 96 ? 256 : 512;
-      if (st.task_end > st.task_begin) {
-        sym.steps.push_back(st);
-        crit += 1.5 + worst;
-      }
-      // fronts beyond LDS at this level: the mid-size ones as one batched launch ...
-      {
-        Step md{};
-        md.kind = STEP_MID;
-        md.task_begin = (int)sym.task_ptr.size() - 1;
+    const int npass = opt.n_parts > 1 ? 2 : 1;
+    for (int pass = 0; pass < npass; pass++) {
+      auto wanted = [&](int f) {
+        if (opt.n_parts <= 1) return true;
+        return pass == 0 ? sym.sn_owner[f] == opt.my_part : sym.sn_owner[f] < 0;
+      };
+      for (int L = 0; L <= maxlvl; L++) {
+        Step st{};
+        st.kind = STEP_TASKS;
+        st.task_begin = (int)sym.task_ptr.size() - 1;
         double worst = 0.0;
-        for (int f = 0; f < S; f++)
-          if (sym.sn_big[f] && !sym.sn_huge[f] && lvl[f] == L) {
+        for (size_t t = 0; t < tasks.size(); t++) {
+          if (task_level[t] != L || tasks[t].empty() || !wanted(tasks[t][0])) continue;
+          double tc = 0.0;
+          for (int f : tasks[t]) {
             sym.task_sn.push_back(f);
-            sym.task_ptr.push_back((int)sym.task_sn.size());
-            md.max_front = std::max(md.max_front, sym.sn_ncols[f] + sym.sn_nrows[f] + 1);
-            worst = std::max(worst, cost[f]);
+            tc += cost[f];
+            st.max_front = std::max(st.max_front, sym.sn_ncols[f] + sym.sn_nrows[f] + 1);
+            st.max_lds_elems = std::max<int64_t>(st.max_lds_elems, lds_elems(sym.sn_ncols[f], sym.sn_nrows[f]));
           }
-        md.task_end = (int)sym.task_ptr.size() - 1;
-        md.threads = 1024;
-        if (md.task_end > md.task_begin) {
-          sym.steps.push_back(md);
+          sym.task_ptr.push_back((int)sym.task_sn.size());
+          worst = std::max(worst, tc);
+        }
+        st.task_end = (int)sym.task_ptr.size() - 1;
+        st.threads = st.max_front <= 20 ? 64 : st.max_front <= 48 ? 128 : st.max_front <= 96 ? 256 : 512;
+        if (st.task_end > st.task_begin) {
+          sym.steps.push_back(st);
           crit += 1.5 + worst;
         }
-      }
-      // ... the huge ones as one batch of tiled launches (grid z = front)
-      {
-        Step b{};
-        b.kind = STEP_BIG;
-        b.sn = -1;
-        b.task_begin = (int)sym.task_ptr.size() - 1;
-        double worst = 0.0;
-        for (int f = 0; f < S; f++)
-          if (sym.sn_huge[f] && lvl[f] == L) {
-            sym.task_sn.push_back(f);
-            sym.task_ptr.push_back((int)sym.task_sn.size());
-            b.max_front = std::max(b.max_front, sym.sn_ncols[f] + sym.sn_nrows[f] + 1);
-            worst = std::max(worst, cost[f]);
+        // fronts beyond LDS at this level: optional one-workgroup class, then the tiled batch
+        for (int cls = 0; cls < 2; cls++) {
+          Step b{};
+          b.kind = cls == 0 ? STEP_MID : STEP_BIG;
+          b.sn = -1;
+          b.task_begin = (int)sym.task_ptr.size() - 1;
+          double w2 = 0.0;
+          for (int f = 0; f < S; f++)
+            if (sym.sn_big[f] && (sym.sn_huge[f] ? 1 : 0) == cls && lvl[f] == L && wanted(f)) {
+              sym.task_sn.push_back(f);
+              sym.task_ptr.push_back((int)sym.task_sn.size());
+              b.max_front = std::max(b.max_front, sym.sn_ncols[f] + sym.sn_nrows[f] + 1);
+              w2 = std::max(w2, cost[f]);
+            }
+          b.task_end = (int)sym.task_ptr.size() - 1;
+          b.threads = 1024;
+          if (b.task_end > b.task_begin) {
+            sym.steps.push_back(b);
+            crit += 1.5 + w2;
           }
-        b.task_end = (int)sym.task_ptr.size() - 1;
-        if (b.task_end > b.task_begin) {
-          sym.steps.push_back(b);
-          crit += worst;
         }
       }
+      if (pass == 0) sym.n_local_steps = opt.n_parts > 1 ? (int)sym.steps.size() : 0;
     }
     sym.est_critical_us = crit;
   }

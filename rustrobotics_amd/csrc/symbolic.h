@@ -23,6 +23,7 @@ struct SymbolicOptions {
   int64_t lds_budget_elems = 19000;  // LDS scalars one workgroup may use for a front (panel + packed update)
   int nd_leaf = 40;         // nested dissection stops below this many nodes
   int n_parts = 1;          // >1: top ND levels are shared, subtrees owned by ranks (power of two)
+  int my_part = 0;          // with n_parts > 1: the rank whose schedule is emitted (own subtrees, then shared top)
   double task_us = 6.0;     // subtrees cheaper than this become one leaf task
   int mid_max_front = 0;    // fronts beyond LDS up to this size go to the one-workgroup in-place path (0: none,
                             // measured slower than the batched tiled path on the 1M-edge lattice)
@@ -98,6 +99,13 @@ struct Symbolic {
   // ---- schedule
   std::vector<int32_t> task_ptr, task_sn;
   std::vector<Step> steps;           // factor order; the back-solve walks it backwards
+  // ---- sharding over ranks (n_parts > 1): steps [0, n_local_steps) are this rank's own subtrees,
+  // the rest are the shared top fronts every rank factors after the exchange.  Boundary fronts
+  // (owned, parent shared) publish their update matrix, packed, in the exchange buffer.
+  int32_t n_local_steps = 0;
+  std::vector<int64_t> sn_xch_off;   // per supernode: offset in the exchange buffer, -1 = not a boundary front
+  int64_t xch_elems = 0;
+  std::vector<int8_t> col_owner;     // per permuted scalar column: owner rank, -1 = shared
   // ---- stats
   int64_t nnz_l_blocks = 0;          // node-level nonzero blocks of L (no padding)
   int64_t factor_flops = 0;

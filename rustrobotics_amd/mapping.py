@@ -67,7 +67,8 @@ class PoseGraph:
 
     @classmethod
     def from_arrays(cls, node_kind, node_state, edge_kind, edge_from, edge_to, edge_meas, edge_info,
-                    solver=PoseGraphSolver.GaussNewton, precision="f64", device=-1, node_id=None):
+                    solver=PoseGraphSolver.GaussNewton, precision="f64", device=-1, node_id=None,
+                    rank=0, world_size=1):
         L = _lib.load()
         keep = [np.ascontiguousarray(node_kind, np.int32), np.ascontiguousarray(node_state, np.float64),
                 np.ascontiguousarray(edge_kind, np.int32), np.ascontiguousarray(edge_from, np.int32),
@@ -92,6 +93,7 @@ class PoseGraph:
         opt.precision = _lib.F64 if precision == "f64" else _lib.F32
         opt.device = device
         opt.solver = solver.value
+        opt.rank, opt.world_size = rank, world_size
         h = C.c_void_p()
         _check(L.rr_pgo_create(C.byref(d), C.byref(opt), C.byref(h)))
         return cls(h, solver)
@@ -104,8 +106,8 @@ class PoseGraph:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
-            _lib.load().rr_pgo_destroy(h)
+        if h and _lib is not None and getattr(_lib, "_lib", None) is not None:   # not during interpreter teardown
+            _lib._lib.rr_pgo_destroy(h)
             self._h = None
 
     # -- fields -------------------------------------------------------------------
@@ -206,6 +208,25 @@ class PoseGraph:
                                  bo.ctypes.data_as(C.POINTER(C.c_int64)), _dp(vals), C.byref(nv), _dp(b)))
         return br, bc, bo, vals, b
 
+    # -- sharding ONE graph over ranks (include/rr_pgo.h, "sharding") --------------------------------
+    def exchange_info(self, which):
+        """(device pointer, element count, element size) of exchange buffer `which` (0: boundary update
+        matrices, 1: the solution dx)."""
+        ptr, n, es = C.c_void_p(), C.c_int64(), C.c_int32()
+        _check(_lib.load().rr_pgo_exchange_buffer(self._h, which, C.byref(ptr), C.byref(n), C.byref(es)))
+        return ptr.value, n.value, es.value
+
+    def bind_exchange(self, which, dev_ptr, n_elems):
+        _check(_lib.load().rr_pgo_set_exchange_buffer(self._h, which, C.c_void_p(dev_ptr), n_elems))
+
+    def stage(self, stage, lam=0.0, lm=False):
+        _check(_lib.load().rr_pgo_stage(self._h, stage, lam, int(lm)))
+
+    def stage_scalars(self):
+        chi, nrm = C.c_double(), C.c_double()
+        _check(_lib.load().rr_pgo_stage_scalars(self._h, C.byref(chi), C.byref(nrm)))
+        return chi.value, nrm.value
+
     def iterate_async(self, iters):
         _check(_lib.load().rr_pgo_iterate_async(self._h, iters))
 
@@ -222,6 +243,35 @@ class PoseGraph:
         n = np.zeros(_lib.NUM_KCLASS, np.int64)
         _check(_lib.load().rr_pgo_profile(self._h, iters, _dp(ms), n.ctypes.data_as(C.POINTER(C.c_int64))))
         return {name: (float(ms[i]), int(n[i])) for i, name in enumerate(_lib.KCLASS_NAMES)}
+
+
+def sharded_gauss_newton(shards, num_iterations, allreduce, tolerance=1e-4):
+    """`PoseGraph::optimize` (GN) on ONE graph sharded over ranks.
+
+    shards    : the handles this process drives -- [own handle] under torch.distributed (one rank per
+                GPU), or all P handles when P ranks are emulated in one process (tests).
+    allreduce : callable(which) doing the SUM all-reduce of exchange buffer `which` over all ranks
+                (RCCL through torch.distributed in production); called after every shard has been
+                synchronised.
+    Returns the chi2 list with the reference's semantics (1 + iterations entries)."""
+    errors = []
+    for _ in range(num_iterations):
+        for stage in (0, 1):
+            for g in shards:
+                g.stage(stage)
+            for g in shards:
+                g.sync()
+            allreduce(stage)
+        for g in shards:
+            g.stage(2)
+        chi, nrm = shards[0].stage_scalars()
+        for g in shards[1:]:
+            g.sync()
+        errors.append(chi)
+        if nrm < tolerance:
+            break
+    errors.append(shards[0].global_error())
+    return errors
 
 
 def synthetic_grid_arrays(width, height, n_edges=0, seed_meas=42, seed_init=43):

@@ -72,32 +72,53 @@ int main(int argc, char **argv) {
   }
   for (int i = 0; i < dim; i++) b[i] = U(rng);
 
-  // ---- schedule check + factor order
+  // ---- schedule check + factor order.  Sharded (PARTS > 1): every rank's schedule is analysed;
+  // all ranks' local steps run first (in rank order, they are independent), then the shared top
+  // steps once -- which is what the all-reduce of the boundary update matrices makes possible.
   std::vector<int> done_step(S, -1), order;
   std::vector<int> pos_in_task(S, -1);
-  int n_sched = 0;
-  for (size_t si = 0; si < y.steps.size(); si++) {
-    const Step &st = y.steps[si];
-    auto check_children = [&](int s, int task) {
-      for (int q = y.child_ptr[s]; q < y.child_ptr[s + 1]; q++) {
-        int c = y.child_list[q];
-        bool ok = done_step[c] >= 0 && (done_step[c] < (int)si || (task >= 0 && pos_in_task[c] == task));
-        if (!ok) { printf("FAIL: supernode %d scheduled before its child %d\n", s, c); exit(1); }
-      }
-    };
-    for (int t = st.task_begin; t < st.task_end; t++)
-      for (int q = y.task_ptr[t]; q < y.task_ptr[t + 1]; q++) {
-        int s = y.task_sn[q];
-        if (st.kind == STEP_TASKS && y.sn_big[s]) { printf("FAIL: big front %d inside an LDS task\n", s); return 1; }
-        if (st.kind != STEP_TASKS && y.task_ptr[t + 1] - y.task_ptr[t] != 1) { printf("FAIL: bad batch task %d\n", t); return 1; }
-        if (st.kind == STEP_MID && (!y.sn_big[s] || y.sn_huge[s])) { printf("FAIL: bad mid front %d\n", s); return 1; }
-        if (st.kind == STEP_BIG && !y.sn_huge[s]) { printf("FAIL: STEP_BIG on a front that is not huge\n"); return 1; }
-        check_children(s, st.kind == STEP_TASKS ? t : -1);
-        done_step[s] = (int)si;
-        pos_in_task[s] = t;
-        order.push_back(s);
-        n_sched++;
-      }
+  int n_sched = 0, step_counter = 0;
+  auto run_steps = [&](const Symbolic &ys, size_t from, size_t to) {
+    for (size_t si = from; si < to; si++, step_counter++) {
+      const Step &st = ys.steps[si];
+      for (int t = st.task_begin; t < st.task_end; t++)
+        for (int q = ys.task_ptr[t]; q < ys.task_ptr[t + 1]; q++) {
+          int s = ys.task_sn[q];
+          if (st.kind == STEP_TASKS && ys.sn_big[s]) { printf("FAIL: big front %d inside an LDS task\n", s); exit(1); }
+          if (st.kind != STEP_TASKS && ys.task_ptr[t + 1] - ys.task_ptr[t] != 1) { printf("FAIL: bad batch task %d\n", t); exit(1); }
+          if (st.kind == STEP_MID && (!ys.sn_big[s] || ys.sn_huge[s])) { printf("FAIL: bad mid front %d\n", s); exit(1); }
+          if (st.kind == STEP_BIG && !ys.sn_huge[s]) { printf("FAIL: STEP_BIG on a front that is not huge\n"); exit(1); }
+          if (done_step[s] >= 0) { printf("FAIL: supernode %d scheduled twice\n", s); exit(1); }
+          for (int cq = ys.child_ptr[s]; cq < ys.child_ptr[s + 1]; cq++) {
+            int c = ys.child_list[cq];
+            bool ok = done_step[c] >= 0 && (done_step[c] < step_counter || (st.kind == STEP_TASKS && pos_in_task[c] == t + 1000000 * (int)(&ys != &y)));
+            if (!ok) { printf("FAIL: supernode %d scheduled before its child %d\n", s, c); exit(1); }
+          }
+          done_step[s] = step_counter;
+          pos_in_task[s] = t + 1000000 * (int)(&ys != &y);
+          order.push_back(s);
+          n_sched++;
+        }
+    }
+  };
+  if (opt.n_parts <= 1) {
+    run_steps(y, 0, y.steps.size());
+  } else {
+    for (int p = 0; p < opt.n_parts; p++) {
+      SymbolicOptions op = opt;
+      op.my_part = p;
+      Symbolic yp;
+      std::string ep = analyze(g, op, yp);
+      if (!ep.empty()) { printf("analyze error (rank %d): %s\n", p, ep.c_str()); return 2; }
+      if (yp.l_elems != y.l_elems || yp.xch_elems != y.xch_elems || yp.S != y.S) { printf("FAIL: rank layouts differ\n"); return 1; }
+      for (int s = 0; s < S; s++)
+        if (yp.sn_owner[s] != y.sn_owner[s]) { printf("FAIL: owners differ between ranks\n"); return 1; }
+      run_steps(yp, 0, (size_t)yp.n_local_steps);
+      if (p == opt.n_parts - 1) run_steps(yp, (size_t)yp.n_local_steps, yp.steps.size());
+    }
+    int nb = 0;
+    for (int s = 0; s < S; s++) nb += y.sn_xch_off[s] >= 0;
+    printf("sharded over %d ranks: %d boundary fronts, exchange buffer %lld scalars\n", opt.n_parts, nb, (long long)y.xch_elems);
   }
   if (n_sched != S) { printf("FAIL: schedule covers %d of %d supernodes\n", n_sched, S); return 1; }
 

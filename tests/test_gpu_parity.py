@@ -342,3 +342,52 @@ def test_se3_update_matches_oracle(api, oracle):
     g.update_nodes(dx); o.update_nodes(dx)
     assert _quat_state_diff(g.state(), o.state()) <= 1e-13
     assert abs(g.global_error() - o.global_error()) <= 1e-11 * o.global_error()
+
+
+# ---- sharding ONE graph over ranks, P ranks emulated on one GPU --------------------------------
+
+def _emulated_allreduce(torch, bufs):
+    def allreduce(which):
+        total = bufs[which][0].clone()
+        for t in bufs[which][1:]:
+            total += t
+        for t in bufs[which]:
+            t.copy_(total)
+        torch.cuda.synchronize()
+    return allreduce
+
+
+@pytest.mark.parametrize("P,precision", [(2, "f64"), (4, "f64"), (4, "f32")])
+def test_sharded_graph_matches_unsharded(api, oracle, P, precision):
+    """One lattice sharded over P ranks (own subtrees per rank, shared top separators, two sum
+    all-reduces per iteration -- here emulated by adding the ranks' exchange buffers on one GPU, with
+    caller-owned torch buffers bound through rr_pgo_set_exchange_buffer like bench.py --shard does):
+    same chi2 trajectory and poses as the unsharded handle / the oracle."""
+    import torch
+    from rustrobotics_amd import synthetic_grid_arrays, sharded_gauss_newton
+    arrays = synthetic_grid_arrays(60, 40)
+    shards = [api[0].from_arrays(*arrays, precision=precision, rank=r, world_size=P) for r in range(P)]
+    dt = torch.float64 if precision == "f64" else torch.float32
+    bufs = {0: [], 1: []}
+    for g in shards:
+        for which in (0, 1):
+            _, n, es = g.exchange_info(which)
+            assert es == (8 if precision == "f64" else 4)
+            t = torch.zeros(max(n, 1), dtype=dt, device="cuda")
+            g.bind_exchange(which, t.data_ptr(), t.numel())
+            bufs[which].append(t)
+    assert shards[0].exchange_info(0)[1] > 0
+    errors = sharded_gauss_newton(shards, 10, _emulated_allreduce(torch, bufs))
+    ref = api[0].from_arrays(*arrays, precision=precision)
+    eref = ref.optimize(10)
+    if precision == "f64":
+        assert len(errors) == len(eref)
+        np.testing.assert_allclose(errors, eref, rtol=1e-9)
+        eo = oracle.from_arrays(*arrays).optimize(10)
+        np.testing.assert_allclose(errors, eo, rtol=1e-9)
+        for g in shards:      # every rank ends with the full, identical state
+            assert _state_diff_se2(g.state(), ref.state()) <= 1e-9
+    else:
+        assert abs(errors[0] - eref[0]) <= 1e-6 * eref[0]
+        assert abs(min(errors) - min(eref)) <= 1e-5 * min(eref)
+        assert _state_diff_se2(shards[0].state(), shards[-1].state()) <= 1e-6   # ranks agree with each other
