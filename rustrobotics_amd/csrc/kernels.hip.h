@@ -885,9 +885,16 @@ __global__ void __launch_bounds__(THREADS) k_factor_mid(FactorArgs<T> a) {
 //   per 128-column super-panel: 4 x { k_big_diag (32-col diagonal block), k_big_trsm (rows below),
 //                                     k_big_update mode 0 (rest of the super-panel, K = 32) }
 //                               then  k_big_update mode 1 (everything right of it, K = 128)
-constexpr int BIG_NB = 32;           // pivot block width
-constexpr int BIG_SUPER = 128;       // super-panel width = K of the big trailing update
-constexpr int BIG_PANEL_ROWS = 224;  // rows below the diagonal block handled by one workgroup
+#ifndef RRPGO_BIG_NB
+#define RRPGO_BIG_NB 32
+#endif
+#ifndef RRPGO_BIG_SUPER
+#define RRPGO_BIG_SUPER 128
+#endif
+constexpr int BIG_NB = RRPGO_BIG_NB;        // pivot block width
+constexpr int BIG_SUPER = RRPGO_BIG_SUPER;  // super-panel width = K of the big trailing update
+constexpr int BIG_PANEL_ROWS = 256;         // rows below the diagonal block handled by one workgroup
+constexpr int BIG_NB2_PER_THREAD = (BIG_NB * BIG_NB + 255) / 256;
 
 template <typename T> __device__ __forceinline__ int big_front(const FactorArgs<T> &a, int slot) {
   return a.task_sn[a.task_ptr[a.task_begin + slot]];
@@ -956,19 +963,19 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_diag(FactorAr
   T *F = a.lvals + m.loff;
   const int M = m.nc + m.nr + 1;
   const int tid = threadIdx.x;
-  T dv[4];
+  T dv[BIG_NB2_PER_THREAD];
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
+  for (int q = 0; q < BIG_NB2_PER_THREAD; q++) {
     const int t = tid + 256 * q, c = t / nb, r = t - c * nb;
     dv[q] = t < nb * nb ? F[(int64_t)(kb + c) * M + kb + r] : (T)0;
   }
 #pragma unroll
-  for (int q = 0; q < 4; q++)
+  for (int q = 0; q < BIG_NB2_PER_THREAD; q++)
     if (tid + 256 * q < nb * nb) Pl[tid + 256 * q] = dv[q];
   __syncthreads();
   panel_factor<T, 256>(Pl, nb, nb, a.err, dinv);
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
+  for (int q = 0; q < BIG_NB2_PER_THREAD; q++) {
     const int t = tid + 256 * q, c = t / nb, r = t - c * nb;
     if (t < nb * nb && r >= c) F[(int64_t)(kb + c) * M + kb + r] = Pl[t];
   }
@@ -987,13 +994,13 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_trsm(FactorAr
   const int r0 = kb + nb + blockIdx.x * BIG_PANEL_ROWS;
   if (r0 >= M) return;
   const int row = r0 + tid;
-  const bool active = tid < BIG_PANEL_ROWS && row < M;
+  const bool active = row < M;
   T *src = F + (int64_t)kb * M;
   T xr[BIG_NB];
 #pragma unroll
   for (int c = 0; c < BIG_NB; c++) xr[c] = (c < nb && active) ? src[(int64_t)c * M + row] : (T)0;
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
+  for (int q = 0; q < BIG_NB2_PER_THREAD; q++) {
     // L11(r, c), r >= c, stored at [c * (BIG_NB+1) + r]; diagonal as reciprocal
     const int t = tid + 256 * q, c = t / nb, r = t - c * nb;
     if (t < nb * nb && r >= c) {
@@ -1021,10 +1028,17 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_trsm(FactorAr
 //   mode 0: after the 32-column panel at kb: the rest of its 128-column super-panel (K = 32)
 //   mode 1: after the super-panel at kb: everything to its right, Schur complement included (K <= 128)
 // One 128 x 128 tile per workgroup, 64 x 64 per wave as 4 x 4 MFMA 16x16x4 tiles (16 independent
-// accumulators per wave); operands straight from L2 (the block column is small and shared).
+// accumulators per wave).  The two 128-row operand strips are staged through LDS in k-chunks of
+// 32 (f32) / 16 (f64), double buffered: the global loads of chunk c+1 are in flight while the
+// MFMAs of chunk c run; one barrier per chunk.
 template <typename T> __global__ void __launch_bounds__(256) k_big_update(FactorArgs<T> a, int kb, int mode) {
   using MM = Mfma16<T>;
-  if (blockIdx.x < blockIdx.y) return;   // lower triangle of tiles only
+  constexpr int KC = sizeof(T) == 4 ? 32 : 16;   // k-chunk staged in LDS (73.7 KB for either precision)
+  constexpr int LDT = 128 + 16;                  // padded row: the four k-rows a wave reads hit disjoint banks
+  constexpr int NLD = KC / 2;                    // global loads per operand per thread per chunk
+  __shared__ T As[2][KC][LDT];                   // As[buf][k][i] =  F(I0 + i, k)
+  __shared__ T Bs[2][KC][LDT];                   // Bs[buf][k][j] = -F(J0 + j, k)
+  if (blockIdx.x < blockIdx.y) return;           // lower triangle of tiles only
   const SnMeta m = a.sn_meta[big_front(a, blockIdx.z)];
   if (kb >= m.nc) return;
   const int M = m.nc + m.nr + 1;
@@ -1033,13 +1047,15 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_update(Factor
   const int ke = mode == 0 ? min(kb + BIG_NB, m.nc) : super_end;
   const int t0 = ke;
   const int jmax = mode == 0 ? super_end : M;
-  if (t0 >= jmax) return;
+  const int I0 = t0 + blockIdx.x * 128, J0 = t0 + blockIdx.y * 128;
+  if (t0 >= jmax || I0 >= M || J0 >= jmax) return;   // uniform over the workgroup
   T *F = a.lvals + m.loff;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i0 = t0 + blockIdx.x * 128 + (wave & 1) * 64;
-  const int j0 = t0 + blockIdx.y * 128 + (wave >> 1) * 64;
-  if (i0 >= M || j0 >= jmax || i0 + 64 <= j0) return;   // nothing of this wave tile is wanted
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
+  const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
+  const int i0 = I0 + wi, j0 = J0 + wj;
+  const bool wave_active = i0 < M && j0 < jmax && i0 + 64 > j0;
+  // ---- accumulators = current C tile
   typename MM::Acc acc[4][4];
 #pragma unroll
   for (int ib = 0; ib < 4; ib++)
@@ -1048,24 +1064,54 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_update(Factor
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int i = i0 + 16 * ib + li, j = j0 + 16 * jb + MM::row(lane, r);
-        acc[ib][jb][r] = (i < M && j < jmax && i >= j) ? F[(int64_t)j * M + i] : (T)0;
+        acc[ib][jb][r] = (wave_active && i < M && j < jmax && i >= j) ? F[(int64_t)j * M + i] : (T)0;
       }
-  for (int k = ka; k < ke; k += 4) {
-    const int kk = k + lk;
-    const bool kok = kk < ke;
-    const T *colk = F + (int64_t)(kok ? kk : ka) * M;
-    T av[4], bv[4];
+  // ---- operand staging: thread t loads row (t & 127) of every second k of the chunk
+  const int sr = tid & 127, sk = tid >> 7;
+  const bool iok = I0 + sr < M, jok = J0 + sr < jmax;
+  T ra[NLD], rb[NLD];
+  auto fetch = [&](int c) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int i = i0 + 16 * q + li, j = j0 + 16 * q + li;
-      bv[q] = (kok && i < M) ? colk[i] : (T)0;
-      av[q] = (kok && j < jmax) ? -colk[j] : (T)0;
+    for (int q = 0; q < NLD; q++) {
+      const int k = ka + c * KC + sk + 2 * q;
+      const T *col = F + (int64_t)(k < ke ? k : ka) * M;
+      ra[q] = (k < ke && iok) ? col[I0 + sr] : (T)0;
+      rb[q] = (k < ke && jok) ? -col[J0 + sr] : (T)0;
     }
+  };
+  auto stash = [&](int buf) {
 #pragma unroll
-    for (int ib = 0; ib < 4; ib++)
+    for (int q = 0; q < NLD; q++) {
+      As[buf][sk + 2 * q][sr] = ra[q];
+      Bs[buf][sk + 2 * q][sr] = rb[q];
+    }
+  };
+  const int nchunks = (ke - ka + KC - 1) / KC;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; c++) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) fetch(c + 1);
+    if (wave_active) {
 #pragma unroll
-      for (int jb = 0; jb < 4; jb++) acc[ib][jb] = MM::mma(av[jb], bv[ib], acc[ib][jb]);
+      for (int s4 = 0; s4 < KC / 4; s4++) {
+        T av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          bv[q] = As[buf][4 * s4 + lk][wi + 16 * q + li];
+          av[q] = Bs[buf][4 * s4 + lk][wj + 16 * q + li];
+        }
+#pragma unroll
+        for (int ib = 0; ib < 4; ib++)
+#pragma unroll
+          for (int jb = 0; jb < 4; jb++) acc[ib][jb] = MM::mma(av[jb], bv[ib], acc[ib][jb]);
+      }
+    }
+    if (c + 1 < nchunks) stash(buf ^ 1);
+    __syncthreads();
   }
+  if (!wave_active) return;
 #pragma unroll
   for (int ib = 0; ib < 4; ib++)
 #pragma unroll
