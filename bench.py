@@ -178,6 +178,21 @@ def main():
                 torch.cuda.current_stream().synchronize()
             g.stage(2)
 
+    def sync():
+        g.sync()                    # the library's own HIP stream
+        torch.cuda.synchronize()
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+
+    def all_max(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     dt = timed_steps(run_steps, sync, barrier, all_max, args.steps, args.warmup, reset=lambda: g.set_state(state0))
     stats = g.stats()
     total_steps = args.steps * (1 if shard else world)   # sharded: all ranks work on the SAME K iterations
