@@ -20,7 +20,10 @@ template <typename T> struct VecT;
 template <> struct VecT<float> { using V4 = float4; using V2 = float2; };
 template <> struct VecT<double> { using V4 = double4; using V2 = double2; };
 
-constexpr int LIN_GROUP = 8;      // lanes cooperating on one node in k_linearize
+#ifndef RRPGO_LIN_GROUP
+#define RRPGO_LIN_GROUP 8
+#endif
+constexpr int LIN_GROUP = RRPGO_LIN_GROUP;   // lanes cooperating on one node in k_linearize (power of two <= 64)
 constexpr int LIN_THREADS = 256;
 constexpr int UPD_THREADS = 256;
 
@@ -111,10 +114,9 @@ __device__ __forceinline__ void edge_linearize_2d(int kind, const typename VecT<
   }
 }
 
-template <typename T> __device__ __forceinline__ T group_sum8(T v) {
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
+template <typename T> __device__ __forceinline__ T group_sum8(T v) {   // sum over the LIN_GROUP lanes of a node
+#pragma unroll
+  for (int o = 1; o < LIN_GROUP; o <<= 1) v += __shfl_xor(v, o);
   return v;
 }
 
