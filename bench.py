@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy)
 # MI355X_MICROARCH.md: f32-input MFMA 157.3 TFLOP/s dense; f64 matrix/vector 78.6 TFLOP/s (datasheet)
-MFMA_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "mixed": 157.3, "f64": 78.6}
 
 WORKLOADS = {"intel": "intel", "m3500": "input_M3500_g2o", "dlr": "dlr", "pose-pose": "simulation-pose-pose",
              "pose-landmark": "simulation-pose-landmark"}
@@ -130,7 +130,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="intel")
-    ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--precision", default="f64", choices=["f64", "f32", "mixed"],
+                    help="f64 (reference arithmetic), f32, or mixed = f64 state/linearisation + f32 factor/solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shard", action="store_true",
                     help="N > 1 only: shard ONE graph over the ranks (own subtrees + shared top separators, two RCCL "
@@ -159,7 +160,7 @@ def main():
         xbuf = []
         for which in (0, 1):
             _, n, es = g.exchange_info(which)
-            t = torch.zeros(max(n, 1), dtype=torch.float64 if es == 8 else torch.float32, device="cuda")
+            t = torch.zeros(max(n, 1), dtype=torch.float64 if es == 8 else torch.float32, device="cuda")  # element size from the handle
             g.bind_exchange(which, t.data_ptr(), t.numel())
             xbuf.append(t)
     else:

@@ -45,8 +45,11 @@ enum { RR_PGO_GAUSS_NEWTON = 0, RR_PGO_LEVENBERG_MARQUARDT = 1 };
 /* enum Node variants, :147-154 ; enum Edge variants, :20-26 */
 enum { RR_PGO_NODE_SE2 = 0, RR_PGO_NODE_XY = 1, RR_PGO_NODE_SE3 = 2 };
 enum { RR_PGO_EDGE_SE2 = 0, RR_PGO_EDGE_SE2_XY = 1, RR_PGO_EDGE_SE3 = 2 };
-/* arithmetic type of the device path (the reference is f64 throughout) */
-enum { RR_PGO_F64 = 0, RR_PGO_F32 = 1 };
+/* arithmetic type of the device path (the reference is f64 throughout).
+ * RR_PGO_MIXED: state, measurements, error / Jacobians / gradient and chi2 in f64; H, its factor and
+ * the solve in f32.  The gradient is exact, so Gauss-Newton converges to the f64 minimum while the
+ * factorisation (all of the cost on large graphs) runs at the f32 rate. */
+enum { RR_PGO_F64 = 0, RR_PGO_F32 = 1, RR_PGO_MIXED = 2 };
 
 /* What parse_g2o returns (g2o.rs:35-45: len, edges, lut, nodes), flattened.
  * All arrays are borrowed for the duration of the call only. */
@@ -64,7 +67,7 @@ typedef struct rr_pgo_graph_desc {
 } rr_pgo_graph_desc;
 
 typedef struct rr_pgo_options {
-  int32_t precision;      /* RR_PGO_F64 (default) or RR_PGO_F32 */
+  int32_t precision;      /* RR_PGO_F64 (default), RR_PGO_F32 or RR_PGO_MIXED */
   int32_t device;         /* HIP device ordinal, -1 = current device */
   int32_t solver;         /* RR_PGO_GAUSS_NEWTON / RR_PGO_LEVENBERG_MARQUARDT (PoseGraph::new's 2nd arg, :215) */
   /* Multi-GPU sharding of ONE graph.  world_size <= 1: single GPU. */

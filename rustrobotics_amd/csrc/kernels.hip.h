@@ -51,13 +51,15 @@ constexpr int UPD_THREADS = 256;
 enum : int { DEVERR_NOT_SPD = 1 };
 
 
-template <typename T> struct LinArgs {
+// TC = type of the state, the measurements and all factor arithmetic; T = type H and b are stored in
+// (TC == T, or TC = double with T = float: "mixed" mode, exact gradient + single-precision factor)
+template <typename T, typename TC = T> struct LinArgs {
   int n_nodes;
-  const typename VecT<T>::V4 *pose;     // x, y, cos, sin  (XY landmarks: x, y, -, -)
+  const typename VecT<TC>::V4 *pose;     // x, y, cos, sin  (XY landmarks: x, y, -, -)
   const int2 *e_idx;                     // from, to
-  const typename VecT<T>::V4 *e_meas;    // SE2: x, y, cos, sin | SE2_XY: x, y, 0, 0
-  const typename VecT<T>::V4 *e_info_a;  // i11 i12 i13 i22
-  const typename VecT<T>::V2 *e_info_b;  // i23 i33
+  const typename VecT<TC>::V4 *e_meas;   // SE2: x, y, cos, sin | SE2_XY: x, y, 0, 0
+  const typename VecT<TC>::V4 *e_info_a; // i11 i12 i13 i22
+  const typename VecT<TC>::V2 *e_info_b; // i23 i33
   const int64_t *e_slot;                 // (offset into hvals << 1) | transposed
   const int32_t *inc_ptr, *inc_list;     // entry = edge << 2 | kind << 1 | role
   const uint8_t *node_dim;               // 3 (SE2) or 2 (XY)
@@ -67,7 +69,7 @@ template <typename T> struct LinArgs {
   T *b;                                  // reference scalar order, already negated (:361)
   double *chi2_partial;                  // one per workgroup
   int anchor;                            // node that gets the 1e7 prior (:330-336), -1 none
-  T lambda;                              // added to every diagonal entry when > 0 (LM, :362-366)
+  TC lambda;                             // added to every diagonal entry when > 0 (LM, :362-366)
   int write_system;                      // 0: chi2 only
 };
 
@@ -137,8 +139,8 @@ template <typename T, int THREADS> __device__ __forceinline__ T block_sum(T v, T
 // (deterministic: no atomics, fixed summation order), builds the node's
 // diagonal block and right-hand side; the lane holding an edge in its `from`
 // role also writes the off-diagonal block and the edge's chi2 term.
-template <typename T>
-__global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<T> a) {
+template <typename TO, typename T>
+__global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<TO, T> a) {
   using V4 = typename VecT<T>::V4;
   using V2 = typename VecT<T>::V2;
   __shared__ double red[LIN_THREADS / 64];
@@ -197,7 +199,7 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<T> a) {
         if (a.write_system) {
           // off-diagonal block H[from rows, to cols] = A^T W B
           const int64_t so = a.e_slot[k];
-          T *dst = a.hvals + (so >> 1);
+          TO *dst = a.hvals + (so >> 1);
           const bool tr = so & 1;
           const int d2 = kind ? 2 : 3;
 #pragma unroll
@@ -206,7 +208,7 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<T> a) {
             for (int j = 0; j < 3; j++) {
               if (j >= d2) continue;
               T s = JW[i][0] * B[0][j] + JW[i][1] * B[1][j] + JW[i][2] * B[2][j];
-              dst[tr ? j * 3 + i : i * d2 + j] = s;
+              dst[tr ? j * 3 + i : i * d2 + j] = (TO)s;
             }
         }
       }
@@ -220,17 +222,17 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<T> a) {
     if (node < a.n_nodes && sub == 0) {
       T add = a.lambda;
       if (node == a.anchor) add += (T)10000000.0;
-      T *d = a.hvals + a.diag_off[node];
+      TO *d = a.hvals + a.diag_off[node];
       if (nd == 3) {
-        d[0] = hd[0] + add; d[1] = hd[1];       d[2] = hd[3];
-        d[3] = hd[1];       d[4] = hd[2] + add; d[5] = hd[4];
-        d[6] = hd[3];       d[7] = hd[4];       d[8] = hd[5] + add;
+        d[0] = (TO)(hd[0] + add); d[1] = (TO)hd[1];         d[2] = (TO)hd[3];
+        d[3] = (TO)hd[1];         d[4] = (TO)(hd[2] + add); d[5] = (TO)hd[4];
+        d[6] = (TO)hd[3];         d[7] = (TO)hd[4];         d[8] = (TO)(hd[5] + add);
       } else {
-        d[0] = hd[0] + add; d[1] = hd[1];
-        d[2] = hd[1];       d[3] = hd[2] + add;
+        d[0] = (TO)(hd[0] + add); d[1] = (TO)hd[1];
+        d[2] = (TO)hd[1];         d[3] = (TO)(hd[2] + add);
       }
-      T *bo = a.b + a.node_offset[node];
-      for (int t = 0; t < nd; t++) bo[t] = -bv[t];
+      TO *bo = a.b + a.node_offset[node];
+      for (int t = 0; t < nd; t++) bo[t] = (TO)(-bv[t]);
     }
   }
   double tot = block_sum<double, LIN_THREADS>(chi, red);
@@ -245,12 +247,12 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<T> a) {
 // Jacobians (cf. the structure hinted at :488-514: A = [-Ra, Ra*skew(t_b); 0, ..], B = [Re, 0; 0, ..]):
 //   B = [ R_E , 0 ; 0 , (s/2)(w_E I + [v_E]x) ]
 //   A = [ -Rz^T , Rz^T [t_C]x ; 0 , -(s/2) vec3x3( L(q_z^-1) R(q_C) ) ] ,  C = Xi^-1 Xj
-template <typename T> struct LinArgs3 {
+template <typename T, typename TC = T> struct LinArgs3 {
   int n_nodes;
-  const typename VecT<T>::V4 *pose;     // 2 per node: (tx,ty,tz,-), (qx,qy,qz,qw)
+  const typename VecT<TC>::V4 *pose;    // 2 per node: (tx,ty,tz,-), (qx,qy,qz,qw)
   const int2 *e_idx;
-  const typename VecT<T>::V4 *e_meas;   // 2 per edge, same packing
-  const T *e_info;                      // 21 per edge, row-major upper triangle
+  const typename VecT<TC>::V4 *e_meas;  // 2 per edge, same packing
+  const TC *e_info;                     // 21 per edge, row-major upper triangle
   const int64_t *e_slot;
   const int32_t *inc_ptr, *inc_list;    // entry = edge << 2 | role
   const int32_t *node_offset;
@@ -259,7 +261,7 @@ template <typename T> struct LinArgs3 {
   T *b;
   double *chi2_partial;
   int anchor;
-  T lambda;
+  TC lambda;
   int write_system;
 };
 
@@ -340,8 +342,8 @@ __device__ void edge_linearize_3d(int role, const T ti[3], const T qi[4], const 
   }
 }
 
-template <typename T>
-__global__ void __launch_bounds__(LIN_THREADS) k_linearize_se3(LinArgs3<T> a) {
+template <typename TO, typename T>
+__global__ void __launch_bounds__(LIN_THREADS) k_linearize_se3(LinArgs3<TO, T> a) {
   using V4 = typename VecT<T>::V4;
   __shared__ double red[LIN_THREADS / 64];
   const int gid = blockIdx.x * LIN_THREADS + threadIdx.x;
@@ -421,7 +423,7 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize_se3(LinArgs3<T> a) {
           T e2[6], Bm[6][6];
           edge_linearize_3d<T>(1, ts, qs, to, qo, tz, qz, e2, Bm);
           const int64_t so = a.e_slot[k];
-          T *dst = a.hvals + (so >> 1);
+          TO *dst = a.hvals + (so >> 1);
           const bool tr = so & 1;
 #pragma unroll
           for (int i = 0; i < 6; i++)
@@ -430,7 +432,7 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize_se3(LinArgs3<T> a) {
               T sacc = 0;
 #pragma unroll
               for (int r = 0; r < 6; r++) sacc += JW[i][r] * Bm[r][j];
-              dst[tr ? j * 6 + i : i * 6 + j] = sacc;
+              dst[tr ? j * 6 + i : i * 6 + j] = (TO)sacc;
             }
         }
       }
@@ -444,50 +446,50 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize_se3(LinArgs3<T> a) {
     if (node < a.n_nodes && sub == 0) {
       T add = a.lambda;
       if (node == a.anchor) add += (T)10000000.0;
-      T *d = a.hvals + a.diag_off[node];
+      TO *d = a.hvals + a.diag_off[node];
       int t = 0;
 #pragma unroll
       for (int i = 0; i < 6; i++)
 #pragma unroll
         for (int j = 0; j <= i; j++) {
           const T v = hd[t++] + (i == j ? add : (T)0);
-          d[i * 6 + j] = v;
-          d[j * 6 + i] = v;
+          d[i * 6 + j] = (TO)v;
+          d[j * 6 + i] = (TO)v;
         }
-      T *bo = a.b + a.node_offset[node];
+      TO *bo = a.b + a.node_offset[node];
 #pragma unroll
-      for (int i = 0; i < 6; i++) bo[i] = -bv[i];
+      for (int i = 0; i < 6; i++) bo[i] = (TO)(-bv[i]);
     }
   }
   double tot = block_sum<double, LIN_THREADS>(chi, red);
   if (threadIdx.x == 0) a.chi2_partial[blockIdx.x] = tot;
 }
 
-template <typename T> struct UpdArgs3 {
+template <typename T, typename TC = T> struct UpdArgs3 {
   int n_nodes;
-  typename VecT<T>::V4 *pose;
+  typename VecT<TC>::V4 *pose;
   const int32_t *node_pcol, *node_offset;
   const T *x, *dx_ref_in;
   T *dx_ref_out;
-  T sign;
+  TC sign;
   double *norm_partial;
 };
 
 // X <- X * (dt, Exp(dw)):  t += R dt ;  q <- normalise( q (x) exp(dw) )
-template <typename T>
-__global__ void __launch_bounds__(UPD_THREADS) k_update_se3(UpdArgs3<T> a) {
+template <typename TO, typename T>
+__global__ void __launch_bounds__(UPD_THREADS) k_update_se3(UpdArgs3<TO, T> a) {
   __shared__ double red[UPD_THREADS / 64];
   const int node = blockIdx.x * UPD_THREADS + threadIdx.x;
   double nrm = 0.0;
   if (node < a.n_nodes) {
     T d[6];
-    const T *src = a.dx_ref_in ? a.dx_ref_in + a.node_offset[node] : a.x + a.node_pcol[node];
+    const TO *src = a.dx_ref_in ? a.dx_ref_in + a.node_offset[node] : a.x + a.node_pcol[node];
 #pragma unroll
-    for (int t = 0; t < 6; t++) d[t] = src[t];
+    for (int t = 0; t < 6; t++) d[t] = (T)src[t];
     if (a.dx_ref_out) {
-      T *dst = a.dx_ref_out + a.node_offset[node];
+      TO *dst = a.dx_ref_out + a.node_offset[node];
 #pragma unroll
-      for (int t = 0; t < 6; t++) dst[t] = d[t];
+      for (int t = 0; t < 6; t++) dst[t] = src[t];
     }
 #pragma unroll
     for (int t = 0; t < 6; t++) { nrm += (double)d[t] * (double)d[t]; d[t] *= a.sign; }
@@ -1358,36 +1360,31 @@ template <typename T> __global__ void k_mask_x(int n, T *x, const int8_t *col_ow
 
 // ------------------------------------------------------------------ update
 
-template <typename T> struct UpdArgs {
+template <typename T, typename TC = T> struct UpdArgs {
   int n_nodes;
-  typename VecT<T>::V4 *pose;
+  typename VecT<TC>::V4 *pose;
   const uint8_t *node_dim;
   const int32_t *node_pcol, *node_offset;
   const T *x;          // permuted solution (used when dx_ref_in == nullptr)
   const T *dx_ref_in;  // reference-order step supplied by the caller (rr_pgo_update)
   T *dx_ref_out;       // reference-order copy of the applied step (may be null)
-  T sign;
+  TC sign;
   double *norm_partial;
 };
 
-template <typename T>
-__global__ void __launch_bounds__(UPD_THREADS) k_update(UpdArgs<T> a) {
+template <typename TO, typename T>
+__global__ void __launch_bounds__(UPD_THREADS) k_update(UpdArgs<TO, T> a) {
   __shared__ double red[UPD_THREADS / 64];
   const int node = blockIdx.x * UPD_THREADS + threadIdx.x;
   double nrm = 0.0;
   if (node < a.n_nodes) {
     const int nd = a.node_dim[node];
     T d[3] = {0, 0, 0};
-    if (a.dx_ref_in) {
-      const T *src = a.dx_ref_in + a.node_offset[node];
-      for (int t = 0; t < nd; t++) d[t] = src[t];
-    } else {
-      const T *src = a.x + a.node_pcol[node];
-      for (int t = 0; t < nd; t++) d[t] = src[t];
-    }
+    const TO *src = a.dx_ref_in ? a.dx_ref_in + a.node_offset[node] : a.x + a.node_pcol[node];
+    for (int t = 0; t < nd; t++) d[t] = (T)src[t];
     if (a.dx_ref_out) {
-      T *dst = a.dx_ref_out + a.node_offset[node];
-      for (int t = 0; t < nd; t++) dst[t] = d[t];
+      TO *dst = a.dx_ref_out + a.node_offset[node];
+      for (int t = 0; t < nd; t++) dst[t] = src[t];
     }
     for (int t = 0; t < nd; t++) nrm += (double)d[t] * (double)d[t];
     auto p = a.pose[node];

@@ -107,9 +107,11 @@ template <typename T> __global__ void k_permute_out(int n, const int32_t *perm, 
   if (i < n) dx_ref[perm[i]] = x[i];
 }
 
-template <typename T> class Engine final : public EngineBase {
-  using V4 = typename VecT<T>::V4;
-  using V2 = typename VecT<T>::V2;
+// T: type of H, b, L, x (factor + solve).  S: type of the state, the measurements and the
+// linearisation arithmetic (S == T, or S = double with T = float: "mixed" mode).
+template <typename T, typename S = T> class Engine final : public EngineBase {
+  using V4 = typename VecT<S>::V4;
+  using V2 = typename VecT<S>::V2;
   const HostGraph &g_;
   const Symbolic &sym_;
   hipStream_t stream_ = nullptr;
@@ -121,7 +123,7 @@ template <typename T> class Engine final : public EngineBase {
   DevBuf<int64_t> e_slot_, diag_off_;
   DevBuf<int32_t> inc_ptr_, inc_list_, node_offset_, node_pcol_;
   DevBuf<uint8_t> node_dim_;
-  DevBuf<T> e_info3_;   // SE(3): 21 information entries per edge
+  DevBuf<S> e_info3_;   // SE(3): 21 information entries per edge
   bool is3d_ = false;
   // sharding over ranks
   int rank_ = 0, world_ = 1;
@@ -166,8 +168,8 @@ template <typename T> class Engine final : public EngineBase {
       std::vector<V4> pose(N);
       for (int i = 0; i < N; i++) {
         const double *s = &g.node_state[g.node_state_off[i]];
-        if (g.node_kind[i] == NODE_SE2) pose[i] = V4{(T)s[0], (T)s[1], (T)std::cos(s[2]), (T)std::sin(s[2])};
-        else pose[i] = V4{(T)s[0], (T)s[1], (T)0, (T)0};
+        if (g.node_kind[i] == NODE_SE2) pose[i] = V4{(S)s[0], (S)s[1], (S)std::cos(s[2]), (S)std::sin(s[2])};
+        else pose[i] = V4{(S)s[0], (S)s[1], (S)0, (S)0};
       }
       pose_.upload(pose);
       std::vector<V4> emeas(E), einfa(E);
@@ -176,13 +178,13 @@ template <typename T> class Engine final : public EngineBase {
         const double *m = &g.edge_meas[g.edge_meas_off[k]];
         const double *w = &g.edge_info[g.edge_info_off[k]];
         if (g.edge_kind[k] == EDGE_SE2) {
-          emeas[k] = V4{(T)m[0], (T)m[1], (T)std::cos(m[2]), (T)std::sin(m[2])};
-          einfa[k] = V4{(T)w[0], (T)w[1], (T)w[2], (T)w[3]};
-          einfb[k] = V2{(T)w[4], (T)w[5]};
+          emeas[k] = V4{(S)m[0], (S)m[1], (S)std::cos(m[2]), (S)std::sin(m[2])};
+          einfa[k] = V4{(S)w[0], (S)w[1], (S)w[2], (S)w[3]};
+          einfb[k] = V2{(S)w[4], (S)w[5]};
         } else {
-          emeas[k] = V4{(T)m[0], (T)m[1], (T)0, (T)0};
-          einfa[k] = V4{(T)w[0], (T)w[1], (T)0, (T)w[2]};
-          einfb[k] = V2{(T)0, (T)0};
+          emeas[k] = V4{(S)m[0], (S)m[1], (S)0, (S)0};
+          einfa[k] = V4{(S)w[0], (S)w[1], (S)0, (S)w[2]};
+          einfb[k] = V2{(S)0, (S)0};
         }
       }
       e_meas_.upload(emeas);
@@ -192,16 +194,16 @@ template <typename T> class Engine final : public EngineBase {
       // SE(3): (t, -), (q) pairs; quaternions normalised like UnitQuaternion::from_quaternion
       auto pack7 = [](const double *s, V4 &a, V4 &b) {
         const double n = std::sqrt(s[3] * s[3] + s[4] * s[4] + s[5] * s[5] + s[6] * s[6]);
-        a = V4{(T)s[0], (T)s[1], (T)s[2], (T)0};
-        b = V4{(T)(s[3] / n), (T)(s[4] / n), (T)(s[5] / n), (T)(s[6] / n)};
+        a = V4{(S)s[0], (S)s[1], (S)s[2], (S)0};
+        b = V4{(S)(s[3] / n), (S)(s[4] / n), (S)(s[5] / n), (S)(s[6] / n)};
       };
       std::vector<V4> pose(2 * (size_t)N), emeas(2 * (size_t)E);
-      std::vector<T> einfo(21 * (size_t)E);
+      std::vector<S> einfo(21 * (size_t)E);
       for (int i = 0; i < N; i++) pack7(&g.node_state[g.node_state_off[i]], pose[2 * i], pose[2 * i + 1]);
       for (int k = 0; k < E; k++) {
         pack7(&g.edge_meas[g.edge_meas_off[k]], emeas[2 * k], emeas[2 * k + 1]);
         const double *w = &g.edge_info[g.edge_info_off[k]];
-        for (int t = 0; t < 21; t++) einfo[21 * (size_t)k + t] = (T)w[t];
+        for (int t = 0; t < 21; t++) einfo[21 * (size_t)k + t] = (S)w[t];
       }
       pose_.upload(pose);
       e_meas_.upload(emeas);
@@ -362,8 +364,8 @@ template <typename T> class Engine final : public EngineBase {
     hipLaunchKernelGGL((k_solve_tasks<T, TH>), dim3(nt), dim3(TH), lds, stream_, a);
   }
 
-  LinArgs<T> lin_args(double lambda, int lm, int write_system) {
-    LinArgs<T> a;
+  LinArgs<T, S> lin_args(double lambda, int lm, int write_system) {
+    LinArgs<T, S> a;
     a.n_nodes = g_.n_nodes();
     a.pose = pose_.p;
     a.e_idx = e_idx_.p;
@@ -380,7 +382,7 @@ template <typename T> class Engine final : public EngineBase {
     a.b = b_.p;
     a.chi2_partial = chi_partial_.p;
     a.anchor = g_.anchor_node;
-    a.lambda = lm ? (T)lambda : (T)0;
+    a.lambda = lm ? (S)lambda : (S)0;
     a.write_system = write_system;
     return a;
   }
@@ -438,10 +440,10 @@ template <typename T> class Engine final : public EngineBase {
   void launch_linearize(double lambda, int lm, int write_system) {
     pbegin();
     if (!is3d_) {
-      hipLaunchKernelGGL(k_linearize<T>, dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_,
+      hipLaunchKernelGGL((k_linearize<T, S>), dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_,
                          lin_args(lambda, lm, write_system));
     } else {
-      LinArgs3<T> a;
+      LinArgs3<T, S> a;
       a.n_nodes = g_.n_nodes();
       a.pose = pose_.p;
       a.e_idx = e_idx_.p;
@@ -456,9 +458,9 @@ template <typename T> class Engine final : public EngineBase {
       a.b = b_.p;
       a.chi2_partial = chi_partial_.p;
       a.anchor = g_.anchor_node;
-      a.lambda = lm ? (T)lambda : (T)0;
+      a.lambda = lm ? (S)lambda : (S)0;
       a.write_system = write_system;
-      hipLaunchKernelGGL(k_linearize_se3<T>, dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_, a);
+      hipLaunchKernelGGL((k_linearize_se3<T, S>), dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_, a);
     }
     check_launch("k_linearize");
     pend(RR_PGO_K_LINEARIZE);
@@ -590,7 +592,7 @@ template <typename T> class Engine final : public EngineBase {
   void launch_update(const T *dx_ref_in, double sign, bool write_ref) {
     pbegin();
     if (!is3d_) {
-      UpdArgs<T> u;
+      UpdArgs<T, S> u;
       u.n_nodes = g_.n_nodes();
       u.pose = pose_.p;
       u.node_dim = node_dim_.p;
@@ -599,11 +601,11 @@ template <typename T> class Engine final : public EngineBase {
       u.x = x_ptr_;
       u.dx_ref_in = dx_ref_in;
       u.dx_ref_out = write_ref ? dx_ref_.p : nullptr;
-      u.sign = (T)sign;
+      u.sign = (S)sign;
       u.norm_partial = norm_partial_.p;
-      hipLaunchKernelGGL(k_update<T>, dim3(n_upd_blocks_), dim3(UPD_THREADS), 0, stream_, u);
+      hipLaunchKernelGGL((k_update<T, S>), dim3(n_upd_blocks_), dim3(UPD_THREADS), 0, stream_, u);
     } else {
-      UpdArgs3<T> u;
+      UpdArgs3<T, S> u;
       u.n_nodes = g_.n_nodes();
       u.pose = pose_.p;
       u.node_pcol = node_pcol_.p;
@@ -611,9 +613,9 @@ template <typename T> class Engine final : public EngineBase {
       u.x = x_ptr_;
       u.dx_ref_in = dx_ref_in;
       u.dx_ref_out = write_ref ? dx_ref_.p : nullptr;
-      u.sign = (T)sign;
+      u.sign = (S)sign;
       u.norm_partial = norm_partial_.p;
-      hipLaunchKernelGGL(k_update_se3<T>, dim3(n_upd_blocks_), dim3(UPD_THREADS), 0, stream_, u);
+      hipLaunchKernelGGL((k_update_se3<T, S>), dim3(n_upd_blocks_), dim3(UPD_THREADS), 0, stream_, u);
     }
     check_launch("k_update");
     pend(RR_PGO_K_UPDATE);
@@ -781,14 +783,14 @@ template <typename T> class Engine final : public EngineBase {
     for (int i = 0; i < N; i++) {
       if (is3d_) {
         const double n = std::sqrt(st[3] * st[3] + st[4] * st[4] + st[5] * st[5] + st[6] * st[6]);
-        pose[2 * i] = V4{(T)st[0], (T)st[1], (T)st[2], (T)0};
-        pose[2 * i + 1] = V4{(T)(st[3] / n), (T)(st[4] / n), (T)(st[5] / n), (T)(st[6] / n)};
+        pose[2 * i] = V4{(S)st[0], (S)st[1], (S)st[2], (S)0};
+        pose[2 * i + 1] = V4{(S)(st[3] / n), (S)(st[4] / n), (S)(st[5] / n), (S)(st[6] / n)};
         st += 7;
       } else if (g_.node_kind[i] == NODE_SE2) {
-        pose[i] = V4{(T)st[0], (T)st[1], (T)std::cos(st[2]), (T)std::sin(st[2])};
+        pose[i] = V4{(S)st[0], (S)st[1], (S)std::cos(st[2]), (S)std::sin(st[2])};
         st += 3;
       } else {
-        pose[i] = V4{(T)st[0], (T)st[1], (T)0, (T)0};
+        pose[i] = V4{(S)st[0], (S)st[1], (S)0, (S)0};
         st += 2;
       }
     }
@@ -954,7 +956,8 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
   rr_pgo_options opt;
   if (opt_in) opt = *opt_in; else rr_pgo_default_options(&opt);
   h->opt = opt;
-  if (opt.precision != RR_PGO_F64 && opt.precision != RR_PGO_F32) throw ApiError(RR_PGO_EINVAL, "bad precision");
+  if (opt.precision != RR_PGO_F64 && opt.precision != RR_PGO_F32 && opt.precision != RR_PGO_MIXED)
+    throw ApiError(RR_PGO_EINVAL, "bad precision");
   if (opt.world_size > 1) {
     if (opt.world_size & (opt.world_size - 1)) throw ApiError(RR_PGO_EINVAL, "world_size must be a power of two");
     if (opt.rank < 0 || opt.rank >= opt.world_size) throw ApiError(RR_PGO_EINVAL, "rank out of range");
@@ -983,7 +986,8 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
   }
   const int wr = opt.world_size > 1 ? opt.rank : 0, ww = opt.world_size > 1 ? opt.world_size : 1;
   if (opt.precision == RR_PGO_F64) h->engine = std::make_unique<Engine<double>>(h->g, h->sym, wr, ww);
-  else h->engine = std::make_unique<Engine<float>>(h->g, h->sym, wr, ww);
+  else if (opt.precision == RR_PGO_F32) h->engine = std::make_unique<Engine<float>>(h->g, h->sym, wr, ww);
+  else h->engine = std::make_unique<Engine<float, double>>(h->g, h->sym, wr, ww);
   // stats
   rr_pgo_stats &s = h->stats;
   std::memset(&s, 0, sizeof s);

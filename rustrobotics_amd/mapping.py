@@ -57,7 +57,7 @@ class PoseGraph:
         L = _lib.load()
         opt = _lib.Options()
         L.rr_pgo_default_options(C.byref(opt))
-        opt.precision = _lib.F64 if precision == "f64" else _lib.F32
+        opt.precision = _lib.PRECISIONS[precision]
         opt.device = device
         opt.solver = solver.value
         h = C.c_void_p()
@@ -90,7 +90,7 @@ class PoseGraph:
         d.edge_info = _dp(keep[6])
         opt = _lib.Options()
         L.rr_pgo_default_options(C.byref(opt))
-        opt.precision = _lib.F64 if precision == "f64" else _lib.F32
+        opt.precision = _lib.PRECISIONS[precision]
         opt.device = device
         opt.solver = solver.value
         opt.rank, opt.world_size = rank, world_size

@@ -391,3 +391,26 @@ def test_sharded_graph_matches_unsharded(api, oracle, P, precision):
         assert abs(errors[0] - eref[0]) <= 1e-6 * eref[0]
         assert abs(min(errors) - min(eref)) <= 1e-5 * min(eref)
         assert _state_diff_se2(shards[0].state(), shards[-1].state()) <= 1e-6   # ranks agree with each other
+
+
+def test_mixed_precision_reaches_the_f64_answer(api, oracle):
+    """RR_PGO_MIXED: f64 state + f64 linearisation (exact gradient), f32 factor / solve: Gauss-Newton
+    then behaves like iterative refinement.  Measured: on intel.g2o it stops by the reference's own
+    |dx| < 1e-4 rule after 7 iterations (f64: 6) with poses 2e-6 from the f64 answer, where pure f32
+    never meets the stop rule; on the 100 x 100 lattice chi2 agrees with f64 to 2e-10 after 12
+    iterations and the one weak global mode (rotation about the anchor) contracts by ~0.65 per iteration."""
+    gi, oi = api[0].new(g2o_path("intel"), precision="mixed"), oracle.load(g2o_path("intel"))
+    ei, eo = gi.optimize(30), oi.optimize(30)
+    assert len(ei) - 1 <= 9                                    # converged by the stop rule
+    assert abs(ei[-1] - eo[-1]) <= 1e-10 * eo[-1]
+    assert np.abs(gi.state() - oi.state()).max() <= 1e-5
+    g32 = api[0].new(g2o_path("intel"), precision="f32")
+    assert len(g32.optimize(30)) - 1 == 30                     # pure f32: step noise ~1e-3 never drops below 1e-4
+    from rustrobotics_amd import synthetic_grid_arrays
+    arrays = synthetic_grid_arrays(100, 100)
+    gm, g64 = api[0].from_arrays(*arrays, precision="mixed"), api[0].from_arrays(*arrays)
+    (em, nm), e64 = gm.optimize(12, return_norms=True), g64.optimize(12)
+    assert abs(em[0] - e64[0]) <= 1e-12 * e64[0]               # chi2 itself is evaluated in f64
+    assert abs(em[-1] - e64[-1]) <= 1e-8 * e64[-1]
+    assert all(b < a for a, b in zip(nm, nm[1:]))              # still contracting
+    assert _state_diff_se2(gm.state(), g64.state()) <= 2e-2
