@@ -1232,39 +1232,17 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
     __syncthreads();
     RRPGO_STAMP(a, s, 4);
   } else {
-    // front in place in HBM (mid / huge fronts): same algorithm, the 64 x 64 diagonal chunk of
-    // L11 is staged per chunk, everything else streams from global memory.
-    T *x2 = work;          // nr
-    T *t1 = work + nr;     // nc
-    T *Lc = t1 + nc;       // 64 x 65 chunk, transposed, reciprocal diagonal
+    // Front in place in HBM (fronts beyond LDS), left-looking over 64-column chunks from the right:
+    //   t_c = y1_c - L[rows below the chunk, chunk]^T * xf[rows below]      one contiguous GEMV
+    //   x_c = L_cc^-T t_c                                                   64-step chunk solve
+    // with xf = [x1 (this front's pivots, filled in as chunks finish) | x[rows] (ancestors)].
+    // A wave streams 4 columns, 4 row-blocks at a time (16 independent loads in flight per lane).
+    T *xf = work;              // M - 1
+    T *Lc = xf + (M - 1);      // 64 x 65 chunk, transposed, reciprocal diagonal
     constexpr int NW = THREADS / 64;
     const int wave = tid >> 6, lane = tid & 63;
     __syncthreads();
-    for (int i = tid; i < nr; i += THREADS) x2[i] = a.x[rows[i]];
-    __syncthreads();
-    for (int j = wave; j < nc; j += 4 * NW) {
-      const int j1 = j + NW, j2 = j + 2 * NW, j3 = j + 3 * NW;
-      const T *c0 = Lg + (int64_t)j * M + nc;
-      const T *c1 = Lg + (int64_t)(j1 < nc ? j1 : j) * M + nc;
-      const T *c2 = Lg + (int64_t)(j2 < nc ? j2 : j) * M + nc;
-      const T *c3 = Lg + (int64_t)(j3 < nc ? j3 : j) * M + nc;
-      T s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-      for (int i = lane; i < nr; i += 64) {
-        const T xv = x2[i];
-        s0 += c0[i] * xv; s1 += c1[i] * xv; s2 += c2[i] * xv; s3 += c3[i] * xv;
-      }
-      for (int o = 32; o > 0; o >>= 1) {
-        s0 += __shfl_down(s0, o); s1 += __shfl_down(s1, o);
-        s2 += __shfl_down(s2, o); s3 += __shfl_down(s3, o);
-      }
-      if (lane == 0) {
-        t1[j] = c0[nr] - s0;
-        if (j1 < nc) t1[j1] = c1[nr] - s1;
-        if (j2 < nc) t1[j2] = c2[nr] - s2;
-        if (j3 < nc) t1[j3] = c3[nr] - s3;
-      }
-    }
-    __syncthreads();
+    for (int i = tid; i < nr; i += THREADS) xf[nc + i] = a.x[rows[i]];
     for (int c0 = ((nc - 1) >> 6) << 6; c0 >= 0; c0 -= 64) {
       const int cw = min(64, nc - c0);
       for (int t = tid; t < cw * cw; t += THREADS) {
@@ -1272,9 +1250,44 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
         if (r > c) Lc[r * 65 + c] = Lg[(int64_t)(c0 + c) * M + c0 + r];
         else if (r == c) Lc[r * 65 + c] = (T)1 / Lg[(int64_t)(c0 + c) * M + c0 + r];
       }
+      __syncthreads();   // also publishes xf entries written by the previous chunk
+      const int rb = c0 + cw, re = M - 1;
+      for (int jb = 4 * wave; jb < cw; jb += 4 * NW) {
+        const T *col[4];
+        T acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; q++) col[q] = Lg + (int64_t)(c0 + min(jb + q, cw - 1)) * M;
+        int i = rb + lane;
+        for (; i + 192 < re; i += 256) {
+          T xv[4], lv[4][4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            xv[u] = xf[i + 64 * u];
+#pragma unroll
+            for (int q = 0; q < 4; q++) lv[q][u] = col[q][i + 64 * u];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[q] += lv[q][u] * xv[u];
+        }
+        for (; i < re; i += 64) {
+          const T xv = xf[i];
+#pragma unroll
+          for (int q = 0; q < 4; q++) acc[q] += col[q][i] * xv;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o);
+        if (lane == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (jb + q < cw) xf[c0 + jb + q] = col[q][M - 1] - acc[q];
+        }
+      }
       __syncthreads();
       if (tid < 64) {
-        T tv = tid < cw ? t1[c0 + tid] : (T)0;
+        T tv = tid < cw ? xf[c0 + tid] : (T)0;
         const T *row = Lc + (cw - 1) * 65;
         T rd = row[cw - 1];
         T rv = tid < cw - 1 ? row[tid] : (T)0;
@@ -1292,26 +1305,11 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
           rd = nd;
           rv = nv;
         }
-        if (tid < cw) t1[c0 + tid] = tv;
+        if (tid < cw) xf[c0 + tid] = tv;
       }
-      __syncthreads();
-      // fold the solved chunk into the entries to its left: t1[i] -= sum_jj L(c0+jj, i) x[c0+jj]
-      {
-        const T xv = lane < cw ? t1[c0 + lane] : (T)0;
-        for (int i = wave; i < c0; i += 2 * NW) {
-          const int i1 = i + NW;
-          T v0 = lane < cw ? Lg[(int64_t)i * M + c0 + lane] * xv : (T)0;
-          T v1 = (i1 < c0 && lane < cw) ? Lg[(int64_t)i1 * M + c0 + lane] * xv : (T)0;
-          for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_down(v0, o); v1 += __shfl_down(v1, o); }
-          if (lane == 0) {
-            t1[i] -= v0;
-            if (i1 < c0) t1[i1] -= v1;
-          }
-        }
-      }
-      __syncthreads();
+      __syncthreads();   // Lc is restaged and xf[c0..] is read by everybody in the next chunk
     }
-    for (int j = tid; j < nc; j += THREADS) a.x[m.col0 + j] = t1[j];
+    for (int j = tid; j < nc; j += THREADS) a.x[m.col0 + j] = xf[j];
     __syncthreads();
   }
 }

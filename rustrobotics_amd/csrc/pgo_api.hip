@@ -318,7 +318,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       } else {
         for (int t = st.task_begin; t < st.task_end; t++) {
           int s = sym.task_sn[sym.task_ptr[t]];
-          need = std::max(need, sym.sn_ncols[s] + sym.sn_nrows[s] + 64 * 65 + 2);
+          need = std::max(need, sym.sn_ncols[s] + sym.sn_nrows[s] + 64 * 65 + 4);
         }
       }
       if ((size_t)need * sizeof(T) > (size_t)kMaxLds) throw ApiError(RR_PGO_EUNSUPPORTED, "front too large for the back-substitution scratch");
