@@ -683,18 +683,16 @@ static void build_coo(const og_graph *g, double lambda, int lm, coo *H, double *
     int fi = n1->offset, ti = n2->offset;
     double A[36], B[36], e[6];
     og_linearize_edge(g, k, A, B, e);
-    double Hii[36], Hij[36], Hjj[36], we[6], bi[6], bj[6];
+    double Hii[36], Hij[36], Hjj[36], bi[6], bj[6];
     atwb(de, d1, d1, A, ed->info, A, Hii);
     atwb(de, d1, d2, A, ed->info, B, Hij);
     atwb(de, d2, d2, B, ed->info, B, Hjj);
     /* b_i = (A^T W) e */
-    double T[36];
     for (int i = 0; i < d1; i++) {
       double s = 0.0;
       for (int j = 0; j < de; j++) {
         double t = 0.0;
         for (int q = 0; q < de; q++) t += A[q * d1 + i] * ed->info[q * de + j];
-        T[i * de + j] = t;
         s += t * e[j];
       }
       bi[i] = s;
@@ -708,7 +706,7 @@ static void build_coo(const og_graph *g, double lambda, int lm, coo *H, double *
       }
       bj[i] = s;
     }
-    (void)we;
+  
     /* set_matrix x4, :184-187 */
     for (int i = 0; i < d1; i++)
       for (int j = 0; j < d1; j++) coo_put(H, fi + i, fi + j, Hii[i * d1 + j]);

@@ -40,8 +40,14 @@ constexpr int UPD_THREADS = 256;
   do {                                                                               \
     if (threadIdx.x == 0 && (ptr)) (ptr)[slot] += wall_clock64() - acc_t0_;         \
   } while (0)
+#ifdef RRPGO_STAMPS_SOLVE   // the back substitution reuses slots 0..4: stamp it OR the factorisation
+#define RRPGO_STAMP_SOLVE(a, s, slot) RRPGO_STAMP(a, s, slot)
+#else
+#define RRPGO_STAMP_SOLVE(a, s, slot) do { } while (0)
+#endif
 #else
 #define RRPGO_STAMP(a, s, slot) do { } while (0)
+#define RRPGO_STAMP_SOLVE(a, s, slot) do { } while (0)
 #define RRPGO_ACC_DECL() do { } while (0)
 #define RRPGO_ACC_BEGIN() do { } while (0)
 #define RRPGO_ACC_END(ptr, slot) do { } while (0)
@@ -655,61 +661,95 @@ __device__ __forceinline__ float fast_rsqrt(float d) {
 // (row per lane, columns exchanged with v_readlane), triangular solve with one
 // thread per row, rank-16 update of the remaining panel columns on the matrix
 // cores (one 16 x 16 tile per wave at a time).
+// diagonal block k0 (nb <= 16 columns) in the registers of the calling wave
+template <typename T>
+__device__ __forceinline__ void diag_block_factor(T *P, int M, int k0, int nb, int *err, T *dinv) {
+  constexpr int NB = 16;
+  const int tid = threadIdx.x & 63;
+  // Row `tid` of the block lives in r[0..tid]; r[j] for j > tid is scratch that is updated like
+  // everything else but never read (no predication, no per-column branches on the critical path).
+  T r[NB];
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < NB; k++) r[k] = (tid < nb && k <= tid && k < nb) ? P[(k0 + k) * M + k0 + tid] : (T)0;
+  if (nb == NB) {
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      T d = lane_bcast(r[k], k);
+      if (!(d > (T)0)) { bad = true; d = (T)1; }
+      const T inv = fast_rsqrt(d);
+      const T lik = tid >= k ? r[k] * inv : (T)0;   // lane k: d * inv = sqrt(d)
+      r[k] = lik;
+      if (tid == k) dinv[k] = inv;
+#pragma unroll
+      for (int j = k + 1; j < NB; j++) r[j] -= lik * lane_bcast(lik, j);
+    }
+  } else {
+    // partial last block: pad with an identity so the same straight-line code runs
+#pragma unroll
+    for (int k = 0; k < NB; k++)
+      if (k >= nb && tid == k) r[k] = (T)1;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      T d = lane_bcast(r[k], k);
+      if (!(d > (T)0)) { bad = true; d = (T)1; }
+      const T inv = fast_rsqrt(d);
+      const T lik = tid >= k ? r[k] * inv : (T)0;
+      r[k] = lik;
+      if (tid == k) dinv[k] = inv;
+      if (k + 1 >= nb) break;  // wave-uniform
+#pragma unroll
+      for (int j = k + 1; j < NB; j++) r[j] -= lik * lane_bcast(lik, j);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NB; k++)
+    if (tid < nb && k <= tid && k < nb) P[(k0 + k) * M + k0 + tid] = r[k];
+  if (bad && tid == 0) atomicOr(err, DEVERR_NOT_SPD);
+}
+
+// Workgroup-wide partial Cholesky of the leading nc columns of the M x nc panel P (column-major,
+// ld M; rows nc.. are the off-diagonal rows and the rhs row), blocked by 16 columns:
+//   diagonal block   registers of wave 0 (row per lane, v_readlane broadcasts, rsqrt + Newton)
+//   rows below       one thread per row (forward substitution against the block)
+//   trailing update  16 x 16 MFMA tiles, one per wave at a time
+// with a one-block LOOK-AHEAD: after the triangular solve of block k only the next block column is
+// updated by everybody; the rest of block k's update runs on waves 1.. while wave 0 already factors
+// diagonal block k+1 (the two touch disjoint columns).
 template <typename T, int THREADS>
 __device__ void panel_factor(T *P, int M, int nc, int *err, T *dinv /* 16 scalars of LDS */,
                              unsigned long long *acc = nullptr) {
   constexpr int NB = 16;
+  constexpr int NW = THREADS / 64;
   const int tid = threadIdx.x;
+  const int wave = tid >> 6;
   RRPGO_ACC_DECL();
+  int pend_k0 = -1;   // block whose "rest" update (block columns 1.. of its trailing part) is still owed
+  auto rest_update = [&](int pk0, int first_wave, int nwaves) {
+    // tiles with jb >= 1 of the update of block pk0 (full 16 columns by construction)
+    const int js = pk0 + NB;
+    const int nj = (nc - js + 15) >> 4, ni = (M - js + 15) >> 4;
+    for (int t = ni + (wave - first_wave); t < nj * ni; t += nwaves) {
+      const int jb = t / ni, ib = t - jb * ni;
+      if (ib < jb) continue;
+      tile_rank_update<T>(P, M, js + 16 * ib, js + 16 * jb, M, nc, pk0, pk0 + NB,
+                          [&](int i, int j) { return P + j * M + i; });
+    }
+  };
   for (int k0 = 0; k0 < nc; k0 += NB) {
     const int nb = min(NB, nc - k0);
     RRPGO_ACC_BEGIN();
-    if (tid < 64) {
-      // Row `tid` of the block lives in r[0..tid]; r[j] for j > tid is scratch
-      // that is updated like everything else but never read (no predication,
-      // no per-column branches on the critical path).
-      T r[NB];
-      bool bad = false;
-#pragma unroll
-      for (int k = 0; k < NB; k++) r[k] = (tid < nb && k <= tid && k < nb) ? P[(k0 + k) * M + k0 + tid] : (T)0;
-      if (nb == NB) {
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-          T d = lane_bcast(r[k], k);
-          if (!(d > (T)0)) { bad = true; d = (T)1; }
-          const T inv = fast_rsqrt(d);
-          const T lik = tid >= k ? r[k] * inv : (T)0;   // lane k: d * inv = sqrt(d)
-          r[k] = lik;
-          if (tid == k) dinv[k] = inv;
-#pragma unroll
-          for (int j = k + 1; j < NB; j++) r[j] -= lik * lane_bcast(lik, j);
-        }
-      } else {
-        // partial last block: pad with an identity so the same straight-line code runs
-#pragma unroll
-        for (int k = 0; k < NB; k++)
-          if (k >= nb && tid == k) r[k] = (T)1;
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-          T d = lane_bcast(r[k], k);
-          if (!(d > (T)0)) { bad = true; d = (T)1; }
-          const T inv = fast_rsqrt(d);
-          const T lik = tid >= k ? r[k] * inv : (T)0;
-          r[k] = lik;
-          if (tid == k) dinv[k] = inv;
-          if (k + 1 >= nb) break;  // wave-uniform
-#pragma unroll
-          for (int j = k + 1; j < NB; j++) r[j] -= lik * lane_bcast(lik, j);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < NB; k++)
-        if (tid < nb && k <= tid && k < nb) P[(k0 + k) * M + k0 + tid] = r[k];
-      if (bad && tid == 0) atomicOr(err, DEVERR_NOT_SPD);
+    if (NW == 1) {
+      if (pend_k0 >= 0) rest_update(pend_k0, 0, 1);
+      diag_block_factor<T>(P, M, k0, nb, err, dinv);
+    } else if (wave == 0) {
+      diag_block_factor<T>(P, M, k0, nb, err, dinv);
+    } else if (pend_k0 >= 0) {
+      rest_update(pend_k0, 1, NW - 1);
     }
+    pend_k0 = -1;
     __syncthreads();
     RRPGO_ACC_END(acc, 7);
-    if (k0 + nb >= M) break;
     RRPGO_ACC_BEGIN();
     // rows below the diagonal block: x * L11^T = row  (forward substitution per row)
     for (int i = k0 + nb + tid; i < M; i += THREADS) {
@@ -728,20 +768,17 @@ __device__ void panel_factor(T *P, int M, int nc, int *err, T *dinv /* 16 scalar
     }
     __syncthreads();
     RRPGO_ACC_END(acc, 8);
-    // remaining pivot columns j in [k0+nb, nc), rows i >= j: P(i,j) -= L(i, blk) L(j, blk)^T
+    // next block column only (jb == 0): P(i,j) -= L(i, blk) L(j, blk)^T, j in [k0+nb, k0+nb+16)
     const int js = k0 + nb;
     if (js < nc) {
       RRPGO_ACC_BEGIN();
-      const int nj = (nc - js + 15) >> 4, ni = (M - js + 15) >> 4;
-      const int wave = tid >> 6;
-      for (int t = wave; t < nj * ni; t += THREADS / 64) {
-        const int jb = t / ni, ib = t - jb * ni;
-        if (ib < jb) continue;
-        tile_rank_update<T>(P, M, js + 16 * ib, js + 16 * jb, M, nc, k0, k0 + nb,
+      const int ni = (M - js + 15) >> 4;
+      for (int ib = wave; ib < ni; ib += NW)
+        tile_rank_update<T>(P, M, js + 16 * ib, js, M, nc, k0, k0 + nb,
                             [&](int i, int j) { return P + j * M + i; });
-      }
       __syncthreads();
       RRPGO_ACC_END(acc, 9);
+      if (js + NB < nc) pend_k0 = k0;   // more block columns to the right: owed, done under the next diagonal block
     }
   }
 }
@@ -1149,7 +1186,7 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
     T *x2 = work + nc * ldt;      // nr
     T *t1 = x2 + nr;              // nc
     __syncthreads();
-    RRPGO_STAMP(a, s, 0);
+    RRPGO_STAMP_SOLVE(a, s, 0);
     for (int i = tid; i < nr; i += THREADS) x2[i] = a.x[rows[i]];
     // stage L11 transposed: element L(r, c), r >= c, goes to Lt[r * ldt + c]
     // (the diagonal is stored as its reciprocal: the divide would otherwise sit on the
@@ -1160,7 +1197,7 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
       else if (r == c) Lt[r * ldt + c] = (T)1 / Lg[(int64_t)c * M + r];
     }
     __syncthreads();
-    RRPGO_STAMP(a, s, 1);
+    RRPGO_STAMP_SOLVE(a, s, 1);
     // t1[j] = y1[j] - sum_i L21[i][j] x2[i]: a wave takes four columns at a time (four
     // independent global load streams in flight), lanes over rows (coalesced)
     {
@@ -1190,7 +1227,7 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
       }
     }
     __syncthreads();
-    RRPGO_STAMP(a, s, 2);
+    RRPGO_STAMP_SOLVE(a, s, 2);
     // L11^T x = t, backward, in 64-column chunks.  Inside a chunk lane l of the first wave
     // owns entry c0+l; step j needs row j of L11 (Lt[j*ldt + c0 ..], contiguous), fetched
     // one step ahead so that the chain between steps is readlane -> mul -> fma.  After a
@@ -1227,10 +1264,10 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
       if (c0 > 0) __syncthreads();
     }
     __syncthreads();
-    RRPGO_STAMP(a, s, 3);
+    RRPGO_STAMP_SOLVE(a, s, 3);
     for (int j = tid; j < nc; j += THREADS) a.x[m.col0 + j] = t1[j];
     __syncthreads();
-    RRPGO_STAMP(a, s, 4);
+    RRPGO_STAMP_SOLVE(a, s, 4);
   } else {
     // Front in place in HBM (fronts beyond LDS), left-looking over 64-column chunks from the right:
     //   t_c = y1_c - L[rows below the chunk, chunk]^T * xf[rows below]      one contiguous GEMV
