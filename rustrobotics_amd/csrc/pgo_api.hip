@@ -971,7 +971,8 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
     so.my_part = opt.rank;
     so.nd_leaf = 64;
   }
-  if (const char *e = std::getenv("RR_PGO_MID_MAX")) so.mid_max_front = std::atoi(e);   // tuning knob
+  if (const char *e = std::getenv("RR_PGO_MID_MAX")) so.mid_max_front = std::atoi(e);   // tuning knobs
+  if (const char *e = std::getenv("RR_PGO_TASK_US")) so.task_us = std::atof(e);
   double t0 = now_ms();
   std::string err = analyze(h->g, so, h->sym);
   if (!err.empty()) throw ApiError(RR_PGO_EINVAL, err);

@@ -24,7 +24,7 @@ struct SymbolicOptions {
   int nd_leaf = 40;         // nested dissection stops below this many nodes
   int n_parts = 1;          // >1: top ND levels are shared, subtrees owned by ranks (power of two)
   int my_part = 0;          // with n_parts > 1: the rank whose schedule is emitted (own subtrees, then shared top)
-  double task_us = 6.0;     // subtrees cheaper than this become one leaf task
+  double task_us = 0.0;     // subtrees cheaper than this (model us) become one leaf task; 0 = pick by the cost model
   int mid_max_front = 0;    // fronts beyond LDS up to this size go to the one-workgroup in-place path (0: none,
                             // measured slower than the batched tiled path on the 1M-edge lattice)
 };
@@ -111,6 +111,7 @@ struct Symbolic {
   int64_t factor_flops = 0;
   int32_t max_front = 0, max_pivot_cols = 0, n_big = 0;
   double est_critical_us = 0.0;
+  double task_us_used = 0.0;
 };
 
 // Returns "" or an error message.

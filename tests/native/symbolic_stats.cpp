@@ -25,9 +25,9 @@ int main(int argc, char **argv) {
   std::string e = analyze(g, opt, s);
   double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (!e.empty()) { printf("analyze error: %s\n", e.c_str()); return 1; }
-  printf("N=%d E=%d dim=%d | analyze %.1f ms | S=%d Lblocks=%lld l_elems=%lld u_elems=%lld flops=%.3g | maxfront=%d maxpiv=%d big=%d | steps=%zu tasks=%zu est_crit=%.1f us\n",
+  printf("N=%d E=%d dim=%d | analyze %.1f ms | S=%d Lblocks=%lld l_elems=%lld u_elems=%lld flops=%.3g | maxfront=%d maxpiv=%d big=%d | steps=%zu tasks=%zu est_crit=%.1f us task_us=%.0f\n",
          s.N, g.n_edges(), s.dim, ms, s.S, (long long)s.nnz_l_blocks, (long long)s.l_elems, (long long)s.u_elems,
-         (double)s.factor_flops, s.max_front, s.max_pivot_cols, s.n_big, s.steps.size(), s.task_ptr.size() - 1, s.est_critical_us);
+         (double)s.factor_flops, s.max_front, s.max_pivot_cols, s.n_big, s.steps.size(), s.task_ptr.size() - 1, s.est_critical_us, s.task_us_used);
   if (getenv("HIST")) {
     // fronts by size class: count, flops share
     const int edges[] = {64, 128, 256, 384, 512, 768, 1024, 1536, 2048, 4096, 1 << 30};
