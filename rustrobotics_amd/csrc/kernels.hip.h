@@ -4,7 +4,7 @@
 //   k_factor_tasks   multifrontal supernodal Cholesky, fronts in LDS  (replaces umfpack.factorize, :138)
 //   k_solve_tasks    back substitution down the supernode tree         (replaces umfpack.solve, :141)
 //   k_update         update_nodes + |dx|^2                             (reference :229-245,273)
-//   k_finalize       fixed-order reduction of the chi2 / |dx|^2 partials
+//   k_finalize_slot  fixed-order reduction of the chi2 / |dx|^2 partials (pgo_api.hip)
 //
 // Wavefront = 64 lanes.  All cross-workgroup dependencies are kernel boundaries
 // on one stream; inside a launch a workgroup only reads what it wrote itself
@@ -1435,23 +1435,6 @@ __global__ void __launch_bounds__(UPD_THREADS) k_update(UpdArgs<TO, T> a) {
   }
   double tot = block_sum<double, UPD_THREADS>(nrm, red);
   if (threadIdx.x == 0) a.norm_partial[blockIdx.x] = tot;
-}
-
-// scalars[0] = chi2 (sum of n_chi partials), scalars[1] = |dx| (sqrt of sum of n_norm partials)
-__global__ void __launch_bounds__(256) k_finalize(const double *chi_partial, int n_chi,
-                                                  const double *norm_partial, int n_norm,
-                                                  double *scalars) {
-  __shared__ double red[4];
-  double c = 0.0, n = 0.0;
-  // fixed order: each thread a strided slice, then the block tree
-  for (int i = threadIdx.x; i < n_chi; i += 256) c += chi_partial[i];
-  for (int i = threadIdx.x; i < n_norm; i += 256) n += norm_partial[i];
-  double ct = block_sum<double, 256>(c, red);
-  double nt = block_sum<double, 256>(n, red);
-  if (threadIdx.x == 0) {
-    if (n_chi > 0) scalars[0] = ct;
-    if (n_norm > 0) scalars[1] = sqrt(nt);
-  }
 }
 
 }  // namespace rrpgo
