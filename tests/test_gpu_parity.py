@@ -414,3 +414,56 @@ def test_mixed_precision_reaches_the_f64_answer(api, oracle):
     assert abs(em[-1] - e64[-1]) <= 1e-8 * e64[-1]
     assert all(b < a for a, b in zip(nm, nm[1:]))              # still contracting
     assert _state_diff_se2(gm.state(), g64.state()) <= 2e-2
+
+
+# ---- more corners of the same path -----------------------------------------------------------------
+
+def test_levenberg_marquardt_on_pose_landmark_graph(api, oracle):
+    """LM (:275-286, :362-366) on dlr.g2o: mixed 3-dim / 2-dim blocks, 17.6 k edges, a start far from the
+    minimum (chi2 rises on rejected steps, which the reference still records)."""
+    from oracle.oracle import LEVENBERG_MARQUARDT
+    g, o = api[0].new(g2o_path("dlr"), api[1].LevenbergMarquardt), oracle.load(g2o_path("dlr"))
+    eg, eo = g.optimize(12), o.optimize(12, LEVENBERG_MARQUARDT)
+    assert len(eg) == len(eo)
+    np.testing.assert_allclose(eg, eo, rtol=1e-6)
+
+
+def test_sharded_se3_graph(api):
+    """6 x 6 blocks through the sharded path (2 emulated ranks) == the unsharded handle."""
+    import torch
+    from rustrobotics_amd import sharded_gauss_newton
+    ref = api[0].new(g2o_path("sphere2500"))
+    arrays = ref.graph_arrays()
+    shards = [api[0].from_arrays(*arrays, rank=r, world_size=2) for r in range(2)]
+    bufs = {0: [], 1: []}
+    for g in shards:
+        for which in (0, 1):
+            _, n, _ = g.exchange_info(which)
+            t = torch.zeros(max(n, 1), dtype=torch.float64, device="cuda")
+            g.bind_exchange(which, t.data_ptr(), t.numel())
+            bufs[which].append(t)
+    errors = sharded_gauss_newton(shards, 12, _emulated_allreduce(torch, bufs))
+    eref = ref.optimize(12)
+    assert abs(errors[-1] - eref[-1]) <= 1e-9 * eref[-1] and abs(errors[-1] - 727.149667) < 1e-4
+    np.testing.assert_allclose(errors[:5], eref[:5], rtol=1e-7)
+    assert _quat_state_diff(shards[0].state(), shards[1].state()) <= 1e-12
+
+
+def test_degenerate_graphs(api, oracle):
+    """Smallest inputs: one edge (the prior makes it solvable, :330-336); no edge at all (no prior is
+    ever added -> singular, the reference's umfpack.factorize returns Err)."""
+    PoseGraph, _, PoseGraphError = api
+    nk = np.zeros(2, np.int32)
+    ns = np.array([0.1, -0.2, 0.05, 1.3, 0.4, -0.1])
+    ek, ef, et = np.zeros(1, np.int32), np.array([0], np.int32), np.array([1], np.int32)
+    em, ei = np.array([1.0, 0.5, -0.2]), np.array([10.0, 1, 0, 20, 2, 30])
+    g, o = PoseGraph.from_arrays(nk, ns, ek, ef, et, em, ei), oracle.from_arrays(nk, ns, ek, ef, et, em, ei)
+    eg, eo = g.optimize(20), o.optimize(20)
+    assert len(eg) == len(eo) and eg[-1] < 1e-12
+    assert np.abs(g.state() - o.state()).max() <= 1e-9
+    assert np.abs(g.state()[:3] - ns[:3]).max() < 1e-6            # the anchored pose stays put
+    g0 = PoseGraph.from_arrays(nk, ns, ek[:0], ef[:0], et[:0], em[:0], ei[:0])
+    assert g0.global_error() == 0.0 and g0.anchor_node == -1
+    with pytest.raises(PoseGraphError) as exc:
+        g0.optimize(1)
+    assert exc.value.code == -5
