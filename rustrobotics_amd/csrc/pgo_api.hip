@@ -142,14 +142,14 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<SnMeta> sn_meta_;
   DevBuf<ChildMeta> child_meta_;
   std::vector<int> step_solve_lds_;  // scalars of LDS the back-solve of each step needs
-  double *host_pair_ = nullptr;      // pinned, 2 doubles
+  double *host_pair_ = nullptr;      // pinned: chi2, |dx|, and (as an int in slot 2) the device error flag
   int n_lin_blocks_ = 0, n_upd_blocks_ = 0;
   int host_counter_ = 0;             // mirrors the device slot counter
 
  public:
   Engine(const HostGraph &g, const Symbolic &sym, int rank, int world) : g_(g), sym_(sym), rank_(rank), world_(world) {
     HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    HIPCHK(hipHostMalloc((void **)&host_pair_, 2 * sizeof(double)));
+    HIPCHK(hipHostMalloc((void **)&host_pair_, 3 * sizeof(double)));
     const int N = g.n_nodes(), E = g.n_edges();
     // ---- graph arrays
     is3d_ = g.has_se3;
@@ -647,22 +647,30 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     HIPCHK(hipGraphDestroy(graph));
   }
 
+  // One host round trip per iteration: the two scalars and the device error flag come back in
+  // two async copies behind a single stream synchronisation.
   void read_slot(int slot, double *chi, double *norm) {
+    int *eflag = reinterpret_cast<int *>(host_pair_ + 2);
     HIPCHK(hipMemcpyAsync(host_pair_, hist_.p + 2 * (slot % HIST), 2 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipMemcpyAsync(eflag, err_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     if (chi) *chi = host_pair_[0];
     if (norm) *norm = host_pair_[1];
+    throw_on_flag(*eflag);
+  }
+
+  void throw_on_flag(int e) {
+    if (!e) return;
+    HIPCHK(hipMemsetAsync(err_.p, 0, sizeof(int), stream_));
+    if (e & DEVERR_NOT_SPD) throw ApiError(RR_PGO_ENOTSPD, "normal matrix is not positive definite (non-positive pivot)");
+    throw ApiError(RR_PGO_ENODEVICE, "device-side error flag " + std::to_string(e));
   }
 
   void check_device_error() {
-    int e = 0;
-    HIPCHK(hipMemcpyAsync(&e, err_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    int *eflag = reinterpret_cast<int *>(host_pair_ + 2);
+    HIPCHK(hipMemcpyAsync(eflag, err_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
-    if (e) {
-      HIPCHK(hipMemsetAsync(err_.p, 0, sizeof(int), stream_));
-      if (e & DEVERR_NOT_SPD) throw ApiError(RR_PGO_ENOTSPD, "normal matrix is not positive definite (non-positive pivot)");
-      throw ApiError(RR_PGO_ENODEVICE, "device-side error flag " + std::to_string(e));
-    }
+    throw_on_flag(*eflag);
   }
 
   void reset_counter() {
@@ -719,7 +727,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         HIPCHK(hipGraphLaunch(gn_exec_, stream_));
         double chi, nrm;
         read_slot(i, &chi, &nrm);
-        check_device_error();
         errors[ne++] = chi;
         if (norms) norms[i] = nrm;
         done = i + 1;
@@ -742,7 +749,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         launch_finalize(true, false, false);
         double error, nrm;
         read_slot(0, &error, &nrm);
-        check_device_error();
         if (last_error < error) {  // :276-281
           launch_update(dx_ref_.p, -1.0, false);
           lambda *= 2.0;
@@ -879,7 +885,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     HIPCHK(hipMemcpyAsync(&c, counter_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     read_slot(c, chi, norm);
-    check_device_error();
   }
 
   void profile(int iters, double *ms, int64_t *launches) override {
