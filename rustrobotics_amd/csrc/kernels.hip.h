@@ -561,6 +561,7 @@ template <typename T> struct FactorArgs {
   T *uvals;                 // packed update matrices
   T *xch;                   // sharded runs: exchange buffer of the boundary fronts' packed update matrices
   T *x;                     // solution, permuted order
+  T *wdiag;                 // [front slot of the level][2][32 * 32] inverse of the current diagonal block, transposed
   int *err;
   unsigned long long *stamps;  // [S][8], diagnostic builds only (else null)
 };
@@ -1063,6 +1064,267 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_trsm(FactorAr
 #pragma unroll
   for (int c = 0; c < BIG_NB; c++)
     if (c < nb && active) src[(int64_t)c * M + row] = xr[c];
+}
+
+// ---- left-looking 32-column blocks inside a 128-column super-panel -------------------------------
+// 16 x 16 Cholesky AND inverse in the registers of one wave: lanes 0..15 hold the rows of the block,
+// lanes 16..31 the rows of an identity, so the column sweep that turns the block into L turns the
+// identity into L^-T (v_readlane broadcasts, rsqrt + Newton, no LDS and no barrier on the chain).
+template <typename T> __device__ __forceinline__ bool chol16_invert(T (&x)[16], int lane) {
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    T d = lane_bcast(x[k], k);
+    if (!(d > (T)0)) { bad = true; d = (T)1; }
+    const T inv = fast_rsqrt(d);
+    const T lik = lane >= k ? x[k] * inv : (T)0;
+    x[k] = lik;
+#pragma unroll
+    for (int j = k + 1; j < 16; j++) x[j] -= lik * lane_bcast(lik, j);
+  }
+  return bad;
+}
+
+// One wave factors the (<= 32)^2 diagonal block and inverts it, as a 2 x 2 recursion over 16 x 16
+// blocks: the two diagonal blocks in registers (above), the off-diagonal blocks on the matrix cores
+//   L21 = A21 W11^T,  S22 = A22 - L21 L21^T,  W21 = -W22 (L21 W11),   W = L^-1.
+// Results move from one MFMA to the next as accumulator registers wherever the contraction index of
+// the next product can be taken in the order the accumulator already has (k-slot = MM::row).
+//   Dl   LDS, Dl[c * 33 + r] = block(r, c) for r >= c  (r, c < nb);  Wl  LDS scratch of the same size
+//   out: F block (lower, in place) and Wt[j * 32 + c] = W(c, j)
+template <typename T>
+__device__ __forceinline__ void diag32_factor_invert(T *Dl, T *Wl, int nb, T *Fblk, int M, T *Wt, int *err) {
+  using MM = Mfma16<T>;
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  const int q = (lane - 16) & 15;
+  // a partial block is padded with an identity; the strictly upper part of W is zero
+  for (int e = lane; e < 32 * 32; e += 64) {
+    const int c = e >> 5, r = e & 31;
+    if (r >= c && (r >= nb || c >= nb)) Dl[c * 33 + r] = r == c ? (T)1 : (T)0;
+    if (r < c) Wl[c * 33 + r] = (T)0;          // Wl[j * 33 + c'] with c' < j
+  }
+  __syncthreads();
+  T x[16];
+  bool bad;
+  // ---- (1,1)
+#pragma unroll
+  for (int c = 0; c < 16; c++) x[c] = lane < 16 ? (c <= lane ? Dl[c * 33 + lane] : (T)0) : (q == c ? (T)1 : (T)0);
+  bad = chol16_invert<T>(x, lane);
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    if (lane < 16) { if (c <= lane) Dl[c * 33 + lane] = x[c]; }
+    else if (lane < 32) Wl[q * 33 + c] = x[c];               // W11(c, q)
+  }
+  __syncthreads();
+  // ---- L21(i, c) = sum_j A21(i, j) W11(c, j): tile rows = c, tile columns = i
+  typename MM::Acc l21 = {0, 0, 0, 0};
+#pragma unroll
+  for (int s4 = 0; s4 < 4; s4++)
+    l21 = MM::mma(Wl[(4 * s4 + lk) * 33 + li], Dl[(4 * s4 + lk) * 33 + 16 + li], l21);
+  // ---- S22(i, j) = A22(i, j) - sum_c L21(i, c) L21(j, c): tile rows = j, tile columns = i
+  typename MM::Acc s22;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int j = MM::row(lane, r);
+    s22[r] = li >= j ? Dl[(16 + j) * 33 + 16 + li] : (T)0;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) s22 = MM::mma(-l21[r], l21[r], s22);
+  // ---- T1(i, j) = sum_c L21(i, c) W11(c, j): tile rows = i, tile columns = j
+  typename MM::Acc t1 = {0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < 4; r++) t1 = MM::mma(l21[r], Wl[li * 33 + MM::row(lane, r)], t1);
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int c = MM::row(lane, r);
+    Dl[c * 33 + 16 + li] = l21[r];
+    if (li >= c) Dl[(16 + c) * 33 + 16 + li] = s22[r];
+  }
+  __syncthreads();
+  // ---- (2,2)
+#pragma unroll
+  for (int c = 0; c < 16; c++) x[c] = lane < 16 ? (c <= lane ? Dl[(16 + c) * 33 + 16 + lane] : (T)0) : (q == c ? (T)1 : (T)0);
+  bad = chol16_invert<T>(x, lane) || bad;
+  if (bad && lane == 0) atomicOr(err, DEVERR_NOT_SPD);
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    if (lane < 16) { if (c <= lane) Dl[(16 + c) * 33 + 16 + lane] = x[c]; }
+    else if (lane < 32) Wl[(16 + q) * 33 + 16 + c] = x[c];   // W22(c, q)
+  }
+  __syncthreads();
+  // ---- W21(p, j) = -sum_i W22(p, i) T1(i, j): tile rows = p, tile columns = j
+  typename MM::Acc w21 = {0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < 4; r++) w21 = MM::mma(-Wl[(16 + MM::row(lane, r)) * 33 + 16 + li], t1[r], w21);
+#pragma unroll
+  for (int r = 0; r < 4; r++) Wl[li * 33 + 16 + MM::row(lane, r)] = w21[r];
+  __syncthreads();
+  for (int e = lane; e < 32 * 32; e += 64) {
+    const int c = e >> 5, r = e & 31;
+    if (r < nb && c <= r) Fblk[(int64_t)c * M + r] = Dl[c * 33 + r];
+    Wt[e] = Wl[c * 33 + r];                                   // e = j * 32 + c'
+  }
+}
+
+// First diagonal block of a super-panel (everything left of it has been applied by the trailing
+// update): one wave per front.
+template <typename T> __global__ void __launch_bounds__(64) k_big_diag32(FactorArgs<T> a, int kb) {
+  __shared__ T Dl[32 * 33], Wl[32 * 33];
+  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  if (kb >= m.nc) return;
+  const int nb = min(BIG_NB, m.nc - kb);
+  const int M = m.nc + m.nr + 1;
+  T *Fblk = a.lvals + m.loff + (int64_t)kb * M + kb;
+  const int lane = threadIdx.x;
+  T v[16];
+#pragma unroll
+  for (int t = 0; t < 16; t++) {   // all 16 loads in flight together
+    const int e = t * 64 + lane, c = e >> 5, r = e & 31;
+    v[t] = (r < nb && c <= r) ? Fblk[(int64_t)c * M + r] : (T)0;
+  }
+#pragma unroll
+  for (int t = 0; t < 16; t++) {
+    const int e = t * 64 + lane, c = e >> 5, r = e & 31;
+    if (c <= r) Dl[c * 33 + r] = v[t];
+  }
+  __syncthreads();
+  diag32_factor_invert<T>(Dl, Wl, nb, Fblk, M, a.wdiag + (int64_t)blockIdx.y * 2048 + ((kb / BIG_NB) & 1) * 1024, a.err);
+}
+
+// Rows below the 32-column block at kb, one wave per 32 rows, everything on the matrix cores:
+//   A  = F[rows, kb:kb+nb] - F[rows, K0:kb] * F[kb:kb+nb, K0:kb]^T     (left-looking update, K <= 96)
+//   X  = A * W^T,  W = inverse of the diagonal block (k_big_diag32 or the previous launch)
+// The accumulators hold the transposed tile (MFMA rows = panel columns j, MFMA columns = rows i, the
+// contiguous direction).  A k-slot of the second product is whatever panel column the accumulator
+// register already holds, so A goes from result to operand without leaving its registers.
+// The wave that owns rows kb+32..kb+63 then forms the NEXT diagonal block the same way (its own X is
+// the last 32 columns of that update), factors and inverts it: one launch per 32 columns on the chain.
+template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(FactorArgs<T> a, int kb, int K0) {
+  static_assert(BIG_NB == 32, "the left-looking panel kernels are written for 32-column blocks");
+  using MM = Mfma16<T>;
+  __shared__ T Dl[32 * 33], Wl[32 * 33];
+  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  if (kb >= m.nc) return;
+  const int nb = min(BIG_NB, m.nc - kb);
+  const int M = m.nc + m.nr + 1;
+  const int R0 = kb + nb + blockIdx.x * 32;
+  if (R0 >= M) return;
+  T *F = a.lvals + m.loff;
+  // two W slots per front, alternating by block: workgroups of one launch are not co-resident, so the
+  // slot this launch reads must not be the one its first workgroup rewrites for the next block
+  const T *Wt = a.wdiag + (int64_t)blockIdx.y * 2048 + ((kb / BIG_NB) & 1) * 1024;
+  const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
+  const int super_end = min(K0 + BIG_SUPER, m.nc);
+  const int kn = kb + BIG_NB;
+  const bool look = blockIdx.x == 0 && kn < super_end;   // nb == 32 here
+  // W operand tiles (cb, jb) = (0,0), (1,0), (1,1); (0,1) is zero
+  T wv[3][4];
+#pragma unroll
+  for (int t = 0; t < 3; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int cb = t == 0 ? 0 : 1, jb = t == 2 ? 1 : 0;
+      wv[t][r] = Wt[(16 * jb + MM::row(lane, r)) * 32 + 16 * cb + li];
+    }
+  typename MM::Acc acc[2][2], nxt[2][2];
+  bool rowok[2];
+#pragma unroll
+  for (int ib = 0; ib < 2; ib++) {
+    const int i = R0 + 16 * ib + li;
+    rowok[ib] = i < M;
+#pragma unroll
+    for (int jb = 0; jb < 2; jb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int j = 16 * jb + MM::row(lane, r);
+        acc[ib][jb][r] = (rowok[ib] && j < nb) ? F[(int64_t)(kb + j) * M + i] : (T)0;
+        // next diagonal block (rows = columns = kn..kn+31), lower part; the rest is never read
+        const int jn = kn + j;
+        nxt[ib][jb][r] = (look && i < m.nc && jn < m.nc && i >= jn) ? F[(int64_t)jn * M + i] : (T)0;
+      }
+  }
+  // the columns K0..kb come in whole 32-column blocks (at most three): all 32 operand loads of a block
+  // are issued before its MFMAs, and the next block's loads before that -- the loop would otherwise pay
+  // one L2 round trip per k-step
+  const int nblk = (kb - K0) / BIG_NB;
+  T av[8][2], bv[8][2], an[8][2], bn[8][2];
+  auto fetch = [&](int blk, T (*xa)[2], T (*xb)[2]) {
+#pragma unroll
+    for (int s4 = 0; s4 < 8; s4++) {
+      const T *col = F + (int64_t)(K0 + blk * BIG_NB + 4 * s4 + lk) * M;
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        xa[s4][t] = (16 * t + li < nb) ? -col[kb + 16 * t + li] : (T)0;
+        xb[s4][t] = rowok[t] ? col[R0 + 16 * t + li] : (T)0;
+      }
+    }
+  };
+  if (nblk > 0) fetch(0, av, bv);
+#pragma unroll
+  for (int blk = 0; blk < BIG_SUPER / BIG_NB - 1; blk++) {
+    if (blk < nblk) {
+      if (blk + 1 < nblk) fetch(blk + 1, an, bn);
+#pragma unroll
+      for (int s4 = 0; s4 < 8; s4++) {
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+          for (int jb = 0; jb < 2; jb++) acc[ib][jb] = MM::mma(av[s4][jb], bv[s4][ib], acc[ib][jb]);
+        if (look) {
+#pragma unroll
+          for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+            for (int jb = 0; jb <= ib; jb++) nxt[ib][jb] = MM::mma(-bv[s4][jb], bv[s4][ib], nxt[ib][jb]);
+        }
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 8; s4++)
+#pragma unroll
+        for (int t = 0; t < 2; t++) { av[s4][t] = an[s4][t]; bv[s4][t] = bn[s4][t]; }
+    }
+  }
+  // X = A * W^T : out[ib][cb] (rows c of the MFMA tile) = sum_j W[c][j] * A[j][i]
+  typename MM::Acc out[2][2];
+#pragma unroll
+  for (int ib = 0; ib < 2; ib++) {
+    out[ib][0] = typename MM::Acc{0, 0, 0, 0};
+    out[ib][1] = typename MM::Acc{0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      out[ib][0] = MM::mma(wv[0][r], acc[ib][0][r], out[ib][0]);
+      out[ib][1] = MM::mma(wv[1][r], acc[ib][0][r], out[ib][1]);
+      out[ib][1] = MM::mma(wv[2][r], acc[ib][1][r], out[ib][1]);
+    }
+  }
+#pragma unroll
+  for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int c = 16 * cb + MM::row(lane, r);
+        if (rowok[ib] && c < nb) F[(int64_t)(kb + c) * M + R0 + 16 * ib + li] = out[ib][cb][r];
+      }
+  if (!look) return;
+  // next diagonal block: the last 32 columns of its update are this wave's own X
+#pragma unroll
+  for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+        for (int jb = 0; jb <= ib; jb++) nxt[ib][jb] = MM::mma(-out[jb][cb][r], out[ib][cb][r], nxt[ib][jb]);
+  const int nbn = min(BIG_NB, m.nc - kn);
+#pragma unroll
+  for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+    for (int jb = 0; jb <= ib; jb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) Dl[(16 * jb + MM::row(lane, r)) * 33 + 16 * ib + li] = nxt[ib][jb][r];
+  __syncthreads();
+  diag32_factor_invert<T>(Dl, Wl, nbn, F + (int64_t)kn * M + kn, M, a.wdiag + (int64_t)blockIdx.y * 2048 + ((kn / BIG_NB) & 1) * 1024, a.err);
 }
 
 // Rank update  C(i,j) -= sum_{k in [ka,ke)} F(i,k) F(j,k)  over i in [t0, M), j in [t0, jmax), i >= j.

@@ -129,11 +129,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   int rank_ = 0, world_ = 1;
   DevBuf<T> xch_own_;               // exchange buffer (boundary update matrices) unless the caller binds one
   T *xch_ = nullptr, *x_ptr_ = nullptr;
+  bool left_looking_ = true;        // RR_PGO_RIGHT_LOOKING=1: the older diag / trsm / K=32 update launches
   DevBuf<int8_t> col_owner_;
   DevBuf<int64_t> pack_list_;       // (front, exchange offset) of the in-place boundary fronts this rank owns
   int n_pack_ = 0, pack_max_nu_ = 0;
   // numeric
-  DevBuf<T> hvals_, b_, x_, dx_ref_, lvals_, uvals_;
+  DevBuf<T> hvals_, b_, x_, dx_ref_, lvals_, uvals_, wdiag_;
   DevBuf<double> chi_partial_, norm_partial_, hist_;
   DevBuf<int> counter_, err_;
   DevBuf<unsigned long long> stamps_;  // diagnostic builds only
@@ -245,6 +246,14 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     lvals_.alloc((size_t)sym.l_elems + 4);
     uvals_.alloc((size_t)sym.u_elems + 4);
     lvals_.zero(); uvals_.zero();
+    {
+      int max_big = 1;   // most huge fronts in one level: two 32 x 32 inverse diagonal blocks each
+      for (const Step &st : sym.steps)
+        if (st.kind == STEP_BIG) max_big = std::max(max_big, st.task_end - st.task_begin);
+      wdiag_.alloc((size_t)max_big * 2048);
+      wdiag_.zero();
+    }
+    left_looking_ = getenv("RR_PGO_RIGHT_LOOKING") == nullptr;
     n_lin_blocks_ = (int)(((int64_t)N * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
     n_upd_blocks_ = (N + UPD_THREADS - 1) / UPD_THREADS;
     chi_partial_.alloc((size_t)n_lin_blocks_);
@@ -408,6 +417,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     a.uvals = uvals_.p;
     a.xch = xch_;
     a.x = x_ptr_;
+    a.wdiag = wdiag_.p;
     a.err = err_.p;
     a.stamps = stamps_.p;
     return a;
@@ -535,6 +545,25 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     }
     if (do_launch) pend(RR_PGO_K_BIGFRONT);   // closes the zero / assemble / extend-add segment
     for (int K0 = 0; K0 < max_nc; K0 += BIG_SUPER) {
+      if (left_looking_) {
+        // left-looking inside the super-panel: the first diagonal block, then ONE launch per 32 columns
+        // (update from the columns K0..kb, multiply by the inverse diagonal block, next diagonal block)
+        if (do_launch) {
+          pbegin();
+          hipLaunchKernelGGL(k_big_diag32<T>, dim3(1, nf), dim3(64), 0, stream_, a, K0);
+          check_launch("k_big_diag32");
+        }
+        n++;
+        for (int kb = K0; kb < std::min(K0 + BIG_SUPER, max_nc); kb += BIG_NB) {
+          const int rb = rows_max(kb) - 1;
+          if (do_launch) {
+            hipLaunchKernelGGL(k_big_panel32<T>, dim3((std::max(rb, 1) + 31) / 32, nf), dim3(64), 0, stream_, a, kb, K0);
+            check_launch("k_big_panel32");
+          }
+          n++;
+        }
+        if (do_launch) pend(RR_PGO_K_BIG_PANEL);
+      } else
       for (int kb = K0; kb < std::min(K0 + BIG_SUPER, max_nc); kb += BIG_NB) {
         const int rb = rows_max(kb) - 1;   // rows below a 1..32 wide block, at least the rhs row
         const int gp = (std::max(rb, 1) + BIG_PANEL_ROWS - 1) / BIG_PANEL_ROWS;
