@@ -633,6 +633,13 @@ __device__ __forceinline__ void tile_rank_update(const T *X, int ldx, int i0, in
     if (valid[r]) *caddr(i, j0 + MM::row(lane, r)) = acc[r];
 }
 
+// Keeps an unconditional load unconditional: without it the compiler sinks a load whose value is only
+// used under a select back into a branch (s_and_saveexec + s_cbranch per access).
+template <typename T> __device__ __forceinline__ T pin(T v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 // value of `v` in lane `src` (wave-uniform src): v_readlane, no LDS crossbar trip
 __device__ __forceinline__ double lane_bcast(double v, int src) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -1090,31 +1097,32 @@ template <typename T> __device__ __forceinline__ bool chol16_invert(T (&x)[16], 
 //   L21 = A21 W11^T,  S22 = A22 - L21 L21^T,  W21 = -W22 (L21 W11),   W = L^-1.
 // Results move from one MFMA to the next as accumulator registers wherever the contraction index of
 // the next product can be taken in the order the accumulator already has (k-slot = MM::row).
-//   Dl   LDS, Dl[c * 33 + r] = block(r, c) for r >= c  (r, c < nb);  Wl  LDS scratch of the same size
-//   out: F block (lower, in place) and Wt[j * 32 + c] = W(c, j)
+// A lone wave pays ~4 ns per instruction and ~30 ns per LDS round trip, and a predicated LDS or global
+// access costs a branch: every access below is unconditional (lanes 32..63 mirror lanes 0..31 and
+// store the same values, the never-read upper triangles take whatever falls out) and selects do the
+// masking.
+//   Sh   LDS, 2 * 32 * 33 scalars: Sh[c * 33 + r] = block(r, c) for r >= c, a partial block (nb < 32)
+//        already padded with an identity by the caller; the second half is scratch for W
+//   out: F block (in place, zeros above the diagonal) and Wt[j * 32 + c] = W(c, j)
 template <typename T>
-__device__ __forceinline__ void diag32_factor_invert(T *Dl, T *Wl, int nb, T *Fblk, int M, T *Wt, int *err) {
+__device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int M, T *Wt, int *err) {
   using MM = Mfma16<T>;
+  constexpr int WOFF = 32 * 33;
+  T *Dl = Sh, *Wl = Sh + WOFF;
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-  const int q = (lane - 16) & 15;
-  // a partial block is padded with an identity; the strictly upper part of W is zero
-  for (int e = lane; e < 32 * 32; e += 64) {
-    const int c = e >> 5, r = e & 31;
-    if (r >= c && (r >= nb || c >= nb)) Dl[c * 33 + r] = r == c ? (T)1 : (T)0;
-    if (r < c) Wl[c * 33 + r] = (T)0;          // Wl[j * 33 + c'] with c' < j
-  }
-  __syncthreads();
+  const int ll = lane & 31, q = lane & 15;
+  const bool rowlane = ll < 16;
   T x[16];
   bool bad;
   // ---- (1,1)
 #pragma unroll
-  for (int c = 0; c < 16; c++) x[c] = lane < 16 ? (c <= lane ? Dl[c * 33 + lane] : (T)0) : (q == c ? (T)1 : (T)0);
-  bad = chol16_invert<T>(x, lane);
-#pragma unroll
   for (int c = 0; c < 16; c++) {
-    if (lane < 16) { if (c <= lane) Dl[c * 33 + lane] = x[c]; }
-    else if (lane < 32) Wl[q * 33 + c] = x[c];               // W11(c, q)
+    const T v = pin(Dl[c * 33 + q]);
+    x[c] = rowlane ? (c <= q ? v : (T)0) : (q == c ? (T)1 : (T)0);
   }
+  bad = chol16_invert<T>(x, ll);
+#pragma unroll
+  for (int c = 0; c < 16; c++) Sh[rowlane ? c * 33 + q : WOFF + q * 33 + c] = x[c];   // L11(q, c) | W11(c, q)
   __syncthreads();
   // ---- L21(i, c) = sum_j A21(i, j) W11(c, j): tile rows = c, tile columns = i
   typename MM::Acc l21 = {0, 0, 0, 0};
@@ -1126,7 +1134,8 @@ __device__ __forceinline__ void diag32_factor_invert(T *Dl, T *Wl, int nb, T *Fb
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int j = MM::row(lane, r);
-    s22[r] = li >= j ? Dl[(16 + j) * 33 + 16 + li] : (T)0;
+    const T v = pin(Dl[(16 + j) * 33 + 16 + li]);
+    s22[r] = li >= j ? v : (T)0;
   }
 #pragma unroll
   for (int r = 0; r < 4; r++) s22 = MM::mma(-l21[r], l21[r], s22);
@@ -1139,19 +1148,19 @@ __device__ __forceinline__ void diag32_factor_invert(T *Dl, T *Wl, int nb, T *Fb
   for (int r = 0; r < 4; r++) {
     const int c = MM::row(lane, r);
     Dl[c * 33 + 16 + li] = l21[r];
-    if (li >= c) Dl[(16 + c) * 33 + 16 + li] = s22[r];
+    Dl[(16 + c) * 33 + 16 + li] = s22[r];
   }
   __syncthreads();
   // ---- (2,2)
 #pragma unroll
-  for (int c = 0; c < 16; c++) x[c] = lane < 16 ? (c <= lane ? Dl[(16 + c) * 33 + 16 + lane] : (T)0) : (q == c ? (T)1 : (T)0);
-  bad = chol16_invert<T>(x, lane) || bad;
+  for (int c = 0; c < 16; c++) {
+    const T v = pin(Dl[(16 + c) * 33 + 16 + q]);
+    x[c] = rowlane ? (c <= q ? v : (T)0) : (q == c ? (T)1 : (T)0);
+  }
+  bad = chol16_invert<T>(x, ll) || bad;
   if (bad && lane == 0) atomicOr(err, DEVERR_NOT_SPD);
 #pragma unroll
-  for (int c = 0; c < 16; c++) {
-    if (lane < 16) { if (c <= lane) Dl[(16 + c) * 33 + 16 + lane] = x[c]; }
-    else if (lane < 32) Wl[(16 + q) * 33 + 16 + c] = x[c];   // W22(c, q)
-  }
+  for (int c = 0; c < 16; c++) Sh[rowlane ? (16 + c) * 33 + 16 + q : WOFF + (16 + q) * 33 + 16 + c] = x[c];
   __syncthreads();
   // ---- W21(p, j) = -sum_i W22(p, i) T1(i, j): tile rows = p, tile columns = j
   typename MM::Acc w21 = {0, 0, 0, 0};
@@ -1160,17 +1169,35 @@ __device__ __forceinline__ void diag32_factor_invert(T *Dl, T *Wl, int nb, T *Fb
 #pragma unroll
   for (int r = 0; r < 4; r++) Wl[li * 33 + 16 + MM::row(lane, r)] = w21[r];
   __syncthreads();
-  for (int e = lane; e < 32 * 32; e += 64) {
-    const int c = e >> 5, r = e & 31;
-    if (r < nb && c <= r) Fblk[(int64_t)c * M + r] = Dl[c * 33 + r];
-    Wt[e] = Wl[c * 33 + r];                                   // e = j * 32 + c'
+  T lo[16], wo[16];
+#pragma unroll
+  for (int t = 0; t < 16; t++) {   // e = j * 32 + c'; the strictly upper parts are zero
+    const int e = t * 64 + lane, c = e >> 5, r = e & 31;
+    const T vl = pin(Dl[c * 33 + r]), vw = pin(Wl[c * 33 + r]);
+    lo[t] = r >= c ? vl : (T)0;
+    wo[t] = r >= c ? vw : (T)0;
+  }
+  if (nb == BIG_NB) {
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      const int e = t * 64 + lane, c = e >> 5, r = e & 31;
+      Fblk[(int64_t)c * M + r] = lo[t];
+      Wt[e] = wo[t];
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      const int e = t * 64 + lane, c = e >> 5, r = e & 31;
+      if (r < nb && c <= r) Fblk[(int64_t)c * M + r] = lo[t];
+      Wt[e] = wo[t];
+    }
   }
 }
 
 // First diagonal block of a super-panel (everything left of it has been applied by the trailing
 // update): one wave per front.
 template <typename T> __global__ void __launch_bounds__(64) k_big_diag32(FactorArgs<T> a, int kb) {
-  __shared__ T Dl[32 * 33], Wl[32 * 33];
+  __shared__ T Sh[2 * 32 * 33];
   const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
   if (kb >= m.nc) return;
   const int nb = min(BIG_NB, m.nc - kb);
@@ -1179,17 +1206,18 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_diag32(FactorA
   const int lane = threadIdx.x;
   T v[16];
 #pragma unroll
-  for (int t = 0; t < 16; t++) {   // all 16 loads in flight together
+  for (int t = 0; t < 16; t++) {   // all 16 loads in flight together, clamped into the block
     const int e = t * 64 + lane, c = e >> 5, r = e & 31;
-    v[t] = (r < nb && c <= r) ? Fblk[(int64_t)c * M + r] : (T)0;
+    const T f = pin(Fblk[(int64_t)min(c, nb - 1) * M + min(r, nb - 1)]);
+    v[t] = (r < nb && c < nb) ? f : (r == c ? (T)1 : (T)0);   // identity padding
   }
 #pragma unroll
   for (int t = 0; t < 16; t++) {
     const int e = t * 64 + lane, c = e >> 5, r = e & 31;
-    if (c <= r) Dl[c * 33 + r] = v[t];
+    Sh[c * 33 + r] = v[t];   // the upper triangle is never read
   }
   __syncthreads();
-  diag32_factor_invert<T>(Dl, Wl, nb, Fblk, M, a.wdiag + (int64_t)blockIdx.y * 2048 + ((kb / BIG_NB) & 1) * 1024, a.err);
+  diag32_factor_invert<T>(Sh, nb, Fblk, M, a.wdiag + (int64_t)blockIdx.y * 2048 + ((kb / BIG_NB) & 1) * 1024, a.err);
 }
 
 // Rows below the 32-column block at kb, one wave per 32 rows, everything on the matrix cores:
@@ -1200,10 +1228,12 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_diag32(FactorA
 // register already holds, so A goes from result to operand without leaving its registers.
 // The wave that owns rows kb+32..kb+63 then forms the NEXT diagonal block the same way (its own X is
 // the last 32 columns of that update), factors and inverts it: one launch per 32 columns on the chain.
+// Loads go to clamped addresses (no branch per load); rows past the front only feed results that are
+// never stored.
 template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(FactorArgs<T> a, int kb, int K0) {
   static_assert(BIG_NB == 32, "the left-looking panel kernels are written for 32-column blocks");
   using MM = Mfma16<T>;
-  __shared__ T Dl[32 * 33], Wl[32 * 33];
+  __shared__ T Sh[2 * 32 * 33];
   const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
   if (kb >= m.nc) return;
   const int nb = min(BIG_NB, m.nc - kb);
@@ -1227,37 +1257,50 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
       const int cb = t == 0 ? 0 : 1, jb = t == 2 ? 1 : 0;
       wv[t][r] = Wt[(16 * jb + MM::row(lane, r)) * 32 + 16 * cb + li];
     }
+  int irow[2];   // this lane's two rows, clamped into the front
+  irow[0] = min(R0 + li, M - 1);
+  irow[1] = min(R0 + 16 + li, M - 1);
   typename MM::Acc acc[2][2], nxt[2][2];
-  bool rowok[2];
 #pragma unroll
-  for (int ib = 0; ib < 2; ib++) {
-    const int i = R0 + 16 * ib + li;
-    rowok[ib] = i < M;
+  for (int jb = 0; jb < 2; jb++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int j = 16 * jb + MM::row(lane, r);
+      const T *ccol = F + (int64_t)(kb + min(j, nb - 1)) * M;
+#pragma unroll
+      for (int ib = 0; ib < 2; ib++) {
+        const T v = pin(ccol[irow[ib]]);
+        acc[ib][jb][r] = j < nb ? v : (T)0;
+      }
+    }
+  if (look) {
+    // next diagonal block (rows = columns = kn..kn+31); entries above its diagonal are never read
 #pragma unroll
     for (int jb = 0; jb < 2; jb++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int j = 16 * jb + MM::row(lane, r);
-        acc[ib][jb][r] = (rowok[ib] && j < nb) ? F[(int64_t)(kb + j) * M + i] : (T)0;
-        // next diagonal block (rows = columns = kn..kn+31), lower part; the rest is never read
-        const int jn = kn + j;
-        nxt[ib][jb][r] = (look && i < m.nc && jn < m.nc && i >= jn) ? F[(int64_t)jn * M + i] : (T)0;
+        const T *ccol = F + (int64_t)min(kn + 16 * jb + MM::row(lane, r), M - 1) * M;
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++) nxt[ib][jb][r] = ccol[irow[ib]];
       }
   }
   // the columns K0..kb come in whole 32-column blocks (at most three): all 32 operand loads of a block
   // are issued before its MFMAs, and the next block's loads before that -- the loop would otherwise pay
   // one L2 round trip per k-step
   const int nblk = (kb - K0) / BIG_NB;
+  const int arow0 = kb + min(li, nb - 1), arow1 = kb + min(16 + li, nb - 1);
+  const bool aok0 = li < nb, aok1 = 16 + li < nb;
   T av[8][2], bv[8][2], an[8][2], bn[8][2];
   auto fetch = [&](int blk, T (*xa)[2], T (*xb)[2]) {
+    const T *col = F + (int64_t)(K0 + blk * BIG_NB + lk) * M;
 #pragma unroll
     for (int s4 = 0; s4 < 8; s4++) {
-      const T *col = F + (int64_t)(K0 + blk * BIG_NB + 4 * s4 + lk) * M;
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        xa[s4][t] = (16 * t + li < nb) ? -col[kb + 16 * t + li] : (T)0;
-        xb[s4][t] = rowok[t] ? col[R0 + 16 * t + li] : (T)0;
-      }
+      const T a0 = pin(col[arow0]), a1 = pin(col[arow1]);
+      xa[s4][0] = aok0 ? -a0 : (T)0;
+      xa[s4][1] = aok1 ? -a1 : (T)0;
+      xb[s4][0] = col[irow[0]];
+      xb[s4][1] = col[irow[1]];
+      col += 4 * (int64_t)M;
     }
   };
   if (nblk > 0) fetch(0, av, bv);
@@ -1297,15 +1340,26 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
       out[ib][1] = MM::mma(wv[2][r], acc[ib][1][r], out[ib][1]);
     }
   }
-#pragma unroll
-  for (int ib = 0; ib < 2; ib++)
+  if (nb == BIG_NB && R0 + 32 <= M) {
 #pragma unroll
     for (int cb = 0; cb < 2; cb++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int c = 16 * cb + MM::row(lane, r);
-        if (rowok[ib] && c < nb) F[(int64_t)(kb + c) * M + R0 + 16 * ib + li] = out[ib][cb][r];
+        T *ccol = F + (int64_t)(kb + 16 * cb + MM::row(lane, r)) * M + R0 + li;
+        ccol[0] = out[0][cb][r];
+        ccol[16] = out[1][cb][r];
       }
+  } else {
+#pragma unroll
+    for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+      for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int c = 16 * cb + MM::row(lane, r), i = R0 + 16 * ib + li;
+          if (i < M && c < nb) F[(int64_t)(kb + c) * M + i] = out[ib][cb][r];
+        }
+  }
   if (!look) return;
   // next diagonal block: the last 32 columns of its update are this wave's own X
 #pragma unroll
@@ -1322,9 +1376,12 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
 #pragma unroll
     for (int jb = 0; jb <= ib; jb++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) Dl[(16 * jb + MM::row(lane, r)) * 33 + 16 * ib + li] = nxt[ib][jb][r];
+      for (int r = 0; r < 4; r++) {
+        const int jc = 16 * jb + MM::row(lane, r), ir = 16 * ib + li;
+        Sh[jc * 33 + ir] = (ir < nbn && jc < nbn) ? nxt[ib][jb][r] : (ir == jc ? (T)1 : (T)0);   // identity padding
+      }
   __syncthreads();
-  diag32_factor_invert<T>(Dl, Wl, nbn, F + (int64_t)kn * M + kn, M, a.wdiag + (int64_t)blockIdx.y * 2048 + ((kn / BIG_NB) & 1) * 1024, a.err);
+  diag32_factor_invert<T>(Sh, nbn, F + (int64_t)kn * M + kn, M, a.wdiag + (int64_t)blockIdx.y * 2048 + ((kn / BIG_NB) & 1) * 1024, a.err);
 }
 
 // Rank update  C(i,j) -= sum_{k in [ka,ke)} F(i,k) F(j,k)  over i in [t0, M), j in [t0, jmax), i >= j.
@@ -1358,28 +1415,38 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_update(Factor
   const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
   const int i0 = I0 + wi, j0 = J0 + wj;
   const bool wave_active = i0 < M && j0 < jmax && i0 + 64 > j0;
+  // A tile strictly below the diagonal and inside the front needs no masks at all.  Elsewhere every
+  // load goes to a CLAMPED address (no branch per load: out-of-range rows only feed entries that are
+  // never stored) and only the stores are predicated.
+  const bool interior = I0 + 128 <= M && J0 + 128 <= jmax && I0 >= J0 + 128;
   // ---- accumulators = current C tile
   typename MM::Acc acc[4][4];
-#pragma unroll
-  for (int ib = 0; ib < 4; ib++)
+  if (wave_active) {
 #pragma unroll
     for (int jb = 0; jb < 4; jb++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int i = i0 + 16 * ib + li, j = j0 + 16 * jb + MM::row(lane, r);
-        acc[ib][jb][r] = (wave_active && i < M && j < jmax && i >= j) ? F[(int64_t)j * M + i] : (T)0;
+        const T *ccol = F + (int64_t)min(j0 + 16 * jb + MM::row(lane, r), jmax - 1) * M;
+#pragma unroll
+        for (int ib = 0; ib < 4; ib++) acc[ib][jb][r] = ccol[min(i0 + 16 * ib + li, M - 1)];
       }
+  }
   // ---- operand staging: thread t loads row (t & 127) of every second k of the chunk
   const int sr = tid & 127, sk = tid >> 7;
-  const bool iok = I0 + sr < M, jok = J0 + sr < jmax;
+  const T *pa = F + (int64_t)(ka + sk) * M + min(I0 + sr, M - 1);
+  const T *pb = F + (int64_t)(ka + sk) * M + min(J0 + sr, M - 1);
+  const int64_t M2 = 2 * (int64_t)M;
+  const int nk = ke - ka;
   T ra[NLD], rb[NLD];
-  auto fetch = [&](int c) {
+  auto fetch = [&](int c) {   // columns past ke are re-read from a valid column and zeroed by a select
+    const T *qa = pa + (int64_t)c * KC * M, *qb = pb + (int64_t)c * KC * M;
 #pragma unroll
     for (int q = 0; q < NLD; q++) {
-      const int k = ka + c * KC + sk + 2 * q;
-      const T *col = F + (int64_t)(k < ke ? k : ka) * M;
-      ra[q] = (k < ke && iok) ? col[I0 + sr] : (T)0;
-      rb[q] = (k < ke && jok) ? -col[J0 + sr] : (T)0;
+      const bool kok = c * KC + sk + 2 * q < nk;
+      const int64_t off = kok ? q * M2 : 0;
+      const T va = qa[off], vb = qb[off];
+      ra[q] = kok ? va : (T)0;
+      rb[q] = kok ? -vb : (T)0;
     }
   };
   auto stash = [&](int buf) {
@@ -1389,7 +1456,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_update(Factor
       Bs[buf][sk + 2 * q][sr] = rb[q];
     }
   };
-  const int nchunks = (ke - ka + KC - 1) / KC;
+  const int nchunks = (nk + KC - 1) / KC;
   fetch(0);
   stash(0);
   __syncthreads();
@@ -1415,15 +1482,26 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_update(Factor
     __syncthreads();
   }
   if (!wave_active) return;
-#pragma unroll
-  for (int ib = 0; ib < 4; ib++)
+  if (interior) {
 #pragma unroll
     for (int jb = 0; jb < 4; jb++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int i = i0 + 16 * ib + li, j = j0 + 16 * jb + MM::row(lane, r);
-        if (i < M && j < jmax && i >= j) F[(int64_t)j * M + i] = acc[ib][jb][r];
+        T *ccol = F + (int64_t)(j0 + 16 * jb + MM::row(lane, r)) * M + i0 + li;
+#pragma unroll
+        for (int ib = 0; ib < 4; ib++) ccol[16 * ib] = acc[ib][jb][r];
       }
+  } else {
+#pragma unroll
+    for (int ib = 0; ib < 4; ib++)
+#pragma unroll
+      for (int jb = 0; jb < 4; jb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int i = i0 + 16 * ib + li, j = j0 + 16 * jb + MM::row(lane, r);
+          if (i < M && j < jmax && i >= j) F[(int64_t)j * M + i] = acc[ib][jb][r];
+        }
+  }
 }
 
 // Back substitution for one supernode:

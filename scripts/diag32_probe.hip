@@ -8,16 +8,19 @@ using namespace rrpgo;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 template <typename T> __global__ void __launch_bounds__(64) probe(T *F, int M, int nb, T *Wt, int *err, long long *st) {
-  __shared__ T Dl[32 * 33], Wl[32 * 33];
+  __shared__ T Dl[2 * 32 * 33];
   const int lane = threadIdx.x;
   long long t0 = clock64();
   for (int e = lane; e < 32 * 32; e += 64) {
     const int c = e >> 5, r = e & 31;
-    if (r < nb && c <= r) Dl[c * 33 + r] = F[(int64_t)c * M + r];
+    Dl[c * 33 + r] = (r < nb && c < nb) ? F[(int64_t)c * M + r] : (r == c ? (T)1 : (T)0);
   }
   __syncthreads();
   long long t1 = clock64();
-  diag32_factor_invert<T>(Dl, Wl, nb, F, M, Wt, err);
+  __builtin_amdgcn_sched_barrier(0);
+  diag32_factor_invert<T>(Dl, nb, F, M, Wt, err);
+  __builtin_amdgcn_sched_barrier(0);
+  __threadfence();
   long long t2 = clock64();
   if (lane == 0) { st[0] = t1 - t0; st[1] = t2 - t1; }
 }
