@@ -598,6 +598,7 @@ template <> struct Mfma16<float> {
 // D = (-X_j) * X_i^T so that a lane's four results are four different columns j
 // of one row i: consecutive lanes touch consecutive i (contiguous in memory).
 // Operands of four k-steps are fetched before the four dependent MFMAs issue.
+template <typename T> __device__ __forceinline__ T pin(T v);
 template <typename T, typename CAddr>
 __device__ __forceinline__ void tile_rank_update(const T *X, int ldx, int i0, int j0, int imax, int jmax,
                                                  int ka, int kb, CAddr caddr) {
@@ -605,24 +606,27 @@ __device__ __forceinline__ void tile_rank_update(const T *X, int ldx, int i0, in
   const int lane = threadIdx.x & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int i = i0 + li;
+  // loads go to clamped addresses (a predicated load is a branch): rows past the tile's range only
+  // feed entries that are never stored, columns past kb are zeroed on one operand
+  const int ic = min(i, imax - 1);
   typename MM::Acc acc;
   bool valid[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int j = j0 + MM::row(lane, r);
     valid[r] = i < imax && j < jmax && i >= j;
-    acc[r] = valid[r] ? *caddr(i, j) : (T)0;
+    acc[r] = *caddr(ic, min(min(j, jmax - 1), ic));
   }
-  const bool iok = i < imax, jok = (j0 + li) < jmax;
-  const T *xi = X + i0 + li, *xj = X + j0 + li;
+  const T *xi = X + ic, *xj = X + min(j0 + li, jmax - 1);
   for (int k = ka; k < kb; k += 16) {
     T av[4], bv[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int kk = k + 4 * q + lk;
-      const bool kok = kk < kb;
-      bv[q] = (iok && kok) ? xi[kk * ldx] : (T)0;
-      av[q] = (jok && kok) ? -xj[kk * ldx] : (T)0;
+      const int kc = min(kk, kb - 1) * ldx;
+      const T vb = pin(xi[kc]), va = pin(xj[kc]);
+      bv[q] = vb;
+      av[q] = kk < kb ? -va : (T)0;
     }
 #pragma unroll
     for (int q = 0; q < 4; q++)
@@ -663,74 +667,71 @@ __device__ __forceinline__ float fast_rsqrt(float d) {
   return y * (1.5f - 0.5f * d * y * y);
 }
 
-// Workgroup-wide partial Cholesky of the leading nc columns of the M x nc panel
-// P (column-major, ld M; rows nc.. are the off-diagonal rows and the rhs row),
-// blocked by NB = 16 columns: diagonal block in the registers of the first wave
-// (row per lane, columns exchanged with v_readlane), triangular solve with one
-// thread per row, rank-16 update of the remaining panel columns on the matrix
-// cores (one 16 x 16 tile per wave at a time).
-// diagonal block k0 (nb <= 16 columns) in the registers of the calling wave
-template <typename T>
-__device__ __forceinline__ void diag_block_factor(T *P, int M, int k0, int nb, int *err, T *dinv) {
-  constexpr int NB = 16;
-  const int tid = threadIdx.x & 63;
-  // Row `tid` of the block lives in r[0..tid]; r[j] for j > tid is scratch that is updated like
-  // everything else but never read (no predication, no per-column branches on the critical path).
-  T r[NB];
+// 16 x 16 Cholesky AND inverse in the registers of one wave: lanes 0..15 hold the rows of the block,
+// lanes 16..31 the rows of an identity, so the column sweep that turns the block into L turns the
+// identity into L^-T (v_readlane broadcasts, rsqrt + Newton, no LDS and no barrier on the chain).
+// `lane` is the lane index modulo 32 (lanes 32..63 mirror 0..31).
+template <typename T> __device__ __forceinline__ bool chol16_invert(T (&x)[16], int lane) {
   bool bad = false;
 #pragma unroll
-  for (int k = 0; k < NB; k++) r[k] = (tid < nb && k <= tid && k < nb) ? P[(k0 + k) * M + k0 + tid] : (T)0;
-  if (nb == NB) {
+  for (int k = 0; k < 16; k++) {
+    T d = lane_bcast(x[k], k);
+    if (!(d > (T)0)) { bad = true; d = (T)1; }
+    const T inv = fast_rsqrt(d);
+    const T lik = lane >= k ? x[k] * inv : (T)0;
+    x[k] = lik;
 #pragma unroll
-    for (int k = 0; k < NB; k++) {
-      T d = lane_bcast(r[k], k);
-      if (!(d > (T)0)) { bad = true; d = (T)1; }
-      const T inv = fast_rsqrt(d);
-      const T lik = tid >= k ? r[k] * inv : (T)0;   // lane k: d * inv = sqrt(d)
-      r[k] = lik;
-      if (tid == k) dinv[k] = inv;
+    for (int j = k + 1; j < 16; j++) x[j] -= lik * lane_bcast(lik, j);
+  }
+  return bad;
+}
+
+// Diagonal block k0 (nb <= 16 columns) of the panel P, by the calling wave: L11 in place and
+// W = L11^-1 to the LDS scratch as wscr[j * 17 + c] = W(c, j).  A partial block is padded with an
+// identity.  All loads unconditional (clamped), two divergent store regions instead of a branch per store.
+template <typename T>
+__device__ __forceinline__ void diag16_factor_invert(T *P, int M, int k0, int nb, int *err, T *wscr) {
+  const int lane = threadIdx.x & 63, ll = lane & 31, q = lane & 15;
+  const bool rowlane = ll < 16;
+  T x[16];
+  const T *prow = P + k0 + min(q, nb - 1);
 #pragma unroll
-      for (int j = k + 1; j < NB; j++) r[j] -= lik * lane_bcast(lik, j);
+  for (int c = 0; c < 16; c++) {
+    const T v = pin(prow[(k0 + min(c, nb - 1)) * M]);
+    x[c] = rowlane ? ((q < nb && c < nb) ? (c <= q ? v : (T)0) : (q == c ? (T)1 : (T)0)) : (q == c ? (T)1 : (T)0);
+  }
+  const bool bad = chol16_invert<T>(x, ll);
+  if (bad && lane == 0) atomicOr(err, DEVERR_NOT_SPD);
+  if (rowlane) {
+    if (q < nb) {
+      T *pw = P + k0 + q;
+#pragma unroll
+      for (int c = 0; c < 16; c++)
+        if (c < nb) pw[(k0 + c) * M] = c <= q ? x[c] : (T)0;   // zeros above the diagonal
     }
   } else {
-    // partial last block: pad with an identity so the same straight-line code runs
 #pragma unroll
-    for (int k = 0; k < NB; k++)
-      if (k >= nb && tid == k) r[k] = (T)1;
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-      T d = lane_bcast(r[k], k);
-      if (!(d > (T)0)) { bad = true; d = (T)1; }
-      const T inv = fast_rsqrt(d);
-      const T lik = tid >= k ? r[k] * inv : (T)0;
-      r[k] = lik;
-      if (tid == k) dinv[k] = inv;
-      if (k + 1 >= nb) break;  // wave-uniform
-#pragma unroll
-      for (int j = k + 1; j < NB; j++) r[j] -= lik * lane_bcast(lik, j);
-    }
+    for (int c = 0; c < 16; c++) wscr[q * 17 + c] = x[c];      // W(c, q)
   }
-#pragma unroll
-  for (int k = 0; k < NB; k++)
-    if (tid < nb && k <= tid && k < nb) P[(k0 + k) * M + k0 + tid] = r[k];
-  if (bad && tid == 0) atomicOr(err, DEVERR_NOT_SPD);
 }
 
 // Workgroup-wide partial Cholesky of the leading nc columns of the M x nc panel P (column-major,
 // ld M; rows nc.. are the off-diagonal rows and the rhs row), blocked by 16 columns:
-//   diagonal block   registers of wave 0 (row per lane, v_readlane broadcasts, rsqrt + Newton)
-//   rows below       one thread per row (forward substitution against the block)
+//   diagonal block   registers of wave 0 (row per lane, v_readlane broadcasts, rsqrt + Newton), which
+//                    also yields W = L11^-1 from 16 identity rows riding along
+//   rows below       X = A W^T on the matrix cores, one 16-row tile per wave at a time
 //   trailing update  16 x 16 MFMA tiles, one per wave at a time
 // with a one-block LOOK-AHEAD: after the triangular solve of block k only the next block column is
 // updated by everybody; the rest of block k's update runs on waves 1.. while wave 0 already factors
 // diagonal block k+1 (the two touch disjoint columns).
 template <typename T, int THREADS>
-__device__ void panel_factor(T *P, int M, int nc, int *err, T *dinv /* 16 scalars of LDS */,
+__device__ void panel_factor(T *P, int M, int nc, int *err, T *wscr /* 16 * 17 scalars of LDS */,
                              unsigned long long *acc = nullptr) {
+  using MM = Mfma16<T>;
   constexpr int NB = 16;
   constexpr int NW = THREADS / 64;
   const int tid = threadIdx.x;
-  const int wave = tid >> 6;
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   RRPGO_ACC_DECL();
   int pend_k0 = -1;   // block whose "rest" update (block columns 1.. of its trailing part) is still owed
   auto rest_update = [&](int pk0, int first_wave, int nwaves) {
@@ -749,9 +750,9 @@ __device__ void panel_factor(T *P, int M, int nc, int *err, T *dinv /* 16 scalar
     RRPGO_ACC_BEGIN();
     if (NW == 1) {
       if (pend_k0 >= 0) rest_update(pend_k0, 0, 1);
-      diag_block_factor<T>(P, M, k0, nb, err, dinv);
+      diag16_factor_invert<T>(P, M, k0, nb, err, wscr);
     } else if (wave == 0) {
-      diag_block_factor<T>(P, M, k0, nb, err, dinv);
+      diag16_factor_invert<T>(P, M, k0, nb, err, wscr);
     } else if (pend_k0 >= 0) {
       rest_update(pend_k0, 1, NW - 1);
     }
@@ -759,18 +760,27 @@ __device__ void panel_factor(T *P, int M, int nc, int *err, T *dinv /* 16 scalar
     __syncthreads();
     RRPGO_ACC_END(acc, 7);
     RRPGO_ACC_BEGIN();
-    // rows below the diagonal block: x * L11^T = row  (forward substitution per row)
-    for (int i = k0 + nb + tid; i < M; i += THREADS) {
-      T xr[NB];
+    // rows below the diagonal block: X(i, c) = sum_j A(i, j) W(c, j); tile rows = c, tile columns = i
+    {
+      const int r0 = k0 + nb;
+      const int ntiles = (M - r0 + 15) >> 4;
+      T wa[4];
 #pragma unroll
-      for (int k = 0; k < NB; k++) {
-        if (k < nb) {
-          T sacc = P[(k0 + k) * M + i];
+      for (int s4 = 0; s4 < 4; s4++) wa[s4] = wscr[(4 * s4 + lk) * 17 + li];
+      for (int ib = wave; ib < ntiles; ib += NW) {
+        const int i = r0 + 16 * ib + li;
+        const T *arow = P + min(i, M - 1);
+        typename MM::Acc x = {0, 0, 0, 0};
 #pragma unroll
-          for (int q = 0; q < NB; q++)
-            if (q < k) sacc -= xr[q] * P[(k0 + q) * M + k0 + k];
-          xr[k] = sacc * dinv[k];
-          P[(k0 + k) * M + i] = xr[k];
+        for (int s4 = 0; s4 < 4; s4++) {
+          const int j = 4 * s4 + lk;
+          const T v = pin(arow[(k0 + min(j, nb - 1)) * M]);
+          x = MM::mma(wa[s4], j < nb ? v : (T)0, x);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int c = MM::row(lane, r);
+          if (i < M && c < nb) P[(k0 + c) * M + i] = x[r];
         }
       }
     }
@@ -906,7 +916,7 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
 template <typename T, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_factor_tasks(FactorArgs<T> a) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  __shared__ T dinv[16];
+  __shared__ T dinv[16 * 17];   // inverse of the current 16 x 16 diagonal block
   T *smem = reinterpret_cast<T *>(smem_raw);
   const int task = a.task_begin + blockIdx.x;
   for (int si = a.task_ptr[task]; si < a.task_ptr[task + 1]; si++) {
@@ -920,7 +930,7 @@ __global__ void __launch_bounds__(THREADS) k_factor_tasks(FactorArgs<T> a) {
 // place in HBM (L storage holds the whole M x M front), one workgroup per front, batched per level.
 template <typename T, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_factor_mid(FactorArgs<T> a) {
-  __shared__ T dinv[16];
+  __shared__ T dinv[16 * 17];
   const int task = a.task_begin + blockIdx.x;
   const int s = a.task_sn[a.task_ptr[task]];
   const SnMeta m = a.sn_meta[s];
@@ -1005,7 +1015,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_extend_add(Fa
 // in the launch that rewrites it.)
 template <typename T> __global__ void __launch_bounds__(256) k_big_diag(FactorArgs<T> a, int kb) {
   __shared__ T Pl[BIG_NB * BIG_NB];
-  __shared__ T dinv[16];
+  __shared__ T dinv[16 * 17];
   const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
   if (kb >= m.nc) return;
   const int nb = min(BIG_NB, m.nc - kb);
@@ -1074,24 +1084,6 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_trsm(FactorAr
 }
 
 // ---- left-looking 32-column blocks inside a 128-column super-panel -------------------------------
-// 16 x 16 Cholesky AND inverse in the registers of one wave: lanes 0..15 hold the rows of the block,
-// lanes 16..31 the rows of an identity, so the column sweep that turns the block into L turns the
-// identity into L^-T (v_readlane broadcasts, rsqrt + Newton, no LDS and no barrier on the chain).
-template <typename T> __device__ __forceinline__ bool chol16_invert(T (&x)[16], int lane) {
-  bool bad = false;
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    T d = lane_bcast(x[k], k);
-    if (!(d > (T)0)) { bad = true; d = (T)1; }
-    const T inv = fast_rsqrt(d);
-    const T lik = lane >= k ? x[k] * inv : (T)0;
-    x[k] = lik;
-#pragma unroll
-    for (int j = k + 1; j < 16; j++) x[j] -= lik * lane_bcast(lik, j);
-  }
-  return bad;
-}
-
 // One wave factors the (<= 32)^2 diagonal block and inverts it, as a 2 x 2 recursion over 16 x 16
 // blocks: the two diagonal blocks in registers (above), the off-diagonal blocks on the matrix cores
 //   L21 = A21 W11^T,  S22 = A22 - L21 L21^T,  W21 = -W22 (L21 W11),   W = L^-1.
