@@ -533,7 +533,7 @@ struct SnMeta {
   int32_t asm_begin, asm_count;     // flat assembly entries (fasm_src / fasm_dst)
   int32_t dup_begin, dup_count;     // entries of parallel-edge blocks, added serially
   int32_t child_begin, child_count; // into child_meta
-  int32_t rows_ptr, pad;            // into sn_rows
+  int32_t rows_ptr, wblk;           // into sn_rows; first 16 x 16 block of this front in winv
   int64_t loff, uoff;               // panel / update-matrix offsets
 };
 static_assert(sizeof(SnMeta) == 64, "SnMeta must stay one 64-byte record");
@@ -561,6 +561,7 @@ template <typename T> struct FactorArgs {
   T *uvals;                 // packed update matrices
   T *xch;                   // sharded runs: exchange buffer of the boundary fronts' packed update matrices
   T *x;                     // solution, permuted order
+  T *winv;                  // inverse 16 x 16 diagonal blocks of the LDS fronts: [block][j][c] = W(j, c)
   T *wdiag;                 // [front slot of the level][2][32 * 32] inverse of the current diagonal block, transposed
   int *err;
   unsigned long long *stamps;  // [S][8], diagnostic builds only (else null)
@@ -618,19 +619,25 @@ __device__ __forceinline__ void tile_rank_update(const T *X, int ldx, int i0, in
     acc[r] = *caddr(ic, min(min(j, jmax - 1), ic));
   }
   const T *xi = X + ic, *xj = X + min(j0 + li, jmax - 1);
-  for (int k = ka; k < kb; k += 16) {
-    T av[4], bv[4];
+  T av[4], bv[4], an[4], bn[4];
+  auto fetch = [&](int k, T *xa, T *xb) {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int kk = k + 4 * q + lk;
       const int kc = min(kk, kb - 1) * ldx;
       const T vb = pin(xi[kc]), va = pin(xj[kc]);
-      bv[q] = vb;
-      av[q] = kk < kb ? -va : (T)0;
+      xb[q] = vb;
+      xa[q] = kk < kb ? -va : (T)0;
     }
+  };
+  fetch(ka, av, bv);
+  for (int k = ka; k < kb; k += 16) {   // operands of the next four k-steps are in flight under these MFMAs
+    if (k + 16 < kb) fetch(k + 16, an, bn);
 #pragma unroll
     for (int q = 0; q < 4; q++)
       if (k + 4 * q < kb) acc = MM::mma(av[q], bv[q], acc);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { av[q] = an[q]; bv[q] = bn[q]; }
   }
 #pragma unroll
   for (int r = 0; r < 4; r++)
@@ -687,10 +694,10 @@ template <typename T> __device__ __forceinline__ bool chol16_invert(T (&x)[16], 
 }
 
 // Diagonal block k0 (nb <= 16 columns) of the panel P, by the calling wave: L11 in place and
-// W = L11^-1 to the LDS scratch as wscr[j * 17 + c] = W(c, j).  A partial block is padded with an
-// identity.  All loads unconditional (clamped), two divergent store regions instead of a branch per store.
+// W = L11^-1 to the LDS scratch as wscr[j * 17 + c] = W(c, j) and, for the back substitution, to
+// wout[block][c * 16 + j].  A partial block is padded with an identity.  All loads unconditional (clamped), two divergent store regions instead of a branch per store.
 template <typename T>
-__device__ __forceinline__ void diag16_factor_invert(T *P, int M, int k0, int nb, int *err, T *wscr) {
+__device__ __forceinline__ void diag16_factor_invert(T *P, int M, int k0, int nb, int *err, T *wscr, T *wout) {
   const int lane = threadIdx.x & 63, ll = lane & 31, q = lane & 15;
   const bool rowlane = ll < 16;
   T x[16];
@@ -712,6 +719,11 @@ __device__ __forceinline__ void diag16_factor_invert(T *P, int M, int k0, int nb
   } else {
 #pragma unroll
     for (int c = 0; c < 16; c++) wscr[q * 17 + c] = x[c];      // W(c, q)
+    if (wout && lane < 32) {   // kept for the back substitution: wout[c * 16 + q] = W(c, q)
+      T *wo = wout + (k0 >> 4) * 256 + q;
+#pragma unroll
+      for (int c = 0; c < 16; c++) wo[c * 16] = x[c];
+    }
   }
 }
 
@@ -725,7 +737,7 @@ __device__ __forceinline__ void diag16_factor_invert(T *P, int M, int k0, int nb
 // updated by everybody; the rest of block k's update runs on waves 1.. while wave 0 already factors
 // diagonal block k+1 (the two touch disjoint columns).
 template <typename T, int THREADS>
-__device__ void panel_factor(T *P, int M, int nc, int *err, T *wscr /* 16 * 17 scalars of LDS */,
+__device__ void panel_factor(T *P, int M, int nc, int *err, T *wscr /* 16 * 17 scalars of LDS */, T *wout,
                              unsigned long long *acc = nullptr) {
   using MM = Mfma16<T>;
   constexpr int NB = 16;
@@ -750,9 +762,9 @@ __device__ void panel_factor(T *P, int M, int nc, int *err, T *wscr /* 16 * 17 s
     RRPGO_ACC_BEGIN();
     if (NW == 1) {
       if (pend_k0 >= 0) rest_update(pend_k0, 0, 1);
-      diag16_factor_invert<T>(P, M, k0, nb, err, wscr);
+      diag16_factor_invert<T>(P, M, k0, nb, err, wscr, wout);
     } else if (wave == 0) {
-      diag16_factor_invert<T>(P, M, k0, nb, err, wscr);
+      diag16_factor_invert<T>(P, M, k0, nb, err, wscr, wout);
     } else if (pend_k0 >= 0) {
       rest_update(pend_k0, 1, NW - 1);
     }
@@ -874,9 +886,9 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
   // ---- partial factorisation + Schur complement
 #ifdef RRPGO_STAMPS
   if (tid == 0 && a.stamps) { a.stamps[(int64_t)s * 12 + 7] = 0; a.stamps[(int64_t)s * 12 + 8] = 0; a.stamps[(int64_t)s * 12 + 9] = 0; }
-  panel_factor<T, THREADS>(P, M, nc, a.err, dinv, a.stamps ? a.stamps + (int64_t)s * 12 : nullptr);
+  panel_factor<T, THREADS>(P, M, nc, a.err, dinv, a.winv + (int64_t)m.wblk * 256, a.stamps ? a.stamps + (int64_t)s * 12 : nullptr);
 #else
-  panel_factor<T, THREADS>(P, M, nc, a.err, dinv);
+  panel_factor<T, THREADS>(P, M, nc, a.err, dinv, a.winv + (int64_t)m.wblk * 256);
 #endif
   RRPGO_STAMP(a, s, 4);
   {
@@ -887,7 +899,9 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
       const int jb = t / nt, ib = t - jb * nt;
       if (ib < jb) continue;
       tile_rank_update<T>(P + nc, M, 16 * ib, 16 * jb, nu, nu, 0, nc,
-                          [&](int i, int j) { return U + tri_index(nu, uld, i, j); });
+                          [&](int i, int j) {   // 32-bit index arithmetic for the packed triangle in LDS
+                            return IN_PLACE ? U + ((int64_t)j * uld + i) : U + (j * nu - ((j * (j - 1)) >> 1) + (i - j));
+                          });
     }
   }
   __syncthreads();
@@ -1032,7 +1046,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_diag(FactorAr
   for (int q = 0; q < BIG_NB2_PER_THREAD; q++)
     if (tid + 256 * q < nb * nb) Pl[tid + 256 * q] = dv[q];
   __syncthreads();
-  panel_factor<T, 256>(Pl, nb, nb, a.err, dinv);
+  panel_factor<T, 256>(Pl, nb, nb, a.err, dinv, (T *)nullptr);
 #pragma unroll
   for (int q = 0; q < BIG_NB2_PER_THREAD; q++) {
     const int t = tid + 256 * q, c = t / nb, r = t - c * nb;
@@ -1520,13 +1534,12 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
     __syncthreads();
     RRPGO_STAMP_SOLVE(a, s, 0);
     for (int i = tid; i < nr; i += THREADS) x2[i] = a.x[rows[i]];
-    // stage L11 transposed: element L(r, c), r >= c, goes to Lt[r * ldt + c]
-    // (the diagonal is stored as its reciprocal: the divide would otherwise sit on the
-    // critical path of every column of the substitution)
-    for (int t = tid; t < nc * nc; t += THREADS) {
-      const int c = t / nc, r = t - c * nc;
-      if (r > c) Lt[r * ldt + c] = Lg[(int64_t)c * M + r];
-      else if (r == c) Lt[r * ldt + c] = (T)1 / Lg[(int64_t)c * M + r];
+    // stage the strictly lower part of L11 transposed, L(r, c) -> Lt[r * ldt + c]: a wave per column,
+    // lanes along the rows (coalesced, no index division); the diagonal blocks are not needed, the
+    // factorisation left their inverses in winv
+    for (int c = tid >> 6; c < nc; c += THREADS / 64) {
+      const T *col = Lg + (int64_t)c * M;
+      for (int r = c + 1 + (tid & 63); r < nc; r += 64) Lt[r * ldt + c] = col[r];
     }
     __syncthreads();
     RRPGO_STAMP_SOLVE(a, s, 1);
@@ -1560,40 +1573,68 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
     }
     __syncthreads();
     RRPGO_STAMP_SOLVE(a, s, 2);
-    // L11^T x = t, backward, in 64-column chunks.  Inside a chunk lane l of the first wave
-    // owns entry c0+l; step j needs row j of L11 (Lt[j*ldt + c0 ..], contiguous), fetched
-    // one step ahead so that the chain between steps is readlane -> mul -> fma.  After a
-    // chunk is solved every thread folds it into the entries to its left.
-    for (int c0 = ((nc - 1) >> 6) << 6; c0 >= 0; c0 -= 64) {
-      const int cw = min(64, nc - c0);
-      if (tid < 64) {
-        T tv = tid < cw ? t1[c0 + tid] : (T)0;
-        const T *row = Lt + (c0 + cw - 1) * ldt + c0;
-        T rd = row[cw - 1];
-        T rv = tid < cw - 1 ? row[tid] : (T)0;
-        for (int jj = cw - 1; jj >= 0; jj--) {
-          T nd = 0, nv = 0;
-          if (jj > 0) {
-            const T *rn = row - ldt;
-            nd = rn[jj - 1];
-            nv = tid < jj - 1 ? rn[tid] : (T)0;
-            row = rn;
-          }
-          const T xj = lane_bcast(tv, jj) * rd;
-          const T upd = tv - rv * xj;          // rv == 0 at and right of the diagonal
-          tv = tid == jj ? xj : upd;
-          rd = nd;
-          rv = nv;
+    // L11^T x = t, backward, by 16-column blocks with the inverse diagonal blocks W_b = L_bb^-1:
+    //   x_b = W_b^T ( t_b - sum_{b' > b} L(b', b)^T x_b' ).
+    // The first wave runs the chain: it applies the block to its right on the fly (registers), then
+    // the 16 x 16 product with W_b^T, both as v_readlane broadcasts + FMAs.  The other waves fold the
+    // finished block into everything two or more blocks to its left, one barrier behind; so there is
+    // one barrier per 16 columns and nobody writes an entry somebody else is reading.
+    {
+      constexpr int NW = THREADS / 64;
+      const int wave = tid >> 6, lane = tid & 63, l16 = lane & 15;
+      const int nblk = (nc + 15) >> 4;
+      const T *Wg = a.winv + (int64_t)m.wblk * 256 + l16;
+      T w0[16], w1[16], w2[16];   // W(j, l16) of the current block and of the next two (global loads, prefetched)
+      if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          w0[j] = Wg[(nblk - 1) * 256 + j * 16];
+          w1[j] = Wg[max(nblk - 2, 0) * 256 + j * 16];
+          w2[j] = Wg[max(nblk - 3, 0) * 256 + j * 16];
         }
-        if (tid < cw) t1[c0 + tid] = tv;
       }
-      __syncthreads();
-      for (int i = tid; i < c0; i += THREADS) {
-        T sacc = 0;
-        for (int jj = 0; jj < cw; jj++) sacc += Lt[(c0 + jj) * ldt + i] * t1[c0 + jj];
-        t1[i] -= sacc;
+      T xprev = 0;
+      for (int b = nblk - 1; b >= 0; b--) {
+        const int c0 = 16 * b, cw = min(16, nc - c0);
+        if (wave == 0) {
+          T v = pin(t1[c0 + min(l16, cw - 1)]);
+          v = l16 < cw ? v : (T)0;
+          if (b + 1 < nblk) {
+            const int cn = c0 + 16, cwn = min(16, nc - cn);
+            T lt[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) lt[j] = Lt[(cn + min(j, cwn - 1)) * ldt + c0 + l16];   // L(cn + j, c0 + l16)
+#pragma unroll
+            for (int j = 0; j < 16; j++) v -= lt[j] * lane_bcast(xprev, j);   // xprev is zero past the block's width
+          }
+          T x = 0;
+#pragma unroll
+          for (int j = 0; j < 16; j++) x += w0[j] * lane_bcast(v, j);
+          x = l16 < cw ? x : (T)0;
+          if (lane < cw) t1[c0 + lane] = x;
+          xprev = x;
+#pragma unroll
+          for (int j = 0; j < 16; j++) {
+            w0[j] = w1[j];
+            w1[j] = w2[j];
+            w2[j] = Wg[max(b - 3, 0) * 256 + j * 16];
+          }
+        }
+        __syncthreads();
+        if (NW == 1 || wave > 0) {
+          const int lim = c0 - 16;
+          for (int i = NW == 1 ? tid : tid - 64; i < lim; i += NW == 1 ? THREADS : THREADS - 64) {
+            T tv = t1[i];
+            if (cw == 16) {
+#pragma unroll
+              for (int j = 0; j < 16; j++) tv -= Lt[(c0 + j) * ldt + i] * t1[c0 + j];
+            } else {
+              for (int j = 0; j < cw; j++) tv -= Lt[(c0 + j) * ldt + i] * t1[c0 + j];
+            }
+            t1[i] = tv;
+          }
+        }
       }
-      if (c0 > 0) __syncthreads();
     }
     __syncthreads();
     RRPGO_STAMP_SOLVE(a, s, 3);

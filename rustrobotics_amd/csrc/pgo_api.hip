@@ -134,7 +134,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<int64_t> pack_list_;       // (front, exchange offset) of the in-place boundary fronts this rank owns
   int n_pack_ = 0, pack_max_nu_ = 0;
   // numeric
-  DevBuf<T> hvals_, b_, x_, dx_ref_, lvals_, uvals_, wdiag_;
+  DevBuf<T> hvals_, b_, x_, dx_ref_, lvals_, uvals_, wdiag_, winv_;
   DevBuf<double> chi_partial_, norm_partial_, hist_;
   DevBuf<int> counter_, err_;
   DevBuf<unsigned long long> stamps_;  // diagnostic builds only
@@ -270,6 +270,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     {
       std::vector<SnMeta> meta(sym.S);
       std::vector<ChildMeta> cm(sym.child_list.size());
+      int64_t wblk_total = 0;
       for (int f = 0; f < sym.S; f++) {
         SnMeta &m = meta[f];
         m.nc = sym.sn_ncols[f];
@@ -284,7 +285,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         m.child_count = sym.child_ptr[f + 1] - sym.child_ptr[f];
         if (sym.sn_rows_ptr[f] > 0x7fffffffLL) throw ApiError(RR_PGO_EUNSUPPORTED, "row structure exceeds 32-bit indexing");
         m.rows_ptr = (int32_t)sym.sn_rows_ptr[f];
-        m.pad = 0;
+        m.wblk = (int32_t)wblk_total;
+        wblk_total += (sym.sn_ncols[f] + 15) / 16;
         m.loff = sym.sn_loff[f];
         m.uoff = sym.sn_uoff[f];
         if (sym.sn_xch_off[f] >= 0 && !sym.sn_big[f]) {   // LDS boundary front: writes straight into the exchange buffer
@@ -305,6 +307,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         }
       }
       sn_meta_.upload(meta);
+      if (wblk_total > 0x7fffff00LL) throw ApiError(RR_PGO_EUNSUPPORTED, "too many diagonal blocks");
+      winv_.alloc((size_t)wblk_total * 256 + 4);
+      winv_.zero();
       child_meta_.upload(cm);
     }
     fasm_src_.upload(sym.fasm_src);
@@ -418,6 +423,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     a.xch = xch_;
     a.x = x_ptr_;
     a.wdiag = wdiag_.p;
+    a.winv = winv_.p;
     a.err = err_.p;
     a.stamps = stamps_.p;
     return a;
