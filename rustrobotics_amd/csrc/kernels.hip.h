@@ -1393,6 +1393,7 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
 // Rank update  C(i,j) -= sum_{k in [ka,ke)} F(i,k) F(j,k)  over i in [t0, M), j in [t0, jmax), i >= j.
 //   mode 0: after the 32-column panel at kb: the rest of its 128-column super-panel (K = 32)
 //   mode 1: after the super-panel at kb: everything to its right, Schur complement included (K <= 128)
+//   mode 2 / 3: mode 1 split into its first 128 columns and the rest
 // One 128 x 128 tile per workgroup, 64 x 64 per wave as 4 x 4 MFMA 16x16x4 tiles (16 independent
 // accumulators per wave).  The two 128-row operand strips are staged through LDS in k-chunks of
 // 32 (f32) / 16 (f64), double buffered: the global loads of chunk c+1 are in flight while the
@@ -1412,8 +1413,12 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_update(Factor
   const int ka = kb;
   const int ke = mode == 0 ? min(kb + BIG_NB, m.nc) : super_end;
   const int t0 = ke;
-  const int jmax = mode == 0 ? super_end : M;
-  const int I0 = t0 + blockIdx.x * 128, J0 = t0 + blockIdx.y * 128;
+  // mode 2 / 3 split the trailing update by column: the 128 columns right of the super-panel (the next
+  // super-panel's own columns, needed by its panel chain) and everything after them (which can run
+  // beside that chain on a second stream)
+  const int jmax = mode == 0 ? super_end : mode == 2 ? min(t0 + 128, M) : M;
+  const int toff = mode == 3 ? 1 : 0;
+  const int I0 = t0 + (blockIdx.x + toff) * 128, J0 = t0 + (blockIdx.y + toff) * 128;
   if (t0 >= jmax || I0 >= M || J0 >= jmax) return;   // uniform over the workgroup
   T *F = a.lvals + m.loff;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;

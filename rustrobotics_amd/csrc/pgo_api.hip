@@ -130,6 +130,10 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<T> xch_own_;               // exchange buffer (boundary update matrices) unless the caller binds one
   T *xch_ = nullptr, *x_ptr_ = nullptr;
   bool left_looking_ = true;        // RR_PGO_RIGHT_LOOKING=1: the older diag / trsm / K=32 update launches
+  bool overlap_ = false;            // RR_PGO_OVERLAP=1: the far part of a trailing update on a second stream, beside the next panel chain (measured neutral so far)
+  bool rest_pending_ = false;       // a rest-update is in flight on stream2_ (ev_rest_ marks its end)
+  hipStream_t stream2_ = nullptr;
+  hipEvent_t ev_chain_ = nullptr, ev_rest_ = nullptr;
   DevBuf<int8_t> col_owner_;
   DevBuf<int64_t> pack_list_;       // (front, exchange offset) of the in-place boundary fronts this rank owns
   int n_pack_ = 0, pack_max_nu_ = 0;
@@ -150,6 +154,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
  public:
   Engine(const HostGraph &g, const Symbolic &sym, int rank, int world) : g_(g), sym_(sym), rank_(rank), world_(world) {
     HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ev_chain_, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev_rest_, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void **)&host_pair_, 3 * sizeof(double)));
     const int N = g.n_nodes(), E = g.n_edges();
     // ---- graph arrays
@@ -254,6 +261,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       wdiag_.zero();
     }
     left_looking_ = getenv("RR_PGO_RIGHT_LOOKING") == nullptr;
+    overlap_ = getenv("RR_PGO_OVERLAP") != nullptr;
     n_lin_blocks_ = (int)(((int64_t)N * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
     n_upd_blocks_ = (N + UPD_THREADS - 1) / UPD_THREADS;
     chi_partial_.alloc((size_t)n_lin_blocks_);
@@ -350,6 +358,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   ~Engine() override {
     if (gn_exec_) (void)hipGraphExecDestroy(gn_exec_);
     if (host_pair_) (void)hipHostFree(host_pair_);
+    if (ev_chain_) (void)hipEventDestroy(ev_chain_);
+    if (ev_rest_) (void)hipEventDestroy(ev_rest_);
+    if (stream2_) (void)hipStreamDestroy(stream2_);
     if (stream_) (void)hipStreamDestroy(stream_);
   }
 
@@ -590,14 +601,36 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       }
       const int rt = rows_max(K0);   // rows from K0 on; the trailing part starts after the super-panel
       const int nti = (std::max(rt, 1) + 127) / 128;
-      if (do_launch) {
-        pbegin();
-        hipLaunchKernelGGL(k_big_update<T>, dim3(nti, nti, nf), dim3(256), 0, stream_, a, K0, 1);
-        check_launch("k_big_update/1");
-        pend(RR_PGO_K_BIG_UPDATE);
+      const bool overlap = left_looking_ && overlap_ && !prof_.on && nti > 2;
+      if (!overlap) {
+        if (do_launch) {
+          if (rest_pending_) { HIPCHK(hipStreamWaitEvent(stream_, ev_rest_, 0)); rest_pending_ = false; }
+          pbegin();
+          hipLaunchKernelGGL(k_big_update<T>, dim3(nti, nti, nf), dim3(256), 0, stream_, a, K0, 1);
+          check_launch("k_big_update/1");
+          pend(RR_PGO_K_BIG_UPDATE);
+        }
+        n++;
+      } else {
+        // the columns of the NEXT super-panel on this stream (its panel chain waits for them); everything
+        // further right on the second stream, beside that chain.  The rest-updates run one after the
+        // other there; the next-columns update of a super-panel waits for the previous rest-update
+        // (same columns), and the level ends with a join.
+        if (do_launch) {
+          HIPCHK(hipEventRecord(ev_chain_, stream_));
+          HIPCHK(hipStreamWaitEvent(stream2_, ev_chain_, 0));
+          if (rest_pending_) HIPCHK(hipStreamWaitEvent(stream_, ev_rest_, 0));
+          hipLaunchKernelGGL(k_big_update<T>, dim3(nti - 1, nti - 1, nf), dim3(256), 0, stream2_, a, K0, 3);
+          check_launch("k_big_update/3");
+          HIPCHK(hipEventRecord(ev_rest_, stream2_));
+          rest_pending_ = true;
+          hipLaunchKernelGGL(k_big_update<T>, dim3(nti, 1, nf), dim3(256), 0, stream_, a, K0, 2);
+          check_launch("k_big_update/2");
+        }
+        n += 2;
       }
-      n++;
     }
+    if (do_launch && rest_pending_) { HIPCHK(hipStreamWaitEvent(stream_, ev_rest_, 0)); rest_pending_ = false; }
     if (do_launch) pbegin();   // re-arm: the caller closes the level with pend(BIGFRONT)
     return n;
   }
