@@ -27,6 +27,20 @@ constexpr int LIN_GROUP = RRPGO_LIN_GROUP;   // lanes cooperating on one node in
 constexpr int LIN_THREADS = 256;
 constexpr int UPD_THREADS = 256;
 
+// Diagnostic build only (-DRRPGO_TRACE with -DRRPGO_STAMPS): first workgroup of a big-front launch
+// appends (tag, wall clock at entry) to a trace region behind the stamps.
+#if defined(RRPGO_TRACE) && defined(RRPGO_STAMPS)
+#define RRPGO_TRACE_MARK(a, tag)                                                                       \
+  do {                                                                                                  \
+    if ((a).trace && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {       \
+      const unsigned long long i_ = atomicAdd((a).trace, 1ull);                                         \
+      if (i_ < 190000) { (a).trace[2 + 2 * i_] = (tag); (a).trace[3 + 2 * i_] = wall_clock64(); }        \
+    }                                                                                                   \
+  } while (0)
+#else
+#define RRPGO_TRACE_MARK(a, tag) do { } while (0)
+#endif
+
 // Diagnostic build only (-DRRPGO_STAMPS): thread 0 of a workgroup records the
 // 100 MHz wall clock at the phase boundaries of every front it processes.
 #ifdef RRPGO_STAMPS
@@ -565,6 +579,7 @@ template <typename T> struct FactorArgs {
   T *wdiag;                 // [front slot of the level][2][32 * 32] inverse of the current diagonal block, transposed
   int *err;
   unsigned long long *stamps;  // [S][8], diagnostic builds only (else null)
+  unsigned long long *trace;   // diagnostic trace region (else null)
 };
 
 // update-matrix element (i >= j) of an n x n lower triangle: packed columns, or
@@ -660,6 +675,26 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
 __device__ __forceinline__ float lane_bcast(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
+// Sum over the 64 lanes of a wave, result valid in lane 63: row shifts + row broadcasts on the DPP
+// path (VALU speed; the ds_bpermute route of __shfl_down costs an LDS crossbar trip per step).
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_get(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_get(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <typename T> __device__ __forceinline__ T wave_sum63(T v) {
+  v += dpp_get<0x111, 0xf>(v);   // row_shr:1
+  v += dpp_get<0x112, 0xf>(v);   // row_shr:2
+  v += dpp_get<0x114, 0xf>(v);   // row_shr:4
+  v += dpp_get<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every row holds the row sum
+  v += dpp_get<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_get<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  return v;
+}
+
 // 1/sqrt(d): hardware seed + Newton steps (the library sqrt + divide pair is a
 // ~40-instruction dependent chain and sits on the critical path of every column)
 __device__ __forceinline__ double fast_rsqrt(double d) {
@@ -1204,6 +1239,7 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
 // update): one wave per front.
 template <typename T> __global__ void __launch_bounds__(64) k_big_diag32(FactorArgs<T> a, int kb) {
   __shared__ T Sh[2 * 32 * 33];
+  RRPGO_TRACE_MARK(a, 300);
   const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
   if (kb >= m.nc) return;
   const int nb = min(BIG_NB, m.nc - kb);
@@ -1240,6 +1276,7 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
   static_assert(BIG_NB == 32, "the left-looking panel kernels are written for 32-column blocks");
   using MM = Mfma16<T>;
   __shared__ T Sh[2 * 32 * 33];
+  RRPGO_TRACE_MARK(a, 200);
   const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
   if (kb >= m.nc) return;
   const int nb = min(BIG_NB, m.nc - kb);
@@ -1405,6 +1442,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_update(Factor
   constexpr int NLD = KC / 2;                    // global loads per operand per thread per chunk
   __shared__ T As[2][KC][LDT];                   // As[buf][k][i] =  F(I0 + i, k)
   __shared__ T Bs[2][KC][LDT];                   // Bs[buf][k][j] = -F(J0 + j, k)
+  RRPGO_TRACE_MARK(a, 100 + mode);
   if (blockIdx.x < blockIdx.y) return;           // lower triangle of tiles only
   const SnMeta m = a.sn_meta[big_front(a, blockIdx.z)];
   if (kb >= m.nc) return;
@@ -1648,16 +1686,18 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
     RRPGO_STAMP_SOLVE(a, s, 4);
   } else {
     // Front in place in HBM (fronts beyond LDS), left-looking over 64-column chunks from the right:
-    //   t_c = y1_c - L[rows below the chunk, chunk]^T * xf[rows below]      one contiguous GEMV
+    //   t_c = t_c - L[pivot rows below the chunk, chunk]^T * xf[those rows]   one contiguous GEMV
     //   x_c = L_cc^-T t_c                                                   64-step chunk solve
-    // with xf = [x1 (this front's pivots, filled in as chunks finish) | x[rows] (ancestors)].
+    // with xf = x1 (this front's pivots: t on entry, the solution as chunks finish).
     // A wave streams 4 columns, 4 row-blocks at a time (16 independent loads in flight per lane).
-    T *xf = work;              // M - 1
-    T *Lc = xf + (M - 1);      // 64 x 65 chunk, transposed, reciprocal diagonal
+    T *xf = work;              // nc
+    T *Lc = xf + nc;           // 64 x 65 chunk, transposed, reciprocal diagonal
     constexpr int NW = THREADS / 64;
     const int wave = tid >> 6, lane = tid & 63;
     __syncthreads();
-    for (int i = tid; i < nr; i += THREADS) xf[nc + i] = a.x[rows[i]];
+    // the product with the rows below the pivot block, y1 - L21^T x[rows], was formed by the
+    // multi-workgroup k_big_gemv_* launches and left in x[col0 ..]: only L11 is streamed here
+    for (int j = tid; j < nc; j += THREADS) xf[j] = a.x[m.col0 + j];
     for (int c0 = ((nc - 1) >> 6) << 6; c0 >= 0; c0 -= 64) {
       const int cw = min(64, nc - c0);
       for (int t = tid; t < cw * cw; t += THREADS) {
@@ -1666,7 +1706,7 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
         else if (r == c) Lc[r * 65 + c] = (T)1 / Lg[(int64_t)(c0 + c) * M + c0 + r];
       }
       __syncthreads();   // also publishes xf entries written by the previous chunk
-      const int rb = c0 + cw, re = M - 1;
+      const int rb = c0 + cw, re = nc;
       for (int jb = 4 * wave; jb < cw; jb += 4 * NW) {
         const T *col[4];
         T acc[4] = {0, 0, 0, 0};
@@ -1697,7 +1737,7 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
         if (lane == 0) {
 #pragma unroll
           for (int q = 0; q < 4; q++)
-            if (jb + q < cw) xf[c0 + jb + q] = col[q][M - 1] - acc[q];
+            if (jb + q < cw) xf[c0 + jb + q] -= acc[q];
         }
       }
       __syncthreads();
@@ -1739,6 +1779,79 @@ __global__ void __launch_bounds__(THREADS) k_solve_tasks(FactorArgs<T> a) {
 }
 
 // mid / huge fronts: one workgroup per front, panel streamed from HBM (task list of single fronts)
+// Back substitution of the fronts beyond LDS, first part:  t = y1 - L21^T x[rows]  for every such front
+// of a level, spread over the whole chip: workgroup (bx, by, front) takes 64 columns and the by-th of
+// R row slices, lanes along the rows (coalesced), a wave 4 columns at a time.  Partial sums go to
+// part[by][col0 + j] (fixed slots, summed in order by k_big_gemv_finish: deterministic).
+template <typename T> __global__ void __launch_bounds__(256) k_big_gemv_partial(FactorArgs<T> a, T *part, int64_t N, int R) {
+  __shared__ T xs[1024];
+  const SnMeta m = a.sn_meta[big_front(a, blockIdx.z)];
+  const int nc = m.nc, nr = m.nr, M = nc + nr + 1;
+  const int j0 = blockIdx.x * 64;
+  if (j0 >= nc) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int by = blockIdx.y;
+  const int i_begin = (int)((int64_t)nr * by / R), i_end = (int)((int64_t)nr * (by + 1) / R);
+  const T *Lg = a.lvals + m.loff;
+  const int32_t *rows = a.sn_rows + m.rows_ptr;
+  T acc[4][4];   // [pass][column of the pass]
+#pragma unroll
+  for (int p = 0; p < 4; p++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[p][q] = 0;
+  for (int ib = i_begin; ib < i_end; ib += 1024) {
+    const int cnt = min(1024, i_end - ib);
+    __syncthreads();
+    for (int t = tid; t < cnt; t += 256) xs[t] = a.x[rows[ib + t]];
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const int jc = j0 + 16 * wave + 4 * p;   // this wave's 4 columns of the pass (clamped: no branch per load)
+      const T *c0 = Lg + (int64_t)min(jc, nc - 1) * M + nc + ib;
+      const T *c1 = Lg + (int64_t)min(jc + 1, nc - 1) * M + nc + ib;
+      const T *c2 = Lg + (int64_t)min(jc + 2, nc - 1) * M + nc + ib;
+      const T *c3 = Lg + (int64_t)min(jc + 3, nc - 1) * M + nc + ib;
+      int i = lane;
+      for (; i + 192 < cnt; i += 256) {
+        T xv[4], l0[4], l1[4], l2[4], l3[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          xv[u] = xs[i + 64 * u];
+          l0[u] = c0[i + 64 * u]; l1[u] = c1[i + 64 * u]; l2[u] = c2[i + 64 * u]; l3[u] = c3[i + 64 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          acc[p][0] += l0[u] * xv[u]; acc[p][1] += l1[u] * xv[u]; acc[p][2] += l2[u] * xv[u]; acc[p][3] += l3[u] * xv[u];
+        }
+      }
+      for (; i < cnt; i += 64) {
+        const T xv = xs[i];
+        acc[p][0] += c0[i] * xv; acc[p][1] += c1[i] * xv; acc[p][2] += c2[i] * xv; acc[p][3] += c3[i] * xv;
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 4; p++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const T sum = wave_sum63<T>(acc[p][q]);
+      const int j = j0 + 16 * wave + 4 * p + q;
+      if (lane == 63 && j < nc) part[(int64_t)by * N + m.col0 + j] = sum;
+    }
+}
+
+// second part: t[j] = y1[j] - sum over the R slices, in slice order, left in x[col0 + j] for k_solve_mid
+template <typename T> __global__ void __launch_bounds__(256) k_big_gemv_finish(FactorArgs<T> a, const T *part, int64_t N, int R) {
+  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= m.nc) return;
+  const int M = m.nc + m.nr + 1;
+  T t = a.lvals[m.loff + (int64_t)j * M + (M - 1)];
+  if (m.nr > 0)
+    for (int r = 0; r < R; r++) t -= part[(int64_t)r * N + m.col0 + j];
+  a.x[m.col0 + j] = t;
+}
+
 template <typename T, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_solve_mid(FactorArgs<T> a) {
   extern __shared__ __align__(16) unsigned char smem_raw[];

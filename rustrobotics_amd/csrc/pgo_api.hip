@@ -138,7 +138,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<int64_t> pack_list_;       // (front, exchange offset) of the in-place boundary fronts this rank owns
   int n_pack_ = 0, pack_max_nu_ = 0;
   // numeric
-  DevBuf<T> hvals_, b_, x_, dx_ref_, lvals_, uvals_, wdiag_, winv_;
+  DevBuf<T> hvals_, b_, x_, dx_ref_, lvals_, uvals_, wdiag_, winv_, gemv_part_;
+  static constexpr int kGemvSlices = 16;   // row slices of the multi-workgroup L21^T x product
   DevBuf<double> chi_partial_, norm_partial_, hist_;
   DevBuf<int> counter_, err_;
   DevBuf<unsigned long long> stamps_;  // diagnostic builds only
@@ -259,6 +260,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         if (st.kind == STEP_BIG) max_big = std::max(max_big, st.task_end - st.task_begin);
       wdiag_.alloc((size_t)max_big * 2048);
       wdiag_.zero();
+      bool any_big = false;
+      for (const Step &st : sym.steps) any_big = any_big || st.kind != STEP_TASKS;
+      gemv_part_.alloc(any_big ? (size_t)kGemvSlices * g.dim : 4);
     }
     left_looking_ = getenv("RR_PGO_RIGHT_LOOKING") == nullptr;
     overlap_ = getenv("RR_PGO_OVERLAP") != nullptr;
@@ -347,12 +351,13 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       step_solve_lds_.push_back(need);
     }
 #ifdef RRPGO_STAMPS
-    stamps_.alloc((size_t)sym.S * 12);
+    stamps_.alloc((size_t)sym.S * 12 + 400000);
     stamps_.zero();
 #endif
     configure_kernels();
     n_launches_per_iter = 3;
-    for (const Step &st : sym.steps) n_launches_per_iter += st.kind == STEP_BIG ? count_big_launches(st) + 1 : 2;
+    for (const Step &st : sym.steps)
+      n_launches_per_iter += st.kind == STEP_BIG ? count_big_launches(st) + 3 : st.kind == STEP_MID ? 4 : 2;
   }
 
   ~Engine() override {
@@ -437,6 +442,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     a.winv = winv_.p;
     a.err = err_.p;
     a.stamps = stamps_.p;
+#if defined(RRPGO_TRACE) && defined(RRPGO_STAMPS)
+    a.trace = stamps_.p ? stamps_.p + (size_t)sym_.S * 12 : nullptr;
+#else
+    a.trace = nullptr;
+#endif
     return a;
   }
 
@@ -650,8 +660,18 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         else launch_solve_tasks<512>(nt, lds, a);
         pend(RR_PGO_K_SOLVE);
       } else {
-        hipLaunchKernelGGL((k_solve_mid<T, 1024>), dim3(st.task_end - st.task_begin), dim3(1024), lds, stream_,
-                           factor_args(st.task_begin));
+        // t = y1 - L21^T x[rows] over the whole chip (two launches), then one workgroup per front for L11
+        const int nf = st.task_end - st.task_begin;
+        int max_nc = 1;
+        for (int z = 0; z < nf; z++) max_nc = std::max(max_nc, sym_.sn_ncols[sym_.task_sn[sym_.task_ptr[st.task_begin + z]]]);
+        const int cb = (max_nc + 63) / 64;
+        const int R = std::max(1, std::min(kGemvSlices, (768 + nf * cb - 1) / (nf * cb)));
+        const FactorArgs<T> fa = factor_args(st.task_begin);
+        hipLaunchKernelGGL(k_big_gemv_partial<T>, dim3(cb, R, nf), dim3(256), 0, stream_, fa, gemv_part_.p, (int64_t)g_.dim, R);
+        check_launch("k_big_gemv_partial");
+        hipLaunchKernelGGL(k_big_gemv_finish<T>, dim3((max_nc + 255) / 256, nf), dim3(256), 0, stream_, fa, (const T *)gemv_part_.p, (int64_t)g_.dim, R);
+        check_launch("k_big_gemv_finish");
+        hipLaunchKernelGGL((k_solve_mid<T, 1024>), dim3(nf), dim3(1024), lds, stream_, fa);
         pend(RR_PGO_K_BIG_SOLVE);
       }
     }
@@ -1294,6 +1314,19 @@ int rr_pgo_stage_scalars(rr_pgo *h, double *chi2, double *norm_dx) {
   return guarded([&] { h->engine->read_last_scalars(chi2, norm_dx); });
 }
 #ifdef RRPGO_STAMPS
+// Diagnostic build only: the launch trace region behind the stamps (count, pad, then (tag, clock) pairs).
+extern "C" int64_t rr_pgo_debug_trace(rr_pgo *h, unsigned long long *out, int64_t cap) {
+  if (!h) return -1;
+  int64_t n = 0;
+  guarded([&] {
+    std::vector<unsigned long long> st;
+    h->engine->read_stamps(st);
+    const size_t off = (size_t)h->sym.S * 12;
+    n = std::min<int64_t>(cap, (int64_t)(st.size() - off));
+    for (int64_t i = 0; i < n; i++) out[i] = st[off + i];
+  });
+  return n;
+}
 // Diagnostic build only: per-supernode phase stamps of the last factorisation
 // plus the supernode -> (step, task, ncols, nrows) map.  out: [S][16] doubles.
 int rr_pgo_debug_stamps(rr_pgo *h, double *out, int32_t *n_sn) {

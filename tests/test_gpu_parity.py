@@ -261,6 +261,24 @@ def test_fronts_beyond_lds_match_oracle_f64(api, oracle):
     assert _state_diff_se2(g.state(), o.state()) <= 1e-8
 
 
+@pytest.mark.parametrize("env", ["RR_PGO_RIGHT_LOOKING", "RR_PGO_OVERLAP"])
+def test_alternate_big_front_launch_sequences_agree(api, env, monkeypatch):
+    """The big-front path has switches read when a handle is created: the older right-looking launch
+    sequence (diag / trsm / K=32 update) and the two-stream trailing update.
+    Each must give the default path's answer on the 100 x 100 lattice (same
+    arithmetic up to the order of the block operations)."""
+    from rustrobotics_amd import synthetic_grid_arrays
+    arrays = synthetic_grid_arrays(100, 100)
+    ref = api[0].from_arrays(*arrays)
+    eref = ref.optimize(3)
+    monkeypatch.setenv(env, "1")
+    alt = api[0].from_arrays(*arrays)
+    monkeypatch.delenv(env)
+    ealt = alt.optimize(3)
+    np.testing.assert_allclose(ealt, eref, rtol=1e-9)
+    assert _state_diff_se2(alt.state(), ref.state()) <= 1e-8
+
+
 def test_fronts_beyond_lds_f32_reaches_the_f64_minimum(api):
     """Same lattice in fp32 (BASELINE config 4's precision): chi2 is reduced in f64, the solve is
     fp32 with a 1e7 prior in the matrix -> same minimum to 1e-5 relative.  The pose
