@@ -575,8 +575,8 @@ template <typename T> struct FactorArgs {
   T *uvals;                 // packed update matrices
   T *xch;                   // sharded runs: exchange buffer of the boundary fronts' packed update matrices
   T *x;                     // solution, permuted order
-  T *winv;                  // inverse 16 x 16 diagonal blocks of the LDS fronts: [block][j][c] = W(j, c)
-  T *wdiag;                 // [front slot of the level][2][32 * 32] inverse of the current diagonal block, transposed
+  T *winv;                  // inverse diagonal blocks, kept for the back substitution: 16 x 16 per 16 columns of an
+                            // LDS front ([block][j][c] = W(j, c)), 32 x 32 per 32 columns of a big front ([block][j][c] = W(c, j))
   int *err;
   unsigned long long *stamps;  // [S][8], diagnostic builds only (else null)
   unsigned long long *trace;   // diagnostic trace region (else null)
@@ -1259,7 +1259,7 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_diag32(FactorA
     Sh[c * 33 + r] = v[t];   // the upper triangle is never read
   }
   __syncthreads();
-  diag32_factor_invert<T>(Sh, nb, Fblk, M, a.wdiag + (int64_t)blockIdx.y * 2048 + ((kb / BIG_NB) & 1) * 1024, a.err);
+  diag32_factor_invert<T>(Sh, nb, Fblk, M, a.winv + (int64_t)m.wblk * 256 + (kb / BIG_NB) * 1024, a.err);
 }
 
 // Rows below the 32-column block at kb, one wave per 32 rows, everything on the matrix cores:
@@ -1284,9 +1284,9 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
   const int R0 = kb + nb + blockIdx.x * 32;
   if (R0 >= M) return;
   T *F = a.lvals + m.loff;
-  // two W slots per front, alternating by block: workgroups of one launch are not co-resident, so the
-  // slot this launch reads must not be the one its first workgroup rewrites for the next block
-  const T *Wt = a.wdiag + (int64_t)blockIdx.y * 2048 + ((kb / BIG_NB) & 1) * 1024;
+  // every 32-column block has its own W slot (kept for the back substitution), so the slot this launch
+  // reads is never the one its first workgroup writes for the next block
+  const T *Wt = a.winv + (int64_t)m.wblk * 256 + (kb / BIG_NB) * 1024;
   const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
   const int super_end = min(K0 + BIG_SUPER, m.nc);
   const int kn = kb + BIG_NB;
@@ -1424,7 +1424,7 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
         Sh[jc * 33 + ir] = (ir < nbn && jc < nbn) ? nxt[ib][jb][r] : (ir == jc ? (T)1 : (T)0);   // identity padding
       }
   __syncthreads();
-  diag32_factor_invert<T>(Sh, nbn, F + (int64_t)kn * M + kn, M, a.wdiag + (int64_t)blockIdx.y * 2048 + ((kn / BIG_NB) & 1) * 1024, a.err);
+  diag32_factor_invert<T>(Sh, nbn, F + (int64_t)kn * M + kn, M, a.winv + (int64_t)m.wblk * 256 + (kn / BIG_NB) * 1024, a.err);
 }
 
 // Rank update  C(i,j) -= sum_{k in [ka,ke)} F(i,k) F(j,k)  over i in [t0, M), j in [t0, jmax), i >= j.
@@ -1852,11 +1852,98 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_gemv_finish(F
   a.x[m.col0 + j] = t;
 }
 
+// Back substitution of one big front (pivot block only: t = y1 - L21^T x[rows] arrives in x[col0..]),
+// by 32-column blocks with the inverse diagonal blocks the factorisation kept:
+//   x_b = W_b^T t_b            on the first wave (32 v_readlane + FMA pairs, W_b staged in LDS a block ahead)
+//   t_i -= sum_j L(c0+j, i) x_j  for every column i left of the block: half a wave per column, lane = j, so
+//                              the 32 values of a column are one 128-byte line (coalesced), each lane
+//                              multiplies by the x_j it holds and a DPP row reduction forms the sum.
+// The loads of a block step do not depend on x_b and are issued before the first wave starts on W_b.
+// (16-byte loads with 8 lanes per column were tried: the column segments are not 16-byte aligned and
+// the kernel got slower.)
+template <typename T> __device__ __forceinline__ T half_wave_sum(T v) {   // sums of lanes 0..31 / 32..63 in lanes 31 / 63
+  v += dpp_get<0x111, 0xf>(v);
+  v += dpp_get<0x112, 0xf>(v);
+  v += dpp_get<0x114, 0xf>(v);
+  v += dpp_get<0x118, 0xf>(v);
+  v += dpp_get<0x142, 0xa>(v);
+  return v;
+}
 template <typename T, int THREADS>
-__global__ void __launch_bounds__(THREADS) k_solve_mid(FactorArgs<T> a) {
+__device__ void solve_big_front(const FactorArgs<T> &a, const SnMeta &m, T *work) {
+  constexpr int NW = THREADS / 64;
+  constexpr int NQ = 32;                // column pairs per wave and pass
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+  const int nc = m.nc, M = nc + m.nr + 1;
+  const T *Lg = a.lvals + m.loff;
+  const T *Wb = a.winv + (int64_t)m.wblk * 256;
+  const int nblk = (nc + 31) >> 5;
+  T *xf = work;                     // nc: t on entry, x as blocks finish
+  T *Ws = work + ((nc + 3) & ~3);   // 2 x (32 x 33): W_b staged transposed, Ws[j * 33 + c] = W_b(j, c)
+  __syncthreads();
+  for (int j = tid; j < nc; j += THREADS) xf[j] = a.x[m.col0 + j];
+  auto stage_w = [&](int b) {   // Wt[c * 32 + j] = W_b(j, c)  ->  Ws[j * 33 + c]
+    if (tid < 1024) {
+      const int c = tid >> 5, j = tid & 31;
+      Ws[(b & 1) * (32 * 33) + j * 33 + c] = Wb[(int64_t)b * 1024 + tid];
+    }
+  };
+  stage_w(nblk - 1);
+  __syncthreads();
+  for (int b = nblk - 1; b >= 0; b--) {
+    const int c0 = 32 * b, cw = min(32, nc - c0);
+    if (b > 0) stage_w(b - 1);
+    // L(c0 + l32, i) for this wave's columns i = 2 (wave + NW q) + half; the first NQ pairs per wave are
+    // requested now, any further pass (pivot blocks wider than 2 NW NQ columns) after the block is solved
+    const int npw = ((c0 + 1) / 2 + NW - 1) / NW;   // column pairs per wave, uniform
+    const T *base = Lg + c0 + min(l32, cw - 1);
+    T lv[NQ];
+    auto fetch = [&](int q0) {
+#pragma unroll
+      for (int q = 0; q < NQ; q++)
+        if (q0 + q < npw) lv[q] = base[(int64_t)min(2 * (wave + NW * (q0 + q)) + half, nc - 1) * M];
+    };
+    fetch(0);
+    if (tid < 64) {
+      const T *ws = Ws + (b & 1) * (32 * 33) + l32;
+      const T tv = pin(xf[c0 + min(l32, cw - 1)]);
+      const T v = l32 < cw ? tv : (T)0;
+      T w[32];
+#pragma unroll
+      for (int j = 0; j < 32; j++) w[j] = ws[j * 33];
+      T x = 0;
+#pragma unroll
+      for (int j = 0; j < 32; j++) x += w[j] * lane_bcast(v, j);   // W is padded with an identity past cw
+      if (lane < cw) xf[c0 + lane] = x;
+    }
+    __syncthreads();
+    {
+      const T xv = pin(xf[c0 + min(l32, cw - 1)]);
+      const T xj = l32 < cw ? xv : (T)0;
+      for (int q0 = 0; q0 < npw; q0 += NQ) {
+        if (q0 > 0) fetch(q0);
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+          if (q0 + q < npw) {
+            const int i = 2 * (wave + NW * (q0 + q)) + half;
+            const T sum = half_wave_sum<T>(lv[q] * xj);
+            if (l32 == 31 && i < c0) xf[i] -= sum;
+          }
+      }
+    }
+    __syncthreads();
+  }
+  for (int j = tid; j < nc; j += THREADS) a.x[m.col0 + j] = xf[j];
+  __syncthreads();
+}
+
+template <typename T, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_solve_mid(FactorArgs<T> a, int w32) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int s = a.task_sn[a.task_ptr[a.task_begin + blockIdx.x]];
-  solve_front<T, THREADS, false>(a, s, reinterpret_cast<T *>(smem_raw));
+  // w32: the front was factored by the 32-column block kernels (inverse diagonal blocks in winv)
+  if (w32) solve_big_front<T, THREADS>(a, a.sn_meta[s], reinterpret_cast<T *>(smem_raw));
+  else solve_front<T, THREADS, false>(a, s, reinterpret_cast<T *>(smem_raw));
 }
 
 // ---- sharding over ranks -----------------------------------------------------------------------

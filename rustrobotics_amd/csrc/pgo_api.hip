@@ -138,7 +138,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<int64_t> pack_list_;       // (front, exchange offset) of the in-place boundary fronts this rank owns
   int n_pack_ = 0, pack_max_nu_ = 0;
   // numeric
-  DevBuf<T> hvals_, b_, x_, dx_ref_, lvals_, uvals_, wdiag_, winv_, gemv_part_;
+  DevBuf<T> hvals_, b_, x_, dx_ref_, lvals_, uvals_, winv_, gemv_part_;
   static constexpr int kGemvSlices = 16;   // row slices of the multi-workgroup L21^T x product
   DevBuf<double> chi_partial_, norm_partial_, hist_;
   DevBuf<int> counter_, err_;
@@ -255,11 +255,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     uvals_.alloc((size_t)sym.u_elems + 4);
     lvals_.zero(); uvals_.zero();
     {
-      int max_big = 1;   // most huge fronts in one level: two 32 x 32 inverse diagonal blocks each
-      for (const Step &st : sym.steps)
-        if (st.kind == STEP_BIG) max_big = std::max(max_big, st.task_end - st.task_begin);
-      wdiag_.alloc((size_t)max_big * 2048);
-      wdiag_.zero();
       bool any_big = false;
       for (const Step &st : sym.steps) any_big = any_big || st.kind != STEP_TASKS;
       gemv_part_.alloc(any_big ? (size_t)kGemvSlices * g.dim : 4);
@@ -298,7 +293,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         if (sym.sn_rows_ptr[f] > 0x7fffffffLL) throw ApiError(RR_PGO_EUNSUPPORTED, "row structure exceeds 32-bit indexing");
         m.rows_ptr = (int32_t)sym.sn_rows_ptr[f];
         m.wblk = (int32_t)wblk_total;
-        wblk_total += (sym.sn_ncols[f] + 15) / 16;
+        // 16 x 16 blocks per 16 columns; the 32-column block kernels of the big fronts keep 32 x 32 per 32 columns
+        wblk_total += sym.sn_big[f] ? 4 * ((sym.sn_ncols[f] + 31) / 32) : (sym.sn_ncols[f] + 15) / 16;
         m.loff = sym.sn_loff[f];
         m.uoff = sym.sn_uoff[f];
         if (sym.sn_xch_off[f] >= 0 && !sym.sn_big[f]) {   // LDS boundary front: writes straight into the exchange buffer
@@ -438,7 +434,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     a.uvals = uvals_.p;
     a.xch = xch_;
     a.x = x_ptr_;
-    a.wdiag = wdiag_.p;
     a.winv = winv_.p;
     a.err = err_.p;
     a.stamps = stamps_.p;
@@ -671,7 +666,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         check_launch("k_big_gemv_partial");
         hipLaunchKernelGGL(k_big_gemv_finish<T>, dim3((max_nc + 255) / 256, nf), dim3(256), 0, stream_, fa, (const T *)gemv_part_.p, (int64_t)g_.dim, R);
         check_launch("k_big_gemv_finish");
-        hipLaunchKernelGGL((k_solve_mid<T, 1024>), dim3(nf), dim3(1024), lds, stream_, fa);
+        hipLaunchKernelGGL((k_solve_mid<T, 1024>), dim3(nf), dim3(1024), lds, stream_, fa, (st.kind == STEP_BIG && left_looking_) ? 1 : 0);
         pend(RR_PGO_K_BIG_SOLVE);
       }
     }
