@@ -223,8 +223,8 @@ def main():
                        "solve": stats["bytes_solve"], "update": stats["bytes_update"]}
         kernel_of = {"linearize": "k_linearize", "factor": "k_factor_tasks", "solve": "k_solve_tasks",
                      "update": "k_update", "reduce": "k_finalize_slot", "big_assembly": "k_big_zero+k_big_assemble+k_big_extend_add",
-                     "big_panel": "k_big_diag+k_big_trsm", "big_update": "k_big_update", "mid_factor": "k_factor_mid",
-                     "big_solve": "k_solve_mid"}
+                     "big_panel": "k_big_diag32+k_big_panel32", "big_update": "k_big_update", "mid_factor": "k_factor_mid",
+                     "big_solve": "k_big_gemv_partial+k_big_gemv_finish+k_solve_mid"}
         dom = max((k for k in per_iter_us if k != "reduce"), key=lambda k: per_iter_us[k])
         n_launch = prof[dom][1] / 20
         dom_us = per_iter_us[dom]
@@ -246,6 +246,14 @@ def main():
                         "avg_launch_us": dom_us / max(n_launch, 1),
                         "algorithmic_bytes_per_launch": nbytes / max(n_launch, 1),
                         "per_step_us_by_kernel_class": per_iter_us}
+        # graphs with fronts beyond LDS: the dense trailing update is the one kernel bounded by the matrix
+        # cores; its utilisation is reported beside the dominant class whichever that is
+        mfma_kernel = None
+        if per_iter_us.get("big_update", 0) > 0:
+            tf = stats["big_update_flops"] / (per_iter_us["big_update"] * 1e-6) / 1e12
+            mfma_kernel = {"kernel": "k_big_update", "achieved": tf, "peak": MFMA_PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+                           "frac": tf / MFMA_PEAK_TFLOPS[args.precision], "us_per_step": per_iter_us["big_update"],
+                           "launches_per_step": prof["big_update"][1] / 20, "flops_per_step": stats["big_update_flops"]}
         # HBM traffic of the dominant kernel: measured offline with rocprofv3 --pmc (separate passes),
         # kept in profiles/pmc_traffic.json; null when no measurement exists for this workload + kernel
         try:
@@ -271,7 +279,7 @@ def main():
             "launches_per_step": stats["n_launches_per_iter"], "supernodes": stats["n_supernodes"],
             "factor_flops": 2 * stats["factor_flops"], "algorithmic_bytes_per_step": sum(class_bytes.values()),
             "big_fronts": stats["n_big_fronts"], "max_front": stats["max_front"],
-            "roofline": roofline,
+            "roofline": roofline, "mfma_kernel": mfma_kernel,
         }
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args.workload)

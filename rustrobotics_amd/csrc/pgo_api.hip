@@ -453,14 +453,14 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     int64_t n[RR_PGO_NUM_KCLASS] = {0};
   } prof_;
   void pbegin() { if (prof_.on) HIPCHK(hipEventRecord(prof_.e0, stream_)); }
-  void pend(int k) {
+  void pend(int k, int launches = 1) {   // launches: kernels in the timed segment
     if (!prof_.on) return;
     HIPCHK(hipEventRecord(prof_.e1, stream_));
     HIPCHK(hipEventSynchronize(prof_.e1));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, prof_.e0, prof_.e1));
     prof_.ms[k] += ms;
-    prof_.n[k]++;
+    prof_.n[k] += launches;
   }
 
   // a launch with an invalid configuration fails silently unless asked
@@ -584,7 +584,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           }
           n++;
         }
-        if (do_launch) pend(RR_PGO_K_BIG_PANEL);
+        if (do_launch) pend(RR_PGO_K_BIG_PANEL, 1 + (std::min(K0 + BIG_SUPER, max_nc) - K0 + BIG_NB - 1) / BIG_NB);
       } else
       for (int kb = K0; kb < std::min(K0 + BIG_SUPER, max_nc); kb += BIG_NB) {
         const int rb = rows_max(kb) - 1;   // rows below a 1..32 wide block, at least the rhs row
@@ -595,7 +595,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           check_launch("k_big_diag");
           hipLaunchKernelGGL(k_big_trsm<T>, dim3(gp, nf), dim3(256), 0, stream_, a, kb);
           check_launch("k_big_trsm");
-          pend(RR_PGO_K_BIG_PANEL);
+          pend(RR_PGO_K_BIG_PANEL, 2);
         }
         n += 2;
         if (kb + BIG_NB < std::min(K0 + BIG_SUPER, max_nc)) {
@@ -667,7 +667,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         hipLaunchKernelGGL(k_big_gemv_finish<T>, dim3((max_nc + 255) / 256, nf), dim3(256), 0, stream_, fa, (const T *)gemv_part_.p, (int64_t)g_.dim, R);
         check_launch("k_big_gemv_finish");
         hipLaunchKernelGGL((k_solve_mid<T, 1024>), dim3(nf), dim3(1024), lds, stream_, fa, (st.kind == STEP_BIG && left_looking_) ? 1 : 0);
-        pend(RR_PGO_K_BIG_SOLVE);
+        pend(RR_PGO_K_BIG_SOLVE, 3);
       }
     }
   }
@@ -1108,13 +1108,17 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
   s.bytes_solve = (double)y.l_elems * sz + 2.0 * dim * sz;
   s.bytes_update = 3.0 * dim * sz;
   (void)N;
-  // rank updates of the huge fronts: column k of a front with M rows touches (M-1-k)(M-k)/2 entries
-  // of the lower triangle to its right, 2 flops each
+  // trailing updates of the huge fronts (k_big_update): a super-panel of w columns updates the lower
+  // triangle of the T rows to its right, w * T (T + 1) / 2 multiply-adds.  (The updates INSIDE a
+  // super-panel belong to the panel kernels and are not counted here.)
   double buf = 0;
   for (int f = 0; f < y.S; f++)
     if (y.sn_huge[f]) {
       const double M = y.sn_ncols[f] + y.sn_nrows[f] + 1;
-      for (int k = 0; k < y.sn_ncols[f]; k++) buf += (M - 1 - k) * (M - k);
+      for (int k0 = 0; k0 < y.sn_ncols[f]; k0 += BIG_SUPER) {
+        const double w = std::min<int>(BIG_SUPER, y.sn_ncols[f] - k0), T = M - (k0 + w);
+        buf += w * T * (T + 1);
+      }
     }
   s.big_update_flops = buf;
 }
