@@ -1009,16 +1009,21 @@ template <typename T> __device__ __forceinline__ int big_front(const FactorArgs<
 }
 
 template <typename T> __global__ void __launch_bounds__(256) k_big_zero(FactorArgs<T> a) {
-  using V4 = typename VecT<T>::V4;
+  // only the lower triangle is ever read: column j is cleared from row j down (rounded down to a
+  // 64-row boundary of the column so that every wave stores whole contiguous runs)
   const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
   const int M = m.nc + m.nr + 1;
-  const int64_t n = (int64_t)M * M;
-  T *F = a.lvals + m.loff;       // loff is a multiple of 4 scalars
-  V4 *F4 = reinterpret_cast<V4 *>(F);
-  const V4 z = {0, 0, 0, 0};
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsz = (int64_t)gridDim.x * 256;
-  for (int64_t t = gid; t < (n >> 2); t += gsz) F4[t] = z;
-  if (gid < (n & 3)) F[(n & ~(int64_t)3) + gid] = 0;
+  T *F = a.lvals + m.loff;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int j = blockIdx.x * 4 + wave; j < M; j += gridDim.x * 4) {
+    T *col = F + (int64_t)j * M;
+    for (int i = (j & ~63) + lane; i < M; i += 256) {
+      col[i] = 0;
+      if (i + 64 < M) col[i + 64] = 0;
+      if (i + 128 < M) col[i + 128] = 0;
+      if (i + 192 < M) col[i + 192] = 0;
+    }
+  }
 }
 
 template <typename T> __global__ void __launch_bounds__(256) k_big_assemble(FactorArgs<T> a) {
@@ -1048,13 +1053,28 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_extend_add(Fa
   const T *Uc = (c.uld > 0 ? a.lvals : c.uld < 0 ? a.xch : a.uvals) + c.uoff;
   const int32_t *rel = a.rel + c.rel_ptr;
   const int ncu = c.ncu;
-  // one column of the child's update matrix per workgroup pass, threads over its rows
+  // one column of the child's update matrix per workgroup pass, threads over its rows, four rows per
+  // thread in flight (index, source and destination loads of the four are independent)
   for (int j = blockIdx.x; j < ncu; j += gridDim.x) {
-    const int64_t dcol = (int64_t)rel[j] * M;
-    for (int i = j + threadIdx.x; i < ncu; i += 256) {
-      if (i == ncu - 1 && j == ncu - 1) continue;
+    T *dcol = F + (int64_t)rel[j] * M;
+    // column j of the child: packed lower triangle (uld == 0) or a plain column-major square
+    const T *ucol = Uc + (c.uld > 0 ? (int64_t)j * c.uld : (int64_t)j * ncu - (int64_t)j * (j - 1) / 2 - j);
+    const int iend = j == ncu - 1 ? ncu - 1 : ncu;   // the (rhs, rhs) corner is never used
+    for (int i0 = j + threadIdx.x; i0 < iend; i0 += 1024) {
+      int ri[4];
+      T uv[4], fv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = min(i0 + 256 * u, iend - 1);
+        ri[u] = rel[i];
+        uv[u] = ucol[i];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) fv[u] = dcol[ri[u]];
       // the in-place front stores panel and update matrix in one M x M array: both land at (li, lj)
-      F[dcol + rel[i]] += Uc[tri_index(ncu, c.uld, i, j)];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (i0 + 256 * u < iend) dcol[ri[u]] = fv[u] + uv[u];
     }
   }
 }
@@ -1437,7 +1457,10 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
 // MFMAs of chunk c run; one barrier per chunk.
 template <typename T> __global__ void __launch_bounds__(256) k_big_update(FactorArgs<T> a, int kb, int mode) {
   using MM = Mfma16<T>;
-  constexpr int KC = sizeof(T) == 4 ? 32 : 16;   // k-chunk staged in LDS (73.7 KB for either precision)
+#ifndef RRPGO_UPD_KC32
+#define RRPGO_UPD_KC32 32
+#endif
+  constexpr int KC = sizeof(T) == 4 ? RRPGO_UPD_KC32 : RRPGO_UPD_KC32 / 2;   // k-chunk staged in LDS (73.7 KB at 32 / 16)
   constexpr int LDT = 128 + 16;                  // padded row: the four k-rows a wave reads hit disjoint banks
   constexpr int NLD = KC / 2;                    // global loads per operand per thread per chunk
   __shared__ T As[2][KC][LDT];                   // As[buf][k][i] =  F(I0 + i, k)

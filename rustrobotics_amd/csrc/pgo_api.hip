@@ -550,7 +550,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         if (sym_.sn_ncols[s] > from) r = std::max(r, sym_.sn_ncols[s] + sym_.sn_nrows[s] + 1 - from);
       return r;
     };
-    const unsigned znb = (unsigned)std::min<int64_t>(((int64_t)maxM * maxM / 4 + 255) / 256, 4096);
+    const unsigned znb = (unsigned)std::min(std::max((maxM + 3) / 4, 1), 8192);   // a wave per column, four per workgroup
     if (do_launch) { hipLaunchKernelGGL(k_big_zero<T>, dim3(znb, nf), dim3(256), 0, stream_, a); check_launch("k_big_zero"); }
     n++;
     if (do_launch) hipLaunchKernelGGL(k_big_assemble<T>, dim3((unsigned)std::min<int64_t>((max_asm + 255) / 256, 2048), nf), dim3(256), 0, stream_, a);
