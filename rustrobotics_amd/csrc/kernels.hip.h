@@ -1053,19 +1053,20 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_extend_add(Fa
   const T *Uc = (c.uld > 0 ? a.lvals : c.uld < 0 ? a.xch : a.uvals) + c.uoff;
   const int32_t *rel = a.rel + c.rel_ptr;
   const int ncu = c.ncu;
-  // one column of the child's update matrix per workgroup pass, threads over its rows, four rows per
-  // thread in flight (index, source and destination loads of the four are independent)
-  for (int j = blockIdx.x; j < ncu; j += gridDim.x) {
+  // one column of the child's update matrix per WAVE pass (four columns per workgroup in flight), lanes
+  // over its rows, four rows per lane in flight (index, source and destination loads are independent)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int j = blockIdx.x * 4 + wave; j < ncu; j += gridDim.x * 4) {
     T *dcol = F + (int64_t)rel[j] * M;
     // column j of the child: packed lower triangle (uld == 0) or a plain column-major square
     const T *ucol = Uc + (c.uld > 0 ? (int64_t)j * c.uld : (int64_t)j * ncu - (int64_t)j * (j - 1) / 2 - j);
     const int iend = j == ncu - 1 ? ncu - 1 : ncu;   // the (rhs, rhs) corner is never used
-    for (int i0 = j + threadIdx.x; i0 < iend; i0 += 1024) {
+    for (int i0 = j + lane; i0 < iend; i0 += 256) {
       int ri[4];
       T uv[4], fv[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int i = min(i0 + 256 * u, iend - 1);
+        const int i = min(i0 + 64 * u, iend - 1);
         ri[u] = rel[i];
         uv[u] = ucol[i];
       }
@@ -1074,7 +1075,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_extend_add(Fa
       // the in-place front stores panel and update matrix in one M x M array: both land at (li, lj)
 #pragma unroll
       for (int u = 0; u < 4; u++)
-        if (i0 + 256 * u < iend) dcol[ri[u]] = fv[u] + uv[u];
+        if (i0 + 64 * u < iend) dcol[ri[u]] = fv[u] + uv[u];
     }
   }
 }

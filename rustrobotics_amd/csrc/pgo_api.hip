@@ -561,7 +561,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       n++;
     }
     for (int q = 0; q < max_kids; q++) {
-      if (do_launch) hipLaunchKernelGGL(k_big_extend_add<T>, dim3((unsigned)std::min<int64_t>(max_ncu, 1024), nf), dim3(256), 0, stream_, a, q);
+      if (do_launch) hipLaunchKernelGGL(k_big_extend_add<T>, dim3((unsigned)std::min<int64_t>((max_ncu + 3) / 4, 2048), nf), dim3(256), 0, stream_, a, q);
       if (do_launch) check_launch("k_big_extend_add");
       n++;
     }
