@@ -1448,6 +1448,209 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
   diag32_factor_invert<T>(Sh, nbn, F + (int64_t)kn * M + kn, M, a.winv + (int64_t)m.wblk * 256 + (kn / BIG_NB) * 1024, a.err);
 }
 
+// ---- a whole 128-column super-panel per step of the chain ------------------------------------------
+// k_big_diag128: one workgroup per front factors the (<= 128)^2 diagonal block of the super-panel in LDS
+// with the workgroup-wide panel_factor (16-column blocks, look-ahead, MFMA), then pairs its 16 x 16
+// inverse diagonal blocks into the 32 x 32 inverses W_b the row kernels and the back substitution use:
+//   W32 = [Wa 0; -Wb L21 Wa, Wb].
+// The block is held with an odd leading dimension (129: one dummy zero row) so that the MFMA operand
+// reads of four k-columns fall into different LDS banks.
+template <typename T> __global__ void __launch_bounds__(512) k_big_diag128(FactorArgs<T> a, int K0) {
+  static_assert(BIG_SUPER == 128 && BIG_NB == 32, "written for 128-column super-panels of 32-column blocks");
+  using MM = Mfma16<T>;
+  constexpr int LD = 129;
+  __shared__ T P[LD * 128];
+  __shared__ T w16[8 * 256];     // W16 blocks of panel_factor: [blk][c * 16 + q] = W(c, q)
+  __shared__ T w21s[4 * 256];    // W21 of the four pairs: [b][p * 16 + j]
+  __shared__ T wscr[16 * 17];
+  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  if (K0 >= m.nc) return;
+  const int nbk = min(BIG_SUPER, m.nc - K0);
+  const int M = m.nc + m.nr + 1;
+  T *Fb = a.lvals + m.loff + (int64_t)K0 * M + K0;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15;
+  // lower triangle in, zeros elsewhere (the dummy row 128 and the rows of a partial super-panel too)
+  for (int c = wave; c < 128; c += 8) {
+    const T *col = Fb + (int64_t)min(c, nbk - 1) * M;
+    for (int r = lane; r < LD; r += 64) {
+      const T v = pin(col[min(r, nbk - 1)]);
+      P[c * LD + r] = (r < nbk && c < nbk && r >= c) ? v : (T)0;
+    }
+  }
+  for (int t = tid; t < 8 * 256; t += 512) w16[t] = ((t & 255) >> 4) == (t & 15) ? (T)1 : (T)0;   // identity where no block exists
+  __syncthreads();
+  panel_factor<T, 512>(P, LD, nbk, a.err, wscr, w16);
+  __syncthreads();
+  const int nb32 = (nbk + 31) >> 5;
+  if (wave < nb32) {
+    // T1(i, j) = sum_c L21(i, c) Wa(c, j);  W21(p, j) = -sum_i Wb(p, i) T1(i, j)   (k-slots = accumulator rows)
+    const int b = wave, o = 32 * b;
+    const T *Wa = w16 + (2 * b) * 256, *Wb = w16 + (2 * b + 1) * 256;
+    typename MM::Acc t1 = {0, 0, 0, 0}, w21 = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int c = MM::row(lane, r);
+      t1 = MM::mma(P[(o + c) * LD + o + 16 + li], Wa[c * 16 + li], t1);   // L21(i = li, c) (zero past the panel)
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) w21 = MM::mma(-Wb[li * 16 + MM::row(lane, r)], t1[r], w21);
+#pragma unroll
+    for (int r = 0; r < 4; r++) w21s[b * 256 + MM::row(lane, r) * 16 + li] = w21[r];   // W21(p = row, j = li)
+  }
+  __syncthreads();
+  // W32 blocks out: Wt[j * 32 + c] = W32(c, j)
+  T *Wt = a.winv + (int64_t)m.wblk * 256 + (int64_t)(K0 / BIG_NB) * 1024;
+  for (int e = tid; e < nb32 * 1024; e += 512) {
+    const int b = e >> 10, j = (e >> 5) & 31, c = e & 31;
+    const T *Wa = w16 + (2 * b) * 256, *Wb = w16 + (2 * b + 1) * 256;
+    T v = 0;
+    if (c < 16 && j < 16) v = Wa[c * 16 + j];
+    else if (c >= 16 && j >= 16) v = Wb[(c - 16) * 16 + (j - 16)];
+    else if (c >= 16) v = w21s[b * 256 + (c - 16) * 16 + j];
+    Wt[e] = v;
+  }
+  // L back in place (lower part of the block)
+  for (int c = wave; c < nbk; c += 8) {
+    T *col = Fb + (int64_t)c * M;
+    for (int r = c + lane; r < nbk; r += 64) col[r] = P[c * LD + r];
+  }
+}
+
+// k_big_trsm128: the rows below the super-panel, one wave per 32 rows, ONE launch for all four 32-column
+// blocks: with L of the diagonal block and the four W_b known there is no dependency between workgroups,
+//   for b = 0..3:  A_b -= sum_{b' < b} X_b' L(b, b')^T ;  X_b = A_b W_b^T
+// all on the matrix cores with X_b' staying in its accumulator registers (k-slot = accumulator row).
+template <typename T> __global__ void __launch_bounds__(256) k_big_trsm128(FactorArgs<T> a, int K0) {
+  using MM = Mfma16<T>;
+  constexpr int LS = 36;                 // padded row of a staged 32 x 32 block: the four k-slot groups of a wave
+                                         // read from different banks
+  __shared__ T Ls[6 * 32 * LS];          // -L(b, b') of the diagonal block, b > b': [pair][c * LS + j]
+  __shared__ T Ws[4 * 32 * LS];          // W_b: [b][j * LS + c] = W_b(c, j)
+  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  if (K0 >= m.nc) return;
+  const int nbk = min(BIG_SUPER, m.nc - K0);
+  const int M = m.nc + m.nr + 1;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15;
+  if (K0 + nbk + 128 * (int)blockIdx.x >= M) return;   // uniform over the workgroup
+  T *F = a.lvals + m.loff;
+  const T *Wt = a.winv + (int64_t)m.wblk * 256 + (int64_t)(K0 / BIG_NB) * 1024;
+  const int nb32 = (nbk + 31) >> 5;
+  // ---- stage the six off-diagonal L blocks (negated) and the four W blocks: every load of the
+  // workgroup is issued at once, one memory round trip for all operands
+  {
+    T lv[6][4], wv[4][4];
+#pragma unroll
+    for (int pr = 0; pr < 6; pr++) {
+      const int b = pr < 1 ? 1 : pr < 3 ? 2 : 3, bp = pr - (b * (b - 1)) / 2;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = tid + 256 * u, c = e >> 5, j = e & 31;
+        const T v = pin(F[(int64_t)(K0 + min(32 * bp + c, nbk - 1)) * M + K0 + min(32 * b + j, nbk - 1)]);
+        lv[pr][u] = (32 * b + j < nbk) ? -v : (T)0;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+      for (int u = 0; u < 4; u++) wv[b][u] = Wt[min(b, nb32 - 1) * 1024 + tid + 256 * u];
+#pragma unroll
+    for (int pr = 0; pr < 6; pr++)
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = tid + 256 * u;
+        Ls[pr * 32 * LS + (e >> 5) * LS + (e & 31)] = lv[pr][u];
+      }
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = tid + 256 * u;
+        Ws[b * 32 * LS + (e >> 5) * LS + (e & 31)] = wv[b][u];
+      }
+  }
+  const int R0 = K0 + nbk + 128 * blockIdx.x + 32 * wave;
+  int irow[2];
+  irow[0] = min(R0 + li, M - 1);
+  irow[1] = min(R0 + 16 + li, M - 1);
+  typename MM::Acc x[4][2][2];   // [block][ib][jb]: A_b, then X_b; tile rows = columns of the block, tile columns = rows i
+#pragma unroll
+  for (int b = 0; b < 4; b++)
+#pragma unroll
+    for (int jb = 0; jb < 2; jb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int j = 32 * b + 16 * jb + MM::row(lane, r);
+        const T *ccol = F + (int64_t)(K0 + min(j, nbk - 1)) * M;
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++) {
+          const T v = pin(ccol[irow[ib]]);
+          x[b][ib][jb][r] = (b < nb32 && j < nbk) ? v : (T)0;
+        }
+      }
+  __syncthreads();
+  if (R0 >= M) return;   // no barriers below
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    if (b < nb32) {   // uniform
+#pragma unroll
+      for (int bp = 0; bp < b; bp++) {
+        const T *lb = Ls + ((b * (b - 1)) / 2 + bp) * 32 * LS;
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const T *lrow = lb + (16 * cb + MM::row(lane, r)) * LS + li;
+            const T la0 = lrow[0], la1 = lrow[16];
+#pragma unroll
+            for (int ib = 0; ib < 2; ib++) {
+              x[b][ib][0] = MM::mma(la0, x[bp][ib][cb][r], x[b][ib][0]);
+              x[b][ib][1] = MM::mma(la1, x[bp][ib][cb][r], x[b][ib][1]);
+            }
+          }
+      }
+      // X_b = A_b W_b^T; W tiles (cb, jb) = (0,0), (1,0), (1,1)
+      const T *wb = Ws + b * 32 * LS;
+      T wv[3][4];
+#pragma unroll
+      for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int cb = t == 0 ? 0 : 1, jb = t == 2 ? 1 : 0;
+          wv[t][r] = wb[(16 * jb + MM::row(lane, r)) * LS + 16 * cb + li];
+        }
+#pragma unroll
+      for (int ib = 0; ib < 2; ib++) {
+        typename MM::Acc o0 = {0, 0, 0, 0}, o1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          o0 = MM::mma(wv[0][r], x[b][ib][0][r], o0);
+          o1 = MM::mma(wv[1][r], x[b][ib][0][r], o1);
+          o1 = MM::mma(wv[2][r], x[b][ib][1][r], o1);
+        }
+        x[b][ib][0] = o0;
+        x[b][ib][1] = o1;
+      }
+    }
+  }
+  const bool full = nbk == BIG_SUPER && R0 + 32 <= M;
+#pragma unroll
+  for (int b = 0; b < 4; b++)
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int c = 32 * b + 16 * cb + MM::row(lane, r);
+        T *ccol = F + (int64_t)(K0 + min(c, nbk - 1)) * M;
+        if (full) {
+          ccol[R0 + li] = x[b][0][cb][r];
+          ccol[R0 + 16 + li] = x[b][1][cb][r];
+        } else if (c < nbk) {
+          if (R0 + li < M) ccol[R0 + li] = x[b][0][cb][r];
+          if (R0 + 16 + li < M) ccol[R0 + 16 + li] = x[b][1][cb][r];
+        }
+      }
+}
+
 // Rank update  C(i,j) -= sum_{k in [ka,ke)} F(i,k) F(j,k)  over i in [t0, M), j in [t0, jmax), i >= j.
 //   mode 0: after the 32-column panel at kb: the rest of its 128-column super-panel (K = 32)
 //   mode 1: after the super-panel at kb: everything to its right, Schur complement included (K <= 128)
