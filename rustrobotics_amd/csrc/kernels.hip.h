@@ -1166,8 +1166,14 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_trsm(FactorAr
 //   Sh   LDS, 2 * 32 * 33 scalars: Sh[c * 33 + r] = block(r, c) for r >= c, a partial block (nb < 32)
 //        already padded with an identity by the caller; the second half is scratch for W
 //   out: F block (in place, zeros above the diagonal) and Wt[j * 32 + c] = W(c, j)
-template <typename T>
+template <typename T, bool WG_IS_ONE_WAVE = true>
 __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int M, T *Wt, int *err) {
+  // orders this wave's LDS writes before its later reads: a workgroup barrier where the workgroup IS the
+  // wave, a wave-level fence where other waves of the workgroup have already left
+  auto sync = [] {
+    if (WG_IS_ONE_WAVE) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+  };
   using MM = Mfma16<T>;
   constexpr int WOFF = 32 * 33;
   T *Dl = Sh, *Wl = Sh + WOFF;
@@ -1185,7 +1191,7 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
   bad = chol16_invert<T>(x, ll);
 #pragma unroll
   for (int c = 0; c < 16; c++) Sh[rowlane ? c * 33 + q : WOFF + q * 33 + c] = x[c];   // L11(q, c) | W11(c, q)
-  __syncthreads();
+  sync();
   // ---- L21(i, c) = sum_j A21(i, j) W11(c, j): tile rows = c, tile columns = i
   typename MM::Acc l21 = {0, 0, 0, 0};
 #pragma unroll
@@ -1205,14 +1211,14 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
   typename MM::Acc t1 = {0, 0, 0, 0};
 #pragma unroll
   for (int r = 0; r < 4; r++) t1 = MM::mma(l21[r], Wl[li * 33 + MM::row(lane, r)], t1);
-  __syncthreads();
+  sync();
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int c = MM::row(lane, r);
     Dl[c * 33 + 16 + li] = l21[r];
     Dl[(16 + c) * 33 + 16 + li] = s22[r];
   }
-  __syncthreads();
+  sync();
   // ---- (2,2)
 #pragma unroll
   for (int c = 0; c < 16; c++) {
@@ -1223,14 +1229,14 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
   if (bad && lane == 0) atomicOr(err, DEVERR_NOT_SPD);
 #pragma unroll
   for (int c = 0; c < 16; c++) Sh[rowlane ? (16 + c) * 33 + 16 + q : WOFF + (16 + q) * 33 + 16 + c] = x[c];
-  __syncthreads();
+  sync();
   // ---- W21(p, j) = -sum_i W22(p, i) T1(i, j): tile rows = p, tile columns = j
   typename MM::Acc w21 = {0, 0, 0, 0};
 #pragma unroll
   for (int r = 0; r < 4; r++) w21 = MM::mma(-Wl[(16 + MM::row(lane, r)) * 33 + 16 + li], t1[r], w21);
 #pragma unroll
   for (int r = 0; r < 4; r++) Wl[li * 33 + 16 + MM::row(lane, r)] = w21[r];
-  __syncthreads();
+  sync();
   T lo[16], wo[16];
 #pragma unroll
   for (int t = 0; t < 16; t++) {   // e = j * 32 + c'; the strictly upper parts are zero
@@ -1659,7 +1665,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_trsm128(Facto
 // accumulators per wave).  The two 128-row operand strips are staged through LDS in k-chunks of
 // 32 (f32) / 16 (f64), double buffered: the global loads of chunk c+1 are in flight while the
 // MFMAs of chunk c run; one barrier per chunk.
-template <typename T> __global__ void __launch_bounds__(256) k_big_update(FactorArgs<T> a, int kb, int mode) {
+template <typename T> __global__ void __launch_bounds__(256) k_big_update(FactorArgs<T> a, int kb, int mode, int diag_tail) {
   using MM = Mfma16<T>;
 #ifndef RRPGO_UPD_KC32
 #define RRPGO_UPD_KC32 32
@@ -1758,6 +1764,10 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_update(Factor
     __syncthreads();
   }
   if (!wave_active) return;
+  // The first wave of the first tile holds the next super-panel's first diagonal block (rows = columns
+  // = t0 .. t0+31) in acc[0..1][0..1]: after the tile is stored it factors and inverts that block here,
+  // which saves the k_big_diag32 launch that would otherwise open the next super-panel's chain.
+  const bool next_diag = diag_tail && (mode == 1 || mode == 2) && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && t0 < m.nc;
   if (interior) {
 #pragma unroll
     for (int jb = 0; jb < 4; jb++)
@@ -1777,6 +1787,23 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_update(Factor
           const int i = i0 + 16 * ib + li, j = j0 + 16 * jb + MM::row(lane, r);
           if (i < M && j < jmax && i >= j) F[(int64_t)j * M + i] = acc[ib][jb][r];
         }
+  }
+  if (next_diag) {
+    T *Sh = &As[0][0][0];   // the staging buffers are idle now (every wave passed the last barrier of the k loop)
+    const int nbn = min(BIG_NB, m.nc - t0);
+#pragma unroll
+    for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+      for (int jb = 0; jb <= ib; jb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int jc = 16 * jb + MM::row(lane, r), ir = 16 * ib + li;
+          Sh[jc * 33 + ir] = (ir < nbn && jc < nbn) ? acc[ib][jb][r] : (ir == jc ? (T)1 : (T)0);   // identity padding
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    diag32_factor_invert<T, false>(Sh, nbn, F + (int64_t)t0 * M + t0, M, a.winv + (int64_t)m.wblk * 256 + (int64_t)(t0 / BIG_NB) * 1024, a.err);
   }
 }
 

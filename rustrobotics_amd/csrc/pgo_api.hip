@@ -133,6 +133,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   bool panel128_ = false;           // RR_PGO_PANEL128=1: two launches per 128-column super-panel (diagonal block in LDS by one
                                     // workgroup, then all rows at once) instead of one per 32 columns; measured 10 % slower
   bool overlap_ = false;            // RR_PGO_OVERLAP=1: the far part of a trailing update on a second stream, beside the next panel chain (measured neutral so far)
+  int overlap_max_nf_ = 1 << 30;    // RR_PGO_OVERLAP=<n>: only on levels with at most n fronts
   bool rest_pending_ = false;       // a rest-update is in flight on stream2_ (ev_rest_ marks its end)
   hipStream_t stream2_ = nullptr;
   hipEvent_t ev_chain_ = nullptr, ev_rest_ = nullptr;
@@ -263,6 +264,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     }
     left_looking_ = getenv("RR_PGO_RIGHT_LOOKING") == nullptr;
     overlap_ = getenv("RR_PGO_OVERLAP") != nullptr;
+    if (overlap_ && std::atoi(getenv("RR_PGO_OVERLAP")) > 1) overlap_max_nf_ = std::atoi(getenv("RR_PGO_OVERLAP"));
     panel128_ = getenv("RR_PGO_PANEL128") != nullptr;
     n_lin_blocks_ = (int)(((int64_t)N * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
     n_upd_blocks_ = (N + UPD_THREADS - 1) / UPD_THREADS;
@@ -586,12 +588,15 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       } else if (left_looking_) {
         // left-looking inside the super-panel: the first diagonal block, then ONE launch per 32 columns
         // (update from the columns K0..kb, multiply by the inverse diagonal block, next diagonal block)
-        if (do_launch) {
-          pbegin();
-          hipLaunchKernelGGL(k_big_diag32<T>, dim3(1, nf), dim3(64), 0, stream_, a, K0);
-          check_launch("k_big_diag32");
+        // the first diagonal block of a later super-panel comes out of the previous trailing update
+        if (do_launch) pbegin();
+        if (K0 == 0) {
+          if (do_launch) {
+            hipLaunchKernelGGL(k_big_diag32<T>, dim3(1, nf), dim3(64), 0, stream_, a, K0);
+            check_launch("k_big_diag32");
+          }
+          n++;
         }
-        n++;
         for (int kb = K0; kb < std::min(K0 + BIG_SUPER, max_nc); kb += BIG_NB) {
           const int rb = rows_max(kb) - 1;
           if (do_launch) {
@@ -600,7 +605,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           }
           n++;
         }
-        if (do_launch) pend(RR_PGO_K_BIG_PANEL, 1 + (std::min(K0 + BIG_SUPER, max_nc) - K0 + BIG_NB - 1) / BIG_NB);
+        if (do_launch) pend(RR_PGO_K_BIG_PANEL, (K0 == 0 ? 1 : 0) + (std::min(K0 + BIG_SUPER, max_nc) - K0 + BIG_NB - 1) / BIG_NB);
       } else
       for (int kb = K0; kb < std::min(K0 + BIG_SUPER, max_nc); kb += BIG_NB) {
         const int rb = rows_max(kb) - 1;   // rows below a 1..32 wide block, at least the rhs row
@@ -616,18 +621,19 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         n += 2;
         if (kb + BIG_NB < std::min(K0 + BIG_SUPER, max_nc)) {
           const int nti = (std::max(rb, 1) + 127) / 128;
-          if (do_launch) { pbegin(); hipLaunchKernelGGL(k_big_update<T>, dim3(nti, 1, nf), dim3(256), 0, stream_, a, kb, 0); check_launch("k_big_update/0"); pend(RR_PGO_K_BIG_UPDATE); }
+          if (do_launch) { pbegin(); hipLaunchKernelGGL(k_big_update<T>, dim3(nti, 1, nf), dim3(256), 0, stream_, a, kb, 0, 0); check_launch("k_big_update/0"); pend(RR_PGO_K_BIG_UPDATE); }
           n++;
         }
       }
+      const int diag_tail = (left_looking_ && !panel128_) ? 1 : 0;
       const int rt = rows_max(K0);   // rows from K0 on; the trailing part starts after the super-panel
       const int nti = (std::max(rt, 1) + 127) / 128;
-      const bool overlap = left_looking_ && overlap_ && !prof_.on && nti > 2;
+      const bool overlap = left_looking_ && overlap_ && !prof_.on && nti > 2 && nf <= overlap_max_nf_;
       if (!overlap) {
         if (do_launch) {
           if (rest_pending_) { HIPCHK(hipStreamWaitEvent(stream_, ev_rest_, 0)); rest_pending_ = false; }
           pbegin();
-          hipLaunchKernelGGL(k_big_update<T>, dim3(nti, nti, nf), dim3(256), 0, stream_, a, K0, 1);
+          hipLaunchKernelGGL(k_big_update<T>, dim3(nti, nti, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail);
           check_launch("k_big_update/1");
           pend(RR_PGO_K_BIG_UPDATE);
         }
@@ -641,11 +647,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           HIPCHK(hipEventRecord(ev_chain_, stream_));
           HIPCHK(hipStreamWaitEvent(stream2_, ev_chain_, 0));
           if (rest_pending_) HIPCHK(hipStreamWaitEvent(stream_, ev_rest_, 0));
-          hipLaunchKernelGGL(k_big_update<T>, dim3(nti - 1, nti - 1, nf), dim3(256), 0, stream2_, a, K0, 3);
+          hipLaunchKernelGGL(k_big_update<T>, dim3(nti - 1, nti - 1, nf), dim3(256), 0, stream2_, a, K0, 3, 0);
           check_launch("k_big_update/3");
           HIPCHK(hipEventRecord(ev_rest_, stream2_));
           rest_pending_ = true;
-          hipLaunchKernelGGL(k_big_update<T>, dim3(nti, 1, nf), dim3(256), 0, stream_, a, K0, 2);
+          hipLaunchKernelGGL(k_big_update<T>, dim3(nti, 1, nf), dim3(256), 0, stream_, a, K0, 2, diag_tail);
           check_launch("k_big_update/2");
         }
         n += 2;
