@@ -772,7 +772,7 @@ __device__ __forceinline__ void diag16_factor_invert(T *P, int M, int k0, int nb
 // updated by everybody; the rest of block k's update runs on waves 1.. while wave 0 already factors
 // diagonal block k+1 (the two touch disjoint columns).
 template <typename T, int THREADS>
-__device__ void panel_factor(T *P, int M, int nc, int *err, T *wscr /* 16 * 17 scalars of LDS */, T *wout,
+__device__ __forceinline__ void panel_factor(T *P, int M, int nc, int *err, T *wscr /* 16 * 17 scalars of LDS */, T *wout,
                              unsigned long long *acc = nullptr) {
   using MM = Mfma16<T>;
   constexpr int NB = 16;
