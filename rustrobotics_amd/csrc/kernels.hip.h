@@ -785,9 +785,13 @@ __device__ __forceinline__ void panel_factor(T *P, int M, int nc, int *err, T *w
     // tiles with jb >= 1 of the update of block pk0 (full 16 columns by construction)
     const int js = pk0 + NB;
     const int nj = (nc - js + 15) >> 4, ni = (M - js + 15) >> 4;
-    for (int t = ni + (wave - first_wave); t < nj * ni; t += nwaves) {
-      const int jb = t / ni, ib = t - jb * ni;
-      if (ib < jb) continue;
+    // tiles (ib >= jb, jb >= 1) dealt round-robin over the waves (balanced: no wave draws the skipped ones)
+    int total = 0;
+    for (int jb = 1; jb < nj; jb++) total += max(ni - jb, 0);
+    for (int t = wave - first_wave; t < total; t += nwaves) {
+      int jb = 1, rem = t;
+      while (rem >= ni - jb) { rem -= ni - jb; jb++; }
+      const int ib = jb + rem;
       tile_rank_update<T>(P, M, js + 16 * ib, js + 16 * jb, M, nc, pk0, pk0 + NB,
                           [&](int i, int j) { return P + j * M + i; });
     }
@@ -930,9 +934,11 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
     // U(i,j) -= sum_k L21[i][k] L21[j][k]  (i >= j), 16 x 16 tiles on the matrix cores
     const int nt = (nu + 15) >> 4;
     const int wave = tid >> 6;
-    for (int t = wave; t < nt * nt; t += THREADS / 64) {
-      const int jb = t / nt, ib = t - jb * nt;
-      if (ib < jb) continue;
+    // the tiles of the lower triangle dealt round-robin: t-th tile of the column-major enumeration
+    for (int t = wave; t < nt * (nt + 1) / 2; t += THREADS / 64) {
+      int jb = 0, rem = t;
+      while (rem >= nt - jb) { rem -= nt - jb; jb++; }
+      const int ib = jb + rem;
       tile_rank_update<T>(P + nc, M, 16 * ib, 16 * jb, nu, nu, 0, nc,
                           [&](int i, int j) {   // 32-bit index arithmetic for the packed triangle in LDS
                             return IN_PLACE ? U + ((int64_t)j * uld + i) : U + (j * nu - ((j * (j - 1)) >> 1) + (i - j));
