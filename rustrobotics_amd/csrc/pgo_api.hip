@@ -130,6 +130,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<T> xch_own_;               // exchange buffer (boundary update matrices) unless the caller binds one
   T *xch_ = nullptr, *x_ptr_ = nullptr;
   bool left_looking_ = true;        // RR_PGO_RIGHT_LOOKING=1: the older diag / trsm / K=32 update launches
+  int factor_threads_max_ = 1024;   // 16-wave workgroups for steps whose fronts exceed 128 rows (RR_PGO_FACTOR_512=1: 8 waves)
   bool panel128_ = false;           // RR_PGO_PANEL128=1: two launches per 128-column super-panel (diagonal block in LDS by one
                                     // workgroup, then all rows at once) instead of one per 32 columns; measured 10 % slower
   bool overlap_ = false;            // RR_PGO_OVERLAP=1: the far part of a trailing update on a second stream, beside the next panel chain (measured neutral so far)
@@ -266,6 +267,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     overlap_ = getenv("RR_PGO_OVERLAP") != nullptr;
     if (overlap_ && std::atoi(getenv("RR_PGO_OVERLAP")) > 1) overlap_max_nf_ = std::atoi(getenv("RR_PGO_OVERLAP"));
     panel128_ = getenv("RR_PGO_PANEL128") != nullptr;
+    factor_threads_max_ = getenv("RR_PGO_FACTOR_512") ? 512 : 1024;
     n_lin_blocks_ = (int)(((int64_t)N * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
     n_upd_blocks_ = (N + UPD_THREADS - 1) / UPD_THREADS;
     chi_partial_.alloc((size_t)n_lin_blocks_);
@@ -385,6 +387,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     set_lds_attr<128>();
     set_lds_attr<256>();
     set_lds_attr<512>();
+    HIPCHK(hipFuncSetAttribute((const void *)k_factor_tasks<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
     HIPCHK(hipFuncSetAttribute((const void *)k_solve_mid<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
   }
 
@@ -515,7 +518,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         if (st.threads == 64) launch_factor_tasks<64>(nt, lds, a);
         else if (st.threads == 128) launch_factor_tasks<128>(nt, lds, a);
         else if (st.threads == 256) launch_factor_tasks<256>(nt, lds, a);
-        else launch_factor_tasks<512>(nt, lds, a);
+        else if (st.threads <= 512 || factor_threads_max_ < 1024) launch_factor_tasks<512>(nt, lds, a);
+        else launch_factor_tasks<1024>(nt, lds, a);
         pend(RR_PGO_K_FACTOR);
       } else if (st.kind == STEP_MID) {
         hipLaunchKernelGGL((k_factor_mid<T, 1024>), dim3(st.task_end - st.task_begin), dim3(1024), 0, stream_,
