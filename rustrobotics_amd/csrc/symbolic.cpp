@@ -952,7 +952,10 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
           worst = std::max(worst, tc);
         }
         st.task_end = (int)sym.task_ptr.size() - 1;
-        st.threads = st.max_front <= 20 ? 64 : st.max_front <= 48 ? 128 : st.max_front <= 96 ? 256 : st.max_front <= 128 ? 512 : 1024;
+        {
+          const int mf = st.max_front << opt.threads_shift;   // tuning knob: shift the size classes
+          st.threads = mf <= 20 ? 64 : mf <= 48 ? 128 : mf <= 96 ? 256 : mf <= 128 ? 512 : 1024;
+        }
         if (st.task_end > st.task_begin) {
           sym.steps.push_back(st);
           crit += 1.5 + worst;
