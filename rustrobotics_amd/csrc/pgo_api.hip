@@ -130,6 +130,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<T> xch_own_;               // exchange buffer (boundary update matrices) unless the caller binds one
   T *xch_ = nullptr, *x_ptr_ = nullptr;
   bool left_looking_ = true;        // RR_PGO_RIGHT_LOOKING=1: the older diag / trsm / K=32 update launches
+  int solve_threads_max_ = 512;     // RR_PGO_SOLVE_THREADS=<n>: cap of the back-substitution workgroup size
   int factor_threads_max_ = 1024;   // 16-wave workgroups for steps whose fronts exceed 128 rows (RR_PGO_FACTOR_512=1: 8 waves)
   bool panel128_ = false;           // RR_PGO_PANEL128=1: two launches per 128-column super-panel (diagonal block in LDS by one
                                     // workgroup, then all rows at once) instead of one per 32 columns; measured 10 % slower
@@ -268,6 +269,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (overlap_ && std::atoi(getenv("RR_PGO_OVERLAP")) > 1) overlap_max_nf_ = std::atoi(getenv("RR_PGO_OVERLAP"));
     panel128_ = getenv("RR_PGO_PANEL128") != nullptr;
     factor_threads_max_ = getenv("RR_PGO_FACTOR_512") ? 512 : 1024;
+    if (const char *e = getenv("RR_PGO_SOLVE_THREADS")) solve_threads_max_ = std::atoi(e);
     n_lin_blocks_ = (int)(((int64_t)N * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
     n_upd_blocks_ = (N + UPD_THREADS - 1) / UPD_THREADS;
     chi_partial_.alloc((size_t)n_lin_blocks_);
@@ -675,9 +677,10 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       if (st.kind == STEP_TASKS) {
         const int nt = st.task_end - st.task_begin;
         FactorArgs<T> a = factor_args(st.task_begin);
-        if (st.threads == 64) launch_solve_tasks<64>(nt, lds, a);
-        else if (st.threads == 128) launch_solve_tasks<128>(nt, lds, a);
-        else if (st.threads == 256) launch_solve_tasks<256>(nt, lds, a);
+        const int sth = std::min(st.threads, solve_threads_max_);
+        if (sth <= 64) launch_solve_tasks<64>(nt, lds, a);
+        else if (sth <= 128) launch_solve_tasks<128>(nt, lds, a);
+        else if (sth <= 256) launch_solve_tasks<256>(nt, lds, a);
         else launch_solve_tasks<512>(nt, lds, a);
         pend(RR_PGO_K_SOLVE);
       } else {
