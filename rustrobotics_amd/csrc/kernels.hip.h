@@ -1836,6 +1836,24 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
     T *t1 = x2 + nr;              // nc
     __syncthreads();
     RRPGO_STAMP_SOLVE(a, s, 0);
+    // The loads of the L21^T x2 product do not depend on x2: when the shape allows (nr <= 128, at most GV
+    // columns per wave) a wave requests all of them before anything else, so that one memory round trip
+    // is hidden under the staging instead of one per group of four columns after it.
+    constexpr int GV = 12;
+    const int gw = tid >> 6, gl = tid & 63;
+    const int gcpw = (nc + THREADS / 64 - 1) / (THREADS / 64);   // columns per wave: j = gw + NW g
+    const bool gfast = nr > 0 && nr <= 128 && gcpw <= GV;
+    T glv[GV][2], gy[GV];
+    if (gfast) {
+#pragma unroll
+      for (int g = 0; g < GV; g++)
+        if (g < gcpw) {
+          const T *col = Lg + (int64_t)min(gw + (THREADS / 64) * g, nc - 1) * M + nc;
+          glv[g][0] = col[min(gl, nr - 1)];
+          glv[g][1] = col[min(gl + 64, nr - 1)];
+          gy[g] = col[nr];
+        }
+    }
     for (int i = tid; i < nr; i += THREADS) x2[i] = a.x[rows[i]];
     // stage the strictly lower part of L11 transposed, L(r, c) -> Lt[r * ldt + c]: a wave per column,
     // lanes along the rows (coalesced, no index division); the diagonal blocks are not needed, the
@@ -1846,9 +1864,20 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
     }
     __syncthreads();
     RRPGO_STAMP_SOLVE(a, s, 1);
-    // t1[j] = y1[j] - sum_i L21[i][j] x2[i]: a wave takes four columns at a time (four
-    // independent global load streams in flight), lanes over rows (coalesced)
-    {
+    // t1[j] = y1[j] - sum_i L21[i][j] x2[i]
+    if (gfast) {
+      const T xa = x2[min(gl, nr - 1)], xb = x2[min(gl + 64, nr - 1)];
+      const T x0 = gl < nr ? xa : (T)0, x1 = gl + 64 < nr ? xb : (T)0;
+#pragma unroll
+      for (int g = 0; g < GV; g++)
+        if (g < gcpw) {
+          const int j = gw + (THREADS / 64) * g;
+          const T sacc = wave_sum63<T>(glv[g][0] * x0 + glv[g][1] * x1);
+          if (gl == 63 && j < nc) t1[j] = gy[g] - sacc;
+        }
+    } else {
+      // general shape: a wave takes four columns at a time (four independent global load streams in
+      // flight), lanes over rows (coalesced)
       const int wave = tid >> 6, lane = tid & 63;
       constexpr int NW = THREADS / 64;
       for (int j = wave; j < nc; j += 4 * NW) {
