@@ -564,6 +564,8 @@ template <typename T> struct FactorArgs {
   const int32_t *task_ptr, *task_sn;
   int task_begin;
   const SnMeta *sn_meta;
+  const SnMeta *task_meta;   // record of the first front of every task: one load instead of three for the
+                             // one-front tasks of the big-front kernels
   const ChildMeta *child_meta;
   const int32_t *fasm_src, *fasm_dst, *fdup_src, *fdup_dst;
   const int32_t *scat, *rel;
@@ -1017,7 +1019,7 @@ template <typename T> __device__ __forceinline__ int big_front(const FactorArgs<
 template <typename T> __global__ void __launch_bounds__(256) k_big_zero(FactorArgs<T> a) {
   // only the lower triangle is ever read: column j is cleared from row j down (rounded down to a
   // 64-row boundary of the column so that every wave stores whole contiguous runs)
-  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
   const int M = m.nc + m.nr + 1;
   T *F = a.lvals + m.loff;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1033,7 +1035,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_zero(FactorAr
 }
 
 template <typename T> __global__ void __launch_bounds__(256) k_big_assemble(FactorArgs<T> a) {
-  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
   T *F = a.lvals + m.loff;
   const int M = m.nc + m.nr + 1;
   const int gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
@@ -1044,14 +1046,14 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_assemble(Fact
 
 // blocks of parallel edges (rare): serial, after the plain stores
 template <typename T> __global__ void k_big_assemble_dup(FactorArgs<T> a) {
-  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
   T *F = a.lvals + m.loff;
   if (blockIdx.x == 0 && threadIdx.x == 0)
     for (int t = 0; t < m.dup_count; t++) F[a.fdup_dst[m.dup_begin + t]] += a.hvals[a.fdup_src[m.dup_begin + t]];
 }
 
 template <typename T> __global__ void __launch_bounds__(256) k_big_extend_add(FactorArgs<T> a, int q) {
-  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
   if (q >= m.child_count) return;
   const ChildMeta c = a.child_meta[m.child_begin + q];
   T *F = a.lvals + m.loff;
@@ -1092,7 +1094,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_extend_add(Fa
 template <typename T> __global__ void __launch_bounds__(256) k_big_diag(FactorArgs<T> a, int kb) {
   __shared__ T Pl[BIG_NB * BIG_NB];
   __shared__ T dinv[16 * 17];
-  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
   if (kb >= m.nc) return;
   const int nb = min(BIG_NB, m.nc - kb);
   T *F = a.lvals + m.loff;
@@ -1120,7 +1122,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_diag(FactorAr
 // workgroup), L11 broadcast from LDS with its diagonal stored as reciprocals.
 template <typename T> __global__ void __launch_bounds__(256) k_big_trsm(FactorArgs<T> a, int kb) {
   __shared__ T L11[BIG_NB * (BIG_NB + 1)];
-  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
   if (kb >= m.nc) return;
   const int nb = min(BIG_NB, m.nc - kb);
   T *F = a.lvals + m.loff;
@@ -1273,7 +1275,7 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
 template <typename T> __global__ void __launch_bounds__(64) k_big_diag32(FactorArgs<T> a, int kb) {
   __shared__ T Sh[2 * 32 * 33];
   RRPGO_TRACE_MARK(a, 300);
-  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
   if (kb >= m.nc) return;
   const int nb = min(BIG_NB, m.nc - kb);
   const int M = m.nc + m.nr + 1;
@@ -1310,7 +1312,7 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
   using MM = Mfma16<T>;
   __shared__ T Sh[2 * 32 * 33];
   RRPGO_TRACE_MARK(a, 200);
-  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
   if (kb >= m.nc) return;
   const int nb = min(BIG_NB, m.nc - kb);
   const int M = m.nc + m.nr + 1;
@@ -1475,7 +1477,7 @@ template <typename T> __global__ void __launch_bounds__(512) k_big_diag128(Facto
   __shared__ T w16[8 * 256];     // W16 blocks of panel_factor: [blk][c * 16 + q] = W(c, q)
   __shared__ T w21s[4 * 256];    // W21 of the four pairs: [b][p * 16 + j]
   __shared__ T wscr[16 * 17];
-  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
   if (K0 >= m.nc) return;
   const int nbk = min(BIG_SUPER, m.nc - K0);
   const int M = m.nc + m.nr + 1;
@@ -1538,7 +1540,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_trsm128(Facto
                                          // read from different banks
   __shared__ T Ls[6 * 32 * LS];          // -L(b, b') of the diagonal block, b > b': [pair][c * LS + j]
   __shared__ T Ws[4 * 32 * LS];          // W_b: [b][j * LS + c] = W_b(c, j)
-  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
   if (K0 >= m.nc) return;
   const int nbk = min(BIG_SUPER, m.nc - K0);
   const int M = m.nc + m.nr + 1;
@@ -1683,7 +1685,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_update(Factor
   __shared__ T Bs[2][KC][LDT];                   // Bs[buf][k][j] = -F(J0 + j, k)
   RRPGO_TRACE_MARK(a, 100 + mode);
   if (blockIdx.x < blockIdx.y) return;           // lower triangle of tiles only
-  const SnMeta m = a.sn_meta[big_front(a, blockIdx.z)];
+  const SnMeta m = a.task_meta[a.task_begin + blockIdx.z];
   if (kb >= m.nc) return;
   const int M = m.nc + m.nr + 1;
   const int super_end = min((kb / BIG_SUPER) * BIG_SUPER + BIG_SUPER, m.nc);
@@ -2074,7 +2076,7 @@ __global__ void __launch_bounds__(THREADS) k_solve_tasks(FactorArgs<T> a) {
 // part[by][col0 + j] (fixed slots, summed in order by k_big_gemv_finish: deterministic).
 template <typename T> __global__ void __launch_bounds__(256) k_big_gemv_partial(FactorArgs<T> a, T *part, int64_t N, int R) {
   __shared__ T xs[1024];
-  const SnMeta m = a.sn_meta[big_front(a, blockIdx.z)];
+  const SnMeta m = a.task_meta[a.task_begin + blockIdx.z];
   const int nc = m.nc, nr = m.nr, M = nc + nr + 1;
   const int j0 = blockIdx.x * 64;
   if (j0 >= nc) return;
@@ -2131,7 +2133,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_gemv_partial(
 
 // second part: t[j] = y1[j] - sum over the R slices, in slice order, left in x[col0 + j] for k_solve_mid
 template <typename T> __global__ void __launch_bounds__(256) k_big_gemv_finish(FactorArgs<T> a, const T *part, int64_t N, int R) {
-  const SnMeta m = a.sn_meta[big_front(a, blockIdx.y)];
+  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= m.nc) return;
   const int M = m.nc + m.nr + 1;

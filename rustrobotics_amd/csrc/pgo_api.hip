@@ -150,7 +150,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<unsigned long long> stamps_;  // diagnostic builds only
   // symbolic tables
   DevBuf<int32_t> task_ptr_, task_sn_, fasm_src_, fasm_dst_, fdup_src_, fdup_dst_, scat_, rel_, perm_, sn_rows_;
-  DevBuf<SnMeta> sn_meta_;
+  DevBuf<SnMeta> sn_meta_, task_meta_;
   DevBuf<ChildMeta> child_meta_;
   std::vector<int> step_solve_lds_;  // scalars of LDS the back-solve of each step needs
   double *host_pair_ = nullptr;      // pinned: chi2, |dx|, and (as an int in slot 2) the device error flag
@@ -324,6 +324,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         }
       }
       sn_meta_.upload(meta);
+      {
+        std::vector<SnMeta> tm(sym.task_ptr.size() - 1);
+        for (size_t t = 0; t + 1 < sym.task_ptr.size(); t++) tm[t] = meta[sym.task_sn[sym.task_ptr[t]]];
+        task_meta_.upload(tm);
+      }
       if (wblk_total > 0x7fffff00LL) throw ApiError(RR_PGO_EUNSUPPORTED, "too many diagonal blocks");
       winv_.alloc((size_t)wblk_total * 256 + 4);
       winv_.zero();
@@ -429,6 +434,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     a.task_sn = task_sn_.p;
     a.task_begin = task_begin;
     a.sn_meta = sn_meta_.p;
+    a.task_meta = task_meta_.p;
     a.child_meta = child_meta_.p;
     a.fasm_src = fasm_src_.p;
     a.fasm_dst = fasm_dst_.p;
