@@ -1097,6 +1097,7 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
   if (const char *e = std::getenv("RR_PGO_MID_MAX")) so.mid_max_front = std::atoi(e);   // tuning knobs
   if (const char *e = std::getenv("RR_PGO_TASK_US")) so.task_us = std::atof(e);
   if (const char *e = std::getenv("RR_PGO_THREADS_SHIFT")) so.threads_shift = std::atoi(e);
+  if (std::getenv("RR_PGO_NO_GEO")) so.geo_nd = false;
   double t0 = now_ms();
   std::string err = analyze(h->g, so, h->sym);
   if (!err.empty()) throw ApiError(RR_PGO_EINVAL, err);

@@ -133,11 +133,13 @@ struct NestedDissection {
   std::vector<int32_t> order;    // output: order[pos] = node
   std::vector<int32_t> part;     // owner partition, -1 shared
   std::vector<int32_t> level, queue, local_id;
+  std::vector<int8_t> side;      // scratch of the coordinate bisection
+  const HostGraph *hg = nullptr; // node positions for coordinate bisection (optional)
   int next_set = 1, part_depth = 0;
 
   NestedDissection(const Adj &a, const std::vector<int32_t> &ww, const SymbolicOptions &o)
       : adj(a), w(ww), opt(o), N((int)ww.size()), set_id(N, 0), ordered(N, 0), part(N, -1),
-        level(N, -1), local_id(N, -1) {
+        level(N, -1), local_id(N, -1), side(N, -1) {
     order.reserve(N);
     queue.reserve(N);
     while ((1 << part_depth) < opt.n_parts) part_depth++;
@@ -201,6 +203,57 @@ struct NestedDissection {
   void assign_part(const std::vector<int32_t> &S, int depth, int path) {
     int p = depth >= part_depth ? (path >> (depth - part_depth)) : (path << (part_depth - depth));
     for (int v : S) part[v] = p;
+  }
+
+  // Coordinate bisection: pose graphs are spatial, and a breadth-first level set from a corner of a
+  // rectangular map is an L-shaped front about twice as long as a straight cut.  Split S at the median
+  // coordinate of its longest axis; the separator is the lighter of the two boundaries of the cut.
+  // Returns the score (separator weight, penalised for imbalance like the level-set search) or < 0.
+  double geo_split(const std::vector<int32_t> &S, int sid, std::vector<int32_t> &left,
+                   std::vector<int32_t> &right, std::vector<int32_t> &sep) {
+    if (!hg || !opt.geo_nd) return -1.0;
+    const int n = (int)S.size(), nd = hg->has_se3 ? 3 : 2;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int v : S)
+      for (int a = 0; a < nd; a++) {
+        const double c = hg->node_state[hg->node_state_off[v] + a];
+        if (!(c == c)) return -1.0;
+        lo[a] = std::min(lo[a], c);
+        hi[a] = std::max(hi[a], c);
+      }
+    int ax = 0;
+    for (int a = 1; a < nd; a++)
+      if (hi[a] - lo[a] > hi[ax] - lo[ax]) ax = a;
+    if (!(hi[ax] - lo[ax] > 0)) return -1.0;
+    std::vector<std::pair<double, int32_t>> key(n);
+    for (int i = 0; i < n; i++) key[i] = {hg->node_state[hg->node_state_off[S[i]] + ax], S[i]};
+    std::sort(key.begin(), key.end());
+    const int half = n / 2;
+    for (int i = 0; i < n; i++) side[key[i].second] = i < half ? 0 : 1;
+    int64_t wb[2] = {0, 0};
+    std::vector<int32_t> bnd[2];
+    for (int v : S) {
+      const int sv = side[v];
+      bool cut = false;
+      for (int p = adj.ptr[v]; p < adj.ptr[v + 1] && !cut; p++) {
+        const int u = adj.idx[p];
+        cut = set_id[u] == sid && side[u] == 1 - sv;
+      }
+      if (cut) { bnd[sv].push_back(v); wb[sv] += w[v]; }
+    }
+    const int pick = wb[0] <= wb[1] ? 0 : 1;
+    double score = -1.0;
+    if (!bnd[pick].empty()) {
+      for (int v : bnd[pick]) side[v] = 2;
+      left.clear(); right.clear(); sep.clear();
+      for (int v : S) (side[v] == 0 ? left : side[v] == 1 ? right : sep).push_back(v);
+      if (!left.empty() && !right.empty()) {
+        const double imb = std::fabs((double)left.size() - (double)right.size()) / (double)n;
+        score = (double)wb[pick] * (1.0 + 4.0 * imb * imb) + (imb > 0.6 ? 1e6 * imb : 0.0);
+      }
+    }
+    for (int v : S) side[v] = -1;
+    return score;
   }
 
   void dissect(std::vector<int32_t> &S, int depth, int path) {
@@ -285,6 +338,16 @@ struct NestedDissection {
         }
       }
       for (int v : S) level[v] = -1;
+      {
+        // the straight cut, if the graph has positions and it is the lighter separator
+        int64_t ws = 0;
+        for (int v : sep) ws += w[v];
+        const double imb = std::fabs((double)left.size() - (double)right.size()) / (double)n;
+        const double bfs_score = (double)ws * (1.0 + 4.0 * imb * imb) + (imb > 0.6 ? 1e6 * imb : 0.0);
+        std::vector<int32_t> gl, gr, gs;
+        const double gscore = geo_split(S, sid, gl, gr, gs);
+        if (gscore >= 0 && gscore < bfs_score) { left.swap(gl); right.swap(gr); sep.swap(gs); }
+      }
     }
     if (depth < part_depth)
       for (int v : sep) part[v] = -1;
@@ -376,6 +439,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
   std::vector<int32_t> order, pos_of(N);
   {
     NestedDissection nd(adj, w, opt);
+    nd.hg = &g;
     std::vector<int32_t> all(N);
     std::iota(all.begin(), all.end(), 0);
     nd.dissect(all, 0, 0);
