@@ -1,6 +1,8 @@
 // symbolic.cpp -- see symbolic.h.  Host only, runs once per graph.
 #include "symbolic.h"
 
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -221,36 +223,72 @@ struct NestedDissection {
         lo[a] = std::min(lo[a], c);
         hi[a] = std::max(hi[a], c);
       }
-    int ax = 0;
-    for (int a = 1; a < nd; a++)
-      if (hi[a] - lo[a] > hi[ax] - lo[ax]) ax = a;
-    if (!(hi[ax] - lo[ax] > 0)) return -1.0;
+    double ext = 0;
+    for (int a = 0; a < nd; a++) ext = std::max(ext, hi[a] - lo[a]);
+    if (!(ext > 0)) return -1.0;
+    // candidates: every axis whose extent is at least half the longest, cut at five quantiles around the
+    // median; the separator of a cut is the lighter of its two boundaries
+    static const double kQuant[5] = {0.5, 0.46, 0.54, 0.42, 0.58};
     std::vector<std::pair<double, int32_t>> key(n);
-    for (int i = 0; i < n; i++) key[i] = {hg->node_state[hg->node_state_off[S[i]] + ax], S[i]};
-    std::sort(key.begin(), key.end());
-    const int half = n / 2;
-    for (int i = 0; i < n; i++) side[key[i].second] = i < half ? 0 : 1;
-    int64_t wb[2] = {0, 0};
-    std::vector<int32_t> bnd[2];
-    for (int v : S) {
-      const int sv = side[v];
-      bool cut = false;
-      for (int p = adj.ptr[v]; p < adj.ptr[v + 1] && !cut; p++) {
-        const int u = adj.idx[p];
-        cut = set_id[u] == sid && side[u] == 1 - sv;
+    double best_score = -1.0;
+    int best_ax = -1, best_cut = 0, best_pick = 0;
+    for (int ax = 0; ax < nd; ax++) {
+      if (hi[ax] - lo[ax] < 0.5 * ext) continue;
+      for (int i = 0; i < n; i++) key[i] = {hg->node_state[hg->node_state_off[S[i]] + ax], S[i]};
+      std::sort(key.begin(), key.end());
+      for (int qi = 0; qi < 5; qi++) {
+        int cut = std::min(std::max((int)(kQuant[qi] * n), 1), n - 1);
+        {
+          // snap to the widest gap between consecutive coordinates nearby: a cut through the middle of a
+          // row of poses with almost equal coordinates would be ragged and its boundary a row thicker
+          const int win = std::max(8, n / 48);
+          int bi = cut;
+          double bg = -1.0;
+          for (int i = std::max(1, cut - win); i <= std::min(n - 1, cut + win); i++) {
+            const double gap = key[i].first - key[i - 1].first;
+            if (gap > bg) { bg = gap; bi = i; }
+          }
+          cut = bi;
+        }
+        for (int i = 0; i < n; i++) side[key[i].second] = i < cut ? 0 : 1;
+        int64_t wb[2] = {0, 0}, nb[2] = {0, 0};
+        for (int v : S) {
+          const int sv = side[v];
+          bool c = false;
+          for (int p = adj.ptr[v]; p < adj.ptr[v + 1] && !c; p++) {
+            const int u = adj.idx[p];
+            c = set_id[u] == sid && side[u] == 1 - sv;
+          }
+          if (c) { wb[sv] += w[v]; nb[sv]++; }
+        }
+        const int pick = wb[0] <= wb[1] ? 0 : 1;
+        if (nb[pick] == 0) continue;
+        const double l = cut - (pick == 0 ? nb[0] : 0), r = (n - cut) - (pick == 1 ? nb[1] : 0);
+        if (l <= 0 || r <= 0) continue;
+        const double imb = std::fabs(l - r) / (double)n;
+        const double sc = (double)wb[pick] * (1.0 + 4.0 * imb * imb) + (imb > 0.6 ? 1e6 * imb : 0.0);
+        if (best_score < 0 || sc < best_score) { best_score = sc; best_ax = ax; best_cut = cut; best_pick = pick; }
       }
-      if (cut) { bnd[sv].push_back(v); wb[sv] += w[v]; }
     }
-    const int pick = wb[0] <= wb[1] ? 0 : 1;
     double score = -1.0;
-    if (!bnd[pick].empty()) {
-      for (int v : bnd[pick]) side[v] = 2;
+    if (best_ax >= 0) {
+      for (int i = 0; i < n; i++) key[i] = {hg->node_state[hg->node_state_off[S[i]] + best_ax], S[i]};
+      std::sort(key.begin(), key.end());
+      for (int i = 0; i < n; i++) side[key[i].second] = i < best_cut ? 0 : 1;
       left.clear(); right.clear(); sep.clear();
-      for (int v : S) (side[v] == 0 ? left : side[v] == 1 ? right : sep).push_back(v);
-      if (!left.empty() && !right.empty()) {
-        const double imb = std::fabs((double)left.size() - (double)right.size()) / (double)n;
-        score = (double)wb[pick] * (1.0 + 4.0 * imb * imb) + (imb > 0.6 ? 1e6 * imb : 0.0);
+      std::vector<int32_t> bnd;
+      for (int v : S) {
+        if (side[v] != best_pick) continue;
+        bool c = false;
+        for (int p = adj.ptr[v]; p < adj.ptr[v + 1] && !c; p++) {
+          const int u = adj.idx[p];
+          c = set_id[u] == sid && side[u] == 1 - best_pick;
+        }
+        if (c) bnd.push_back(v);
       }
+      for (int v : bnd) side[v] = 2;
+      for (int v : S) (side[v] == 0 ? left : side[v] == 1 ? right : sep).push_back(v);
+      score = best_score;
     }
     for (int v : S) side[v] = -1;
     return score;
