@@ -1098,8 +1098,29 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
   if (const char *e = std::getenv("RR_PGO_TASK_US")) so.task_us = std::atof(e);
   if (const char *e = std::getenv("RR_PGO_THREADS_SHIFT")) so.threads_shift = std::atoi(e);
   if (std::getenv("RR_PGO_NO_GEO")) so.geo_nd = false;
+  if (const char *e = std::getenv("RR_PGO_ND_LEAF")) so.nd_leaf = std::atoi(e);
   double t0 = now_ms();
-  std::string err = analyze(h->g, so, h->sym);
+  std::string err;
+  if (h->g.n_nodes() <= 6000 && opt.world_size <= 1 && !std::getenv("RR_PGO_ND_LEAF")) {
+    // Small graphs are bound by the critical path through the supernode tree, not by flops: a few
+    // nested-dissection cuts above minimum-degree leaves shorten that path on the larger ones (M3500, dlr,
+    // sphere2500: +20..26 % measured) and lengthen it on intel.  The front cost model ranks the candidates
+    // the way the measurements do, so the estimated critical path picks the leaf size.
+    static const int kLeaf[] = {1 << 30, 3000, 2000, 1400, 1000, 700};
+    Symbolic best;
+    double best_crit = -1.0;
+    for (int leaf : kLeaf) {
+      if (leaf != (1 << 30) && leaf >= h->g.n_nodes()) continue;   // same as no cut at all
+      so.nd_leaf = leaf;
+      Symbolic cand;
+      err = analyze(h->g, so, cand);
+      if (!err.empty()) break;
+      if (best_crit < 0 || cand.est_critical_us < best_crit) { best_crit = cand.est_critical_us; best = std::move(cand); }
+    }
+    if (err.empty()) h->sym = std::move(best);
+  } else {
+    err = analyze(h->g, so, h->sym);
+  }
   if (!err.empty()) throw ApiError(RR_PGO_EINVAL, err);
   double t1 = now_ms();
   // device
