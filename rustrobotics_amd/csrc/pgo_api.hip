@@ -1089,6 +1089,7 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
   SymbolicOptions so;
   so.lds_budget_elems = opt.precision == RR_PGO_F64 ? 19000 : 38000;
   so.nd_leaf = h->g.n_nodes() <= 6000 ? (1 << 30) : 64;
+  so.split_separators = h->g.n_nodes() > 6000;   // wide top fronts: see symbolic.cpp, supernode pass
   if (opt.world_size > 1) {   // sharding needs the nested-dissection top levels
     so.n_parts = opt.world_size;
     so.my_part = opt.rank;
@@ -1098,6 +1099,7 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
   if (const char *e = std::getenv("RR_PGO_TASK_US")) so.task_us = std::atof(e);
   if (const char *e = std::getenv("RR_PGO_THREADS_SHIFT")) so.threads_shift = std::atoi(e);
   if (std::getenv("RR_PGO_NO_GEO")) so.geo_nd = false;
+  if (std::getenv("RR_PGO_JOIN_SEPARATORS")) so.split_separators = false;
   if (const char *e = std::getenv("RR_PGO_ND_LEAF")) so.nd_leaf = std::atoi(e);
   double t0 = now_ms();
   std::string err;

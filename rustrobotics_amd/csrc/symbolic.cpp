@@ -136,12 +136,13 @@ struct NestedDissection {
   std::vector<int32_t> part;     // owner partition, -1 shared
   std::vector<int32_t> level, queue, local_id;
   std::vector<int8_t> side;      // scratch of the coordinate bisection
+  std::vector<int32_t> sep_of;   // separator a node belongs to (-1: inside a leaf)
   const HostGraph *hg = nullptr; // node positions for coordinate bisection (optional)
   int next_set = 1, part_depth = 0;
 
   NestedDissection(const Adj &a, const std::vector<int32_t> &ww, const SymbolicOptions &o)
       : adj(a), w(ww), opt(o), N((int)ww.size()), set_id(N, 0), ordered(N, 0), part(N, -1),
-        level(N, -1), local_id(N, -1), side(N, -1) {
+        level(N, -1), local_id(N, -1), side(N, -1), sep_of(N, -1) {
     order.reserve(N);
     queue.reserve(N);
     while ((1 << part_depth) < opt.n_parts) part_depth++;
@@ -399,6 +400,7 @@ struct NestedDissection {
     for (int v : sep) {
       order.push_back(v);
       ordered[v] = 1;
+      sep_of[v] = zid;
     }
   }
 };
@@ -474,7 +476,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
   const int64_t lds_budget = opt.lds_budget_elems;
 
   // ---- 1. ordering ---------------------------------------------------------
-  std::vector<int32_t> order, pos_of(N);
+  std::vector<int32_t> order, pos_of(N), node_sep;
   {
     NestedDissection nd(adj, w, opt);
     nd.hg = &g;
@@ -483,6 +485,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     nd.dissect(all, 0, 0);
     order.swap(nd.order);
     sym.node_part.swap(nd.part);
+    node_sep.swap(nd.sep_of);
     if ((int)order.size() != N) return "internal: ordering lost nodes";
     if (opt.n_parts <= 1) std::fill(sym.node_part.begin(), sym.node_part.end(), 0);
   }
@@ -538,8 +541,13 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
   // ---- 4. zero-fill supernodes, then relaxed amalgamation -------------------
   std::vector<int32_t> sn_of(N), s_first, s_last;
   for (int j = 0; j < N; j++) {
+    // The last separator of a dissected region has the structure of its parent separator and would
+    // chain into one supernode with it; kept apart, it is factored in the same batch as its sibling
+    // separator one level down, which shortens the sequential panel chain of the wide top fronts.
+    const bool other_sep = j > 0 && opt.split_separators && node_sep[order[j - 1]] >= 0 && node_sep[order[j]] >= 0 &&
+                           node_sep[order[j - 1]] != node_sep[order[j]];
     bool join = j > 0 && parent[j - 1] == j && cc[j - 1] == cc[j] + w[order[j]] &&
-                sym.node_part[order[j - 1]] == sym.node_part[order[j]];
+                sym.node_part[order[j - 1]] == sym.node_part[order[j]] && !other_sep;
     if (!join) {
       s_first.push_back(j);
       s_last.push_back(j);
@@ -569,6 +577,9 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     for (int c : ch) {
       if (part_of_sn(c) != part_of_sn(p)) continue;
       int64_t np2 = npiv[c] + npiv[p];
+      if (opt.split_separators && np2 > 256 && node_sep[order[s_first[c]]] >= 0 && node_sep[order[s_first[p]]] >= 0 &&
+          node_sep[order[s_first[c]]] != node_sep[order[s_first[p]]])
+        continue;   // wide sibling separators stay fronts of their own (see the supernode pass above)
       int64_t z = npiv[c] * (npiv[p] + nrow[p] - nrow[c]);
       if (z < 0) z = 0;
       int64_t ztot = zeros[c] + zeros[p] + z;

@@ -20,6 +20,7 @@
 namespace rrpgo {
 
 struct SymbolicOptions {
+  bool split_separators = false;     // do not chain a region's last separator into its parent separator's supernode
   bool geo_nd = true;                // nested dissection may cut along a coordinate axis (pose graphs are spatial)
   int threads_shift = 1;             // workgroup size classes: front size is shifted left by this before the lookup
   int64_t lds_budget_elems = 19000;  // LDS scalars one workgroup may use for a front (panel + packed update)
