@@ -1470,7 +1470,7 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
 // The block is held with an odd leading dimension (129: one dummy zero row) so that the MFMA operand
 // reads of four k-columns fall into different LDS banks.
 template <typename T> __global__ void __launch_bounds__(512) k_big_diag128(FactorArgs<T> a, int K0) {
-  static_assert(BIG_SUPER == 128 && BIG_NB == 32, "written for 128-column super-panels of 32-column blocks");
+  static_assert(BIG_NB == 32, "written for 32-column blocks");   // and for 128-column super-panels: the launcher only uses it then
   using MM = Mfma16<T>;
   constexpr int LD = 129;
   __shared__ T P[LD * 128];
