@@ -41,6 +41,20 @@ constexpr int UPD_THREADS = 256;
 #define RRPGO_TRACE_MARK(a, tag) do { } while (0)
 #endif
 
+#if defined(RRPGO_TRACE) && defined(RRPGO_STAMPS)
+#define RRPGO_PHASE_MARK(a, cond, tag)                                                                  \
+  do {                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if ((a).trace && (cond) && threadIdx.x == 0 && blockIdx.y == 0) {                                   \
+      const unsigned long long i_ = atomicAdd((a).trace, 1ull);                                         \
+      if (i_ < 190000) { (a).trace[2 + 2 * i_] = (tag); (a).trace[3 + 2 * i_] = clock64(); }            \
+    }                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+  } while (0)
+#else
+#define RRPGO_PHASE_MARK(a, cond, tag) do { } while (0)
+#endif
+
 // Diagnostic build only (-DRRPGO_STAMPS): thread 0 of a workgroup records the
 // 100 MHz wall clock at the phase boundaries of every front it processes.
 #ifdef RRPGO_STAMPS
@@ -1326,6 +1340,7 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
   const int super_end = min(K0 + BIG_SUPER, m.nc);
   const int kn = kb + BIG_NB;
   const bool look = blockIdx.x == 0 && kn < super_end;   // nb == 32 here
+  RRPGO_PHASE_MARK(a, look, 500);
   // W operand tiles (cb, jb) = (0,0), (1,0), (1,1); (0,1) is zero
   T wv[3][4];
 #pragma unroll
@@ -1338,6 +1353,29 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
   int irow[2];   // this lane's two rows, clamped into the front
   irow[0] = min(R0 + li, M - 1);
   irow[1] = min(R0 + 16 + li, M - 1);
+  // Operands of the left-looking update, columns K0..kb in whole 32-column blocks (at most three): their
+  // loads are requested FIRST, together with everything else this wave reads, so that the launch pays one
+  // memory round trip instead of one per block (measured: 3.9 + 4.7 us of a 15.7 us chain step were
+  // waits on two to four serial round trips).  fp64 keeps two blocks in registers and refills.
+  constexpr int PRE = sizeof(T) == 4 ? 3 : 2;
+  const int nblk = (kb - K0) / BIG_NB;
+  const int arow0 = kb + min(li, nb - 1), arow1 = kb + min(16 + li, nb - 1);
+  const T am0 = li < nb ? (T)-1 : (T)0, am1 = 16 + li < nb ? (T)-1 : (T)0;   // sign and mask of the a-operand
+  T av[PRE][8][2], bv[PRE][8][2];
+  auto fetch = [&](int blk, T (*xa)[2], T (*xb)[2]) {
+    const T *col = F + (int64_t)(K0 + blk * BIG_NB + lk) * M;
+#pragma unroll
+    for (int s4 = 0; s4 < 8; s4++) {
+      xa[s4][0] = col[arow0] * am0;
+      xa[s4][1] = col[arow1] * am1;
+      xb[s4][0] = col[irow[0]];
+      xb[s4][1] = col[irow[1]];
+      col += 4 * (int64_t)M;
+    }
+  };
+#pragma unroll
+  for (int p = 0; p < PRE; p++)
+    if (p < nblk) fetch(p, av[p], bv[p]);
   typename MM::Acc acc[2][2], nxt[2][2];
 #pragma unroll
   for (int jb = 0; jb < 2; jb++)
@@ -1362,49 +1400,29 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
         for (int ib = 0; ib < 2; ib++) nxt[ib][jb][r] = ccol[irow[ib]];
       }
   }
-  // the columns K0..kb come in whole 32-column blocks (at most three): all 32 operand loads of a block
-  // are issued before its MFMAs, and the next block's loads before that -- the loop would otherwise pay
-  // one L2 round trip per k-step
-  const int nblk = (kb - K0) / BIG_NB;
-  const int arow0 = kb + min(li, nb - 1), arow1 = kb + min(16 + li, nb - 1);
-  const bool aok0 = li < nb, aok1 = 16 + li < nb;
-  T av[8][2], bv[8][2], an[8][2], bn[8][2];
-  auto fetch = [&](int blk, T (*xa)[2], T (*xb)[2]) {
-    const T *col = F + (int64_t)(K0 + blk * BIG_NB + lk) * M;
-#pragma unroll
-    for (int s4 = 0; s4 < 8; s4++) {
-      const T a0 = pin(col[arow0]), a1 = pin(col[arow1]);
-      xa[s4][0] = aok0 ? -a0 : (T)0;
-      xa[s4][1] = aok1 ? -a1 : (T)0;
-      xb[s4][0] = col[irow[0]];
-      xb[s4][1] = col[irow[1]];
-      col += 4 * (int64_t)M;
-    }
-  };
-  if (nblk > 0) fetch(0, av, bv);
+  RRPGO_PHASE_MARK(a, look, 501);
 #pragma unroll
   for (int blk = 0; blk < BIG_SUPER / BIG_NB - 1; blk++) {
     if (blk < nblk) {
-      if (blk + 1 < nblk) fetch(blk + 1, an, bn);
+      constexpr int dummy = 0; (void)dummy;
+      const int slot = blk % PRE;   // compile-time after unrolling
 #pragma unroll
       for (int s4 = 0; s4 < 8; s4++) {
 #pragma unroll
         for (int ib = 0; ib < 2; ib++)
 #pragma unroll
-          for (int jb = 0; jb < 2; jb++) acc[ib][jb] = MM::mma(av[s4][jb], bv[s4][ib], acc[ib][jb]);
+          for (int jb = 0; jb < 2; jb++) acc[ib][jb] = MM::mma(av[slot][s4][jb], bv[slot][s4][ib], acc[ib][jb]);
         if (look) {
 #pragma unroll
           for (int ib = 0; ib < 2; ib++)
 #pragma unroll
-            for (int jb = 0; jb <= ib; jb++) nxt[ib][jb] = MM::mma(-bv[s4][jb], bv[s4][ib], nxt[ib][jb]);
+            for (int jb = 0; jb <= ib; jb++) nxt[ib][jb] = MM::mma(-bv[slot][s4][jb], bv[slot][s4][ib], nxt[ib][jb]);
         }
       }
-#pragma unroll
-      for (int s4 = 0; s4 < 8; s4++)
-#pragma unroll
-        for (int t = 0; t < 2; t++) { av[s4][t] = an[s4][t]; bv[s4][t] = bn[s4][t]; }
+      if (PRE < BIG_SUPER / BIG_NB - 1 && blk + PRE < nblk) fetch(blk + PRE, av[slot], bv[slot]);   // refill the freed set
     }
   }
+  RRPGO_PHASE_MARK(a, look, 502);
   // X = A * W^T : out[ib][cb] (rows c of the MFMA tile) = sum_j W[c][j] * A[j][i]
   typename MM::Acc out[2][2];
 #pragma unroll
@@ -1439,6 +1457,7 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
         }
   }
   if (!look) return;
+  RRPGO_PHASE_MARK(a, look, 503);
   // next diagonal block: the last 32 columns of its update are this wave's own X
 #pragma unroll
   for (int cb = 0; cb < 2; cb++)
@@ -1459,7 +1478,9 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
         Sh[jc * 33 + ir] = (ir < nbn && jc < nbn) ? nxt[ib][jb][r] : (ir == jc ? (T)1 : (T)0);   // identity padding
       }
   __syncthreads();
+  RRPGO_PHASE_MARK(a, look, 504);
   diag32_factor_invert<T>(Sh, nbn, F + (int64_t)kn * M + kn, M, a.winv + (int64_t)m.wblk * 256 + (kn / BIG_NB) * 1024, a.err);
+  RRPGO_PHASE_MARK(a, look, 505);
 }
 
 // ---- a whole 128-column super-panel per step of the chain ------------------------------------------
