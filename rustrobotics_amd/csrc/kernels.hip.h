@@ -1362,15 +1362,23 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
   const int arow0 = kb + min(li, nb - 1), arow1 = kb + min(16 + li, nb - 1);
   const T am0 = li < nb ? (T)-1 : (T)0, am1 = 16 + li < nb ? (T)-1 : (T)0;   // sign and mask of the a-operand
   T av[PRE][8][2], bv[PRE][8][2];
+  // 32-bit byte offsets from the (uniform) front base: one VALU add per load instead of 64-bit pointer
+  // arithmetic (a front is at most a few hundred MB)
+  const char *Fb = reinterpret_cast<const char *>(F);
+  const uint32_t colb = (uint32_t)((K0 + lk) * M) * (uint32_t)sizeof(T);
+  const uint32_t oa0 = colb + (uint32_t)arow0 * (uint32_t)sizeof(T), oa1 = colb + (uint32_t)arow1 * (uint32_t)sizeof(T);
+  const uint32_t ob0 = colb + (uint32_t)irow[0] * (uint32_t)sizeof(T), ob1 = colb + (uint32_t)irow[1] * (uint32_t)sizeof(T);
+  const uint32_t kstep = (uint32_t)(4 * M) * (uint32_t)sizeof(T);
+  auto ld = [&](uint32_t off) { return *reinterpret_cast<const T *>(Fb + off); };
   auto fetch = [&](int blk, T (*xa)[2], T (*xb)[2]) {
-    const T *col = F + (int64_t)(K0 + blk * BIG_NB + lk) * M;
+    uint32_t d = (uint32_t)(blk * 8) * kstep;
 #pragma unroll
     for (int s4 = 0; s4 < 8; s4++) {
-      xa[s4][0] = col[arow0] * am0;
-      xa[s4][1] = col[arow1] * am1;
-      xb[s4][0] = col[irow[0]];
-      xb[s4][1] = col[irow[1]];
-      col += 4 * (int64_t)M;
+      xa[s4][0] = ld(oa0 + d) * am0;
+      xa[s4][1] = ld(oa1 + d) * am1;
+      xb[s4][0] = ld(ob0 + d);
+      xb[s4][1] = ld(ob1 + d);
+      d += kstep;
     }
   };
 #pragma unroll
