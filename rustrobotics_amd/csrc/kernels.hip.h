@@ -1738,6 +1738,8 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_update(Factor
   // load goes to a CLAMPED address (no branch per load: out-of-range rows only feed entries that are
   // never stored) and only the stores are predicated.
   const bool interior = I0 + 128 <= M && J0 + 128 <= jmax && I0 >= J0 + 128;
+  const bool pm = blockIdx.x == 2 && blockIdx.y == 0 && blockIdx.z == 0;
+  RRPGO_PHASE_MARK(a, pm, 600);
   // ---- accumulators = current C tile
   typename MM::Acc acc[4][4];
   if (wave_active) {
@@ -1779,6 +1781,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_update(Factor
   fetch(0);
   stash(0);
   __syncthreads();
+  RRPGO_PHASE_MARK(a, pm, 601);
   for (int c = 0; c < nchunks; c++) {
     const int buf = c & 1;
     if (c + 1 < nchunks) fetch(c + 1);
@@ -1800,6 +1803,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_update(Factor
     if (c + 1 < nchunks) stash(buf ^ 1);
     __syncthreads();
   }
+  RRPGO_PHASE_MARK(a, pm, 602);
   if (!wave_active) return;
   // The first wave of the first tile holds the next super-panel's first diagonal block (rows = columns
   // = t0 .. t0+31) in acc[0..1][0..1]: after the tile is stored it factors and inverts that block here,
@@ -1825,6 +1829,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_update(Factor
           if (i < M && j < jmax && i >= j) F[(int64_t)j * M + i] = acc[ib][jb][r];
         }
   }
+  RRPGO_PHASE_MARK(a, pm, 603);
   if (next_diag) {
     T *Sh = &As[0][0][0];   // the staging buffers are idle now (every wave passed the last barrier of the k loop)
     const int nbn = min(BIG_NB, m.nc - t0);
