@@ -1694,6 +1694,9 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_trsm128(Facto
       }
 }
 
+#ifndef RRPGO_UPD_WAVES
+#define RRPGO_UPD_WAVES 3   // fp32: waves per SIMD the register allocation aims at (three workgroups per CU with the 37 KB chunks); fp64 would spill
+#endif
 // Rank update  C(i,j) -= sum_{k in [ka,ke)} F(i,k) F(j,k)  over i in [t0, M), j in [t0, jmax), i >= j.
 //   mode 0: after the 32-column panel at kb: the rest of its 128-column super-panel (K = 32)
 //   mode 1: after the super-panel at kb: everything to its right, Schur complement included (K <= 128)
@@ -1702,12 +1705,9 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_trsm128(Facto
 // accumulators per wave).  The two 128-row operand strips are staged through LDS in k-chunks of
 // 32 (f32) / 16 (f64), double buffered: the global loads of chunk c+1 are in flight while the
 // MFMAs of chunk c run; one barrier per chunk.
-template <typename T> __global__ void __launch_bounds__(256) k_big_update(FactorArgs<T> a, int kb, int mode, int diag_tail) {
+template <typename T> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_update(FactorArgs<T> a, int kb, int mode, int diag_tail) {
   using MM = Mfma16<T>;
-#ifndef RRPGO_UPD_KC32
-#define RRPGO_UPD_KC32 32
-#endif
-  constexpr int KC = sizeof(T) == 4 ? RRPGO_UPD_KC32 : RRPGO_UPD_KC32 / 2;   // k-chunk staged in LDS (73.7 KB at 32 / 16)
+  constexpr int KC = 16;   // k-chunk staged in LDS: 36.9 KB in fp32 (three workgroups per CU), 73.7 KB in fp64 (two)
   constexpr int LDT = 128 + 16;                  // padded row: the four k-rows a wave reads hit disjoint banks
   constexpr int NLD = KC / 2;                    // global loads per operand per thread per chunk
   __shared__ T As[2][KC][LDT];                   // As[buf][k][i] =  F(I0 + i, k)
@@ -1738,7 +1738,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_update(Factor
   // load goes to a CLAMPED address (no branch per load: out-of-range rows only feed entries that are
   // never stored) and only the stores are predicated.
   const bool interior = I0 + 128 <= M && J0 + 128 <= jmax && I0 >= J0 + 128;
-  const bool pm = blockIdx.x == 2 && blockIdx.y == 0 && blockIdx.z == 0;
+  [[maybe_unused]] const bool pm = blockIdx.x == 2 && blockIdx.y == 0 && blockIdx.z == 0;
   RRPGO_PHASE_MARK(a, pm, 600);
   // ---- accumulators = current C tile
   typename MM::Acc acc[4][4];
