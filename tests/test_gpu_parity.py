@@ -488,3 +488,33 @@ def test_degenerate_graphs(api, oracle):
     with pytest.raises(PoseGraphError) as exc:
         g0.optimize(1)
     assert exc.value.code == -5
+
+
+@pytest.mark.parametrize("layout", ["coincident", "scattered", "line"])
+def test_large_graph_orderings_with_unhelpful_positions(api, oracle, layout):
+    """Graphs above 6000 nodes are ordered by nested dissection whose separators may be coordinate cuts
+    of the INITIAL positions.  Positions are only a hint: with all poses at one point (no extent: level
+    sets only), with positions unrelated to the graph (every cut is heavy) or on a line, the ordering
+    must still be valid and the answer the oracle's.  7000-pose odometry chain + 700 loop closures."""
+    rng = np.random.default_rng(7)
+    n = 7000
+    truth = np.stack([np.cos(np.arange(n) * 0.01) * 50, np.sin(np.arange(n) * 0.013) * 30, np.arange(n) * 0.002], 1)
+    ef = np.concatenate([np.arange(n - 1), rng.integers(0, n - 400, 700)]).astype(np.int32)
+    et = np.concatenate([np.arange(1, n), np.zeros(700, dtype=np.int64)]).astype(np.int32)
+    et[n - 1:] = ef[n - 1:] + rng.integers(50, 400, 700).astype(np.int32)
+    def rel(a, b):
+        c, s = np.cos(a[:, 2]), np.sin(a[:, 2])
+        dx, dy = b[:, 0] - a[:, 0], b[:, 1] - a[:, 1]
+        return np.stack([c * dx + s * dy, -s * dx + c * dy, b[:, 2] - a[:, 2]], 1)
+    em = (rel(truth[ef], truth[et]) + rng.normal(0, 0.01, (len(ef), 3))).ravel()
+    ei = np.tile(np.array([100.0, 0, 0, 100, 0, 400]), len(ef))
+    if layout == "coincident": init = np.zeros((n, 3))
+    elif layout == "scattered": init = np.concatenate([rng.uniform(-100, 100, (n, 2)), truth[:, 2:]], 1)
+    else: init = np.stack([np.arange(n) * 0.1, np.zeros(n), truth[:, 2]], 1)
+    nk, ek = np.zeros(n, np.int32), np.zeros(len(ef), np.int32)
+    g = api[0].from_arrays(nk, init.ravel(), ek, ef, et, em, ei)
+    o = oracle.from_arrays(nk, init.ravel(), ek, ef, et, em, ei)
+    assert g.stats()["n_supernodes"] > 0
+    np.testing.assert_allclose(g.global_error(), o.global_error(), rtol=1e-12)
+    dg, do = g.linearize_and_solve(), o.linearize_and_solve()
+    np.testing.assert_allclose(dg, do, rtol=0, atol=1e-7 * max(1.0, np.abs(do).max()))
