@@ -7,7 +7,7 @@ src/mapping/pose_graph_optimization.rs:269-301): linearise + assemble, factor, s
 (the convergence break is disabled so that exactly K steps run; after convergence a step does the
 same work on the same pattern).  Default workload = BASELINE.json configs[1]: intel.g2o, fp64.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload intel|m3500|dlr|sphere2500|grid:WxH[:E]] [--precision f64|f32|mixed] [--shard]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload intel|m3500|dlr|sphere2500|torus3d|parking-garage|grid:WxH[:E]] [--precision f64|f32|mixed] [--shard]
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): each rank optimises its own replica of
 the workload -- independent graphs, no data-path collective ("replicas", weak scaling); the
@@ -32,7 +32,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s mea
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "mixed": 157.3, "f64": 78.6}
 
 WORKLOADS = {"intel": "intel", "m3500": "input_M3500_g2o", "dlr": "dlr", "pose-pose": "simulation-pose-pose",
-             "pose-landmark": "simulation-pose-landmark", "sphere2500": "sphere2500"}
+             "pose-landmark": "simulation-pose-landmark", "sphere2500": "sphere2500",
+             "torus3d": "torus3D", "parking-garage": "parking-garage"}
 
 
 def g2o_file(name):
