@@ -1103,11 +1103,12 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
   if (const char *e = std::getenv("RR_PGO_ND_LEAF")) so.nd_leaf = std::atoi(e);
   double t0 = now_ms();
   std::string err;
-  if (h->g.n_nodes() <= 6000 && opt.world_size <= 1 && !std::getenv("RR_PGO_ND_LEAF")) {
+  if (h->g.n_nodes() >= 2400 && h->g.n_nodes() <= 6000 && opt.world_size <= 1 && !std::getenv("RR_PGO_ND_LEAF")) {
     // Small graphs are bound by the critical path through the supernode tree, not by flops: a few
     // nested-dissection cuts above minimum-degree leaves shorten that path on the larger ones (M3500, dlr,
     // sphere2500: +20..26 % measured) and lengthen it on intel.  The front cost model ranks the candidates
-    // the way the measurements do, so the estimated critical path picks the leaf size.
+    // the way the measurements do, so the estimated critical path picks the leaf size.  Below 2400 nodes
+    // no cut ever won and the extra analyses would only lengthen set-up (one-shot callers time it).
     static const int kLeaf[] = {1 << 30, 3000, 2000, 1400, 1000, 700};
     Symbolic best;
     double best_crit = -1.0;

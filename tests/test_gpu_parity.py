@@ -5,6 +5,8 @@ the reference's own goldens, and through size-independent properties at BASELINE
 Tolerances (fp64 path): converged chi2 1e-9 relative, per-iteration chi2 1e-7 (north star asks 1e-6), poses 1e-8 absolute,
 assembled H / b 1e-11 relative to the block scale.  fp32 path: stated per test.
 """
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -540,3 +542,21 @@ def test_large_graph_orderings_with_unhelpful_positions(api, oracle, layout):
     np.testing.assert_allclose(g.global_error(), o.global_error(), rtol=1e-12)
     dg, do = g.linearize_and_solve(), o.linearize_and_solve()
     np.testing.assert_allclose(dg, do, rtol=0, atol=1e-7 * max(1.0, np.abs(do).max()))
+
+
+def test_cli_mirrors_the_reference_example_output():
+    """python -m rustrobotics_amd <file> = examples/mapping/pose_graph_optimization.rs:49-50 without the
+    menus: optimize(50, log = true, plot = false) and the reference's log lines (:258-265, :288-293)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "rustrobotics_amd", g2o_path("simulation-pose-landmark")],
+                       capture_output=True, text=True, cwd=root, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "Loaded graph with 77 nodes and 297 edges"
+    assert lines[1].startswith("initial error :3030.31304")
+    assert lines[2].startswith("step   0 : |dx| = ") and "error = " in lines[2]
+    assert lines[-1].split("error = ")[1].startswith("474.0995")
+    b = subprocess.run([sys.executable, "-m", "rustrobotics_amd", g2o_path("intel"), "--bench", "--repeats", "3"],
+                       capture_output=True, text=True, cwd=root, timeout=300)
+    assert b.returncode == 0 and "final chi2 359.996" in b.stdout
