@@ -5,6 +5,8 @@
 //   k_solve_tasks    back substitution down the supernode tree         (replaces umfpack.solve, :141)
 //   k_update         update_nodes + |dx|^2                             (reference :229-245,273)
 //   k_finalize_slot  fixed-order reduction of the chi2 / |dx|^2 partials (pgo_api.hip)
+//   k_big_* / k_solve_mid / k_factor_mid   fronts beyond LDS (see "huge fronts" below)
+//   k_linearize_se3 / k_update_se3, k_pack_boundary / k_mask_x   SE(3), sharding over ranks
 //
 // Wavefront = 64 lanes.  All cross-workgroup dependencies are kernel boundaries
 // on one stream; inside a launch a workgroup only reads what it wrote itself
@@ -1012,9 +1014,14 @@ __global__ void __launch_bounds__(THREADS) k_factor_mid(FactorArgs<T> a) {
 // level batched in the launch (grid y or z = front slot; the level's fronts are the single-front
 // tasks task_begin, task_begin+1, ...).  Each M x M front lies in L storage (column-major, ld M).
 //   k_big_zero / k_big_assemble / k_big_extend_add (one launch per child rank: fixed order)
-//   per 128-column super-panel: 4 x { k_big_diag (32-col diagonal block), k_big_trsm (rows below),
-//                                     k_big_update mode 0 (rest of the super-panel, K = 32) }
-//                               then  k_big_update mode 1 (everything right of it, K = 128)
+//   per 128-column super-panel (default, left-looking):
+//       k_big_diag32 for the first super-panel of a level only (later ones: tail of the previous update)
+//       4 x k_big_panel32   rows below a 32-column block: update from the super-panel's earlier columns,
+//                           multiply by the inverse diagonal block; its first wave prepares the next block
+//       k_big_update mode 1 everything right of the super-panel (K = 128, the dense MFMA contraction)
+//   alternatives kept for comparison: k_big_diag / k_big_trsm / k_big_update mode 0 (right-looking, K = 32),
+//   k_big_diag128 / k_big_trsm128 (a whole super-panel per chain step), k_big_update modes 2 / 3 (two streams)
+//   back substitution: k_big_gemv_partial / k_big_gemv_finish (L21^T x over the chip), k_solve_mid (L11)
 #ifndef RRPGO_BIG_NB
 #define RRPGO_BIG_NB 32
 #endif
