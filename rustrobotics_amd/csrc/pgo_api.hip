@@ -5,6 +5,7 @@
 // one-off symbolic analysis; optimize = the GN / LM loop with every kernel of an
 // iteration replayed from one hipGraph on the handle's own stream; the host
 // reads two scalars (chi2, |dx|) per iteration.
+#include <mutex>
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -38,17 +39,77 @@ static thread_local std::string g_last_error;
       throw ApiError(RR_PGO_ENODEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));   \
   } while (0)
 
+// One handle makes ~45 device buffers, and hipMalloc / hipFree cost 50-100 us each (the frees also
+// synchronise): a caller that builds a graph, runs ten iterations and drops it -- the reference's own
+// criterion bench -- would spend more time there than iterating.  Buffers are carved out of a few large
+// chunks owned by the engine instead; a DevBuf only calls hipMalloc itself when no arena is active.
+struct DeviceArena {
+  struct Chunk { char *base; size_t cap, used; };
+  std::vector<Chunk> chunks;
+  size_t next_chunk = 8u << 20;
+  DeviceArena() = default;
+  DeviceArena(const DeviceArena &) = delete;
+  DeviceArena &operator=(const DeviceArena &) = delete;
+  ~DeviceArena() { for (Chunk &c : chunks) (void)hipFree(c.base); }
+  void reserve(size_t bytes) { next_chunk = std::max(next_chunk, bytes); }
+  void *take(size_t bytes) {
+    for (Chunk &c : chunks) {
+      const size_t off = (c.used + 255) & ~(size_t)255;
+      if (off + bytes <= c.cap) { c.used = off + bytes; return c.base + off; }
+    }
+    Chunk c{nullptr, std::max(next_chunk, bytes + 256), 0};
+    HIPCHK(hipMalloc((void **)&c.base, c.cap));
+    next_chunk = std::max<size_t>(8u << 20, c.cap / 4);
+    c.used = bytes;
+    chunks.push_back(c);
+    return c.base;
+  }
+};
+static thread_local DeviceArena *t_arena = nullptr;   // set while an engine allocates
+
+// hipStreamCreate costs ~2 ms (a hardware queue) and hipStreamDestroy about as much: more than the ten
+// Gauss-Newton iterations of the reference's bench on intel.g2o.  Streams of destroyed handles are kept
+// per device and handed to the next handle (idle: they were synchronised before being returned).
+struct StreamPool {
+  std::mutex mu;
+  std::vector<std::pair<int, hipStream_t>> idle;
+  hipStream_t get() {
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (size_t i = 0; i < idle.size(); i++)
+        if (idle[i].first == dev) { hipStream_t s = idle[i].second; idle.erase(idle.begin() + (long)i); return s; }
+    }
+    hipStream_t s = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return s;
+  }
+  void put(hipStream_t s) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipStreamDestroy(s); return; }
+    std::lock_guard<std::mutex> lk(mu);
+    if (idle.size() < 16) idle.emplace_back(dev, s);
+    else (void)hipStreamDestroy(s);
+  }
+};
+static StreamPool &stream_pool() { static StreamPool *p = new StreamPool; return *p; }   // leaked on purpose: outlives the runtime's teardown order
+
 template <typename U> struct DevBuf {
   U *p = nullptr;
   size_t n = 0;
+  bool owned = false;   // false: lives in the engine's arena
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  ~DevBuf() { if (p && owned) (void)hipFree(p); }
   void alloc(size_t count) {
-    if (p) { (void)hipFree(p); p = nullptr; }
+    if (p && owned) (void)hipFree(p);
+    p = nullptr;
     n = count;
-    if (count) HIPCHK(hipMalloc((void **)&p, count * sizeof(U)));
+    if (!count) return;
+    if (t_arena) { p = (U *)t_arena->take(count * sizeof(U)); owned = false; }
+    else { HIPCHK(hipMalloc((void **)&p, count * sizeof(U))); owned = true; }
   }
   void upload(const std::vector<U> &v) {
     alloc(v.size());
@@ -114,6 +175,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   using V2 = typename VecT<S>::V2;
   const HostGraph &g_;
   const Symbolic &sym_;
+  DeviceArena arena_;   // declared before every DevBuf: destroyed after them
   hipStream_t stream_ = nullptr;
   hipGraphExec_t gn_exec_ = nullptr;
   // graph data
@@ -159,10 +221,13 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
 
  public:
   Engine(const HostGraph &g, const Symbolic &sym, int rank, int world) : g_(g), sym_(sym), rank_(rank), world_(world) {
-    HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&ev_chain_, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ev_rest_, hipEventDisableTiming));
+    struct ArenaScope {   // every DevBuf::alloc of this constructor draws from arena_
+      explicit ArenaScope(DeviceArena *a) { t_arena = a; }
+      ~ArenaScope() { t_arena = nullptr; }
+    } scope(&arena_);
+    // the factor storage dominates: one chunk sized for it and the value arrays, tables follow in 8 MB chunks
+    arena_.reserve((size_t)(sym.l_elems + sym.u_elems + sym.n_hvals + 8 * (int64_t)g.dim + sym.xch_elems) * sizeof(T) + (4u << 20));
+    stream_ = stream_pool().get();
     HIPCHK(hipHostMalloc((void **)&host_pair_, 3 * sizeof(double)));
     const int N = g.n_nodes(), E = g.n_edges();
     // ---- graph arrays
@@ -266,6 +331,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     }
     left_looking_ = getenv("RR_PGO_RIGHT_LOOKING") == nullptr;
     overlap_ = getenv("RR_PGO_OVERLAP") != nullptr;
+    if (overlap_) {   // the second stream and its events only exist for this experiment
+      stream2_ = stream_pool().get();
+      HIPCHK(hipEventCreateWithFlags(&ev_chain_, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&ev_rest_, hipEventDisableTiming));
+    }
     if (overlap_ && std::atoi(getenv("RR_PGO_OVERLAP")) > 1) overlap_max_nf_ = std::atoi(getenv("RR_PGO_OVERLAP"));
     panel128_ = getenv("RR_PGO_PANEL128") != nullptr;
     factor_threads_max_ = getenv("RR_PGO_FACTOR_512") ? 512 : 1024;
@@ -375,8 +445,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (host_pair_) (void)hipHostFree(host_pair_);
     if (ev_chain_) (void)hipEventDestroy(ev_chain_);
     if (ev_rest_) (void)hipEventDestroy(ev_rest_);
-    if (stream2_) (void)hipStreamDestroy(stream2_);
-    if (stream_) (void)hipStreamDestroy(stream_);
+    if (stream2_) stream_pool().put(stream2_);
+    if (stream_) stream_pool().put(stream_);
   }
 
   hipStream_t stream() override { return stream_; }
