@@ -46,13 +46,22 @@ bool to_u32(std::string_view s, uint32_t &v) {
 }
 
 bool to_f64(std::string_view s, double &v) {
-  // Rust's f64::from_str: optional sign, decimal / exponent, inf / nan; no hex.
-  if (s.empty() || s.size() > 63) return false;
+  // Rust's f64::from_str: optional sign, decimal / exponent, inf / nan; no hex.  std::from_chars parses
+  // the same grammar (correctly rounded, no locale, no copy) except for a leading '+'.
+  if (s.empty()) return false;
+  if (s[0] == '+') {
+    s.remove_prefix(1);
+    if (s.empty() || s[0] == '-' || s[0] == '+') return false;
+  }
+  auto r = std::from_chars(s.data(), s.data() + s.size(), v, std::chars_format::general);
+  if (r.ec == std::errc() && r.ptr == s.data() + s.size()) return true;
+  // anything unusual (overflow to infinity, underflow, "infinity") takes the strtod route
+  if (s.size() > 62) return false;
   char buf[64];
   std::memcpy(buf, s.data(), s.size());
   buf[s.size()] = 0;
   const char *p = buf;
-  if (*p == '+' || *p == '-') p++;
+  if (*p == '-') p++;
   if (p[0] == '0' && (p[1] == 'x' || p[1] == 'X')) return false;
   char *end = nullptr;
   v = std::strtod(buf, &end);
