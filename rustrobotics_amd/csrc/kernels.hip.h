@@ -1712,11 +1712,16 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_trsm128(Facto
 // accumulators per wave).  The two 128-row operand strips are staged through LDS in k-chunks of
 // 32 (f32) / 16 (f64), double buffered: the global loads of chunk c+1 are in flight while the
 // MFMAs of chunk c run; one barrier per chunk.
-template <typename T> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_update(FactorArgs<T> a, int kb, int mode, int diag_tail) {
+// NT = MFMA tiles per wave and dimension: 4 -> 64 x 64 per wave, 128 x 128 per workgroup; 2 -> 32 x 32 per wave,
+// 64 x 64 per workgroup, for launches that would not fill the chip with the large tile (the top levels of
+// the tree: a quarter of the MFMA work per wave on the critical path of the launch).
+template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_update(FactorArgs<T> a, int kb, int mode, int diag_tail) {
   using MM = Mfma16<T>;
   constexpr int KC = 16;   // k-chunk staged in LDS: 36.9 KB in fp32 (three workgroups per CU), 73.7 KB in fp64 (two)
-  constexpr int LDT = 128 + 16;                  // padded row: the four k-rows a wave reads hit disjoint banks
-  constexpr int NLD = KC / 2;                    // global loads per operand per thread per chunk
+  constexpr int TILE = 32 * NT, WTILE = 16 * NT;  // workgroup tile, wave tile
+  constexpr int KSTEP = 256 / TILE;               // k-rows of a chunk loaded per pass of the 256 threads
+  constexpr int LDT = TILE + 16;                  // padded row: the four k-rows a wave reads hit disjoint banks
+  constexpr int NLD = KC / KSTEP;                 // global loads per operand per thread per chunk
   __shared__ T As[2][KC][LDT];                   // As[buf][k][i] =  F(I0 + i, k)
   __shared__ T Bs[2][KC][LDT];                   // Bs[buf][k][j] = -F(J0 + j, k)
   RRPGO_TRACE_MARK(a, 100 + mode);
@@ -1732,45 +1737,46 @@ template <typename T> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? R
   // super-panel's own columns, needed by its panel chain) and everything after them (which can run
   // beside that chain on a second stream)
   const int jmax = mode == 0 ? super_end : mode == 2 ? min(t0 + 128, M) : M;
-  const int toff = mode == 3 ? 1 : 0;
-  const int I0 = t0 + (blockIdx.x + toff) * 128, J0 = t0 + (blockIdx.y + toff) * 128;
+  static_assert(NT == 4 || NT == 2, "tile shapes");
+  const int toff = mode == 3 ? 128 / TILE : 0;   // mode 3 starts one 128-column strip further right
+  const int I0 = t0 + (blockIdx.x + toff) * TILE, J0 = t0 + (blockIdx.y + toff) * TILE;
   if (t0 >= jmax || I0 >= M || J0 >= jmax) return;   // uniform over the workgroup
   T *F = a.lvals + m.loff;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
-  const int wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
+  const int wi = (wave & 1) * WTILE, wj = (wave >> 1) * WTILE;
   const int i0 = I0 + wi, j0 = J0 + wj;
-  const bool wave_active = i0 < M && j0 < jmax && i0 + 64 > j0;
+  const bool wave_active = i0 < M && j0 < jmax && i0 + WTILE > j0;
   // A tile strictly below the diagonal and inside the front needs no masks at all.  Elsewhere every
   // load goes to a CLAMPED address (no branch per load: out-of-range rows only feed entries that are
   // never stored) and only the stores are predicated.
-  const bool interior = I0 + 128 <= M && J0 + 128 <= jmax && I0 >= J0 + 128;
+  const bool interior = I0 + TILE <= M && J0 + TILE <= jmax && I0 >= J0 + TILE;
   [[maybe_unused]] const bool pm = blockIdx.x == 2 && blockIdx.y == 0 && blockIdx.z == 0;
   RRPGO_PHASE_MARK(a, pm, 600);
   // ---- accumulators = current C tile
-  typename MM::Acc acc[4][4];
+  typename MM::Acc acc[NT][NT];
   if (wave_active) {
 #pragma unroll
-    for (int jb = 0; jb < 4; jb++)
+    for (int jb = 0; jb < NT; jb++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const T *ccol = F + (int64_t)min(j0 + 16 * jb + MM::row(lane, r), jmax - 1) * M;
 #pragma unroll
-        for (int ib = 0; ib < 4; ib++) acc[ib][jb][r] = ccol[min(i0 + 16 * ib + li, M - 1)];
+        for (int ib = 0; ib < NT; ib++) acc[ib][jb][r] = ccol[min(i0 + 16 * ib + li, M - 1)];
       }
   }
-  // ---- operand staging: thread t loads row (t & 127) of every second k of the chunk
-  const int sr = tid & 127, sk = tid >> 7;
+  // ---- operand staging: thread t loads row (t % TILE) of every KSTEP-th k of the chunk
+  const int sr = tid % TILE, sk = tid / TILE;
   const T *pa = F + (int64_t)(ka + sk) * M + min(I0 + sr, M - 1);
   const T *pb = F + (int64_t)(ka + sk) * M + min(J0 + sr, M - 1);
-  const int64_t M2 = 2 * (int64_t)M;
+  const int64_t M2 = KSTEP * (int64_t)M;
   const int nk = ke - ka;
   T ra[NLD], rb[NLD];
   auto fetch = [&](int c) {   // columns past ke are re-read from a valid column and zeroed by a select
     const T *qa = pa + (int64_t)c * KC * M, *qb = pb + (int64_t)c * KC * M;
 #pragma unroll
     for (int q = 0; q < NLD; q++) {
-      const bool kok = c * KC + sk + 2 * q < nk;
+      const bool kok = c * KC + sk + KSTEP * q < nk;
       const int64_t off = kok ? q * M2 : 0;
       const T va = qa[off], vb = qb[off];
       ra[q] = kok ? va : (T)0;
@@ -1780,8 +1786,8 @@ template <typename T> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? R
   auto stash = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < NLD; q++) {
-      As[buf][sk + 2 * q][sr] = ra[q];
-      Bs[buf][sk + 2 * q][sr] = rb[q];
+      As[buf][sk + KSTEP * q][sr] = ra[q];
+      Bs[buf][sk + KSTEP * q][sr] = rb[q];
     }
   };
   const int nchunks = (nk + KC - 1) / KC;
@@ -1795,16 +1801,16 @@ template <typename T> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? R
     if (wave_active) {
 #pragma unroll
       for (int s4 = 0; s4 < KC / 4; s4++) {
-        T av[4], bv[4];
+        T av[NT], bv[NT];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < NT; q++) {
           bv[q] = As[buf][4 * s4 + lk][wi + 16 * q + li];
           av[q] = Bs[buf][4 * s4 + lk][wj + 16 * q + li];
         }
 #pragma unroll
-        for (int ib = 0; ib < 4; ib++)
+        for (int ib = 0; ib < NT; ib++)
 #pragma unroll
-          for (int jb = 0; jb < 4; jb++) acc[ib][jb] = MM::mma(av[jb], bv[ib], acc[ib][jb]);
+          for (int jb = 0; jb < NT; jb++) acc[ib][jb] = MM::mma(av[jb], bv[ib], acc[ib][jb]);
       }
     }
     if (c + 1 < nchunks) stash(buf ^ 1);
@@ -1818,18 +1824,18 @@ template <typename T> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? R
   const bool next_diag = diag_tail && (mode == 1 || mode == 2) && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && t0 < m.nc;
   if (interior) {
 #pragma unroll
-    for (int jb = 0; jb < 4; jb++)
+    for (int jb = 0; jb < NT; jb++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         T *ccol = F + (int64_t)(j0 + 16 * jb + MM::row(lane, r)) * M + i0 + li;
 #pragma unroll
-        for (int ib = 0; ib < 4; ib++) ccol[16 * ib] = acc[ib][jb][r];
+        for (int ib = 0; ib < NT; ib++) ccol[16 * ib] = acc[ib][jb][r];
       }
   } else {
 #pragma unroll
-    for (int ib = 0; ib < 4; ib++)
+    for (int ib = 0; ib < NT; ib++)
 #pragma unroll
-      for (int jb = 0; jb < 4; jb++)
+      for (int jb = 0; jb < NT; jb++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int i = i0 + 16 * ib + li, j = j0 + 16 * jb + MM::row(lane, r);

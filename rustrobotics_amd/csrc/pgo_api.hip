@@ -192,6 +192,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<T> xch_own_;               // exchange buffer (boundary update matrices) unless the caller binds one
   T *xch_ = nullptr, *x_ptr_ = nullptr;
   bool left_looking_ = true;        // RR_PGO_RIGHT_LOOKING=1: the older diag / trsm / K=32 update launches
+  int small_tile_below_ = 1 << 30;  // trailing updates of fewer 128 x 128 tiles than this use 64 x 64 tiles: measured best on EVERY
+                                    // launch (finer scheduling granularity beats the operand reuse of the large tile);
+                                    // RR_PGO_SMALL_TILE=0 brings the 128 x 128 tiles back
   int solve_threads_max_ = 512;     // RR_PGO_SOLVE_THREADS=<n>: cap of the back-substitution workgroup size
   int factor_threads_max_ = 1024;   // 16-wave workgroups for steps whose fronts exceed 128 rows (RR_PGO_FACTOR_512=1: 8 waves)
   bool panel128_ = false;           // RR_PGO_PANEL128=1: two launches per 128-column super-panel (diagonal block in LDS by one
@@ -340,6 +343,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     panel128_ = getenv("RR_PGO_PANEL128") != nullptr;
     factor_threads_max_ = getenv("RR_PGO_FACTOR_512") ? 512 : 1024;
     if (const char *e = getenv("RR_PGO_SOLVE_THREADS")) solve_threads_max_ = std::atoi(e);
+    if (const char *e = getenv("RR_PGO_SMALL_TILE")) small_tile_below_ = std::atoi(e);
     n_lin_blocks_ = (int)(((int64_t)N * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
     n_upd_blocks_ = (N + UPD_THREADS - 1) / UPD_THREADS;
     chi_partial_.alloc((size_t)n_lin_blocks_);
@@ -703,7 +707,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         n += 2;
         if (kb + BIG_NB < std::min(K0 + BIG_SUPER, max_nc)) {
           const int nti = (std::max(rb, 1) + 127) / 128;
-          if (do_launch) { pbegin(); hipLaunchKernelGGL(k_big_update<T>, dim3(nti, 1, nf), dim3(256), 0, stream_, a, kb, 0, 0); check_launch("k_big_update/0"); pend(RR_PGO_K_BIG_UPDATE); }
+          if (do_launch) { pbegin(); hipLaunchKernelGGL((k_big_update<T, 4>), dim3(nti, 1, nf), dim3(256), 0, stream_, a, kb, 0, 0); check_launch("k_big_update/0"); pend(RR_PGO_K_BIG_UPDATE); }
           n++;
         }
       }
@@ -715,7 +719,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         if (do_launch) {
           if (rest_pending_) { HIPCHK(hipStreamWaitEvent(stream_, ev_rest_, 0)); rest_pending_ = false; }
           pbegin();
-          hipLaunchKernelGGL(k_big_update<T>, dim3(nti, nti, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail);
+          if ((int64_t)nf * nti * (nti + 1) / 2 < small_tile_below_) {
+            const int nt64 = (std::max(rt, 1) + 63) / 64;
+            hipLaunchKernelGGL((k_big_update<T, 2>), dim3(nt64, nt64, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail);
+          } else {
+            hipLaunchKernelGGL((k_big_update<T, 4>), dim3(nti, nti, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail);
+          }
           check_launch("k_big_update/1");
           pend(RR_PGO_K_BIG_UPDATE);
         }
@@ -729,11 +738,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           HIPCHK(hipEventRecord(ev_chain_, stream_));
           HIPCHK(hipStreamWaitEvent(stream2_, ev_chain_, 0));
           if (rest_pending_) HIPCHK(hipStreamWaitEvent(stream_, ev_rest_, 0));
-          hipLaunchKernelGGL(k_big_update<T>, dim3(nti - 1, nti - 1, nf), dim3(256), 0, stream2_, a, K0, 3, 0);
+          hipLaunchKernelGGL((k_big_update<T, 4>), dim3(nti - 1, nti - 1, nf), dim3(256), 0, stream2_, a, K0, 3, 0);
           check_launch("k_big_update/3");
           HIPCHK(hipEventRecord(ev_rest_, stream2_));
           rest_pending_ = true;
-          hipLaunchKernelGGL(k_big_update<T>, dim3(nti, 1, nf), dim3(256), 0, stream_, a, K0, 2, diag_tail);
+          hipLaunchKernelGGL((k_big_update<T, 4>), dim3(nti, 1, nf), dim3(256), 0, stream_, a, K0, 2, diag_tail);
           check_launch("k_big_update/2");
         }
         n += 2;
