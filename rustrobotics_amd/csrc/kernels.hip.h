@@ -780,6 +780,42 @@ __device__ __forceinline__ void diag16_factor_invert(T *P, int M, int k0, int nb
   }
 }
 
+// The same for a FULL block whose strict upper triangle in P is zero (fronts are zeroed before assembly
+// and every later store is to i >= j) and with a 16 x 16 identity at wscr + 16 * 17: lanes 0..15 stream
+// the rows of the block, lanes 16..31 the rows of the identity, through ONE per-lane (base, stride) pair
+// -- no select on the way in or out (an fp64 select is two v_cndmask; the general version spends ~380
+// instructions, 1.3 us of a lone wave, around the 1.9 us sweep).  W goes to LDS only; the caller copies
+// it to global memory for the back substitution with another wave (copy_w16).
+constexpr int W16_SCR = 16 * 17 + 256;   // LDS scalars: W scratch + identity
+template <typename T>
+__device__ __forceinline__ void diag16_factor_invert_full(T *P, int M, int k0, int *err, T *wscr) {
+  const int lane = threadIdx.x & 63, ll = lane & 31, q = lane & 15;
+  const bool rowlane = ll < 16;
+  const T *src = rowlane ? P + k0 * M + k0 + q : wscr + 16 * 17 + q;   // element (q, c) at src[c * sstride]
+  const int sstride = rowlane ? M : 16;
+  T x[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) x[c] = src[c * sstride];
+  const bool bad = chol16_invert<T>(x, ll);
+  if (bad && lane == 0) atomicOr(err, DEVERR_NOT_SPD);
+  T *dst = rowlane ? P + k0 * M + k0 + q : wscr + q * 17;              // L(q, c) in place | W(c, q)
+  const int dstride = rowlane ? M : 1;
+#pragma unroll
+  for (int c = 0; c < 16; c++) dst[c * dstride] = x[c];
+}
+// wscr (W(c, q) at [q * 17 + c]) -> wout[c * 16 + q], one wave
+template <typename T> __device__ __forceinline__ void copy_w16(const T *wscr, T *wout) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int e = lane + 64 * u;
+    wout[e] = wscr[(e & 15) * 17 + (e >> 4)];
+  }
+}
+template <typename T> __device__ __forceinline__ void init_w16_identity(T *wscr, int tid, int nthreads) {
+  for (int t = tid; t < 256; t += nthreads) wscr[16 * 17 + t] = (t >> 4) == (t & 15) ? (T)1 : (T)0;
+}
+
 // Workgroup-wide partial Cholesky of the leading nc columns of the M x nc panel P (column-major,
 // ld M; rows nc.. are the off-diagonal rows and the rhs row), blocked by 16 columns:
 //   diagonal block   registers of wave 0 (row per lane, v_readlane broadcasts, rsqrt + Newton), which
@@ -789,8 +825,10 @@ __device__ __forceinline__ void diag16_factor_invert(T *P, int M, int k0, int nb
 // with a one-block LOOK-AHEAD: after the triangular solve of block k only the next block column is
 // updated by everybody; the rest of block k's update runs on waves 1.. while wave 0 already factors
 // diagonal block k+1 (the two touch disjoint columns).
-template <typename T, int THREADS>
-__device__ __forceinline__ void panel_factor(T *P, int M, int nc, int *err, T *wscr /* 16 * 17 scalars of LDS */, T *wout,
+// FAST: the strict upper triangles of P's diagonal blocks are zero and wscr has W16_SCR scalars with the
+// identity set (init_w16_identity) -- full blocks then take diag16_factor_invert_full.
+template <typename T, int THREADS, bool FAST = false>
+__device__ __forceinline__ void panel_factor(T *P, int M, int nc, int *err, T *wscr /* 16 * 17 (FAST: W16_SCR) scalars of LDS */, T *wout,
                              unsigned long long *acc = nullptr) {
   using MM = Mfma16<T>;
   constexpr int NB = 16;
@@ -817,11 +855,14 @@ __device__ __forceinline__ void panel_factor(T *P, int M, int nc, int *err, T *w
   for (int k0 = 0; k0 < nc; k0 += NB) {
     const int nb = min(NB, nc - k0);
     RRPGO_ACC_BEGIN();
+    const bool fast = FAST && nb == NB;
     if (NW == 1) {
       if (pend_k0 >= 0) rest_update(pend_k0, 0, 1);
-      diag16_factor_invert<T>(P, M, k0, nb, err, wscr, wout);
+      if (fast) diag16_factor_invert_full<T>(P, M, k0, err, wscr);
+      else diag16_factor_invert<T>(P, M, k0, nb, err, wscr, wout);
     } else if (wave == 0) {
-      diag16_factor_invert<T>(P, M, k0, nb, err, wscr, wout);
+      if (fast) diag16_factor_invert_full<T>(P, M, k0, err, wscr);
+      else diag16_factor_invert<T>(P, M, k0, nb, err, wscr, wout);
     } else if (pend_k0 >= 0) {
       rest_update(pend_k0, 1, NW - 1);
     }
@@ -836,6 +877,7 @@ __device__ __forceinline__ void panel_factor(T *P, int M, int nc, int *err, T *w
       T wa[4];
 #pragma unroll
       for (int s4 = 0; s4 < 4; s4++) wa[s4] = wscr[(4 * s4 + lk) * 17 + li];
+      if (fast && wout && wave == NW - 1) copy_w16<T>(wscr, wout + (k0 >> 4) * 256);   // kept for the back substitution
       for (int ib = wave; ib < ntiles; ib += NW) {
         const int i = r0 + 16 * ib + li;
         const T *arow = P + min(i, M - 1);
@@ -943,9 +985,9 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
   // ---- partial factorisation + Schur complement
 #ifdef RRPGO_STAMPS
   if (tid == 0 && a.stamps) { a.stamps[(int64_t)s * 12 + 7] = 0; a.stamps[(int64_t)s * 12 + 8] = 0; a.stamps[(int64_t)s * 12 + 9] = 0; }
-  panel_factor<T, THREADS>(P, M, nc, a.err, dinv, a.winv + (int64_t)m.wblk * 256, a.stamps ? a.stamps + (int64_t)s * 12 : nullptr);
+  panel_factor<T, THREADS, !IN_PLACE>(P, M, nc, a.err, dinv, a.winv + (int64_t)m.wblk * 256, a.stamps ? a.stamps + (int64_t)s * 12 : nullptr);
 #else
-  panel_factor<T, THREADS>(P, M, nc, a.err, dinv, a.winv + (int64_t)m.wblk * 256);
+  panel_factor<T, THREADS, !IN_PLACE>(P, M, nc, a.err, dinv, a.winv + (int64_t)m.wblk * 256);
 #endif
   RRPGO_STAMP(a, s, 4);
   {
@@ -989,8 +1031,9 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
 template <typename T, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_factor_tasks(FactorArgs<T> a) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  __shared__ T dinv[16 * 17];   // inverse of the current 16 x 16 diagonal block
+  __shared__ T dinv[W16_SCR];   // inverse of the current 16 x 16 diagonal block + an identity (diag16_factor_invert_full)
   T *smem = reinterpret_cast<T *>(smem_raw);
+  init_w16_identity<T>(dinv, threadIdx.x, THREADS);   // process_front has barriers before the first use
   const int task = a.task_begin + blockIdx.x;
   for (int si = a.task_ptr[task]; si < a.task_ptr[task + 1]; si++) {
     const int s = a.task_sn[si];
@@ -1003,7 +1046,8 @@ __global__ void __launch_bounds__(THREADS) k_factor_tasks(FactorArgs<T> a) {
 // place in HBM (L storage holds the whole M x M front), one workgroup per front, batched per level.
 template <typename T, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_factor_mid(FactorArgs<T> a) {
-  __shared__ T dinv[16 * 17];
+  __shared__ T dinv[W16_SCR];
+  init_w16_identity<T>(dinv, threadIdx.x, THREADS);
   const int task = a.task_begin + blockIdx.x;
   const int s = a.task_sn[a.task_ptr[task]];
   const SnMeta m = a.sn_meta[s];

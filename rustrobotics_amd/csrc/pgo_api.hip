@@ -456,7 +456,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   hipStream_t stream() override { return stream_; }
 
  private:
-  static constexpr int kMaxLds = 160 * 1024 - 4096;  // the kernels also hold static __shared__ scratch (inverse diagonal block)
+  static constexpr int kMaxLds = 160 * 1024 - 4608;  // the kernels also hold static __shared__ scratch (inverse diagonal block + identity: W16_SCR scalars)
 
   template <int TH> void set_lds_attr() {
     HIPCHK(hipFuncSetAttribute((const void *)k_factor_tasks<T, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
