@@ -803,6 +803,35 @@ __device__ __forceinline__ void diag16_factor_invert_full(T *P, int M, int k0, i
 #pragma unroll
   for (int c = 0; c < 16; c++) dst[c * dstride] = x[c];
 }
+// The same for a PARTIAL last block (nb < 16 columns), padded with an identity: rows q >= nb stream identity
+// rows too, columns c >= nb of the block's own rows are redirected to a zero entry of the identity on the
+// way in and to a dump slot (padding column of wscr) on the way out -- a select on a 32-bit LDS address per
+// column instead of nested fp64 selects.
+template <typename T>
+__device__ __forceinline__ void diag16_factor_invert_part(T *P, int M, int k0, int nb, int *err, T *wscr) {
+  const int lane = threadIdx.x & 63, ll = lane & 31, q = lane & 15;
+  const bool rowlane = ll < 16;
+  const bool prow = rowlane && q < nb;   // lanes that hold a row of the block
+  T *ident = wscr + 16 * 17;
+  const T *src = prow ? P + k0 * M + k0 + q : ident + q;
+  const int sstride = prow ? M : 16;
+  T x[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    const T *pc = (prow && c >= nb) ? ident + 1 : src + c * sstride;
+    x[c] = *pc;
+  }
+  const bool bad = chol16_invert<T>(x, ll);
+  if (bad && lane == 0) atomicOr(err, DEVERR_NOT_SPD);
+  T *dump = wscr + 16;
+  T *dst = prow ? P + k0 * M + k0 + q : rowlane ? dump : wscr + q * 17;
+  const int dstride = prow ? M : rowlane ? 0 : 1;
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    T *pc = (prow && c >= nb) ? dump : dst + c * dstride;
+    *pc = x[c];
+  }
+}
 // wscr (W(c, q) at [q * 17 + c]) -> wout[c * 16 + q], one wave
 template <typename T> __device__ __forceinline__ void copy_w16(const T *wscr, T *wout) {
   const int lane = threadIdx.x & 63;
@@ -855,14 +884,17 @@ __device__ __forceinline__ void panel_factor(T *P, int M, int nc, int *err, T *w
   for (int k0 = 0; k0 < nc; k0 += NB) {
     const int nb = min(NB, nc - k0);
     RRPGO_ACC_BEGIN();
-    const bool fast = FAST && nb == NB;
+    constexpr bool fast = FAST;
+    auto diag = [&] {
+      if (!FAST) diag16_factor_invert<T>(P, M, k0, nb, err, wscr, wout);
+      else if (nb == NB) diag16_factor_invert_full<T>(P, M, k0, err, wscr);
+      else diag16_factor_invert_part<T>(P, M, k0, nb, err, wscr);
+    };
     if (NW == 1) {
       if (pend_k0 >= 0) rest_update(pend_k0, 0, 1);
-      if (fast) diag16_factor_invert_full<T>(P, M, k0, err, wscr);
-      else diag16_factor_invert<T>(P, M, k0, nb, err, wscr, wout);
+      diag();
     } else if (wave == 0) {
-      if (fast) diag16_factor_invert_full<T>(P, M, k0, err, wscr);
-      else diag16_factor_invert<T>(P, M, k0, nb, err, wscr, wout);
+      diag();
     } else if (pend_k0 >= 0) {
       rest_update(pend_k0, 1, NW - 1);
     }
@@ -918,6 +950,10 @@ __device__ __forceinline__ void panel_factor(T *P, int M, int nc, int *err, T *w
 // held in LDS (P and U contiguous: U = P + M*nc) both are copied to global
 // memory at the end; a front that lives in global memory (IN_PLACE) is already
 // where it has to be.
+// Workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains the vector
+// memory counter, i.e. it would wait for global loads that were requested early on purpose.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <typename T, int THREADS, bool IN_PLACE>
 __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *P, T *U, int uld, T *dinv) {
   const int tid = threadIdx.x;
@@ -925,19 +961,39 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
   const int M = nc + nr + 1, nu = nr + 1;
   const int psize = M * nc, usize = nu * (nu + 1) / 2;
   RRPGO_STAMP(a, s, 0);
+  // ---- original entries of H that live in this front's pivot columns and the rhs row: index, then
+  // value -- two dependent global round trips (~1.2 us).  The first APRE entries of every thread are
+  // requested BEFORE the zeroing pass and its barrier, which hides them.
+  constexpr int APRE = 2;
+  const int32_t *asrc = a.fasm_src + m.asm_begin, *adst = a.fasm_dst + m.asm_begin;
+  int pd[APRE];
+  T pv[APRE], pb = 0;
+#pragma unroll
+  for (int u = 0; u < APRE; u++) {
+    const int t = tid + u * THREADS;
+    pd[u] = -1;
+    pv[u] = 0;
+    if (t < m.asm_count) { pd[u] = adst[t]; pv[u] = a.hvals[asrc[t]]; }
+  }
+  if (tid < nc) pb = a.b[a.perm[m.col0 + tid]];
+  ChildMeta cnext{};
+  if (m.child_count > 0) cnext = a.child_meta[m.child_begin];
   if (IN_PLACE) {
     for (int64_t t = tid; t < (int64_t)M * M; t += THREADS) P[t] = 0;  // whole front, ld M
   } else {
     for (int t = tid; t < psize + usize; t += THREADS) P[t] = 0;
   }
-  __syncthreads();
+  if (IN_PLACE) __syncthreads();
+  else lds_barrier();
   RRPGO_STAMP(a, s, 1);
-  // ---- original entries of H that live in this front's pivot columns (plain stores: every
-  // destination is hit once), then the rhs row
+  // plain stores: every destination is hit once
   {
-    const int32_t *src = a.fasm_src + m.asm_begin, *dst = a.fasm_dst + m.asm_begin;
-    for (int t = tid; t < m.asm_count; t += THREADS) P[dst[t]] = a.hvals[src[t]];
-    for (int j = tid; j < nc; j += THREADS) P[j * M + (M - 1)] = a.b[a.perm[m.col0 + j]];
+#pragma unroll
+    for (int u = 0; u < APRE; u++)
+      if (pd[u] >= 0) P[pd[u]] = pv[u];
+    for (int t = tid + APRE * THREADS; t < m.asm_count; t += THREADS) P[adst[t]] = a.hvals[asrc[t]];
+    if (tid < nc) P[tid * M + (M - 1)] = pb;
+    for (int j = tid + THREADS; j < nc; j += THREADS) P[j * M + (M - 1)] = a.b[a.perm[m.col0 + j]];
   }
   if (m.dup_count > 0) {  // blocks of parallel edges (rare): serial, fixed order
     __syncthreads();
@@ -947,7 +1003,8 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
   RRPGO_STAMP(a, s, 2);
   // ---- extend-add of the children's update matrices, fixed child order
   for (int q = 0; q < m.child_count; q++) {
-    const ChildMeta c = a.child_meta[m.child_begin + q];
+    const ChildMeta c = cnext;
+    if (q + 1 < m.child_count) cnext = a.child_meta[m.child_begin + q + 1];   // the next record in flight under this child
     const T *Uc = (c.uld > 0 ? a.lvals : c.uld < 0 ? a.xch : a.uvals) + c.uoff;
     __syncthreads();
     if (!IN_PLACE && c.scat_ptr >= 0) {
