@@ -983,6 +983,24 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
   } else {
     for (int t = tid; t < psize + usize; t += THREADS) P[t] = 0;
   }
+  constexpr int EPRE = 4;
+  int ed[EPRE];
+  T ev[EPRE];
+  auto child_u = [&](const ChildMeta &c) { return (c.uld > 0 ? a.lvals : c.uld < 0 ? a.xch : a.uvals) + c.uoff; };
+  auto prefetch = [&](const ChildMeta &c) {
+#pragma unroll
+    for (int u = 0; u < EPRE; u++) { ed[u] = -1; ev[u] = 0; }
+    if (IN_PLACE || c.scat_ptr < 0) return;
+    const int32_t *map = a.scat + c.scat_ptr;
+    const T *Uc = child_u(c);
+    const int cnt = c.ncu * (c.ncu + 1) / 2;
+#pragma unroll
+    for (int u = 0; u < EPRE; u++) {
+      const int t = tid + u * THREADS;
+      if (t < cnt) { ed[u] = map[t]; ev[u] = Uc[t]; }
+    }
+  };
+  if (m.child_count > 0) prefetch(cnext);   // under the barrier and the assembly stores
   if (IN_PLACE) __syncthreads();
   else lds_barrier();
   RRPGO_STAMP(a, s, 1);
@@ -1001,17 +1019,23 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
       for (int t = 0; t < m.dup_count; t++) P[a.fdup_dst[m.dup_begin + t]] += a.hvals[a.fdup_src[m.dup_begin + t]];
   }
   RRPGO_STAMP(a, s, 2);
-  // ---- extend-add of the children's update matrices, fixed child order
+  // ---- extend-add of the children's update matrices, fixed child order.  A packed child into an LDS
+  // parent has one precomputed destination per element; the first EPRE elements per thread of child q+1
+  // are requested while child q is being added (each child is otherwise a global round trip + a barrier).
   for (int q = 0; q < m.child_count; q++) {
     const ChildMeta c = cnext;
     if (q + 1 < m.child_count) cnext = a.child_meta[m.child_begin + q + 1];   // the next record in flight under this child
-    const T *Uc = (c.uld > 0 ? a.lvals : c.uld < 0 ? a.xch : a.uvals) + c.uoff;
+    const T *Uc = child_u(c);
     __syncthreads();
     if (!IN_PLACE && c.scat_ptr >= 0) {
       // packed child, LDS parent: one precomputed destination per element, coalesced
       const int32_t *map = a.scat + c.scat_ptr;
       const int cnt = c.ncu * (c.ncu + 1) / 2;
-      int t = tid;
+#pragma unroll
+      for (int u = 0; u < EPRE; u++)
+        if (ed[u] >= 0) P[ed[u]] += ev[u];
+      if (q + 1 < m.child_count) prefetch(cnext);
+      int t = tid + EPRE * THREADS;
       for (; t + 3 * THREADS < cnt; t += 4 * THREADS) {
         const int d0 = map[t], d1 = map[t + THREADS], d2 = map[t + 2 * THREADS], d3 = map[t + 3 * THREADS];
         const T v0 = Uc[t], v1 = Uc[t + THREADS], v2 = Uc[t + 2 * THREADS], v3 = Uc[t + 3 * THREADS];
@@ -1025,6 +1049,7 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
         if (d0 >= 0) P[d0] += Uc[t];
       }
     } else {
+      if (q + 1 < m.child_count) prefetch(cnext);
       const int32_t *rel = a.rel + c.rel_ptr;
       const int ncu = c.ncu;
       for (int t = tid; t < ncu * ncu; t += THREADS) {
