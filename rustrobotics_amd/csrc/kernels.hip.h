@@ -641,40 +641,58 @@ __device__ __forceinline__ void tile_rank_update(const T *X, int ldx, int i0, in
   const int li = lane & 15, lk = lane >> 4;
   const int i = i0 + li;
   // loads go to clamped addresses (a predicated load is a branch): rows past the tile's range only
-  // feed entries that are never stored, columns past kb are zeroed on one operand
+  // feed entries that are never stored, columns past kb are zeroed on one operand.
+  // The accumulator holds -C (one negation on the way in and out instead of one per operand).
   const int ic = min(i, imax - 1);
   typename MM::Acc acc;
   bool valid[4];
+  T *pc[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int j = j0 + MM::row(lane, r);
     valid[r] = i < imax && j < jmax && i >= j;
-    acc[r] = *caddr(ic, min(min(j, jmax - 1), ic));
+    pc[r] = caddr(ic, min(min(j, jmax - 1), ic));   // the true address wherever valid
+    acc[r] = -*pc[r];
   }
-  const T *xi = X + ic, *xj = X + min(j0 + li, jmax - 1);
+  // whole 16-column chunks need no clamp: one pointer per operand, bumped by 4 columns per load
+  const int nfull = (kb - ka) >> 4;
+  const int step = 4 * ldx;
+  const T *xi = X + ic + (ka + lk) * ldx, *xj = X + min(j0 + li, jmax - 1) + (ka + lk) * ldx;
   T av[4], bv[4], an[4], bn[4];
-  auto fetch = [&](int k, T *xa, T *xb) {
+  auto fetch = [&](T *xa, T *xb) {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const int kk = k + 4 * q + lk;
-      const int kc = min(kk, kb - 1) * ldx;
-      const T vb = pin(xi[kc]), va = pin(xj[kc]);
-      xb[q] = vb;
-      xa[q] = kk < kb ? -va : (T)0;
+      xb[q] = xi[q * step];
+      xa[q] = xj[q * step];
     }
+    xi += 4 * step;
+    xj += 4 * step;
   };
-  fetch(ka, av, bv);
-  for (int k = ka; k < kb; k += 16) {   // operands of the next four k-steps are in flight under these MFMAs
-    if (k + 16 < kb) fetch(k + 16, an, bn);
+  if (nfull > 0) fetch(av, bv);
+  for (int c = 0; c < nfull; c++) {   // operands of the next four k-steps are in flight under these MFMAs
+    if (c + 1 < nfull) fetch(an, bn);
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-      if (k + 4 * q < kb) acc = MM::mma(av[q], bv[q], acc);
+    for (int q = 0; q < 4; q++) acc = MM::mma(av[q], bv[q], acc);
 #pragma unroll
     for (int q = 0; q < 4; q++) { av[q] = an[q]; bv[q] = bn[q]; }
   }
+  const int rem = (kb - ka) & 15;
+  if (rem > 0) {   // the last 1..15 columns: clamped column index, zero on one operand
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int kk = 4 * q + lk;
+      const int off = (min(kk, rem - 1) - lk) * ldx;
+      const T vb = pin(xi[off]), va = pin(xj[off]);
+      bv[q] = vb;
+      av[q] = kk < rem ? va : (T)0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (4 * q < rem) acc = MM::mma(av[q], bv[q], acc);
+  }
 #pragma unroll
   for (int r = 0; r < 4; r++)
-    if (valid[r]) *caddr(i, j0 + MM::row(lane, r)) = acc[r];
+    if (valid[r]) *pc[r] = -acc[r];
 }
 
 // Keeps an unconditional load unconditional: without it the compiler sinks a load whose value is only
