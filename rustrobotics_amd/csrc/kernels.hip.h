@@ -874,9 +874,14 @@ template <typename T> __device__ __forceinline__ void init_w16_identity(T *wscr,
 // diagonal block k+1 (the two touch disjoint columns).
 // FAST: the strict upper triangles of P's diagonal blocks are zero and wscr has W16_SCR scalars with the
 // identity set (init_w16_identity) -- full blocks then take diag16_factor_invert_full.
-template <typename T, int THREADS, bool FAST = false>
+// nu > 0: the front's (nu x nu) update matrix lives at uaddr(i, j) (rows nc.. of the panel are its operand):
+// the Schur complement of every block but the last is then applied here, block by block, by the waves that
+// idle while wave 0 factors the next diagonal block; the caller applies the last block (columns
+// 16 * ((nc - 1) / 16) .. nc) after the panel.
+struct NoUAddr { __device__ float *operator()(int, int) const { return nullptr; } };
+template <typename T, int THREADS, bool FAST = false, typename UAddr = NoUAddr>
 __device__ __forceinline__ void panel_factor(T *P, int M, int nc, int *err, T *wscr /* 16 * 17 (FAST: W16_SCR) scalars of LDS */, T *wout,
-                             unsigned long long *acc = nullptr) {
+                             unsigned long long *acc = nullptr, int nu = 0, UAddr uaddr = UAddr()) {
   using MM = Mfma16<T>;
   constexpr int NB = 16;
   constexpr int NW = THREADS / 64;
@@ -891,12 +896,23 @@ __device__ __forceinline__ void panel_factor(T *P, int M, int nc, int *err, T *w
     // tiles (ib >= jb, jb >= 1) dealt round-robin over the waves (balanced: no wave draws the skipped ones)
     int total = 0;
     for (int jb = 1; jb < nj; jb++) total += max(ni - jb, 0);
-    for (int t = wave - first_wave; t < total; t += nwaves) {
-      int jb = 1, rem = t;
-      while (rem >= ni - jb) { rem -= ni - jb; jb++; }
-      const int ib = jb + rem;
-      tile_rank_update<T>(P, M, js + 16 * ib, js + 16 * jb, M, nc, pk0, pk0 + NB,
-                          [&](int i, int j) { return P + j * M + i; });
+    const int nt = (nu + 15) >> 4;   // tiles of the update matrix (lower triangle), after the panel's own
+    const int utotal = nt * (nt + 1) / 2;
+    for (int t = wave - first_wave; t < total + utotal; t += nwaves) {
+      if (t < total) {
+        int jb = 1, rem = t;
+        while (rem >= ni - jb) { rem -= ni - jb; jb++; }
+        const int ib = jb + rem;
+        tile_rank_update<T>(P, M, js + 16 * ib, js + 16 * jb, M, nc, pk0, pk0 + NB,
+                            [&](int i, int j) { return P + j * M + i; });
+      } else {
+        if constexpr (!std::is_same<UAddr, NoUAddr>::value) {
+          int jb = 0, rem = t - total;
+          while (rem >= nt - jb) { rem -= nt - jb; jb++; }
+          const int ib = jb + rem;
+          tile_rank_update<T>(P + nc, M, 16 * ib, 16 * jb, nu, nu, pk0, pk0 + NB, uaddr);
+        }
+      }
     }
   };
   for (int k0 = 0; k0 < nc; k0 += NB) {
@@ -957,7 +973,7 @@ __device__ __forceinline__ void panel_factor(T *P, int M, int nc, int *err, T *w
                             [&](int i, int j) { return P + j * M + i; });
       __syncthreads();
       RRPGO_ACC_END(acc, 9);
-      if (js + NB < nc) pend_k0 = k0;   // more block columns to the right: owed, done under the next diagonal block
+      if (js + NB < nc || nu > 0) pend_k0 = k0;   // more block columns to the right (or the update matrix): owed, done under the next diagonal block
     }
   }
 }
@@ -1083,15 +1099,20 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
   __syncthreads();
   RRPGO_STAMP(a, s, 3);
   // ---- partial factorisation + Schur complement
+  auto uaddr = [&](int i, int j) {   // 32-bit index arithmetic for the packed triangle in LDS
+    return IN_PLACE ? U + ((int64_t)j * uld + i) : U + (j * nu - ((j * (j - 1)) >> 1) + (i - j));
+  };
 #ifdef RRPGO_STAMPS
   if (tid == 0 && a.stamps) { a.stamps[(int64_t)s * 12 + 7] = 0; a.stamps[(int64_t)s * 12 + 8] = 0; a.stamps[(int64_t)s * 12 + 9] = 0; }
-  panel_factor<T, THREADS, !IN_PLACE>(P, M, nc, a.err, dinv, a.winv + (int64_t)m.wblk * 256, a.stamps ? a.stamps + (int64_t)s * 12 : nullptr);
+  panel_factor<T, THREADS, !IN_PLACE>(P, M, nc, a.err, dinv, a.winv + (int64_t)m.wblk * 256, a.stamps ? a.stamps + (int64_t)s * 12 : nullptr, nu, uaddr);
 #else
-  panel_factor<T, THREADS, !IN_PLACE>(P, M, nc, a.err, dinv, a.winv + (int64_t)m.wblk * 256);
+  panel_factor<T, THREADS, !IN_PLACE>(P, M, nc, a.err, dinv, a.winv + (int64_t)m.wblk * 256, nullptr, nu, uaddr);
 #endif
   RRPGO_STAMP(a, s, 4);
   {
-    // U(i,j) -= sum_k L21[i][k] L21[j][k]  (i >= j), 16 x 16 tiles on the matrix cores
+    // U(i,j) -= sum_k L21[i][k] L21[j][k]  (i >= j), 16 x 16 tiles on the matrix cores: the columns of the
+    // LAST 16-column block only, the earlier blocks went in under the diagonal chain (panel_factor)
+    const int klast = ((nc - 1) >> 4) << 4;
     const int nt = (nu + 15) >> 4;
     const int wave = tid >> 6;
     // the tiles of the lower triangle dealt round-robin: t-th tile of the column-major enumeration
@@ -1099,10 +1120,7 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
       int jb = 0, rem = t;
       while (rem >= nt - jb) { rem -= nt - jb; jb++; }
       const int ib = jb + rem;
-      tile_rank_update<T>(P + nc, M, 16 * ib, 16 * jb, nu, nu, 0, nc,
-                          [&](int i, int j) {   // 32-bit index arithmetic for the packed triangle in LDS
-                            return IN_PLACE ? U + ((int64_t)j * uld + i) : U + (j * nu - ((j * (j - 1)) >> 1) + (i - j));
-                          });
+      tile_rank_update<T>(P + nc, M, 16 * ib, 16 * jb, nu, nu, klast, nc, uaddr);
     }
   }
   __syncthreads();
