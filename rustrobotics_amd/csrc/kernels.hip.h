@@ -2118,49 +2118,66 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
     RRPGO_STAMP_SOLVE(a, s, 2);
     // L11^T x = t, backward, by 16-column blocks with the inverse diagonal blocks W_b = L_bb^-1:
     //   x_b = W_b^T ( t_b - sum_{b' > b} L(b', b)^T x_b' ).
-    // The first wave runs the chain: it applies the block to its right on the fly (registers), then
-    // the 16 x 16 product with W_b^T, both as v_readlane broadcasts + FMAs.  The other waves fold the
-    // finished block into everything two or more blocks to its left, one barrier behind; so there is
-    // one barrier per 16 columns and nobody writes an entry somebody else is reading.
+    // The first wave runs the chain on the matrix cores with every vector in BROADCAST FORM: register s of
+    // lane (lk, li) holds entry MM::row(lane, s) of the vector, the same in all 16 columns li.  That is at
+    // once the accumulator layout of a 16 x 16 result with equal columns and the b-operand layout of the next
+    // product (k-slot = MM::row), so  u = t_b - L(b+1, b)^T x_(b+1)  and  x_b = W_b^T u  are eight dependent
+    // MFMAs with no lane broadcast in between (the v_readlane version spent ~100 instructions per block).
+    // The other waves fold the finished block into everything two or more blocks to its left, one barrier
+    // behind; so there is one barrier per 16 columns and nobody writes an entry somebody else is reading.
     {
+      using MM = Mfma16<T>;
       constexpr int NW = THREADS / 64;
       const int wave = tid >> 6, lane = tid & 63, l16 = lane & 15;
       const int nblk = (nc + 15) >> 4;
+      int kr[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) kr[r] = MM::row(lane, r);
+      // a-operand of x = W^T u: A[m = l16][k-slot r] = W(kr[r], l16) = winv[kr[r] * 16 + l16]; three blocks in flight
       const T *Wg = a.winv + (int64_t)m.wblk * 256 + l16;
-      T w0[16], w1[16], w2[16];   // W(j, l16) of the current block and of the next two (global loads, prefetched)
+      T w0[4], w1[4], w2[4];
       if (wave == 0) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-          w0[j] = Wg[(nblk - 1) * 256 + j * 16];
-          w1[j] = Wg[max(nblk - 2, 0) * 256 + j * 16];
-          w2[j] = Wg[max(nblk - 3, 0) * 256 + j * 16];
+        for (int r = 0; r < 4; r++) {
+          w0[r] = Wg[(nblk - 1) * 256 + kr[r] * 16];
+          w1[r] = Wg[max(nblk - 2, 0) * 256 + kr[r] * 16];
+          w2[r] = Wg[max(nblk - 3, 0) * 256 + kr[r] * 16];
         }
       }
-      T xprev = 0;
+      typename MM::Acc xprev = {0, 0, 0, 0};
       for (int b = nblk - 1; b >= 0; b--) {
         const int c0 = 16 * b, cw = min(16, nc - c0);
         if (wave == 0) {
-          T v = pin(t1[c0 + min(l16, cw - 1)]);
-          v = l16 < cw ? v : (T)0;
+          typename MM::Acc v;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const T tv = pin(t1[c0 + min(kr[r], cw - 1)]);
+            v[r] = kr[r] < cw ? tv : (T)0;
+          }
           if (b + 1 < nblk) {
             const int cn = c0 + 16, cwn = min(16, nc - cn);
-            T lt[16];
+            T lt[4];
 #pragma unroll
-            for (int j = 0; j < 16; j++) lt[j] = Lt[(cn + min(j, cwn - 1)) * ldt + c0 + l16];   // L(cn + j, c0 + l16)
+            for (int r = 0; r < 4; r++) lt[r] = Lt[(cn + min(kr[r], cwn - 1)) * ldt + c0 + l16];   // L(cn + k, c0 + m), m = l16
 #pragma unroll
-            for (int j = 0; j < 16; j++) v -= lt[j] * lane_bcast(xprev, j);   // xprev is zero past the block's width
+            for (int r = 0; r < 4; r++) v = MM::mma(-lt[r], xprev[r], v);   // xprev is zero past the block's width
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = kr[r] < cw ? v[r] : (T)0;   // rows m >= cw saw unstaged LDS
           }
-          T x = 0;
+          typename MM::Acc x = {0, 0, 0, 0};
 #pragma unroll
-          for (int j = 0; j < 16; j++) x += w0[j] * lane_bcast(v, j);
-          x = l16 < cw ? x : (T)0;
-          if (lane < cw) t1[c0 + lane] = x;
+          for (int r = 0; r < 4; r++) x = MM::mma(w0[r], v[r], x);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            x[r] = kr[r] < cw ? x[r] : (T)0;
+            if (l16 == 0 && kr[r] < cw) t1[c0 + kr[r]] = x[r];
+          }
           xprev = x;
 #pragma unroll
-          for (int j = 0; j < 16; j++) {
-            w0[j] = w1[j];
-            w1[j] = w2[j];
-            w2[j] = Wg[max(b - 3, 0) * 256 + j * 16];
+          for (int r = 0; r < 4; r++) {
+            w0[r] = w1[r];
+            w1[r] = w2[r];
+            w2[r] = Wg[max(b - 3, 0) * 256 + kr[r] * 16];
           }
         }
         __syncthreads();

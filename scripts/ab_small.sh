@@ -3,4 +3,3 @@ timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -2
 for w in intel input_M3500_g2o sphere2500; do
   for l in librr_pgo_base.so librr_pgo.so; do python scripts/ab_bench.py rustrobotics_amd/$l $w | tail -1; done
 done
-python scripts/gpu_stamps.py intel | grep -A1 "^step" | grep -v "^--"
