@@ -450,12 +450,15 @@ void postorder_forest(const std::vector<int32_t> &parent, std::vector<int32_t> &
   }
 }
 
-// Measured on MI355X with the in-kernel stamps (fp64, intel.g2o): ~3 us fixed per front (zero,
-// assemble, extend-add, store), ~0.45 us per pivot column (diagonal block + TRSM + look-ahead
-// update, all latency bound), Schur complement ~2e-5 us per (nr+1)^2 * nc.
-double front_cost_us(int nc, int nr) {
+// Least-squares fit to the in-kernel stamps on MI355X (fp64; 966 fronts of intel, M3500 and dlr,
+// scripts/fit_front_cost.py, rms residual 0.34 us on a mean of 11 us): a fixed part (zero, assemble,
+// store), the 16-column blocks of the pivot chain (diagonal block + triangular solve + look-ahead, all
+// latency bound), one global round trip per child in the extend-add, the last block's Schur complement
+// and the LDS image that is zeroed and copied out.
+double front_cost_us(int nc, int nr, int kids) {
   const double nu = nr + 1;
-  return 3.0 + 0.45 * (double)nc + 2e-5 * (double)nc * nu * nu;
+  const double elems = (double)(nc + nr + 1) * nc + 0.5 * nu * nu;
+  return 2.3 + 3.37 * (double)((nc + 15) / 16) + 0.65 * kids + 1.12e-5 * (double)nc * nu * nu + 3.6e-4 * elems;
 }
 
 int64_t lds_elems(int nc, int nr) {
@@ -982,9 +985,12 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     sym.task_ptr.clear();
     sym.task_sn.clear();
     sym.steps.clear();
-    std::vector<double> cost(S), sub(S, 0.0);
+    std::vector<double> cost(S), scost(S), sub(S, 0.0);
     for (int f = 0; f < S; f++) {
-      cost[f] = front_cost_us(sym.sn_ncols[f], sym.sn_nrows[f]);
+      cost[f] = front_cost_us(sym.sn_ncols[f], sym.sn_nrows[f], sym.child_ptr[f + 1] - sym.child_ptr[f]);
+      // back substitution of the same front (the solve launches reuse the task partition): staging +
+      // product with the rows below + one chain step per 16 columns
+      scost[f] = 1.6 + 1.3 * (double)((sym.sn_ncols[f] + 15) / 16);
       sub[f] += cost[f];
       if (sym.sn_parent[f] >= 0) sub[sym.sn_parent[f]] += sub[f];
     }
@@ -1051,18 +1057,20 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
         Step st{};
         st.kind = STEP_TASKS;
         st.task_begin = (int)sym.task_ptr.size() - 1;
-        double worst = 0.0;
+        double worst = 0.0, worst_solve = 0.0;
         for (size_t t = 0; t < tasks.size(); t++) {
           if (task_level[t] != L || tasks[t].empty() || !wanted(tasks[t][0])) continue;
-          double tc = 0.0;
+          double tc = 0.0, ts = 0.0;
           for (int f : tasks[t]) {
             sym.task_sn.push_back(f);
             tc += cost[f];
+            ts += scost[f];
             st.max_front = std::max(st.max_front, sym.sn_ncols[f] + sym.sn_nrows[f] + 1);
             st.max_lds_elems = std::max<int64_t>(st.max_lds_elems, lds_elems(sym.sn_ncols[f], sym.sn_nrows[f]));
           }
           sym.task_ptr.push_back((int)sym.task_sn.size());
           worst = std::max(worst, tc);
+          worst_solve = std::max(worst_solve, ts);
         }
         st.task_end = (int)sym.task_ptr.size() - 1;
         {
@@ -1071,7 +1079,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
         }
         if (st.task_end > st.task_begin) {
           sym.steps.push_back(st);
-          crit += 1.5 + worst;
+          crit += 1.5 + worst + 1.5 + worst_solve;
         }
         // fronts beyond LDS at this level: optional one-workgroup class, then the tiled batch
         for (int cls = 0; cls < 2; cls++) {
@@ -1103,9 +1111,10 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
   if (opt.task_us > 0) {
     build_schedule(opt.task_us);
   } else {
-    const double cands[] = {15, 30, 60, 90, 120, 150, 200};
-    double best = 1e300, best_t = 120;
-    for (double t : cands) {
+    // the score is a jagged function of the threshold (a subtree flips between "leaf task" and "top"):
+    // a dense geometric grid, each candidate costs one O(S) pass
+    double best = 1e300, best_t = 90;
+    for (double t = 10.0; t < 260.0; t *= 1.09) {
       const double c = build_schedule(t);
       if (c < best) { best = c; best_t = t; }
     }

@@ -1,5 +1,5 @@
 #!/bin/bash
 timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -2
-for w in intel input_M3500_g2o sphere2500; do
+for w in intel input_M3500_g2o dlr sphere2500 torus3D parking-garage; do
   for l in librr_pgo_base.so librr_pgo.so; do python scripts/ab_bench.py rustrobotics_amd/$l $w | tail -1; done
 done
