@@ -2041,15 +2041,13 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
   const T *Lg = a.lvals + m.loff;
   const int32_t *rows = a.sn_rows + m.rows_ptr;
   if (STAGE) {
-    const int ldt = nc | 1;
-    T *Lt = work;                 // Lt[i * ldt + j] = L11(j, i)  (row j of L11 is contiguous in j... see below)
-    T *x2 = work + nc * ldt;      // nr
+    T *x2 = work;                 // nr
     T *t1 = x2 + nr;              // nc
     __syncthreads();
     RRPGO_STAMP_SOLVE(a, s, 0);
     // The loads of the L21^T x2 product do not depend on x2: when the shape allows (nr <= 128, at most GV
     // columns per wave) a wave requests all of them before anything else, so that one memory round trip
-    // is hidden under the staging instead of one per group of four columns after it.
+    // is hidden under the gather of x2 instead of one per group of four columns after it.
     constexpr int GV = 12;
     const int gw = tid >> 6, gl = tid & 63;
     const int gcpw = (nc + THREADS / 64 - 1) / (THREADS / 64);   // columns per wave: j = gw + NW g
@@ -2066,13 +2064,6 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
         }
     }
     for (int i = tid; i < nr; i += THREADS) x2[i] = a.x[rows[i]];
-    // stage the strictly lower part of L11 transposed, L(r, c) -> Lt[r * ldt + c]: a wave per column,
-    // lanes along the rows (coalesced, no index division); the diagonal blocks are not needed, the
-    // factorisation left their inverses in winv
-    for (int c = tid >> 6; c < nc; c += THREADS / 64) {
-      const T *col = Lg + (int64_t)c * M;
-      for (int r = c + 1 + (tid & 63); r < nc; r += 64) Lt[r * ldt + c] = col[r];
-    }
     __syncthreads();
     RRPGO_STAMP_SOLVE(a, s, 1);
     // t1[j] = y1[j] - sum_i L21[i][j] x2[i]
@@ -2114,8 +2105,6 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
         }
       }
     }
-    __syncthreads();
-    RRPGO_STAMP_SOLVE(a, s, 2);
     // L11^T x = t, backward, by 16-column blocks with the inverse diagonal blocks W_b = L_bb^-1:
     //   x_b = W_b^T ( t_b - sum_{b' > b} L(b', b)^T x_b' ).
     // The first wave runs the chain on the matrix cores with every vector in BROADCAST FORM: register s of
@@ -2125,6 +2114,9 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
     // MFMAs with no lane broadcast in between (the v_readlane version spent ~100 instructions per block).
     // The other waves fold the finished block into everything two or more blocks to its left, one barrier
     // behind; so there is one barrier per 16 columns and nobody writes an entry somebody else is reading.
+    // L11 is read straight from global memory (no LDS image): the chain wave keeps the operand blocks of the
+    // next two steps in flight like W, a fold thread owns one column i and requests its 16 contiguous
+    // entries L(c0.., i) BEFORE the barrier that releases the block -- no address depends on x.
     {
       using MM = Mfma16<T>;
       constexpr int NW = THREADS / 64;
@@ -2136,6 +2128,15 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
       // a-operand of x = W^T u: A[m = l16][k-slot r] = W(kr[r], l16) = winv[kr[r] * 16 + l16]; three blocks in flight
       const T *Wg = a.winv + (int64_t)m.wblk * 256 + l16;
       T w0[4], w1[4], w2[4];
+      // a-operand of u = t_b - L(b+1, b)^T x_(b+1): -L(16 (b+1) + k, 16 b + m), m = l16; rows clamped into the front
+      T la0[4], la1[4];
+      auto lblock = [&](int b, T (&dst)[4]) {   // operand block of chain step b (uses block b + 1), b clamped
+        const int bc = max(min(b, nblk - 2), 0);
+        const T *col = Lg + (int64_t)(16 * bc + l16) * M + 16 * bc + 16;
+        const int cwn = nc - (16 * bc + 16);   // >= 1 when nblk >= 2
+#pragma unroll
+        for (int r = 0; r < 4; r++) dst[r] = col[max(min(kr[r], cwn - 1), 0)];
+      };
       if (wave == 0) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -2143,10 +2144,26 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
           w1[r] = Wg[max(nblk - 2, 0) * 256 + kr[r] * 16];
           w2[r] = Wg[max(nblk - 3, 0) * 256 + kr[r] * 16];
         }
+        if (nblk >= 2) {
+          lblock(nblk - 2, la0);
+          lblock(nblk - 3, la1);
+        }
       }
+      __syncthreads();
+      RRPGO_STAMP_SOLVE(a, s, 2);
       typename MM::Acc xprev = {0, 0, 0, 0};
+      const int fi = NW == 1 ? tid : tid - 64;            // the fold thread's column
+      constexpr int FSTRIDE = NW == 1 ? THREADS : THREADS - 64;
       for (int b = nblk - 1; b >= 0; b--) {
         const int c0 = 16 * b, cw = min(16, nc - c0);
+        const int lim = c0 - 16;
+        T fl[16];
+        const bool folder = (NW == 1 || wave > 0) && fi >= 0 && fi < lim;
+        if (NW > 1 && folder) {   // requested before the barrier
+          const T *lcol = Lg + (int64_t)fi * M + c0;
+#pragma unroll
+          for (int j = 0; j < 16; j++) fl[j] = lcol[min(j, cw - 1)];
+        }
         if (wave == 0) {
           typename MM::Acc v;
 #pragma unroll
@@ -2155,14 +2172,11 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
             v[r] = kr[r] < cw ? tv : (T)0;
           }
           if (b + 1 < nblk) {
-            const int cn = c0 + 16, cwn = min(16, nc - cn);
-            T lt[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) lt[r] = Lt[(cn + min(kr[r], cwn - 1)) * ldt + c0 + l16];   // L(cn + k, c0 + m), m = l16
+            for (int r = 0; r < 4; r++) v = MM::mma(-la0[r], xprev[r], v);   // xprev is zero past the block's width
 #pragma unroll
-            for (int r = 0; r < 4; r++) v = MM::mma(-lt[r], xprev[r], v);   // xprev is zero past the block's width
-#pragma unroll
-            for (int r = 0; r < 4; r++) v[r] = kr[r] < cw ? v[r] : (T)0;   // rows m >= cw saw unstaged LDS
+            for (int r = 0; r < 4; r++) la0[r] = la1[r];
+            lblock(b - 2, la1);
           }
           typename MM::Acc x = {0, 0, 0, 0};
 #pragma unroll
@@ -2182,15 +2196,24 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
         }
         __syncthreads();
         if (NW == 1 || wave > 0) {
-          const int lim = c0 - 16;
-          for (int i = NW == 1 ? tid : tid - 64; i < lim; i += NW == 1 ? THREADS : THREADS - 64) {
-            T tv = t1[i];
-            if (cw == 16) {
+          if (NW == 1 && folder) {
+            const T *lcol = Lg + (int64_t)fi * M + c0;
 #pragma unroll
-              for (int j = 0; j < 16; j++) tv -= Lt[(c0 + j) * ldt + i] * t1[c0 + j];
-            } else {
-              for (int j = 0; j < cw; j++) tv -= Lt[(c0 + j) * ldt + i] * t1[c0 + j];
+            for (int j = 0; j < 16; j++) fl[j] = lcol[min(j, cw - 1)];
+          }
+          if (folder) {
+            T tv = t1[fi];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+              const T xj = t1[c0 + min(j, cw - 1)];
+              tv -= fl[j] * (j < cw ? xj : (T)0);
             }
+            t1[fi] = tv;
+          }
+          for (int i = fi + FSTRIDE; i < lim; i += FSTRIDE) {   // fronts wider than the workgroup (not on the LDS path today)
+            const T *lcol = Lg + (int64_t)i * M + c0;
+            T tv = t1[i];
+            for (int j = 0; j < cw; j++) tv -= lcol[j] * t1[c0 + j];
             t1[i] = tv;
           }
         }

@@ -440,7 +440,7 @@ def test_mixed_precision_reaches_the_f64_answer(api, oracle):
     """RR_PGO_MIXED: f64 state + f64 linearisation (exact gradient), f32 factor / solve: Gauss-Newton
     then behaves like iterative refinement.  Measured: on intel.g2o it stops by the reference's own
     |dx| < 1e-4 rule after 7 iterations (f64: 6) with poses 2e-6 from the f64 answer, where pure f32
-    meets it only by chance, much later or never; on the 100 x 100 lattice chi2 agrees with f64 to 2e-10 after 12
+    meets it only by chance and ends 1e-8 relative away in chi2; on the 100 x 100 lattice chi2 agrees with f64 to 2e-10 after 12
     iterations and the one weak global mode (rotation about the anchor) contracts by ~0.65 per iteration."""
     gi, oi = api[0].new(g2o_path("intel"), precision="mixed"), oracle.load(g2o_path("intel"))
     ei, eo = gi.optimize(30), oi.optimize(30)
@@ -449,8 +449,8 @@ def test_mixed_precision_reaches_the_f64_answer(api, oracle):
     assert np.abs(gi.state() - oi.state()).max() <= 1e-5
     g32 = api[0].new(g2o_path("intel"), precision="f32")
     e32 = g32.optimize(30)                                     # pure f32: |dx| hovers around 1e-3..1e-4 (rounding noise
-    assert len(e32) - 1 > len(ei) - 1                          # of the f32 gradient) and meets the stop rule late or never
-    assert abs(e32[-1] - eo[-1]) <= 1e-5 * eo[-1]
+    assert abs(e32[-1] - eo[-1]) <= 1e-5 * eo[-1]              # of the f32 gradient): it meets the stop rule by chance
+    assert abs(e32[-1] - eo[-1]) > abs(ei[-1] - eo[-1])        # (after 6..14 iterations, build dependent), further from f64
     from rustrobotics_amd import synthetic_grid_arrays
     arrays = synthetic_grid_arrays(100, 100)
     gm, g64 = api[0].from_arrays(*arrays, precision="mixed"), api[0].from_arrays(*arrays)
