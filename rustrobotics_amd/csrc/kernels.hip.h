@@ -1153,9 +1153,18 @@ __global__ void __launch_bounds__(THREADS) k_factor_tasks(FactorArgs<T> a) {
   T *smem = reinterpret_cast<T *>(smem_raw);
   init_w16_identity<T>(dinv, threadIdx.x, THREADS);   // process_front has barriers before the first use
   const int task = a.task_begin + blockIdx.x;
-  for (int si = a.task_ptr[task]; si < a.task_ptr[task + 1]; si++) {
-    const int s = a.task_sn[si];
-    const SnMeta m = a.sn_meta[s];
+  // the record of the NEXT front is requested before the current one is processed: index, then record, are
+  // two dependent scalar loads (~0.5 us) that would otherwise sit between any two fronts of a task
+  const int sbeg = a.task_ptr[task], send = a.task_ptr[task + 1];
+  int snext = a.task_sn[sbeg];
+  SnMeta mnext = a.sn_meta[snext];
+  for (int si = sbeg; si < send; si++) {
+    const int s = snext;
+    const SnMeta m = mnext;
+    if (si + 1 < send) {
+      snext = a.task_sn[si + 1];
+      mnext = a.sn_meta[snext];
+    }
     process_front<T, THREADS, false>(a, s, m, smem, smem + (m.nc + m.nr + 1) * m.nc, 0, dinv);
   }
 }
@@ -2033,9 +2042,8 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
 // rows), partial sums combined per column through LDS.
 // work: STAGE: nc*ldt + nr + nc*NSLICE ; else nr + nc scalars.
 template <typename T, int THREADS, bool STAGE>
-__device__ void solve_front(const FactorArgs<T> &a, int s, T *work) {
+__device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *work) {
   const int tid = threadIdx.x;
-  const SnMeta m = a.sn_meta[s];
   const int nc = m.nc, nr = m.nr;
   const int M = nc + nr + 1;
   const T *Lg = a.lvals + m.loff;
@@ -2314,8 +2322,18 @@ __global__ void __launch_bounds__(THREADS) k_solve_tasks(FactorArgs<T> a) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
   const int task = a.task_begin + blockIdx.x;
-  for (int si = a.task_ptr[task + 1] - 1; si >= a.task_ptr[task]; si--)
-    solve_front<T, THREADS, true>(a, a.task_sn[si], smem);
+  const int sbeg = a.task_ptr[task], send = a.task_ptr[task + 1];
+  int snext = a.task_sn[send - 1];   // next front's record in flight under the current front (see k_factor_tasks)
+  SnMeta mnext = a.sn_meta[snext];
+  for (int si = send - 1; si >= sbeg; si--) {
+    const int s = snext;
+    const SnMeta m = mnext;
+    if (si > sbeg) {
+      snext = a.task_sn[si - 1];
+      mnext = a.sn_meta[snext];
+    }
+    solve_front<T, THREADS, true>(a, s, m, smem);
+  }
 }
 
 // mid / huge fronts: one workgroup per front, panel streamed from HBM (task list of single fronts)
@@ -2483,7 +2501,7 @@ __global__ void __launch_bounds__(THREADS) k_solve_mid(FactorArgs<T> a, int w32)
   const int s = a.task_sn[a.task_ptr[a.task_begin + blockIdx.x]];
   // w32: the front was factored by the 32-column block kernels (inverse diagonal blocks in winv)
   if (w32) solve_big_front<T, THREADS>(a, a.sn_meta[s], reinterpret_cast<T *>(smem_raw));
-  else solve_front<T, THREADS, false>(a, s, reinterpret_cast<T *>(smem_raw));
+  else solve_front<T, THREADS, false>(a, s, a.sn_meta[s], reinterpret_cast<T *>(smem_raw));
 }
 
 // ---- sharding over ranks -----------------------------------------------------------------------
