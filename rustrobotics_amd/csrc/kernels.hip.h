@@ -83,6 +83,10 @@ constexpr int UPD_THREADS = 256;
 #define RRPGO_ACC_END(ptr, slot) do { } while (0)
 #endif
 
+// The wave's index in its workgroup as a SCALAR: `threadIdx.x >> 6` lives in a vector register, and every
+// tile index, column offset and loop bound derived from it would be 64-lane VALU arithmetic.
+__device__ __forceinline__ int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 // device-side error flags (sticky, read by the host at sync points)
 enum : int { DEVERR_NOT_SPD = 1 };
 
@@ -161,7 +165,7 @@ template <typename T> __device__ __forceinline__ T group_sum8(T v) {   // sum ov
 template <typename T, int THREADS> __device__ __forceinline__ T block_sum(T v, T *scratch) {
   // wave reduction then one value per wave through LDS; result valid in thread 0
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = wave_index(), lane = threadIdx.x & 63;
   __syncthreads();
   if (lane == 0) scratch[wave] = v;
   __syncthreads();
@@ -886,7 +890,7 @@ __device__ __forceinline__ void panel_factor(T *P, int M, int nc, int *err, T *w
   constexpr int NB = 16;
   constexpr int NW = THREADS / 64;
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int wave = wave_index(), lane = tid & 63, li = lane & 15, lk = lane >> 4;
   RRPGO_ACC_DECL();
   int pend_k0 = -1;   // block whose "rest" update (block columns 1.. of its trailing part) is still owed
   auto rest_update = [&](int pk0, int first_wave, int nwaves) {
@@ -1114,7 +1118,7 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
     // LAST 16-column block only, the earlier blocks went in under the diagonal chain (panel_factor)
     const int klast = ((nc - 1) >> 4) << 4;
     const int nt = (nu + 15) >> 4;
-    const int wave = tid >> 6;
+    const int wave = wave_index();
     // the tiles of the lower triangle dealt round-robin: t-th tile of the column-major enumeration
     for (int t = wave; t < nt * (nt + 1) / 2; t += THREADS / 64) {
       int jb = 0, rem = t;
@@ -1214,7 +1218,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_zero(FactorAr
   const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
   const int M = m.nc + m.nr + 1;
   T *F = a.lvals + m.loff;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = wave_index(), lane = threadIdx.x & 63;
   for (int j = blockIdx.x * 4 + wave; j < M; j += gridDim.x * 4) {
     T *col = F + (int64_t)j * M;
     for (int i = (j & ~63) + lane; i < M; i += 256) {
@@ -1255,7 +1259,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_extend_add(Fa
   const int ncu = c.ncu;
   // one column of the child's update matrix per WAVE pass (four columns per workgroup in flight), lanes
   // over its rows, four rows per lane in flight (index, source and destination loads are independent)
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = wave_index(), lane = threadIdx.x & 63;
   for (int j = blockIdx.x * 4 + wave; j < ncu; j += gridDim.x * 4) {
     T *dcol = F + (int64_t)rel[j] * M;
     // column j of the child: packed lower triangle (uld == 0) or a plain column-major square
@@ -1689,7 +1693,7 @@ template <typename T> __global__ void __launch_bounds__(512) k_big_diag128(Facto
   const int nbk = min(BIG_SUPER, m.nc - K0);
   const int M = m.nc + m.nr + 1;
   T *Fb = a.lvals + m.loff + (int64_t)K0 * M + K0;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15;
+  const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63, li = lane & 15;
   // lower triangle in, zeros elsewhere (the dummy row 128 and the rows of a partial super-panel too)
   for (int c = wave; c < 128; c += 8) {
     const T *col = Fb + (int64_t)min(c, nbk - 1) * M;
@@ -1751,7 +1755,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_trsm128(Facto
   if (K0 >= m.nc) return;
   const int nbk = min(BIG_SUPER, m.nc - K0);
   const int M = m.nc + m.nr + 1;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15;
+  const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63, li = lane & 15;
   if (K0 + nbk + 128 * (int)blockIdx.x >= M) return;   // uniform over the workgroup
   T *F = a.lvals + m.loff;
   const T *Wt = a.winv + (int64_t)m.wblk * 256 + (int64_t)(K0 / BIG_NB) * 1024;
@@ -1913,7 +1917,7 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
   const int I0 = t0 + (blockIdx.x + toff) * TILE, J0 = t0 + (blockIdx.y + toff) * TILE;
   if (t0 >= jmax || I0 >= M || J0 >= jmax) return;   // uniform over the workgroup
   T *F = a.lvals + m.loff;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int wi = (wave & 1) * WTILE, wj = (wave >> 1) * WTILE;
   const int i0 = I0 + wi, j0 = J0 + wj;
@@ -2057,7 +2061,7 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *w
     // columns per wave) a wave requests all of them before anything else, so that one memory round trip
     // is hidden under the gather of x2 instead of one per group of four columns after it.
     constexpr int GV = 12;
-    const int gw = tid >> 6, gl = tid & 63;
+    const int gw = wave_index(), gl = tid & 63;
     const int gcpw = (nc + THREADS / 64 - 1) / (THREADS / 64);   // columns per wave: j = gw + NW g
     const bool gfast = nr > 0 && nr <= 128 && gcpw <= GV;
     T glv[GV][2], gy[GV];
@@ -2085,10 +2089,13 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *w
           const T sacc = wave_sum63<T>(glv[g][0] * x0 + glv[g][1] * x1);
           if (gl == 63 && j < nc) t1[j] = gy[g] - sacc;
         }
+    } else if (nr == 0) {
+      // a root front has no rows below its pivot block: t1 is its rhs row
+      for (int j = tid; j < nc; j += THREADS) t1[j] = Lg[(int64_t)j * M + nc];
     } else {
       // general shape: a wave takes four columns at a time (four independent global load streams in
       // flight), lanes over rows (coalesced)
-      const int wave = tid >> 6, lane = tid & 63;
+      const int wave = wave_index(), lane = tid & 63;
       constexpr int NW = THREADS / 64;
       for (int j = wave; j < nc; j += 4 * NW) {
         const int j1 = j + NW, j2 = j + 2 * NW, j3 = j + 3 * NW;
@@ -2128,7 +2135,7 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *w
     {
       using MM = Mfma16<T>;
       constexpr int NW = THREADS / 64;
-      const int wave = tid >> 6, lane = tid & 63, l16 = lane & 15;
+      const int wave = wave_index(), lane = tid & 63, l16 = lane & 15;
       const int nblk = (nc + 15) >> 4;
       int kr[4];
 #pragma unroll
@@ -2241,7 +2248,7 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *w
     T *xf = work;              // nc
     T *Lc = xf + nc;           // 64 x 65 chunk, transposed, reciprocal diagonal
     constexpr int NW = THREADS / 64;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = wave_index(), lane = tid & 63;
     __syncthreads();
     // the product with the rows below the pivot block, y1 - L21^T x[rows], was formed by the
     // multi-workgroup k_big_gemv_* launches and left in x[col0 ..]: only L11 is streamed here
@@ -2347,7 +2354,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_gemv_partial(
   const int nc = m.nc, nr = m.nr, M = nc + nr + 1;
   const int j0 = blockIdx.x * 64;
   if (j0 >= nc) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63;
   const int by = blockIdx.y;
   const int i_begin = (int)((int64_t)nr * by / R), i_end = (int)((int64_t)nr * (by + 1) / R);
   const T *Lg = a.lvals + m.loff;
@@ -2431,7 +2438,7 @@ template <typename T, int THREADS>
 __device__ void solve_big_front(const FactorArgs<T> &a, const SnMeta &m, T *work) {
   constexpr int NW = THREADS / 64;
   constexpr int NQ = 32;                // column pairs per wave and pass
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+  const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63, l32 = lane & 31, half = lane >> 5;
   const int nc = m.nc, M = nc + m.nr + 1;
   const T *Lg = a.lvals + m.loff;
   const T *Wb = a.winv + (int64_t)m.wblk * 256;
