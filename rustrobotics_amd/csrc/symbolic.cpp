@@ -1,5 +1,8 @@
 // symbolic.cpp -- see symbolic.h.  Host only, runs once per graph.
 #include "symbolic.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include <cstdio>
 #include <cstdlib>
@@ -467,6 +470,18 @@ int64_t lds_elems(int nc, int nr) {
 
 }  // namespace
 
+// RR_PGO_ANALYZE_TIMES=1: wall time of every phase of analyze() on stderr (diagnostic)
+struct PhaseTimer {
+  bool on = std::getenv("RR_PGO_ANALYZE_TIMES") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void mark(const char *what) {
+    if (!on) return;
+    auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "analyze: %-12s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+
 std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sym) {
   sym = Symbolic();
   const int N = g.n_nodes(), E = g.n_edges();
@@ -478,6 +493,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
   const Adj adj = build_adjacency(g);
   const int64_t lds_budget = opt.lds_budget_elems;
 
+  PhaseTimer ptimer;
   // ---- 1. ordering ---------------------------------------------------------
   std::vector<int32_t> order, pos_of(N), node_sep;
   {
@@ -494,6 +510,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
   }
   for (int p = 0; p < N; p++) pos_of[order[p]] = p;
 
+  ptimer.mark("ordering");
   // ---- 2. etree + postorder -------------------------------------------------
   std::vector<int32_t> parent;
   elimination_tree(adj, order, pos_of, parent);
@@ -507,6 +524,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     elimination_tree(adj, order, pos_of, parent);
   }
 
+  ptimer.mark("etree");
   // ---- 3. node-level column structures -> weighted counts -------------------
   std::vector<int64_t> cc(N, 0);  // scalar rows strictly below the diagonal block
   {
@@ -541,6 +559,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     sym.nnz_l_blocks = nblk;
   }
 
+  ptimer.mark("colcounts");
   // ---- 4. zero-fill supernodes, then relaxed amalgamation -------------------
   std::vector<int32_t> sn_of(N), s_first, s_last;
   for (int j = 0; j < N; j++) {
@@ -702,6 +721,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     }
   }
 
+  ptimer.mark("supernodes");
   // ---- 5. supernodal symbolic factorisation on the final partition ----------
   std::vector<int32_t> sn_at_pos(N);
   for (int f = 0; f < S; f++)
@@ -756,6 +776,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     }
   }
 
+  ptimer.mark("symbolic");
   // ---- 6. storage layout, big-front classification --------------------------
   sym.sn_loff.resize(S);
   sym.sn_uoff.resize(S);
@@ -815,6 +836,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     sym.xch_elems = xo;
   }
 
+  ptimer.mark("layout");
   // ---- 7. H block structure + assembly lists --------------------------------
   sym.diag_off.resize(N);
   int64_t hv = 0;
@@ -954,29 +976,37 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     sym.fasm_ptr[f + 1] = (int64_t)sym.fasm_src.size();
     sym.fdup_ptr[f + 1] = (int64_t)sym.fdup_src.size();
   }
-  for (int c = 0; c < S; c++) {
-    const int p = sym.sn_parent[c];
-    if (p < 0 || sym.sn_big[c] || sym.sn_big[p]) continue;
-    const int ncu = sym.sn_nrows[c] + 1;
-    const int ncp = sym.sn_ncols[p], Mp = ncp + sym.sn_nrows[p] + 1, nup = sym.sn_nrows[p] + 1;
-    const int32_t *rel = sym.rel.data() + sym.rel_ptr[c];
-    sym.scat_ptr[c] = (int64_t)sym.scat.size();
-    for (int j = 0; j < ncu; j++)
-      for (int i = j; i < ncu; i++) {
-        int32_t d;
-        if (i == ncu - 1 && j == ncu - 1) d = -1;
-        else {
-          const int li = rel[i], lj = rel[j];
-          if (lj < ncp) d = lj * Mp + li;
-          else {
-            const int a2 = li - ncp, b2 = lj - ncp;
-            d = Mp * ncp + (b2 * nup - b2 * (b2 - 1) / 2 + (a2 - b2));
-          }
-        }
-        sym.scat.push_back(d);
+  {
+    // one destination per element of a child's packed update matrix (the LDS image of the parent): sized
+    // once, filled column by column with the column's part of the index hoisted
+    int64_t total = 0;
+    for (int c = 0; c < S; c++) {
+      const int p = sym.sn_parent[c];
+      if (p < 0 || sym.sn_big[c] || sym.sn_big[p]) continue;
+      const int64_t ncu = sym.sn_nrows[c] + 1;
+      sym.scat_ptr[c] = total;
+      total += ncu * (ncu + 1) / 2;
+    }
+    sym.scat.resize(total);
+    for (int c = 0; c < S; c++) {
+      const int p = sym.sn_parent[c];
+      if (p < 0 || sym.sn_big[c] || sym.sn_big[p]) continue;
+      const int ncu = sym.sn_nrows[c] + 1;
+      const int ncp = sym.sn_ncols[p], Mp = ncp + sym.sn_nrows[p] + 1, nup = sym.sn_nrows[p] + 1;
+      const int32_t *rel = sym.rel.data() + sym.rel_ptr[c];
+      int32_t *out = sym.scat.data() + sym.scat_ptr[c];
+      for (int j = 0; j < ncu; j++) {
+        const int lj = rel[j];
+        // d = lj * Mp + li  (pivot column of the parent)  |  Mp * ncp + b2 * nup - b2 (b2 - 1) / 2 + (li - ncp - b2)
+        const int b2 = lj - ncp;
+        const int base = lj < ncp ? lj * Mp : Mp * ncp + (b2 * nup - b2 * (b2 - 1) / 2) - ncp - b2;
+        for (int i = j; i < ncu; i++) *out++ = base + rel[i];
       }
+      out[-1] = -1;   // the (rhs, rhs) corner is never used
+    }
   }
 
+  ptimer.mark("asm lists");
   // ---- 8. schedule ----------------------------------------------------------
   // The task granularity trades launches (levels) against the serialisation of independent sibling
   // fronts inside one workgroup; the best threshold depends on the tree.  Candidates are scored with
@@ -1114,13 +1144,14 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     // the score is a jagged function of the threshold (a subtree flips between "leaf task" and "top"):
     // a dense geometric grid, each candidate costs one O(S) pass
     double best = 1e300, best_t = 90;
-    for (double t = 10.0; t < 260.0; t *= 1.09) {
+    for (double t = 10.0; t < 260.0; t *= 1.12) {
       const double c = build_schedule(t);
       if (c < best) { best = c; best_t = t; }
     }
     build_schedule(best_t);
     sym.task_us_used = best_t;
   }
+  ptimer.mark("schedule");
   return "";
 }
 
