@@ -975,7 +975,9 @@ __device__ __forceinline__ void panel_factor(T *P, int M, int nc, int *err, T *w
       for (int ib = wave; ib < ni; ib += NW)
         tile_rank_update<T>(P, M, js + 16 * ib, js, M, nc, k0, k0 + nb,
                             [&](int i, int j) { return P + j * M + i; });
-      __syncthreads();
+      // no barrier here: the first wave owns tile 0 (the next diagonal block) and goes straight on to
+      // factor it; the other tiles of this block column are first read by the triangular solve of the next
+      // block, which comes after the barrier that follows that factorisation
       RRPGO_ACC_END(acc, 9);
       if (js + NB < nc || nu > 0) pend_k0 = k0;   // more block columns to the right (or the update matrix): owed, done under the next diagonal block
     }
