@@ -275,6 +275,15 @@ def main():
             if ent and ent["kernel"] == roofline["kernel"]:
                 roofline["traffic"] = ent["traffic_bytes_per_launch"]
                 roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"
+            # the dense trailing update against its OTHER roof: K = 128 columns per pass over the trailing matrix
+            # bounds its arithmetic intensity, so the measured HBM traffic per launch prices it against HBM too
+            ent = pmc.get(f"{args.workload}:{args.precision}:k_big_update")
+            if ent and mfma_kernel:
+                us = mfma_kernel["us_per_step"] / mfma_kernel["launches_per_step"]
+                mfma_kernel["traffic"] = ent["traffic_bytes_per_launch"]
+                mfma_kernel["hbm_achieved_GBps"] = ent["traffic_bytes_per_launch"] / (us * 1e-6) / 1e9
+                mfma_kernel["hbm_frac"] = mfma_kernel["hbm_achieved_GBps"] / HBM_PEAK_GBPS
+                mfma_kernel["flop_per_byte"] = mfma_kernel["flops_per_step"] / mfma_kernel["launches_per_step"] / ent["traffic_bytes_per_launch"]
         except (OSError, ValueError):
             pass
         out = {
