@@ -1369,9 +1369,43 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_trsm(FactorAr
 // access costs a branch: every access below is unconditional (lanes 32..63 mirror lanes 0..31 and
 // store the same values, the never-read upper triangles take whatever falls out) and selects do the
 // masking.
-//   Sh   LDS, 2 * 32 * 33 scalars: Sh[c * 33 + r] = block(r, c) for r >= c, a partial block (nb < 32)
+//   Sh   LDS, DIAG32_LDS scalars: Sh[c * 33 + r] = block(r, c) for r >= c, ZERO for r < c, a partial block (nb < 32)
 //        already padded with an identity by the caller; the second half is scratch for W
 //   out: F block (in place, zeros above the diagonal) and Wt[j * 32 + c] = W(c, j)
+// The caller's part of the contract (all unconditional stores of one wave, before the barrier that precedes
+// diag32_factor_invert): the image has ZEROS strictly above the diagonal (sh_image_from_acc / the loaders do
+// that in the select they need anyway for the identity padding), a 16 x 16 identity sits behind the two
+// images and the never-written (0,1) tile of the W image is zero -- so the sweeps stream block rows and
+// identity rows through one per-lane (base, stride) pair and the results leave without a single select
+// (an fp64 select is two v_cndmask: the selects used to be ~260 of the ~2100 instructions of this chain).
+constexpr int DIAG32_LDS = 2 * 32 * 33 + 256;   // block image | W image | identity
+template <typename T> __device__ __forceinline__ void diag32_init_tables(T *Sh) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int e = lane + 64 * u;
+    Sh[2 * 32 * 33 + e] = (e >> 4) == (e & 15) ? (T)1 : (T)0;          // ident[c * 16 + q]
+    Sh[32 * 33 + (16 + (e >> 4)) * 33 + (e & 15)] = (T)0;               // W image, columns 16.., rows 0..15
+  }
+}
+// a 32 x 32 diagonal block held as 2 x 2 accumulator tiles (transposed layout: tile rows = block columns)
+// -> the image, identity padding past nbn
+template <typename T>
+__device__ __forceinline__ void sh_image_from_acc(T *Sh, const typename Mfma16<T>::Acc (&q)[2][2], int nbn) {
+  using MM = Mfma16<T>;
+  const int lane = threadIdx.x & 63, li = lane & 15;
+#pragma unroll
+  for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+    for (int jb = 0; jb < 2; jb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int jc = 16 * jb + MM::row(lane, r), ir = 16 * ib + li;
+        if (jb > ib) Sh[jc * 33 + ir] = (T)0;
+        else Sh[jc * 33 + ir] = (ir < nbn && jc < nbn && ir >= jc) ? q[ib][jb][r] : ((ir == jc && ir >= nbn) ? (T)1 : (T)0);
+      }
+}
+
 template <typename T, bool WG_IS_ONE_WAVE = true>
 __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int M, T *Wt, int *err) {
   // orders this wave's LDS writes before its later reads: a workgroup barrier where the workgroup IS the
@@ -1388,11 +1422,13 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
   const bool rowlane = ll < 16;
   T x[16];
   bool bad;
+  const T *ident = Sh + 2 * WOFF;
+  const int sstride = rowlane ? 33 : 16;
   // ---- (1,1)
+  {
+    const T *src = rowlane ? Dl + q : ident + q;
 #pragma unroll
-  for (int c = 0; c < 16; c++) {
-    const T v = pin(Dl[c * 33 + q]);
-    x[c] = rowlane ? (c <= q ? v : (T)0) : (q == c ? (T)1 : (T)0);
+    for (int c = 0; c < 16; c++) x[c] = src[c * sstride];
   }
   bad = chol16_invert<T>(x, ll);
 #pragma unroll
@@ -1408,8 +1444,7 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int j = MM::row(lane, r);
-    const T v = pin(Dl[(16 + j) * 33 + 16 + li]);
-    s22[r] = li >= j ? v : (T)0;
+    s22[r] = Dl[(16 + j) * 33 + 16 + li];   // zero above the diagonal (contract)
   }
 #pragma unroll
   for (int r = 0; r < 4; r++) s22 = MM::mma(-l21[r], l21[r], s22);
@@ -1422,14 +1457,14 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
   for (int r = 0; r < 4; r++) {
     const int c = MM::row(lane, r);
     Dl[c * 33 + 16 + li] = l21[r];
-    Dl[(16 + c) * 33 + 16 + li] = s22[r];
+    Dl[(16 + c) * 33 + 16 + li] = li >= c ? s22[r] : (T)0;   // the product filled the upper triangle too
   }
   sync();
   // ---- (2,2)
+  {
+    const T *src = rowlane ? Dl + 16 * 33 + 16 + q : ident + q;
 #pragma unroll
-  for (int c = 0; c < 16; c++) {
-    const T v = pin(Dl[(16 + c) * 33 + 16 + q]);
-    x[c] = rowlane ? (c <= q ? v : (T)0) : (q == c ? (T)1 : (T)0);
+    for (int c = 0; c < 16; c++) x[c] = src[c * sstride];
   }
   bad = chol16_invert<T>(x, ll) || bad;
   if (bad && lane == 0) atomicOr(err, DEVERR_NOT_SPD);
@@ -1447,9 +1482,8 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
 #pragma unroll
   for (int t = 0; t < 16; t++) {   // e = j * 32 + c'; the strictly upper parts are zero
     const int e = t * 64 + lane, c = e >> 5, r = e & 31;
-    const T vl = pin(Dl[c * 33 + r]), vw = pin(Wl[c * 33 + r]);
-    lo[t] = r >= c ? vl : (T)0;
-    wo[t] = r >= c ? vw : (T)0;
+    lo[t] = Dl[c * 33 + r];   // both images are exactly zero above the diagonal by now
+    wo[t] = Wl[c * 33 + r];
   }
   if (nb == BIG_NB) {
 #pragma unroll
@@ -1471,7 +1505,7 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
 // First diagonal block of a super-panel (everything left of it has been applied by the trailing
 // update): one wave per front.
 template <typename T> __global__ void __launch_bounds__(64) k_big_diag32(FactorArgs<T> a, int kb) {
-  __shared__ T Sh[2 * 32 * 33];
+  __shared__ T Sh[DIAG32_LDS];
   RRPGO_TRACE_MARK(a, 300);
   const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
   if (kb >= m.nc) return;
@@ -1484,13 +1518,14 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_diag32(FactorA
   for (int t = 0; t < 16; t++) {   // all 16 loads in flight together, clamped into the block
     const int e = t * 64 + lane, c = e >> 5, r = e & 31;
     const T f = pin(Fblk[(int64_t)min(c, nb - 1) * M + min(r, nb - 1)]);
-    v[t] = (r < nb && c < nb) ? f : (r == c ? (T)1 : (T)0);   // identity padding
+    v[t] = (r < nb && c < nb && r >= c) ? f : ((r == c && r >= nb) ? (T)1 : (T)0);   // identity padding, zeros above the diagonal
   }
 #pragma unroll
   for (int t = 0; t < 16; t++) {
     const int e = t * 64 + lane, c = e >> 5, r = e & 31;
-    Sh[c * 33 + r] = v[t];   // the upper triangle is never read
+    Sh[c * 33 + r] = v[t];
   }
+  diag32_init_tables<T>(Sh);
   __syncthreads();
   diag32_factor_invert<T>(Sh, nb, Fblk, M, a.winv + (int64_t)m.wblk * 256 + (kb / BIG_NB) * 1024, a.err);
 }
@@ -1508,7 +1543,7 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_diag32(FactorA
 template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(FactorArgs<T> a, int kb, int K0) {
   static_assert(BIG_NB == 32, "the left-looking panel kernels are written for 32-column blocks");
   using MM = Mfma16<T>;
-  __shared__ T Sh[2 * 32 * 33];
+  __shared__ T Sh[DIAG32_LDS];
   RRPGO_TRACE_MARK(a, 200);
   const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
   if (kb >= m.nc) return;
@@ -1660,15 +1695,8 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
 #pragma unroll
         for (int jb = 0; jb <= ib; jb++) nxt[ib][jb] = MM::mma(-out[jb][cb][r], out[ib][cb][r], nxt[ib][jb]);
   const int nbn = min(BIG_NB, m.nc - kn);
-#pragma unroll
-  for (int ib = 0; ib < 2; ib++)
-#pragma unroll
-    for (int jb = 0; jb <= ib; jb++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int jc = 16 * jb + MM::row(lane, r), ir = 16 * ib + li;
-        Sh[jc * 33 + ir] = (ir < nbn && jc < nbn) ? nxt[ib][jb][r] : (ir == jc ? (T)1 : (T)0);   // identity padding
-      }
+  sh_image_from_acc<T>(Sh, nxt, nbn);
+  diag32_init_tables<T>(Sh);
   __syncthreads();
   RRPGO_PHASE_MARK(a, look, 504);
   diag32_factor_invert<T>(Sh, nbn, F + (int64_t)kn * M + kn, M, a.winv + (int64_t)m.wblk * 256 + (kn / BIG_NB) * 1024, a.err);
@@ -2023,15 +2051,13 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
   if (next_diag) {
     T *Sh = &As[0][0][0];   // the staging buffers are idle now (every wave passed the last barrier of the k loop)
     const int nbn = min(BIG_NB, m.nc - t0);
-#pragma unroll
-    for (int ib = 0; ib < 2; ib++)
-#pragma unroll
-      for (int jb = 0; jb <= ib; jb++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int jc = 16 * jb + MM::row(lane, r), ir = 16 * ib + li;
-          Sh[jc * 33 + ir] = (ir < nbn && jc < nbn) ? acc[ib][jb][r] : (ir == jc ? (T)1 : (T)0);   // identity padding
-        }
+    static_assert(DIAG32_LDS <= 2 * KC * LDT, "the diagonal-block images fit the first operand strip");
+    if constexpr (NT == 2) sh_image_from_acc<T>(Sh, acc, nbn);
+    else {
+      const typename MM::Acc corner[2][2] = {{acc[0][0], acc[0][1]}, {acc[1][0], acc[1][1]}};
+      sh_image_from_acc<T>(Sh, corner, nbn);
+    }
+    diag32_init_tables<T>(Sh);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

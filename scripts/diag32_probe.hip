@@ -8,13 +8,14 @@ using namespace rrpgo;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 template <typename T> __global__ void __launch_bounds__(64) probe(T *F, int M, int nb, T *Wt, int *err, long long *st) {
-  __shared__ T Dl[2 * 32 * 33];
+  __shared__ T Dl[DIAG32_LDS];
   const int lane = threadIdx.x;
   long long t0 = clock64();
-  for (int e = lane; e < 32 * 32; e += 64) {
+  for (int e = lane; e < 32 * 32; e += 64) {   // the image contract: zeros above the diagonal, identity padding
     const int c = e >> 5, r = e & 31;
-    Dl[c * 33 + r] = (r < nb && c < nb) ? F[(int64_t)c * M + r] : (r == c ? (T)1 : (T)0);
+    Dl[c * 33 + r] = (r < nb && c < nb && r >= c) ? F[(int64_t)c * M + r] : ((r == c && r >= nb) ? (T)1 : (T)0);
   }
+  diag32_init_tables<T>(Dl);
   __syncthreads();
   long long t1 = clock64();
   __builtin_amdgcn_sched_barrier(0);
