@@ -2463,7 +2463,7 @@ template <typename T> __device__ __forceinline__ T half_wave_sum(T v) {   // sum
   return v;
 }
 template <typename T, int THREADS>
-__device__ void solve_big_front(const FactorArgs<T> &a, const SnMeta &m, T *work) {
+__device__ void solve_big_front(const FactorArgs<T> &a, const SnMeta &m, T *work, const T *part, int64_t N, int R) {
   constexpr int NW = THREADS / 64;
   constexpr int NQ = 32;                // column pairs per wave and pass
   const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63, l32 = lane & 31, half = lane >> 5;
@@ -2474,7 +2474,14 @@ __device__ void solve_big_front(const FactorArgs<T> &a, const SnMeta &m, T *work
   T *xf = work;                     // nc: t on entry, x as blocks finish
   T *Ws = work + ((nc + 3) & ~3);   // 2 x (32 x 33): W_b staged transposed, Ws[j * 33 + c] = W_b(j, c)
   __syncthreads();
-  for (int j = tid; j < nc; j += THREADS) xf[j] = a.x[m.col0 + j];
+  // t = y1 - L21^T x[rows]: the R row slices of k_big_gemv_partial summed here, in slice order (what a separate
+  // k_big_gemv_finish launch used to do)
+  for (int j = tid; j < nc; j += THREADS) {
+    T t = Lg[(int64_t)j * M + (M - 1)];
+    if (m.nr > 0)
+      for (int r = 0; r < R; r++) t -= part[(int64_t)r * N + m.col0 + j];
+    xf[j] = t;
+  }
   auto stage_w = [&](int b) {   // Wt[c * 32 + j] = W_b(j, c)  ->  Ws[j * 33 + c]
     if (tid < 1024) {
       const int c = tid >> 5, j = tid & 31;
@@ -2531,11 +2538,12 @@ __device__ void solve_big_front(const FactorArgs<T> &a, const SnMeta &m, T *work
 }
 
 template <typename T, int THREADS>
-__global__ void __launch_bounds__(THREADS) k_solve_mid(FactorArgs<T> a, int w32) {
+__global__ void __launch_bounds__(THREADS) k_solve_mid(FactorArgs<T> a, int w32, const T *part, int64_t N, int R) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int s = a.task_sn[a.task_ptr[a.task_begin + blockIdx.x]];
-  // w32: the front was factored by the 32-column block kernels (inverse diagonal blocks in winv)
-  if (w32) solve_big_front<T, THREADS>(a, a.sn_meta[s], reinterpret_cast<T *>(smem_raw));
+  // w32: the front was factored by the 32-column block kernels (inverse diagonal blocks in winv); it also sums
+  // the partial products itself.  Otherwise k_big_gemv_finish has left t in x.
+  if (w32) solve_big_front<T, THREADS>(a, a.sn_meta[s], reinterpret_cast<T *>(smem_raw), part, N, R);
   else solve_front<T, THREADS, false>(a, s, a.sn_meta[s], reinterpret_cast<T *>(smem_raw));
 }
 

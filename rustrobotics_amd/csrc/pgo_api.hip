@@ -441,7 +441,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     configure_kernels();
     n_launches_per_iter = 3;
     for (const Step &st : sym.steps)
-      n_launches_per_iter += st.kind == STEP_BIG ? count_big_launches(st) + 3 : st.kind == STEP_MID ? 4 : 2;
+      n_launches_per_iter += st.kind == STEP_BIG ? count_big_launches(st) + (left_looking_ ? 2 : 3) : st.kind == STEP_MID ? 4 : 2;
   }
 
   ~Engine() override {
@@ -778,10 +778,13 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         const FactorArgs<T> fa = factor_args(st.task_begin);
         hipLaunchKernelGGL(k_big_gemv_partial<T>, dim3(cb, R, nf), dim3(256), 0, stream_, fa, gemv_part_.p, (int64_t)g_.dim, R);
         check_launch("k_big_gemv_partial");
-        hipLaunchKernelGGL(k_big_gemv_finish<T>, dim3((max_nc + 255) / 256, nf), dim3(256), 0, stream_, fa, (const T *)gemv_part_.p, (int64_t)g_.dim, R);
-        check_launch("k_big_gemv_finish");
-        hipLaunchKernelGGL((k_solve_mid<T, 1024>), dim3(nf), dim3(1024), lds, stream_, fa, (st.kind == STEP_BIG && left_looking_) ? 1 : 0);
-        pend(RR_PGO_K_BIG_SOLVE, 3);
+        const int w32 = (st.kind == STEP_BIG && left_looking_) ? 1 : 0;
+        if (!w32) {
+          hipLaunchKernelGGL(k_big_gemv_finish<T>, dim3((max_nc + 255) / 256, nf), dim3(256), 0, stream_, fa, (const T *)gemv_part_.p, (int64_t)g_.dim, R);
+          check_launch("k_big_gemv_finish");
+        }
+        hipLaunchKernelGGL((k_solve_mid<T, 1024>), dim3(nf), dim3(1024), lds, stream_, fa, w32, (const T *)gemv_part_.p, (int64_t)g_.dim, R);
+        pend(RR_PGO_K_BIG_SOLVE, w32 ? 2 : 3);
       }
     }
   }
