@@ -2479,7 +2479,14 @@ __device__ void solve_big_front(const FactorArgs<T> &a, const SnMeta &m, T *work
   for (int j = tid; j < nc; j += THREADS) {
     T t = Lg[(int64_t)j * M + (M - 1)];
     if (m.nr > 0)
-      for (int r = 0; r < R; r++) t -= part[(int64_t)r * N + m.col0 + j];
+      for (int r0 = 0; r0 < R; r0 += 8) {   // eight slices requested together, subtracted in slice order
+        T p[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) p[u] = part[(int64_t)min(r0 + u, R - 1) * N + m.col0 + j];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (r0 + u < R) t -= p[u];
+      }
     xf[j] = t;
   }
   auto stage_w = [&](int b) {   // Wt[c * 32 + j] = W_b(j, c)  ->  Ws[j * 33 + c]

@@ -774,7 +774,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         int max_nc = 1;
         for (int z = 0; z < nf; z++) max_nc = std::max(max_nc, sym_.sn_ncols[sym_.task_sn[sym_.task_ptr[st.task_begin + z]]]);
         const int cb = (max_nc + 63) / 64;
-        const int R = std::max(1, std::min(kGemvSlices, (768 + nf * cb - 1) / (nf * cb)));
+        int max_nr = 1;
+        for (int z = 0; z < nf; z++) max_nr = std::max(max_nr, sym_.sn_nrows[sym_.task_sn[sym_.task_ptr[st.task_begin + z]]]);
+        // row slices: enough workgroups to fill the chip, but never thinner than 128 rows (every slice is a
+        // partial sum k_solve_mid has to fetch and add per column)
+        const int R = std::max(1, std::min(std::min(kGemvSlices, (max_nr + 127) / 128), (768 + nf * cb - 1) / (nf * cb)));
         const FactorArgs<T> fa = factor_args(st.task_begin);
         hipLaunchKernelGGL(k_big_gemv_partial<T>, dim3(cb, R, nf), dim3(256), 0, stream_, fa, gemv_part_.p, (int64_t)g_.dim, R);
         check_launch("k_big_gemv_partial");
