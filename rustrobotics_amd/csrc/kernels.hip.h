@@ -1407,7 +1407,8 @@ __device__ __forceinline__ void sh_image_from_acc(T *Sh, const typename Mfma16<T
 }
 
 template <typename T, bool WG_IS_ONE_WAVE = true>
-__device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int M, T *Wt, int *err) {
+__device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int M, T *Wt, int *err, bool store_l = true,
+                                                     bool store_w = true) {
   // orders this wave's LDS writes before its later reads: a workgroup barrier where the workgroup IS the
   // wave, a wave-level fence where other waves of the workgroup have already left
   auto sync = [] {
@@ -1485,19 +1486,22 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
     lo[t] = Dl[c * 33 + r];   // both images are exactly zero above the diagonal by now
     wo[t] = Wl[c * 33 + r];
   }
+  if (store_w) {
+#pragma unroll
+    for (int t = 0; t < 16; t++) Wt[t * 64 + lane] = wo[t];
+  }
+  if (!store_l) return;
   if (nb == BIG_NB) {
 #pragma unroll
     for (int t = 0; t < 16; t++) {
       const int e = t * 64 + lane, c = e >> 5, r = e & 31;
       Fblk[(int64_t)c * M + r] = lo[t];
-      Wt[e] = wo[t];
     }
   } else {
 #pragma unroll
     for (int t = 0; t < 16; t++) {
       const int e = t * 64 + lane, c = e >> 5, r = e & 31;
       if (r < nb && c <= r) Fblk[(int64_t)c * M + r] = lo[t];
-      Wt[e] = wo[t];
     }
   }
 }
@@ -1540,7 +1544,7 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_diag32(FactorA
 // the last 32 columns of that update), factors and inverts it: one launch per 32 columns on the chain.
 // Loads go to clamped addresses (no branch per load); rows past the front only feed results that are
 // never stored.
-template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(FactorArgs<T> a, int kb, int K0) {
+template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(FactorArgs<T> a, int kb, int K0, int first) {
   static_assert(BIG_NB == 32, "the left-looking panel kernels are written for 32-column blocks");
   using MM = Mfma16<T>;
   __shared__ T Sh[DIAG32_LDS];
@@ -1562,13 +1566,29 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
   RRPGO_PHASE_MARK(a, look, 500);
   // W operand tiles (cb, jb) = (0,0), (1,0), (1,1); (0,1) is zero
   T wv[3][4];
+  if (!first) {
 #pragma unroll
-  for (int t = 0; t < 3; t++)
+    for (int t = 0; t < 3; t++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int cb = t == 0 ? 0 : 1, jb = t == 2 ? 1 : 0;
-      wv[t][r] = Wt[(16 * jb + MM::row(lane, r)) * 32 + 16 * cb + li];
+      for (int r = 0; r < 4; r++) {
+        const int cb = t == 0 ? 0 : 1, jb = t == 2 ? 1 : 0;
+        wv[t][r] = Wt[(16 * jb + MM::row(lane, r)) * 32 + 16 * cb + li];
+      }
+  }
+  // first: the very first block of a level.  No trailing update came before it to leave W behind, and a
+  // k_big_diag32 launch for it would sit alone on the chain: every workgroup of this launch factors and inverts
+  // the block for itself instead (same arithmetic, same bits), the first one keeps W for the solve.  The block
+  // itself stays as assembled in F -- nothing reads a diagonal block of L once its W exists, and storing it
+  // here would race with the other workgroups that are still reading it.
+  T dv[16];
+  if (first) {
+    const T *Fblk = F + (int64_t)kb * M + kb;
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      const int e = t * 64 + lane, c = e >> 5, r = e & 31;
+      dv[t] = Fblk[(int64_t)min(c, nb - 1) * M + min(r, nb - 1)];
     }
+  }
   int irow[2];   // this lane's two rows, clamped into the front
   irow[0] = min(R0 + li, M - 1);
   irow[1] = min(R0 + 16 + li, M - 1);
@@ -1626,6 +1646,25 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
 #pragma unroll
         for (int ib = 0; ib < 2; ib++) nxt[ib][jb][r] = ccol[irow[ib]];
       }
+  }
+  if (first) {
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      const int e = t * 64 + lane, c = e >> 5, r = e & 31;
+      Sh[c * 33 + r] = (r < nb && c < nb && r >= c) ? dv[t] : ((r == c && r >= nb) ? (T)1 : (T)0);
+    }
+    diag32_init_tables<T>(Sh);
+    __syncthreads();
+    diag32_factor_invert<T>(Sh, nb, F + (int64_t)kb * M + kb, M, const_cast<T *>(Wt), a.err, false, blockIdx.x == 0);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int cb = t == 0 ? 0 : 1, jb = t == 2 ? 1 : 0;
+        wv[t][r] = Sh[32 * 33 + (16 * jb + MM::row(lane, r)) * 33 + 16 * cb + li];   // the LDS image of W
+      }
+    __syncthreads();   // Sh is free again for the next diagonal block's image
   }
   RRPGO_PHASE_MARK(a, look, 501);
 #pragma unroll

@@ -197,6 +197,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
                                     // RR_PGO_SMALL_TILE=0 brings the 128 x 128 tiles back
   int solve_threads_max_ = 512;     // RR_PGO_SOLVE_THREADS=<n>: cap of the back-substitution workgroup size
   int factor_threads_max_ = 1024;   // 16-wave workgroups for steps whose fronts exceed 128 rows (RR_PGO_FACTOR_512=1: 8 waves)
+  bool separate_diag32_ = false;    // RR_PGO_SEPARATE_DIAG32=1: a k_big_diag32 launch for the first block of every level
   bool panel128_ = false;           // RR_PGO_PANEL128=1: two launches per 128-column super-panel (diagonal block in LDS by one
                                     // workgroup, then all rows at once) instead of one per 32 columns; measured 10 % slower
   bool overlap_ = false;            // RR_PGO_OVERLAP=1: the far part of a trailing update on a second stream, beside the next panel chain (measured neutral so far)
@@ -341,6 +342,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     }
     if (overlap_ && std::atoi(getenv("RR_PGO_OVERLAP")) > 1) overlap_max_nf_ = std::atoi(getenv("RR_PGO_OVERLAP"));
     panel128_ = getenv("RR_PGO_PANEL128") != nullptr;
+    separate_diag32_ = getenv("RR_PGO_SEPARATE_DIAG32") != nullptr;
     factor_threads_max_ = getenv("RR_PGO_FACTOR_512") ? 512 : 1024;
     if (const char *e = getenv("RR_PGO_SOLVE_THREADS")) solve_threads_max_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_SMALL_TILE")) small_tile_below_ = std::atoi(e);
@@ -676,7 +678,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         // (update from the columns K0..kb, multiply by the inverse diagonal block, next diagonal block)
         // the first diagonal block of a later super-panel comes out of the previous trailing update
         if (do_launch) pbegin();
-        if (K0 == 0) {
+        const bool sep_diag = K0 == 0 && separate_diag32_;
+        if (sep_diag) {
           if (do_launch) {
             hipLaunchKernelGGL(k_big_diag32<T>, dim3(1, nf), dim3(64), 0, stream_, a, K0);
             check_launch("k_big_diag32");
@@ -686,12 +689,14 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         for (int kb = K0; kb < std::min(K0 + BIG_SUPER, max_nc); kb += BIG_NB) {
           const int rb = rows_max(kb) - 1;
           if (do_launch) {
-            hipLaunchKernelGGL(k_big_panel32<T>, dim3((std::max(rb, 1) + 31) / 32, nf), dim3(64), 0, stream_, a, kb, K0);
+            // the level's first block is factored and inverted inside its own row launch (by every workgroup)
+            hipLaunchKernelGGL(k_big_panel32<T>, dim3((std::max(rb, 1) + 31) / 32, nf), dim3(64), 0, stream_, a, kb, K0,
+                               (kb == 0 && !separate_diag32_) ? 1 : 0);
             check_launch("k_big_panel32");
           }
           n++;
         }
-        if (do_launch) pend(RR_PGO_K_BIG_PANEL, (K0 == 0 ? 1 : 0) + (std::min(K0 + BIG_SUPER, max_nc) - K0 + BIG_NB - 1) / BIG_NB);
+        if (do_launch) pend(RR_PGO_K_BIG_PANEL, (sep_diag ? 1 : 0) + (std::min(K0 + BIG_SUPER, max_nc) - K0 + BIG_NB - 1) / BIG_NB);
       } else
       for (int kb = K0; kb < std::min(K0 + BIG_SUPER, max_nc); kb += BIG_NB) {
         const int rb = rows_max(kb) - 1;   // rows below a 1..32 wide block, at least the rhs row
