@@ -1620,9 +1620,10 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
       d += kstep;
     }
   };
-#pragma unroll
-  for (int p = 0; p < PRE; p++)
-    if (p < nblk) fetch(p, av[p], bv[p]);
+  // Request order = the order the results are needed in: a wave has at most 63 vector loads in flight, so
+  // the ~140 loads of a chain step return in two or three memory round trips (HBM: the data was written by
+  // an earlier launch), and the left-looking MFMAs of block 0 can run under the later ones -- the tile
+  // itself first, then the operand blocks, the next diagonal block last.
   typename MM::Acc acc[2][2], nxt[2][2];
 #pragma unroll
   for (int jb = 0; jb < 2; jb++)
@@ -1631,11 +1632,11 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
       const int j = 16 * jb + MM::row(lane, r);
       const T *ccol = F + (int64_t)(kb + min(j, nb - 1)) * M;
 #pragma unroll
-      for (int ib = 0; ib < 2; ib++) {
-        const T v = pin(ccol[irow[ib]]);
-        acc[ib][jb][r] = j < nb ? v : (T)0;
-      }
+      for (int ib = 0; ib < 2; ib++) acc[ib][jb][r] = ccol[irow[ib]];   // masked below, once it is here
     }
+#pragma unroll
+  for (int p = 0; p < PRE; p++)
+    if (p < nblk) fetch(p, av[p], bv[p]);
   if (look) {
     // next diagonal block (rows = columns = kn..kn+31); entries above its diagonal are never read
 #pragma unroll
@@ -1647,6 +1648,17 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
         for (int ib = 0; ib < 2; ib++) nxt[ib][jb][r] = ccol[irow[ib]];
       }
   }
+#pragma unroll
+  for (int jb = 0; jb < 2; jb++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int j = 16 * jb + MM::row(lane, r);
+#pragma unroll
+      for (int ib = 0; ib < 2; ib++) {
+        const T v = pin(acc[ib][jb][r]);
+        acc[ib][jb][r] = j < nb ? v : (T)0;
+      }
+    }
   if (first) {
 #pragma unroll
     for (int t = 0; t < 16; t++) {
