@@ -272,6 +272,8 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             ent = pmc.get(f"{args.workload}:{args.precision}")
+            if not (ent and ent["kernel"] == roofline["kernel"]):   # the dominant class may be the MFMA kernel
+                ent = pmc.get(f"{args.workload}:{args.precision}:{roofline['kernel']}")
             if ent and ent["kernel"] == roofline["kernel"]:
                 roofline["traffic"] = ent["traffic_bytes_per_launch"]
                 roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"
