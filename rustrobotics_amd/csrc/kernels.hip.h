@@ -1192,13 +1192,15 @@ __global__ void __launch_bounds__(THREADS) k_factor_mid(FactorArgs<T> a) {
 // tasks task_begin, task_begin+1, ...).  Each M x M front lies in L storage (column-major, ld M).
 //   k_big_zero / k_big_assemble / k_big_extend_add (one launch per child rank: fixed order)
 //   per 128-column super-panel (default, left-looking):
-//       k_big_diag32 for the first super-panel of a level only (later ones: tail of the previous update)
+//       the first diagonal block: inside the level's first k_big_panel32 launch (every workgroup for itself),
+//       or the tail of the previous trailing update; k_big_diag32 is the stand-alone launch (RR_PGO_SEPARATE_DIAG32)
 //       4 x k_big_panel32   rows below a 32-column block: update from the super-panel's earlier columns,
 //                           multiply by the inverse diagonal block; its first wave prepares the next block
 //       k_big_update mode 1 everything right of the super-panel (K = 128, the dense MFMA contraction)
 //   alternatives kept for comparison: k_big_diag / k_big_trsm / k_big_update mode 0 (right-looking, K = 32),
 //   k_big_diag128 / k_big_trsm128 (a whole super-panel per chain step), k_big_update modes 2 / 3 (two streams)
-//   back substitution: k_big_gemv_partial / k_big_gemv_finish (L21^T x over the chip), k_solve_mid (L11)
+//   back substitution: k_big_gemv_partial (L21^T x over the chip, row slices), k_solve_mid (sums the slices, L11);
+//   k_big_gemv_finish sums them in a launch of its own for the right-looking alternative
 #ifndef RRPGO_BIG_NB
 #define RRPGO_BIG_NB 32
 #endif
