@@ -216,7 +216,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<unsigned long long> stamps_;  // diagnostic builds only
   // symbolic tables
   DevBuf<int32_t> task_ptr_, task_sn_, fasm_src_, fasm_dst_, fdup_src_, fdup_dst_, scat_, rel_, perm_, sn_rows_;
-  DevBuf<SnMeta> sn_meta_, task_meta_;
+  DevBuf<SnMeta> sn_meta_, task_meta_, big_all_meta_;
+  int n_big_all_ = 0, big_all_maxM_ = 0;
+  int64_t big_all_max_asm_ = 0;
+  bool big_all_dup_ = false, big_all_small_ = false;
+  bool merged_head_ = false;         // set with the table below; RR_PGO_SERIAL_ASSEMBLY=1: zero + assemble per level
+  bool head_done_ = false;           // this factorisation has already zeroed and assembled every big front
   DevBuf<ChildMeta> child_meta_;
   std::vector<int> step_solve_lds_;  // scalars of LDS the back-solve of each step needs
   double *host_pair_ = nullptr;      // pinned: chi2, |dx|, and (as an int in slot 2) the device error flag
@@ -404,6 +409,26 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         std::vector<SnMeta> tm(sym.task_ptr.size() - 1);
         for (size_t t = 0; t + 1 < sym.task_ptr.size(); t++) tm[t] = meta[sym.task_sn[sym.task_ptr[t]]];
         task_meta_.upload(tm);
+        // all fronts beyond LDS, level after level: zeroed and assembled by ONE launch each per iteration (they
+        // only need the linearisation) instead of a pair of ~5 us launches on the chain of every level
+        std::vector<SnMeta> ba;
+        for (const Step &st : sym.steps)
+          if (st.kind == STEP_BIG)
+            for (int t = st.task_begin; t < st.task_end; t++) {
+              const int sn = sym.task_sn[sym.task_ptr[t]];
+              ba.push_back(meta[sn]);
+              big_all_maxM_ = std::max(big_all_maxM_, sym.sn_ncols[sn] + sym.sn_nrows[sn] + 1);
+              big_all_max_asm_ = std::max<int64_t>(big_all_max_asm_, std::max<int64_t>(sym.fasm_ptr[sn + 1] - sym.fasm_ptr[sn], sym.sn_ncols[sn]));
+              big_all_dup_ = big_all_dup_ || sym.fdup_ptr[sn + 1] > sym.fdup_ptr[sn];
+            }
+        n_big_all_ = (int)ba.size();
+        if (n_big_all_ > 0) big_all_meta_.upload(ba);
+        // ... as long as all of them stay cache resident until they are used: zeroed a GB at a time (the 1M-edge
+        // lattice) the later levels come back from HBM and the step is 3-4 % slower than zeroing level by level
+        double big_bytes = 0.0;
+        for (const SnMeta &bm : ba) big_bytes += (double)(bm.nc + bm.nr + 1) * (bm.nc + bm.nr + 1) * sizeof(T);
+        big_all_small_ = n_big_all_ > 0 && big_bytes <= 192.0 * 1024 * 1024;
+        merged_head_ = world_ == 1 && big_all_small_ && getenv("RR_PGO_SERIAL_ASSEMBLY") == nullptr;
       }
       if (wblk_total > 0x7fffff00LL) throw ApiError(RR_PGO_EUNSUPPORTED, "too many diagonal blocks");
       winv_.alloc((size_t)wblk_total * 256 + 4);
@@ -590,8 +615,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     pend(RR_PGO_K_LINEARIZE);
   }
 
-  void launch_factor() { launch_factor_range(0, sym_.steps.size()); }
+  void launch_factor() {
+    head_done_ = false;
+    launch_factor_range(0, sym_.steps.size());
+  }
   void launch_factor_range(size_t from, size_t to) {
+    if (from == 0) head_done_ = false;
     for (size_t si = from; si < to; si++) {
       const Step &st = sym_.steps[si];
       pbegin();
@@ -614,6 +643,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         pend(RR_PGO_K_BIGFRONT);
       }
     }
+  }
+
+  const Step *first_big_step() const {
+    for (const Step &st : sym_.steps)
+      if (st.kind == STEP_BIG) return &st;
+    return nullptr;
   }
 
   // The huge fronts of one level, batched: zero, assemble, extend-add (one launch per child rank),
@@ -643,15 +678,33 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         if (sym_.sn_ncols[s] > from) r = std::max(r, sym_.sn_ncols[s] + sym_.sn_nrows[s] + 1 - from);
       return r;
     };
-    const unsigned znb = (unsigned)std::min(std::max((maxM + 3) / 4, 1), 8192);   // a wave per column, four per workgroup
-    if (do_launch) { hipLaunchKernelGGL(k_big_zero<T>, dim3(znb, nf), dim3(256), 0, stream_, a); check_launch("k_big_zero"); }
-    n++;
-    if (do_launch) hipLaunchKernelGGL(k_big_assemble<T>, dim3((unsigned)std::min<int64_t>((max_asm + 255) / 256, 2048), nf), dim3(256), 0, stream_, a);
-    if (do_launch) check_launch("k_big_assemble");
-    n++;
-    if (any_dup) {
-      if (do_launch) hipLaunchKernelGGL(k_big_assemble_dup<T>, dim3(1, nf), dim3(64), 0, stream_, a);
+    if (merged_head_) {
+      // every big front of every level in one zero and one assemble launch, at the first big level
+      const bool first_big = &st == first_big_step();
+      if (do_launch && !head_done_) {
+        FactorArgs<T> all = a;
+        all.task_meta = big_all_meta_.p;
+        all.task_begin = 0;
+        const unsigned znb = (unsigned)std::min(std::max((big_all_maxM_ + 3) / 4, 1), 8192);
+        hipLaunchKernelGGL(k_big_zero<T>, dim3(znb, n_big_all_), dim3(256), 0, stream_, all);
+        check_launch("k_big_zero");
+        hipLaunchKernelGGL(k_big_assemble<T>, dim3((unsigned)std::min<int64_t>((big_all_max_asm_ + 255) / 256, 2048), n_big_all_), dim3(256), 0, stream_, all);
+        check_launch("k_big_assemble");
+        if (big_all_dup_) hipLaunchKernelGGL(k_big_assemble_dup<T>, dim3(1, n_big_all_), dim3(64), 0, stream_, all);
+        head_done_ = true;
+      }
+      if (first_big) n += 2 + (big_all_dup_ ? 1 : 0);
+    } else {
+      const unsigned znb = (unsigned)std::min(std::max((maxM + 3) / 4, 1), 8192);   // a wave per column, four per workgroup
+      if (do_launch) { hipLaunchKernelGGL(k_big_zero<T>, dim3(znb, nf), dim3(256), 0, stream_, a); check_launch("k_big_zero"); }
       n++;
+      if (do_launch) hipLaunchKernelGGL(k_big_assemble<T>, dim3((unsigned)std::min<int64_t>((max_asm + 255) / 256, 2048), nf), dim3(256), 0, stream_, a);
+      if (do_launch) check_launch("k_big_assemble");
+      n++;
+      if (any_dup) {
+        if (do_launch) hipLaunchKernelGGL(k_big_assemble_dup<T>, dim3(1, nf), dim3(64), 0, stream_, a);
+        n++;
+      }
     }
     for (int q = 0; q < max_kids; q++) {
       if (do_launch) hipLaunchKernelGGL(k_big_extend_add<T>, dim3((unsigned)std::min<int64_t>((max_ncu + 3) / 4, 2048), nf), dim3(256), 0, stream_, a, q);
