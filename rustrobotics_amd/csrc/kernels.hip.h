@@ -513,6 +513,8 @@ template <typename T, typename TC = T> struct UpdArgs3 {
   T *dx_ref_out;
   TC sign;
   double *norm_partial;
+  int export_only;     // 1: only write dx_ref_out
+  const int *err;      // sticky device error flag: a failed factorisation must not touch the state
 };
 
 // X <- X * (dt, Exp(dw)):  t += R dt ;  q <- normalise( q (x) exp(dw) )
@@ -521,7 +523,8 @@ __global__ void __launch_bounds__(UPD_THREADS) k_update_se3(UpdArgs3<TO, T> a) {
   __shared__ double red[UPD_THREADS / 64];
   const int node = blockIdx.x * UPD_THREADS + threadIdx.x;
   double nrm = 0.0;
-  if (node < a.n_nodes) {
+  const bool failed = a.err && *a.err != 0;
+  if (node < a.n_nodes && !failed) {
     T d[6];
     const TO *src = a.dx_ref_in ? a.dx_ref_in + a.node_offset[node] : a.x + a.node_pcol[node];
 #pragma unroll
@@ -531,6 +534,7 @@ __global__ void __launch_bounds__(UPD_THREADS) k_update_se3(UpdArgs3<TO, T> a) {
 #pragma unroll
       for (int t = 0; t < 6; t++) dst[t] = src[t];
     }
+    if (a.export_only) return;
 #pragma unroll
     for (int t = 0; t < 6; t++) { nrm += (double)d[t] * (double)d[t]; d[t] *= a.sign; }
     auto pt = a.pose[2 * node], pq = a.pose[2 * node + 1];
@@ -553,6 +557,7 @@ __global__ void __launch_bounds__(UPD_THREADS) k_update_se3(UpdArgs3<TO, T> a) {
     a.pose[2 * node] = pt;
     a.pose[2 * node + 1] = pq;
   }
+  if (a.export_only) return;
   double tot = block_sum<double, UPD_THREADS>(nrm, red);
   if (threadIdx.x == 0) a.norm_partial[blockIdx.x] = tot;
 }
@@ -2697,6 +2702,50 @@ template <typename T> __global__ void k_mask_x(int n, T *x, const int8_t *col_ow
   }
 }
 
+// ------------------------------------------------------------------ gauge transfer (single-precision factor)
+// The reference removes the gauge freedom of the SE(2) graph with a 1e7 prior on ONE node (:330-336).  A
+// rigid motion of the whole graph leaves every error unchanged, so J V = 0 for the three fields
+//   V = [ (1,0,0) ; (0,1,0) ; (-(y_i - y_o), x_i - x_o, 1) ]_i      (translations, rotation about o)
+// and H0 = J^T W J is singular with null space V, b is orthogonal to V, and the reference's solution is the
+// ONE solution of H0 dx = b whose anchor entries vanish (V^T (H0 + P) dx = V_a^T 1e7 dx_a = 0, V_a invertible).
+// The anchor is a weak hinge, though: "rotate everything but the anchor" costs only the strain of the anchor's
+// few edges against a lever of the graph's whole extent -- the smallest eigenvalue is ~1e-5 on the 400 x 250
+// lattice against entries of 1e5..1e7, beyond what a single-precision factor resolves.
+// With a single-precision factor the engine therefore solves the SAME singular system in another gauge and
+// transfers the result:
+//   (H0 + V_S diag(mu) V_S^T) y = b,  S = the pivot nodes of the root front (dense anyway: no extra fill);
+//        every solution of H0 y = b with V_S^T y_S = 0 solves it, so y = dx + V c exactly;
+//   dx = y - V c,  c = y_a  (rotation taken about the anchor's position)   -- re-gauged in k_update.
+// Now the hinge is a whole separator.  Exact in exact arithmetic; fp64 handles keep the reference formulation.
+template <typename T, typename TC> struct GaugeArgs {
+  const typename VecT<TC>::V4 *pose;
+  const int32_t *col_node;   // per pivot column of the root front: node << 2 | component
+  int nc, M;
+  T *F;                      // the root front (in place, ld M)
+  T *v;                      // 3 * nc scratch: the three fields on the root's pivot columns
+  TC ox, oy;                 // origin of the rotation field (centroid of S at set-up: conditioning only)
+  T mu_t, mu_r;
+};
+
+template <typename T, typename TC> __global__ void __launch_bounds__(256) k_gauge_vectors(GaugeArgs<T, TC> a) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.nc) return;
+  const int ent = a.col_node[j], node = ent >> 2, comp = ent & 3;
+  const auto p = a.pose[node];
+  a.v[j] = comp == 0 ? (T)1 : (T)0;
+  a.v[a.nc + j] = comp == 1 ? (T)1 : (T)0;
+  a.v[2 * a.nc + j] = comp == 0 ? (T)(-(p.y - a.oy)) : comp == 1 ? (T)(p.x - a.ox) : (T)1;
+}
+
+// F(i, j) += mu_t (tx_i tx_j + ty_i ty_j) + mu_r rot_i rot_j on the lower triangle of the root's pivot block
+template <typename T, typename TC> __global__ void __launch_bounds__(256) k_big_gauge(GaugeArgs<T, TC> a) {
+  const int j = blockIdx.x;
+  const T *v0 = a.v, *v1 = a.v + a.nc, *v2 = a.v + 2 * a.nc;
+  const T a0 = a.mu_t * v0[j], a1 = a.mu_t * v1[j], a2 = a.mu_r * v2[j];
+  T *col = a.F + (int64_t)j * a.M;
+  for (int i = j + threadIdx.x; i < a.nc; i += 256) col[i] += a0 * v0[i] + a1 * v1[i] + a2 * v2[i];
+}
+
 // ------------------------------------------------------------------ update
 
 template <typename T, typename TC = T> struct UpdArgs {
@@ -2709,34 +2758,54 @@ template <typename T, typename TC = T> struct UpdArgs {
   T *dx_ref_out;       // reference-order copy of the applied step (may be null)
   TC sign;
   double *norm_partial;
+  int gauge_anchor;    // >= 0: x is a solution in the root-separator gauge; transfer it to the anchor gauge first
+  int export_only;     // 1: only write dx_ref_out (rr_pgo_linearize_solve), the state stays as it is
+  const int *err;      // sticky device error flag: a failed factorisation must not touch the state
 };
 
+// update_nodes (:229-245) + |dx|^2 (:273).  The step of a failed factorisation (non-positive pivot) is NOT
+// applied: the reference returns Err from solve() at :271 before update_nodes(), its state stays intact.
 template <typename TO, typename T>
 __global__ void __launch_bounds__(UPD_THREADS) k_update(UpdArgs<TO, T> a) {
   __shared__ double red[UPD_THREADS / 64];
   const int node = blockIdx.x * UPD_THREADS + threadIdx.x;
   double nrm = 0.0;
-  if (node < a.n_nodes) {
+  const bool failed = a.err && *a.err != 0;
+  if (node < a.n_nodes && !failed) {
     const int nd = a.node_dim[node];
     T d[3] = {0, 0, 0};
     const TO *src = a.dx_ref_in ? a.dx_ref_in + a.node_offset[node] : a.x + a.node_pcol[node];
     for (int t = 0; t < nd; t++) d[t] = (T)src[t];
+    auto p = a.pose[node];
+    const bool regauge = a.gauge_anchor >= 0 && !a.dx_ref_in;
+    if (regauge) {
+      // dx = y - V c, c = y_anchor, rotation field about the anchor's position (see "gauge transfer")
+      const TO *ya = a.x + a.node_pcol[a.gauge_anchor];
+      const T c0 = (T)ya[0], c1 = (T)ya[1], c2 = (T)ya[2];
+      const auto pa = a.pose[a.gauge_anchor];
+      d[0] = d[0] - c0 + c2 * (p.y - pa.y);
+      d[1] = d[1] - c1 - c2 * (p.x - pa.x);
+      if (nd == 3) d[2] -= c2;
+      if (node == a.gauge_anchor) { d[0] = 0; d[1] = 0; d[2] = 0; }
+    }
     if (a.dx_ref_out) {
       TO *dst = a.dx_ref_out + a.node_offset[node];
-      for (int t = 0; t < nd; t++) dst[t] = src[t];
+      for (int t = 0; t < nd; t++) dst[t] = (TO)d[t];
     }
-    for (int t = 0; t < nd; t++) nrm += (double)d[t] * (double)d[t];
-    auto p = a.pose[node];
-    p.x += a.sign * d[0];
-    p.y += a.sign * d[1];
-    if (nd == 3) {  // rotation *= UnitComplex::from_angle(dtheta), no renormalisation (:236)
-      const T c = cos(a.sign * d[2]), s = sin(a.sign * d[2]);
-      const T re = p.z * c - p.w * s, im = p.z * s + p.w * c;
-      p.z = re;
-      p.w = im;
+    if (!a.export_only && !(regauge && node == a.gauge_anchor)) {
+      for (int t = 0; t < nd; t++) nrm += (double)d[t] * (double)d[t];
+      p.x += a.sign * d[0];
+      p.y += a.sign * d[1];
+      if (nd == 3) {  // rotation *= UnitComplex::from_angle(dtheta), no renormalisation (:236)
+        const T c = cos(a.sign * d[2]), s = sin(a.sign * d[2]);
+        const T re = p.z * c - p.w * s, im = p.z * s + p.w * c;
+        p.z = re;
+        p.w = im;
+      }
+      a.pose[node] = p;
     }
-    a.pose[node] = p;
   }
+  if (a.export_only) return;
   double tot = block_sum<double, UPD_THREADS>(nrm, red);
   if (threadIdx.x == 0) a.norm_partial[blockIdx.x] = tot;
 }

@@ -163,11 +163,6 @@ __global__ void k_finalize_slot(const double *chi_partial, int n_chi, const doub
   }
 }
 
-template <typename T> __global__ void k_permute_out(int n, const int32_t *perm, const T *x, T *dx_ref) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) dx_ref[perm[i]] = x[i];
-}
-
 // T: type of H, b, L, x (factor + solve).  S: type of the state, the measurements and the
 // linearisation arithmetic (S == T, or S = double with T = float: "mixed" mode).
 template <typename T, typename S = T> class Engine final : public EngineBase {
@@ -206,6 +201,13 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   hipStream_t stream2_ = nullptr;
   hipEvent_t ev_chain_ = nullptr, ev_rest_ = nullptr;
   DevBuf<int8_t> col_owner_;
+  // gauge transfer (single-precision factor, Gauss-Newton; kernels.hip.h "gauge transfer")
+  bool gauge_ok_ = false;            // the root front is a big front with an SE2 pivot node
+  bool gauge_now_ = false;           // the system being factored was linearised without the anchor prior
+  int gauge_root_ = -1;              // supernode that takes the rank-3 term
+  DevBuf<int32_t> gauge_col_node_;
+  DevBuf<T> gauge_v_;
+  double gauge_ox_ = 0, gauge_oy_ = 0, gauge_mu_t_ = 0, gauge_mu_r_ = 0;
   DevBuf<int64_t> pack_list_;       // (front, exchange offset) of the in-place boundary fronts this rank owns
   int n_pack_ = 0, pack_max_nu_ = 0;
   // numeric
@@ -330,6 +332,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       n_pack_ = (int)pl.size() / 2;
       pack_list_.upload(pl);
     }
+    setup_gauge();
     lvals_.alloc((size_t)sym.l_elems + 4);
     uvals_.alloc((size_t)sym.u_elems + 4);
     lvals_.zero(); uvals_.zero();
@@ -483,6 +486,58 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   hipStream_t stream() override { return stream_; }
 
  private:
+  // Gauge transfer applies to a single-precision factor (T = float) of an SE(2) graph whose root front is
+  // one of the big in-place fronts; RR_PGO_GAUGE=0 keeps the reference's anchor prior (comparison runs).
+  void setup_gauge() {
+    if (sizeof(T) != 4 || is3d_ || g_.anchor_node < 0 || sym_.S == 0) return;
+    if (const char *e = getenv("RR_PGO_GAUGE")) if (std::atoi(e) == 0) return;
+    const int root = sym_.S - 1;
+    if (!sym_.sn_big[root] || !sym_.sn_huge[root] || sym_.sn_nrows[root] != 0) return;
+    std::vector<int32_t> cn;
+    double sx = 0, sy = 0, ext = 0;
+    int n_se2 = 0, n_nodes = 0;
+    for (int p = sym_.sn_first_pos[root]; p < sym_.sn_first_pos[root] + sym_.sn_npos[root]; p++) {
+      const int node = sym_.order[p];
+      const double *st = &g_.node_state[g_.node_state_off[node]];
+      sx += st[0]; sy += st[1]; n_nodes++;
+      n_se2 += g_.node_kind[node] == NODE_SE2;
+      for (int t = 0; t < node_dim(g_.node_kind[node]); t++) cn.push_back((node << 2) | t);
+    }
+    if (n_se2 == 0 || (int)cn.size() != sym_.sn_ncols[root]) return;
+    gauge_ox_ = sx / n_nodes; gauge_oy_ = sy / n_nodes;
+    for (int p = sym_.sn_first_pos[root]; p < sym_.sn_first_pos[root] + sym_.sn_npos[root]; p++) {
+      const double *st = &g_.node_state[g_.node_state_off[sym_.order[p]]];
+      ext = std::max(ext, std::max(std::fabs(st[0] - gauge_ox_), std::fabs(st[1] - gauge_oy_)));
+    }
+    // entries of the added term stay at the scale of the information matrices: mu * max|v|^2 = w
+    double w = 0;
+    for (int k = 0; k < g_.n_edges(); k++) {
+      const double *wi = &g_.edge_info[g_.edge_info_off[k]];
+      w = std::max(w, std::fabs(wi[0]));
+    }
+    if (const char *e = getenv("RR_PGO_GAUGE_W")) w = std::atof(e);
+    gauge_mu_t_ = w;
+    gauge_mu_r_ = w / std::max(1.0, ext * ext);
+    gauge_root_ = root;
+    gauge_col_node_.upload(cn);
+    gauge_v_.alloc(3 * cn.size());
+    gauge_ok_ = true;
+  }
+  void launch_gauge_term() {
+    GaugeArgs<T, S> ga;
+    ga.pose = pose_.p;
+    ga.col_node = gauge_col_node_.p;
+    ga.nc = sym_.sn_ncols[gauge_root_];
+    ga.M = ga.nc + sym_.sn_nrows[gauge_root_] + 1;
+    ga.F = lvals_.p + sym_.sn_loff[gauge_root_];
+    ga.v = gauge_v_.p;
+    ga.ox = (S)gauge_ox_; ga.oy = (S)gauge_oy_;
+    ga.mu_t = (T)gauge_mu_t_; ga.mu_r = (T)gauge_mu_r_;
+    hipLaunchKernelGGL((k_gauge_vectors<T, S>), dim3((ga.nc + 255) / 256), dim3(256), 0, stream_, ga);
+    hipLaunchKernelGGL((k_big_gauge<T, S>), dim3(ga.nc), dim3(256), 0, stream_, ga);
+    check_launch("k_big_gauge");
+  }
+
   static constexpr int kMaxLds = 160 * 1024 - 4608;  // the kernels also hold static __shared__ scratch (inverse diagonal block + identity: W16_SCR scalars)
 
   template <int TH> void set_lds_attr() {
@@ -506,7 +561,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     hipLaunchKernelGGL((k_solve_tasks<T, TH>), dim3(nt), dim3(TH), lds, stream_, a);
   }
 
-  LinArgs<T, S> lin_args(double lambda, int lm, int write_system) {
+  LinArgs<T, S> lin_args(double lambda, int lm, int write_system, bool reference_prior = false) {
+    // Gauss-Newton with a single-precision factor: no anchor prior, the root front carries the gauge term
+    if (write_system) gauge_now_ = gauge_ok_ && !lm && !reference_prior;
     LinArgs<T, S> a;
     a.n_nodes = g_.n_nodes();
     a.pose = pose_.p;
@@ -523,7 +580,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     a.hvals = hvals_.p;
     a.b = b_.p;
     a.chi2_partial = chi_partial_.p;
-    a.anchor = g_.anchor_node;
+    a.anchor = (write_system && gauge_now_) ? -1 : g_.anchor_node;
     a.lambda = lm ? (S)lambda : (S)0;
     a.write_system = write_system;
     return a;
@@ -586,11 +643,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (e != hipSuccess) throw ApiError(RR_PGO_ENODEVICE, std::string("kernel launch failed (") + what + "): " + hipGetErrorString(e));
   }
 
-  void launch_linearize(double lambda, int lm, int write_system) {
+  void launch_linearize(double lambda, int lm, int write_system, bool reference_prior = false) {
     pbegin();
     if (!is3d_) {
       hipLaunchKernelGGL((k_linearize<T, S>), dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_,
-                         lin_args(lambda, lm, write_system));
+                         lin_args(lambda, lm, write_system, reference_prior));
     } else {
       LinArgs3<T, S> a;
       a.n_nodes = g_.n_nodes();
@@ -710,6 +767,14 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       if (do_launch) hipLaunchKernelGGL(k_big_extend_add<T>, dim3((unsigned)std::min<int64_t>((max_ncu + 3) / 4, 2048), nf), dim3(256), 0, stream_, a, q);
       if (do_launch) check_launch("k_big_extend_add");
       n++;
+    }
+    if (gauge_ok_) {
+      bool has_root = false;
+      for (int s : fr) has_root = has_root || s == gauge_root_;
+      if (has_root) {
+        if (do_launch && gauge_now_) launch_gauge_term();
+        n += 2;
+      }
     }
     if (do_launch) pend(RR_PGO_K_BIGFRONT);   // closes the zero / assemble / extend-add segment
     for (int K0 = 0; K0 < max_nc; K0 += BIG_SUPER) {
@@ -851,7 +916,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     }
   }
 
-  void launch_update(const T *dx_ref_in, double sign, bool write_ref) {
+  void launch_update(const T *dx_ref_in, double sign, bool write_ref, bool export_only = false) {
     pbegin();
     if (!is3d_) {
       UpdArgs<T, S> u;
@@ -865,6 +930,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       u.dx_ref_out = write_ref ? dx_ref_.p : nullptr;
       u.sign = (S)sign;
       u.norm_partial = norm_partial_.p;
+      u.gauge_anchor = (!dx_ref_in && gauge_now_) ? g_.anchor_node : -1;
+      u.export_only = export_only ? 1 : 0;
+      u.err = dx_ref_in ? nullptr : err_.p;
       hipLaunchKernelGGL((k_update<T, S>), dim3(n_upd_blocks_), dim3(UPD_THREADS), 0, stream_, u);
     } else {
       UpdArgs3<T, S> u;
@@ -877,6 +945,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       u.dx_ref_out = write_ref ? dx_ref_.p : nullptr;
       u.sign = (S)sign;
       u.norm_partial = norm_partial_.p;
+      u.export_only = export_only ? 1 : 0;
+      u.err = dx_ref_in ? nullptr : err_.p;
       hipLaunchKernelGGL((k_update_se3<T, S>), dim3(n_upd_blocks_), dim3(UPD_THREADS), 0, stream_, u);
     }
     check_launch("k_update");
@@ -957,7 +1027,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     launch_linearize(lambda, lm, 1);
     launch_factor();
     launch_solve();
-    hipLaunchKernelGGL(k_permute_out<T>, dim3((g_.dim + 255) / 256), dim3(256), 0, stream_, g_.dim, perm_.p, x_ptr_, dx_ref_.p);
+    launch_update(nullptr, 1.0, true, true);   // permuted solution -> reference order (and the anchor gauge), state untouched
     std::vector<T> tmp((size_t)g_.dim);
     HIPCHK(hipMemcpyAsync(tmp.data(), dx_ref_.p, tmp.size() * sizeof(T), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
@@ -1067,7 +1137,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   }
 
   void assemble(double lambda, int lm, std::vector<double> &hv, std::vector<double> &b) override {
-    launch_linearize(lambda, lm, 1);
+    launch_linearize(lambda, lm, 1, true);   // always the reference's system (anchor prior), whatever the factor's gauge
     std::vector<T> th((size_t)sym_.n_hvals), tb((size_t)g_.dim);
     HIPCHK(hipMemcpyAsync(th.data(), hvals_.p, th.size() * sizeof(T), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipMemcpyAsync(tb.data(), b_.p, tb.size() * sizeof(T), hipMemcpyDeviceToHost, stream_));
