@@ -5,17 +5,24 @@ A "step" is ONE Gauss-Newton iteration of `PoseGraph::optimize`'s loop body (ref
 src/mapping/pose_graph_optimization.rs:269-301): linearise + assemble, factor, solve, update, chi2,
 |dx| -- all on the GPU, graph state resident in HBM, no host round trip inside the timed region
 (the convergence break is disabled so that exactly K steps run; after convergence a step does the
-same work on the same pattern).  Default workload = BASELINE.json configs[1]: intel.g2o, fp64.
+same work on the same pattern).  Headline workload = BASELINE.json configs[1]: intel.g2o, fp64.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload intel|m3500|dlr|sphere2500|torus3d|parking-garage|grid:WxH[:E]] [--precision f64|f32|mixed] [--shard]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload intel|m3500|dlr|sphere2500|torus3d|parking-garage|grid:WxH[:E]]
+                  [--precision f64|f32|mixed] [--shard] [--no-secondary] [--no-cpu-baseline]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): each rank optimises its own replica of
-the workload -- independent graphs, no data-path collective ("replicas", weak scaling); the
-barrier and the max-over-ranks time use RCCL through torch.distributed.
+Prints ONE JSON line (rank 0): the contract keys for the headline workload plus
+  roofline       dominant kernel class of the headline, HIP-event timing on the library's own stream
+  cpu_baseline   the CPU oracle (1 thread, bounded sample; `nproc` = cores of the box), N = 1 only
+  secondary      the other BASELINE configs, each timed with the SAME timed_steps contract (W warm-up steps,
+                 barrier + sync, K steps, sync + barrier, max over ranks): configs[2] M3500 fp64, configs[3] the
+                 1M-edge lattice (fp32 and mixed = fp64 state + fp32 factor), configs[4] sphere2500 fp64.
 
-Prints ONE JSON line (rank 0) with the contract keys plus `roofline` (dominant kernel class, HIP
-event timing on the library's own stream) and `cpu_baseline` (the CPU oracle, 1 thread, bounded
-sample, rank 0 at N = 1 only).
+N > 1 (launched by torch.distributed.run, one rank per GPU):
+  headline   every rank optimises its own replica of the workload -- "replicas (no communication)": the
+             6 k-edge datasets do not shard usefully; RCCL only carries the barrier and the max.
+  secondary  ONE lattice (and ONE sphere2500) sharded over the N ranks (rr_pgo_stage + RCCL collectives,
+             strong scaling) -- the multi-GPU numbers of configs[3] and configs[4].
+--shard makes a sharded workload the headline line instead (strong scaling).
 """
 import argparse
 import json
@@ -34,6 +41,11 @@ MFMA_PEAK_TFLOPS = {"f32": 157.3, "mixed": 157.3, "f64": 78.6}
 WORKLOADS = {"intel": "intel", "m3500": "input_M3500_g2o", "dlr": "dlr", "pose-pose": "simulation-pose-pose",
              "pose-landmark": "simulation-pose-landmark", "sphere2500": "sphere2500",
              "torus3d": "torus3D", "parking-garage": "parking-garage"}
+LATTICE = "grid:400x250:1000000"   # BASELINE configs[3]
+KERNEL_OF = {"linearize": "k_linearize", "factor": "k_factor_tasks", "solve": "k_solve_tasks",
+             "update": "k_update", "reduce": "k_finalize_slot", "big_assembly": "k_big_zero+k_big_assemble+k_big_extend_add",
+             "big_panel": "k_big_diag32+k_big_panel32", "big_update": "k_big_update", "mid_factor": "k_factor_mid",
+             "big_solve": "k_big_gemv_partial+k_big_gemv_finish+k_solve_mid"}
 
 
 def g2o_file(name):
@@ -62,25 +74,26 @@ def timed_steps(run_steps, sync, barrier, all_max, steps, warmup, reset=None):
     return all_max(dt)
 
 
+def grid_spec(workload):
+    parts = workload.split(":")
+    w, h = (int(x) for x in parts[1].lower().split("x"))
+    return w, h, (int(parts[2]) if len(parts) > 2 else 0)
+
+
 def make_graph(workload, precision, device):
     from rustrobotics_amd import PoseGraph, PoseGraphSolver
     if workload.startswith("grid:"):
-        parts = workload.split(":")
-        w, h = (int(x) for x in parts[1].lower().split("x"))
-        e = int(parts[2]) if len(parts) > 2 else 0
+        w, h, e = grid_spec(workload)
         return PoseGraph.synthetic_grid(w, h, e, solver=PoseGraphSolver.GaussNewton, precision=precision, device=device)
     return PoseGraph.new(g2o_file(workload), PoseGraphSolver.GaussNewton, precision=precision, device=device)
 
 
-def make_sharded_graph(workload, precision, device, rank, world):
+def workload_arrays(workload):
     from rustrobotics_amd import PoseGraph, synthetic_grid_arrays
     if workload.startswith("grid:"):
-        parts = workload.split(":")
-        w, h = (int(x) for x in parts[1].lower().split("x"))
-        arrays = synthetic_grid_arrays(w, h, int(parts[2]) if len(parts) > 2 else 0)
-    else:
-        arrays = PoseGraph.new(g2o_file(workload), precision=precision, device=device).graph_arrays()
-    return PoseGraph.from_arrays(*arrays, precision=precision, device=device, rank=rank, world_size=world)
+        return synthetic_grid_arrays(*grid_spec(workload))
+    from rustrobotics_amd.mapping import parse_g2o_arrays
+    return parse_g2o_arrays(g2o_file(workload))
 
 
 def cpu_baseline(workload, budget_s=12.0):
@@ -88,15 +101,14 @@ def cpu_baseline(workload, budget_s=12.0):
     factorisation redone every iteration like the reference's UMFPACK path), 1 thread.
 
     A lattice too large for the oracle to finish an iteration in the budget (the 1M-edge config
-    needs minutes per iteration on one core) is sampled by a 100 x 100 lattice of the SAME generator
-    and reported in edges*iterations/s, the size-independent half of BASELINE.json's metric."""
+    needs five minutes per iteration on one core: tests/golden/grid400x250.json records that run) is
+    sampled by a 100 x 100 lattice of the SAME generator and reported in edges*iterations/s, the
+    size-independent half of BASELINE.json's metric."""
     from oracle.oracle import OracleGraph
     sample_note, n_edges = workload, None
     if workload.startswith("grid:"):
         from rustrobotics_amd import synthetic_grid_arrays
-        parts = workload.split(":")
-        w, h = (int(x) for x in parts[1].lower().split("x"))
-        e = int(parts[2]) if len(parts) > 2 else 0
+        w, h, e = grid_spec(workload)
         if w * h > 12000:
             w, h, e = 100, 100, 0
             sample_note = f"100x100 lattice of the same generator (stand-in for {workload})"
@@ -115,14 +127,189 @@ def cpu_baseline(workload, budget_s=12.0):
         iters += len(errs) - 1
         restarts += 1
         last = errs
-    out = {"value": iters / spent, "unit": "GN iterations/s", "cores": 1, "kind": "port",
+    out = {"value": iters / spent, "unit": "GN iterations/s", "cores": 1, "nproc": os.cpu_count(), "kind": "port",
            "sample": f"{sample_note}: {iters} GN iterations in {restarts} runs of optimize(10) "
-                     f"(stops at |dx|<1e-4), {spent:.1f} s of CPU",
+                     f"(stops at |dx|<1e-4), {spent:.1f} s of CPU on 1 of the box's {os.cpu_count()} cores",
            "edges_iters_per_s": iters * n_edges / spent,
            "chi2_final": float(last[-1]), "errors": [float(x) for x in last]}
     if sample_note != workload:
         out["value"], out["unit"] = out["edges_iters_per_s"], "edges*iterations/s"
     return out
+
+
+def pmc_entry(key):
+    """HBM traffic measured offline with rocprofv3 --pmc (separate passes), kept in profiles/pmc_traffic.json."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key)
+    except (OSError, ValueError):
+        return None
+
+
+def roofline_of(g, workload, precision, prof_iters=20):
+    """Per-kernel-class timing with HIP events on the library's own stream (eager launches) -> the roofline
+    object of the dominant class, plus the MFMA utilisation of the dense trailing update when there is one."""
+    stats = g.stats()
+    prof = g.profile(prof_iters)
+    per_iter_us = {k: 1e3 * v[0] / prof_iters for k, v in prof.items()}
+    class_bytes = {"linearize": stats["bytes_linearize"], "factor": stats["bytes_factor"],
+                   "solve": stats["bytes_solve"], "update": stats["bytes_update"]}
+    dom = max((k for k in per_iter_us if k != "reduce"), key=lambda k: per_iter_us[k])
+    n_launch = prof[dom][1] / prof_iters
+    dom_us = per_iter_us[dom]
+    if dom == "big_update":
+        # the rank updates of the huge fronts are dense contractions on the matrix cores
+        achieved = stats["big_update_flops"] / (dom_us * 1e-6) / 1e12
+        peak = MFMA_PEAK_TFLOPS[precision]
+        roofline = {"bound": "mfma", "kernel": KERNEL_OF[dom], "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                    "frac": achieved / peak, "traffic": None, "launches_per_step": n_launch,
+                    "avg_launch_us": dom_us / max(n_launch, 1),
+                    "algorithmic_flops_per_launch": stats["big_update_flops"] / max(n_launch, 1),
+                    "per_step_us_by_kernel_class": per_iter_us}
+    else:
+        # fronts beyond LDS share the factor/solve byte budget with the LDS fronts
+        nbytes = class_bytes.get(dom, stats["bytes_solve"] if dom == "big_solve" else stats["bytes_factor"])
+        achieved = nbytes / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": KERNEL_OF[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "launches_per_step": n_launch,
+                    "avg_launch_us": dom_us / max(n_launch, 1),
+                    "algorithmic_bytes_per_launch": nbytes / max(n_launch, 1),
+                    "per_step_us_by_kernel_class": per_iter_us}
+    mfma_kernel = None
+    if per_iter_us.get("big_update", 0) > 0:
+        tf = stats["big_update_flops"] / (per_iter_us["big_update"] * 1e-6) / 1e12
+        mfma_kernel = {"kernel": "k_big_update", "achieved": tf, "peak": MFMA_PEAK_TFLOPS[precision], "unit": "TFLOP/s",
+                       "frac": tf / MFMA_PEAK_TFLOPS[precision], "us_per_step": per_iter_us["big_update"],
+                       "launches_per_step": prof["big_update"][1] / prof_iters, "flops_per_step": stats["big_update_flops"]}
+    pkey = "f32" if precision == "mixed" else precision   # the factor of a mixed handle IS the f32 factor
+    ent = pmc_entry(f"{workload}:{pkey}")
+    if not (ent and ent["kernel"] == roofline["kernel"]):
+        ent = pmc_entry(f"{workload}:{pkey}:{roofline['kernel']}")
+    if ent and ent["kernel"] == roofline["kernel"]:
+        roofline["traffic"] = ent["traffic_bytes_per_launch"]
+        roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"
+    ent = pmc_entry(f"{workload}:{pkey}:k_big_update")
+    if ent and mfma_kernel:
+        # the dense trailing update against its OTHER roof: K = 128 columns per pass over the trailing matrix
+        us = mfma_kernel["us_per_step"] / mfma_kernel["launches_per_step"]
+        mfma_kernel["traffic"] = ent["traffic_bytes_per_launch"]
+        mfma_kernel["hbm_achieved_GBps"] = ent["traffic_bytes_per_launch"] / (us * 1e-6) / 1e9
+        mfma_kernel["hbm_frac"] = mfma_kernel["hbm_achieved_GBps"] / HBM_PEAK_GBPS
+        mfma_kernel["flop_per_byte"] = mfma_kernel["flops_per_step"] / mfma_kernel["launches_per_step"] / ent["traffic_bytes_per_launch"]
+    return roofline, mfma_kernel, class_bytes
+
+
+def golden_chi2(workload):
+    """final chi2 of the CPU oracle on the 1M-edge lattice (tests/golden/grid400x250.json: data, generated once
+    by scripts/gen_grid_golden.py -- five minutes per iteration on one core)."""
+    if workload != LATTICE:
+        return None
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "grid400x250.json")))["errors"][-1]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+class Ctx:
+    """torch / torch.distributed plumbing shared by every measurement of this process."""
+
+    def __init__(self, rank, local_rank, world):
+        import torch
+        self.torch, self.rank, self.local_rank, self.world = torch, rank, local_rank, world
+        self.dist = None
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+    def all_max(self, x):
+        if not self.dist:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def measure_single(ctx, workload, precision, steps, warmup):
+    """One handle per rank (the whole graph on this rank's GPU): K iterations of one hipGraph replay each."""
+    g = make_graph(workload, precision, ctx.local_rank)
+    state0 = g.state()
+
+    def sync():
+        g.sync()                    # the library's own HIP stream
+        ctx.torch.cuda.synchronize()
+
+    dt = timed_steps(g.iterate_async, sync, ctx.barrier, ctx.all_max, steps, warmup, reset=lambda: g.set_state(state0))
+    return g, state0, dt
+
+
+def measure_sharded(ctx, workload, precision, steps, warmup, force_collectives=False):
+    """ONE graph sharded over the ranks: rr_pgo_stage + RCCL collectives issued on the library's own stream
+    (rustrobotics_amd.sharding.TorchShardDriver); no host synchronisation inside an iteration."""
+    from rustrobotics_amd.sharding import TorchShardDriver
+    drv = TorchShardDriver(workload_arrays(workload), precision, ctx.local_rank, ctx.rank, ctx.world,
+                           ctx.dist, force_collectives=force_collectives)
+    state0 = drv.graph.state()
+
+    def sync():
+        drv.graph.sync()
+        ctx.torch.cuda.synchronize()
+
+    dt = timed_steps(drv.run_steps, sync, ctx.barrier, ctx.all_max, steps, warmup, reset=lambda: drv.graph.set_state(state0))
+    return drv, state0, dt
+
+
+def secondary_entry(ctx, workload, precision, steps, warmup, sharded):
+    """A BASELINE config other than the headline, same timing contract; rank 0 returns the record."""
+    t_wall = time.perf_counter()
+    try:
+        if sharded:
+            drv, state0, dt = measure_sharded(ctx, workload, precision, steps, warmup, force_collectives=True)
+            g = drv.graph
+        else:
+            g, state0, dt = measure_single(ctx, workload, precision, steps, warmup)
+            drv = None
+    except Exception as e:   # noqa: BLE001 -- a secondary config must never take the headline line down
+        if ctx.dist:
+            raise
+        return {"workload": workload, "dtype": precision, "error": f"{type(e).__name__}: {e}"}
+    value = steps / dt * (1 if sharded else ctx.world)
+    rec = {"workload": f"{workload} ({g.num_nodes} poses / {g.num_edges} edges / dim {g.len})", "dtype": precision,
+           "n_gpus": ctx.world, "parallelism": (f"sharded{ctx.world}" if sharded else "single" if ctx.world == 1 else "replicas (no communication)"),
+           "scaling": "strong" if sharded else "weak", "steps": steps, "warmup": warmup,
+           "value": value, "unit": "GN iterations/s", "ms_per_step": 1e3 * dt / steps,
+           "edges_iters_per_s": value * g.num_edges}
+    # correctness leg: the reference's loop from the initial state, with its stop rule
+    g.set_state(state0)
+    if sharded:
+        errors, norms = drv.optimize(10)
+        rec["exchange_bytes_per_step"] = drv.exchange_bytes_per_step()
+        rec["collectives"] = drv.collectives_description()
+    else:
+        errors, norms = g.optimize(10, return_norms=True)
+    rec["errors"] = [float(e) for e in errors]
+    rec["norm_dx"] = [float(n) for n in norms]
+    rec["chi2_final"] = float(errors[-1])
+    rec["stopped_by_reference_rule"] = bool(len(norms) > 0 and norms[-1] < 1e-4)   # :298-300
+    gold = golden_chi2(workload)
+    if gold is not None:
+        rec["chi2_oracle_fixture"] = gold
+        rec["chi2_rel_diff_vs_oracle"] = abs(min(errors) - gold) / gold
+    if not sharded and ctx.rank == 0:
+        stats = g.stats()
+        g.set_state(state0)
+        roofline, mfma_kernel, class_bytes = roofline_of(g, workload, precision, prof_iters=10)
+        rec.update({"launches_per_step": stats["n_launches_per_iter"], "factor_flops": 2 * stats["factor_flops"],
+                    "algorithmic_bytes_per_step": sum(class_bytes.values()), "analyze_ms": stats["analyze_ms"],
+                    "roofline": roofline, "mfma_kernel": mfma_kernel})
+        if mfma_kernel:
+            rec["step_tflops"] = 2 * stats["factor_flops"] / (dt / steps) / 1e12
+    rec["wall_s"] = time.perf_counter() - t_wall
+    return rec if ctx.rank == 0 else None
 
 
 def main():
@@ -134,9 +321,10 @@ def main():
     ap.add_argument("--precision", default="f64", choices=["f64", "f32", "mixed"],
                     help="f64 (reference arithmetic), f32, or mixed = f64 state/linearisation + f32 factor/solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="headline workload only")
     ap.add_argument("--shard", action="store_true",
-                    help="N > 1 only: shard ONE graph over the ranks (own subtrees + shared top separators, two RCCL "
-                         "all-reduces per iteration) instead of one replica per rank; strong scaling")
+                    help="shard ONE graph (--workload) over the ranks as the headline line (strong scaling); with one rank "
+                         "the collectives still run, over a one-rank RCCL group")
     args = ap.parse_args()
 
     import numpy as np
@@ -149,175 +337,128 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    use_dist = world > 1
-    if use_dist:
-        import torch.distributed as dist
+    if args.shard and world == 1:   # a one-rank RCCL group so that the collective path really executes
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        import torch.distributed as dist
+        ctx = Ctx(0, local_rank, 1)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    shard = args.shard and use_dist
-    if shard:
-        g = make_sharded_graph(args.workload, args.precision, local_rank, rank, world)
-        xbuf = []
-        for which in (0, 1):
-            _, n, es = g.exchange_info(which)
-            t = torch.zeros(max(n, 1), dtype=torch.float64 if es == 8 else torch.float32, device="cuda")  # element size from the handle
-            g.bind_exchange(which, t.data_ptr(), t.numel())
-            xbuf.append(t)
+        ctx.dist = dist
     else:
-        g = make_graph(args.workload, args.precision, local_rank)
-    state0 = g.state()
-
-    def run_steps(k):
-        if not shard:
-            g.iterate_async(k)
-            return
-        for _ in range(k):          # one GN iteration = 3 stages, 2 sum all-reduces over RCCL
-            for stage in (0, 1):
-                g.stage(stage)
-                g.sync()
-                dist.all_reduce(xbuf[stage], op=dist.ReduceOp.SUM)
-                torch.cuda.current_stream().synchronize()
-            g.stage(2)
-
-    def sync():
-        g.sync()                    # the library's own HIP stream
-        torch.cuda.synchronize()
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-
-    def all_max(x):
-        if not use_dist:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    dt = timed_steps(run_steps, sync, barrier, all_max, args.steps, args.warmup, reset=lambda: g.set_state(state0))
-    stats = g.stats()
-    total_steps = args.steps * (1 if shard else world)   # sharded: all ranks work on the SAME K iterations
-    value = total_steps / dt
+        ctx = Ctx(rank, local_rank, world)
 
     out = None
-    if rank == 0 and shard:
-        out = {"metric": "GN iterations/s", "value": value, "unit": "GN iterations/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
-               "vs_baseline": None, "dtype": args.precision, "data": "synthetic" if args.workload.startswith("grid:") else "reference dataset file",
-               "config": {"workload": f"{args.workload} ({g.num_nodes} poses / {g.num_edges} edges / dim {g.len}), Gauss-Newton, "
-                                      f"ONE graph sharded over {world} ranks", "solver": "GaussNewton", "parallelism": "sharded%d" % world},
-               "edges_iters_per_s": value * g.num_edges, "chi2_final": g.global_error(),
-               "exchange_bytes_per_step": [int(t.numel() * t.element_size()) for t in xbuf],
-               "roofline": None, "cpu_baseline": None}
-    elif rank == 0:
-        # correctness leg: the reference's bench shape, optimize(10) from the initial state
+    if args.shard:
+        drv, state0, dt = measure_sharded(ctx, args.workload, args.precision, args.steps, args.warmup, force_collectives=True)
+        g = drv.graph
+        value = args.steps / dt      # all ranks work on the SAME K iterations
         g.set_state(state0)
-        t0 = time.perf_counter()
-        errors = g.optimize(10)
-        opt_ms = (time.perf_counter() - t0) * 1e3
-        # the reference's criterion closure (benches/graph_slam.rs:9-10): PoseGraph::new(file)?.optimize(10, false, false),
-        # parsing, analysis, device set-up and tear-down all inside; only for file workloads
-        closure_ms = None
-        if not args.workload.startswith("grid:"):
-            reps = []
-            for _ in range(5):
-                t0 = time.perf_counter()
-                gg = make_graph(args.workload, args.precision, local_rank)
-                gg.optimize(10)
-                del gg
-                reps.append((time.perf_counter() - t0) * 1e3)
-            closure_ms = sorted(reps)[len(reps) // 2]
-        # per-kernel-class timing with HIP events on the library's stream (eager launches)
-        g.set_state(state0)
-        prof = g.profile(20)
-        per_iter_us = {k: 1e3 * v[0] / 20 for k, v in prof.items()}   # HIP events on the library's stream
-        class_bytes = {"linearize": stats["bytes_linearize"], "factor": stats["bytes_factor"],
-                       "solve": stats["bytes_solve"], "update": stats["bytes_update"]}
-        kernel_of = {"linearize": "k_linearize", "factor": "k_factor_tasks", "solve": "k_solve_tasks",
-                     "update": "k_update", "reduce": "k_finalize_slot", "big_assembly": "k_big_zero+k_big_assemble+k_big_extend_add",
-                     "big_panel": "k_big_diag32+k_big_panel32", "big_update": "k_big_update", "mid_factor": "k_factor_mid",
-                     "big_solve": "k_big_gemv_partial+k_big_gemv_finish+k_solve_mid"}
-        dom = max((k for k in per_iter_us if k != "reduce"), key=lambda k: per_iter_us[k])
-        n_launch = prof[dom][1] / 20
-        dom_us = per_iter_us[dom]
-        if dom == "big_update":
-            # the rank updates of the huge fronts are dense contractions on the matrix cores
-            achieved = stats["big_update_flops"] / (dom_us * 1e-6) / 1e12
-            peak = MFMA_PEAK_TFLOPS[args.precision]
-            roofline = {"bound": "mfma", "kernel": kernel_of[dom], "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                        "frac": achieved / peak, "traffic": None, "launches_per_step": n_launch,
-                        "avg_launch_us": dom_us / max(n_launch, 1),
-                        "algorithmic_flops_per_launch": stats["big_update_flops"] / max(n_launch, 1),
-                        "per_step_us_by_kernel_class": per_iter_us}
-        else:
-            # fronts beyond LDS share the factor/solve byte budget with the LDS fronts
-            nbytes = class_bytes.get(dom, stats["bytes_solve"] if dom == "big_solve" else stats["bytes_factor"])
-            achieved = nbytes / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
-            roofline = {"bound": "hbm", "kernel": kernel_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "launches_per_step": n_launch,
-                        "avg_launch_us": dom_us / max(n_launch, 1),
-                        "algorithmic_bytes_per_launch": nbytes / max(n_launch, 1),
-                        "per_step_us_by_kernel_class": per_iter_us}
-        # graphs with fronts beyond LDS: the dense trailing update is the one kernel bounded by the matrix
-        # cores; its utilisation is reported beside the dominant class whichever that is
-        mfma_kernel = None
-        if per_iter_us.get("big_update", 0) > 0:
-            tf = stats["big_update_flops"] / (per_iter_us["big_update"] * 1e-6) / 1e12
-            mfma_kernel = {"kernel": "k_big_update", "achieved": tf, "peak": MFMA_PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
-                           "frac": tf / MFMA_PEAK_TFLOPS[args.precision], "us_per_step": per_iter_us["big_update"],
-                           "launches_per_step": prof["big_update"][1] / 20, "flops_per_step": stats["big_update_flops"]}
-        # HBM traffic of the dominant kernel: measured offline with rocprofv3 --pmc (separate passes),
-        # kept in profiles/pmc_traffic.json; null when no measurement exists for this workload + kernel
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            ent = pmc.get(f"{args.workload}:{args.precision}")
-            if not (ent and ent["kernel"] == roofline["kernel"]):   # the dominant class may be the MFMA kernel
-                ent = pmc.get(f"{args.workload}:{args.precision}:{roofline['kernel']}")
-            if ent and ent["kernel"] == roofline["kernel"]:
-                roofline["traffic"] = ent["traffic_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"
-            # the dense trailing update against its OTHER roof: K = 128 columns per pass over the trailing matrix
-            # bounds its arithmetic intensity, so the measured HBM traffic per launch prices it against HBM too
-            ent = pmc.get(f"{args.workload}:{args.precision}:k_big_update")
-            if ent and mfma_kernel:
-                us = mfma_kernel["us_per_step"] / mfma_kernel["launches_per_step"]
-                mfma_kernel["traffic"] = ent["traffic_bytes_per_launch"]
-                mfma_kernel["hbm_achieved_GBps"] = ent["traffic_bytes_per_launch"] / (us * 1e-6) / 1e9
-                mfma_kernel["hbm_frac"] = mfma_kernel["hbm_achieved_GBps"] / HBM_PEAK_GBPS
-                mfma_kernel["flop_per_byte"] = mfma_kernel["flops_per_step"] / mfma_kernel["launches_per_step"] / ent["traffic_bytes_per_launch"]
-        except (OSError, ValueError):
-            pass
-        out = {
-            "metric": "GN iterations/s", "value": value, "unit": "GN iterations/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
-            "dtype": args.precision, "data": "reference dataset file" if not args.workload.startswith("grid:") else "synthetic",
-            "config": {"workload": f"{args.workload} ({g.num_nodes} poses / {g.num_edges} edges / dim {g.len}), "
-                                   f"Gauss-Newton, " + ("ONE graph sharded over the ranks" if shard else "one independent replica per GPU"),
-                       "solver": "GaussNewton",
-                       "parallelism": ("sharded%d" % world) if shard else ("replicas" if world > 1 else "single")},
-            "edges_iters_per_s": value * g.num_edges,
-            "optimize10_ms": opt_ms, "new_plus_optimize10_ms": closure_ms, "errors": [float(e) for e in errors],
-            "analyze_ms": stats["analyze_ms"], "parse_ms": stats["parse_ms"],
-            "launches_per_step": stats["n_launches_per_iter"], "supernodes": stats["n_supernodes"],
-            "factor_flops": 2 * stats["factor_flops"], "algorithmic_bytes_per_step": sum(class_bytes.values()),
-            "big_fronts": stats["n_big_fronts"], "max_front": stats["max_front"],
-            "roofline": roofline, "mfma_kernel": mfma_kernel,
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(args.workload)
-            ref = np.array(cb.pop("errors"))
-            out["cpu_baseline"] = cb
-            out["chi2_final"] = float(errors[-1])
-            if cb["unit"] == "GN iterations/s":   # same graph on both sides
-                out["chi2_rel_diff_vs_cpu"] = abs(min(errors) - ref[-1]) / ref[-1]
-                out["speedup_vs_cpu_baseline"] = value / cb["value"]
+        errors, norms = drv.optimize(10)
+        if rank == 0:
+            out = {"metric": "GN iterations/s", "value": value, "unit": "GN iterations/s", "n_gpus": world, "steps": args.steps,
+                   "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+                   "vs_baseline": None, "dtype": args.precision,
+                   "data": "synthetic" if args.workload.startswith("grid:") else "reference dataset file",
+                   "config": {"workload": f"{args.workload} ({g.num_nodes} poses / {g.num_edges} edges / dim {g.len}), Gauss-Newton, "
+                                          f"ONE graph sharded over {world} ranks", "solver": "GaussNewton", "parallelism": "sharded%d" % world},
+                   "edges_iters_per_s": value * g.num_edges, "errors": [float(e) for e in errors], "norm_dx": [float(n) for n in norms],
+                   "chi2_final": float(errors[-1]), "exchange_bytes_per_step": drv.exchange_bytes_per_step(),
+                   "collectives": drv.collectives_description(), "roofline": None, "cpu_baseline": None}
+            gold = golden_chi2(args.workload)
+            if gold is not None:
+                out["chi2_rel_diff_vs_oracle"] = abs(min(errors) - gold) / gold
+    else:
+        g, state0, dt = measure_single(ctx, args.workload, args.precision, args.steps, args.warmup)
+        value = args.steps * world / dt
+        if rank == 0:
+            stats = g.stats()
+            # correctness leg: the reference's bench shape, optimize(10) from the initial state
+            g.set_state(state0)
+            t0 = time.perf_counter()
+            errors = g.optimize(10)
+            opt_ms = (time.perf_counter() - t0) * 1e3
+            # the reference's criterion closure (benches/graph_slam.rs:9-10): PoseGraph::new(file)?.optimize(10, false, false),
+            # parsing, analysis, device set-up and tear-down all inside; only for file workloads
+            closure_ms = None
+            if not args.workload.startswith("grid:"):
+                reps = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    gg = make_graph(args.workload, args.precision, local_rank)
+                    gg.optimize(10)
+                    del gg
+                    reps.append((time.perf_counter() - t0) * 1e3)
+                closure_ms = sorted(reps)[len(reps) // 2]
+            g.set_state(state0)
+            roofline, mfma_kernel, class_bytes = roofline_of(g, args.workload, args.precision)
+            out = {
+                "metric": "GN iterations/s", "value": value, "unit": "GN iterations/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": args.precision, "data": "reference dataset file" if not args.workload.startswith("grid:") else "synthetic",
+                "config": {"workload": f"{args.workload} ({g.num_nodes} poses / {g.num_edges} edges / dim {g.len}), "
+                                       f"Gauss-Newton, " + ("one graph on one GPU" if world == 1 else
+                                                            f"{world} independent replicas, one per GPU: replicas (no communication)"),
+                           "solver": "GaussNewton",
+                           "parallelism": "single" if world == 1 else "replicas (no communication)"},
+                "edges_iters_per_s": value * g.num_edges,
+                "optimize10_ms": opt_ms, "new_plus_optimize10_ms": closure_ms, "errors": [float(e) for e in errors],
+                "analyze_ms": stats["analyze_ms"], "parse_ms": stats["parse_ms"],
+                "launches_per_step": stats["n_launches_per_iter"], "supernodes": stats["n_supernodes"],
+                "factor_flops": 2 * stats["factor_flops"], "algorithmic_bytes_per_step": sum(class_bytes.values()),
+                "big_fronts": stats["n_big_fronts"], "max_front": stats["max_front"],
+                "roofline": roofline, "mfma_kernel": mfma_kernel,
+            }
+            gold = golden_chi2(args.workload)
+            if gold is not None:
+                out["chi2_rel_diff_vs_oracle"] = abs(min(errors) - gold) / gold
+            if world == 1 and not args.no_cpu_baseline:
+                cb = cpu_baseline(args.workload)
+                ref = np.array(cb.pop("errors"))
+                out["cpu_baseline"] = cb
+                out["chi2_final"] = float(errors[-1])
+                if cb["unit"] == "GN iterations/s":   # same graph on both sides
+                    out["chi2_rel_diff_vs_cpu"] = abs(min(errors) - ref[-1]) / ref[-1]
+                    out["speedup_vs_cpu_baseline"] = value / cb["value"]
+                else:
+                    out["speedup_vs_cpu_baseline_edges_iters"] = out["edges_iters_per_s"] / cb["edges_iters_per_s"]
+        del g
+
+    # ---- the other BASELINE configs, same contract (skipped when a non-default workload was asked for)
+    if not args.no_secondary and not args.shard and args.workload == "intel" and args.precision == "f64":
+        sec = []
+        plan = [("m3500", "f64", False), (LATTICE, "f32", False), (LATTICE, "mixed", False), ("sphere2500", "f64", False)]
+        if world > 1:   # multi-GPU legs of configs[3] and configs[4]: ONE graph over all ranks
+            plan = [(LATTICE, "mixed", True), (LATTICE, "f32", True), ("sphere2500", "f64", True)]
+        elif os.environ.get("RR_PGO_BENCH_NCCL1", "1") != "0":
+            plan.append((LATTICE, "mixed", "nccl1"))
+        for workload, precision, sharded in plan:
+            if sharded == "nccl1":
+                # the sharded protocol over a ONE-rank RCCL group: same stages and collectives as at N > 1, so the
+                # RCCL code path executes on a single-GPU box (its time is the protocol's overhead at P = 1)
+                try:
+                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                    os.environ.setdefault("MASTER_PORT", "29517")
+                    import torch.distributed as dist
+                    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+                    ctx.dist = dist
+                    rec = secondary_entry(ctx, workload, precision, min(args.steps, 50), min(args.warmup, 5), True)
+                    dist.destroy_process_group()
+                    ctx.dist = None
+                except Exception as e:   # noqa: BLE001
+                    ctx.dist = None
+                    rec = {"workload": workload, "dtype": precision, "parallelism": "sharded1", "error": f"{type(e).__name__}: {e}"}
             else:
-                out["speedup_vs_cpu_baseline_edges_iters"] = out["edges_iters_per_s"] / cb["edges_iters_per_s"]
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+                rec = secondary_entry(ctx, workload, precision, args.steps, args.warmup, sharded)
+            if rec is not None:
+                sec.append(rec)
+        if out is not None:
+            out["secondary"] = sec
+    if ctx.dist:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out))
 

@@ -31,11 +31,18 @@ typedef struct rr_pgo rr_pgo; /* opaque: replaces `struct PoseGraph`, pose_graph
 
 enum {
   RR_PGO_OK = 0,
-  RR_PGO_EINVAL = -1,   /* bad argument / malformed description */
+  RR_PGO_EINVAL = -1,   /* bad argument / malformed description.  Deliberate deviations from the reference, which
+                         * accepts these inputs and then fails (or silently misbehaves) in the solver: a self-loop
+                         * edge (from == to; the reference sums H_ii, H_ij, H_ji, H_jj into one block) and, for the
+                         * loader, a repeated VERTEX id (the reference overwrites the node but keeps the first
+                         * offset, leaving structurally empty rows => singular system) are rejected up front:
+                         * RR_PGO_EINVAL from rr_pgo_create, RR_PGO_EPARSE from rr_pgo_load_g2o. */
   RR_PGO_EIO = -2,      /* file could not be read                         (Err(io) at g2o.rs:51) */
   RR_PGO_EPARSE = -3,   /* malformed g2o text                             (Err/panic at g2o.rs:53-139) */
   RR_PGO_ENODEVICE = -4,/* no usable HIP device / HIP runtime error */
-  RR_PGO_ENOTSPD = -5,  /* factorisation hit a non-positive pivot         (Err from umfpack.factorize, :138) */
+  RR_PGO_ENOTSPD = -5,  /* factorisation hit a non-positive pivot         (Err from umfpack.factorize, :138).
+                         * Like the reference (Err at :271 comes before update_nodes) the handle's state is the one
+                         * before the failed iteration: the step is not applied, the caller may retry, e.g. with LM. */
   RR_PGO_ENOMEM = -6,
   RR_PGO_EUNSUPPORTED = -7
 };
@@ -70,9 +77,11 @@ typedef struct rr_pgo_options {
   int32_t precision;      /* RR_PGO_F64 (default), RR_PGO_F32 or RR_PGO_MIXED */
   int32_t device;         /* HIP device ordinal, -1 = current device */
   int32_t solver;         /* RR_PGO_GAUSS_NEWTON / RR_PGO_LEVENBERG_MARQUARDT (PoseGraph::new's 2nd arg, :215) */
-  /* Multi-GPU sharding of ONE graph.  world_size <= 1: single GPU. */
+  /* Multi-GPU sharding of ONE graph.  world_size <= 1: single GPU; else a power of two <= 64. */
   int32_t rank, world_size;
-  int32_t reserved[11];   /* zero */
+  int32_t sharded;        /* 1: build the handle for rr_pgo_stage even with world_size <= 1 (a one-rank group: same
+                           * stages, same collectives); world_size > 1 implies it */
+  int32_t reserved[10];   /* zero */
 } rr_pgo_options;
 
 void rr_pgo_default_options(rr_pgo_options *opt);
@@ -203,27 +212,38 @@ void rr_pgo_synth_free(rr_pgo_synth *s);
 
 /* ---- sharding ONE graph over ranks ------------------------------ */
 
-/* A handle created with opt.world_size = P > 1 (power of two) and opt.rank = r owns the subtrees
- * of partition r of the nested dissection; the top log2(P) separator levels are shared.  Every rank
- * creates its handle from the SAME graph.  One Gauss-Newton iteration is three stages with two
- * sum all-reduces (RCCL) between them, done by the caller on the two exchange buffers:
+/* A handle created with opt.world_size = P > 1 (power of two, <= 64) and opt.rank = r owns the subtrees
+ * of partition r of the nested dissection (its nodes, their edges, their fronts); the top log2(P)
+ * separator levels -- and the anchor node -- are shared: every rank holds their state and factors their
+ * fronts redundantly, so there is no panel traffic on the sequential chain of the top fronts.  Every rank
+ * creates its handle from the SAME graph.  One Gauss-Newton iteration is two stages and two collectives
+ * (the reference has no counterpart: its only parallel construct is pose_graph_optimization.rs:230):
  *
- *   rr_pgo_stage(h, 0, lambda, lm)   linearise, factor own subtrees, publish boundary update matrices
- *   all-reduce(sum) buffer 0         (boundary update matrices; zero where this rank owns nothing)
- *   rr_pgo_stage(h, 1, ...)          shared top fronts (redundant), back substitution, mask the solution
- *   all-reduce(sum) buffer 1         (the solution dx in permuted order; each entry owned by one rank)
- *   rr_pgo_stage(h, 2, ...)          update all poses, chi2 / |dx| -> rr_pgo_stage_scalars
+ *   rr_pgo_stage(h, 0, lambda, lm)   linearise the rank's nodes (:305-369 restricted to own + shared nodes),
+ *                                    factor its own subtrees, publish the boundary fronts' update matrices in
+ *                                    chunk r of exchange buffer 0
+ *   ALL-GATHER of buffer 0           in place: rank r contributes elements [r * n / P, (r + 1) * n / P)
+ *   rr_pgo_stage(h, 1, ...)          shared top fronts, back substitution (top + own subtrees), update_nodes
+ *                                    (:229-245) for own + shared nodes, partial chi2 / |dx|^2 -> buffer 1
+ *   ALL-REDUCE (sum) of buffer 1     two doubles; only the stop rule (:298-300) and the log need them
+ *   rr_pgo_stage(h, 2, ...)          chi2 of the current state only (partial -> buffer 1, then the same
+ *                                    all-reduce): the last entry of optimize()'s error list
  *
- * rr_pgo_sync(h) must separate a stage from the collective that follows it (the library runs on its
- * own stream).  Buffers are device memory of element size *elem_size (4 or 8); the caller may bind
- * memory it allocated itself (so that its collective library can register it) with
- * rr_pgo_set_exchange_buffer before the first stage. */
+ * Every edge's chi2 term and every node's |dx|^2 is counted by exactly one rank.  A rank's copy of the state
+ * is valid for its own and the shared nodes (rr_pgo_node_owner says which); rr_pgo_get_state returns the
+ * rank's copy.  The library enqueues on its own stream (rr_pgo_stream): issue the collectives on that stream
+ * and an iteration needs no host synchronisation.  Buffers are device memory of element size *elem_size (4 or
+ * 8 for buffer 0, 8 for buffer 1); the caller may bind memory it allocated itself (so that its collective
+ * library can register it) with rr_pgo_set_exchange_buffer before the first stage. */
 int rr_pgo_exchange_buffer(rr_pgo *h, int32_t which, void **dev_ptr, int64_t *n_elems, int32_t *elem_size);
 int rr_pgo_set_exchange_buffer(rr_pgo *h, int32_t which, void *dev_ptr, int64_t n_elems);
 int rr_pgo_stage(rr_pgo *h, int32_t stage, double lambda, int lm);
-/* chi2 of the state BEFORE the iteration's update and |dx| of the step, valid after stage 2 */
+/* after the all-reduce of buffer 1: chi2 of the state BEFORE the iteration's update and |dx| of the step
+ * (stage 1), or chi2 of the current state (stage 2).  Synchronises the handle's stream. */
 int rr_pgo_stage_scalars(rr_pgo *h, double *chi2, double *norm_dx);
 void *rr_pgo_stream(rr_pgo *h);                           /* hipStream_t the handle launches on */
+/* owner[n_nodes]: rank that owns the node, -1 = shared (top separators, anchor); all 0 on an unsharded handle */
+int rr_pgo_node_owner(const rr_pgo *h, int32_t *owner);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,7 @@ EXPORTS = (
     "rr_pgo_get_state", "rr_pgo_set_state", "rr_pgo_assemble", "rr_pgo_iterate_async", "rr_pgo_sync",
     "rr_pgo_get_stats", "rr_pgo_profile", "rr_pgo_synth_grid", "rr_pgo_synth_free",
     "rr_pgo_exchange_buffer", "rr_pgo_set_exchange_buffer", "rr_pgo_stage", "rr_pgo_stage_scalars", "rr_pgo_stream",
+    "rr_pgo_node_owner",
 )
 
 
@@ -39,7 +40,7 @@ class GraphDesc(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("precision", C.c_int32), ("device", C.c_int32), ("solver", C.c_int32), ("rank", C.c_int32),
-                ("world_size", C.c_int32), ("reserved", C.c_int32 * 11)]
+                ("world_size", C.c_int32), ("sharded", C.c_int32), ("reserved", C.c_int32 * 10)]
 
 
 class Stats(C.Structure):
@@ -65,6 +66,15 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). rustrobotics_amd has no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64; a process that loads /opt/rocm's copy first (through this
+    # library) and torch's later ends up with two HIP runtimes, and the second one finds no device.  Loading
+    # torch first makes both resolve to the same runtime (same SONAME).  RR_PGO_NO_TORCH_PRELOAD=1 skips this
+    # for torch-free callers.
+    if not os.environ.get("RR_PGO_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)
     L.rr_pgo_default_options.argtypes = [C.POINTER(Options)]
@@ -100,5 +110,6 @@ def load():
     L.rr_pgo_stage_scalars.argtypes = [vp, dp, dp]
     L.rr_pgo_stream.argtypes = [vp]
     L.rr_pgo_stream.restype = vp
+    L.rr_pgo_node_owner.argtypes = [vp, ip]
     _lib = L
     return L

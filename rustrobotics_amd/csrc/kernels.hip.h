@@ -101,7 +101,9 @@ template <typename T, typename TC = T> struct LinArgs {
   const typename VecT<TC>::V4 *e_info_a; // i11 i12 i13 i22
   const typename VecT<TC>::V2 *e_info_b; // i23 i33
   const int64_t *e_slot;                 // (offset into hvals << 1) | transposed
-  const int32_t *inc_ptr, *inc_list;     // entry = edge << 2 | kind << 1 | role
+  const int32_t *inc_ptr, *inc_list;     // entry = edge << 4 | offdiag << 3 | owns << 2 | kind << 1 | role (sharded runs: see Engine)
+  const int32_t *node_list;              // sharded runs: the nodes this rank linearises (own + shared), else null;
+                                         // n_nodes is then the length of the list
   const uint8_t *node_dim;               // 3 (SE2) or 2 (XY)
   const int32_t *node_offset;            // reference scalar offset
   const int64_t *diag_off;
@@ -111,6 +113,7 @@ template <typename T, typename TC = T> struct LinArgs {
   int anchor;                            // node that gets the 1e7 prior (:330-336), -1 none
   TC lambda;                             // added to every diagonal entry when > 0 (LM, :362-366)
   int write_system;                      // 0: chi2 only
+  const uint8_t *adds_diag;              // sharded runs: per node, 1 = this rank adds prior / lambda (shared nodes: rank 0)
 };
 
 // ---------------------------------------------------------------- factor maths
@@ -185,18 +188,24 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<TO, T> a) {
   using V2 = typename VecT<T>::V2;
   __shared__ double red[LIN_THREADS / 64];
   const int gid = blockIdx.x * LIN_THREADS + threadIdx.x;
-  const int node = gid / LIN_GROUP, sub = gid % LIN_GROUP;
+  const int slot = gid / LIN_GROUP, sub = gid % LIN_GROUP;
+  const int node = slot < a.n_nodes ? (a.node_list ? a.node_list[slot] : slot) : -1;
   double chi = 0.0;
   T hd[6] = {0, 0, 0, 0, 0, 0};  // 00 10 11 20 21 22
   T bv[3] = {0, 0, 0};
   int nd = 0;
-  if (node < a.n_nodes) {
+  if (node >= 0) {
     nd = a.node_dim[node];
     const V4 self = a.pose[node];
     const int q1 = a.inc_ptr[node + 1];
     for (int q = a.inc_ptr[node] + sub; q < q1; q += LIN_GROUP) {
       const int ent = a.inc_list[q];
-      const int k = ent >> 2, kind = (ent >> 1) & 1, role = ent & 1;
+      // sharded runs: an edge contributes to diagonal blocks, right-hand side and chi2 on ONE rank (bit 2, its
+      // owner -- the other ranks' copies of a far endpoint are stale); the off-diagonal block of an edge between
+      // two shared nodes is written by every rank (bit 3)
+      if (!(ent & 12)) continue;
+      const bool owns = ent & 4;
+      const int k = ent >> 4, kind = (ent >> 1) & 1, role = ent & 1;
       const int2 ft = a.e_idx[k];
       const V4 other = a.pose[role ? ft.x : ft.y];
       const V4 z = a.e_meas[k];
@@ -216,7 +225,7 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<TO, T> a) {
           for (int r = 0; r < 3; r++) s += (role ? B[r][i] : A[r][i]) * W[r][j];
           JW[i][j] = s;
         }
-      if (a.write_system) {
+      if (a.write_system && owns) {
         int t = 0;
 #pragma unroll
         for (int i = 0; i < 3; i++)
@@ -235,8 +244,8 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<TO, T> a) {
         T we0 = W[0][0] * e[0] + W[0][1] * e[1] + W[0][2] * e[2];
         T we1 = W[1][0] * e[0] + W[1][1] * e[1] + W[1][2] * e[2];
         T we2 = W[2][0] * e[0] + W[2][1] * e[1] + W[2][2] * e[2];
-        chi += (double)(e[0] * we0 + e[1] * we1 + e[2] * we2);
-        if (a.write_system) {
+        if (owns) chi += (double)(e[0] * we0 + e[1] * we1 + e[2] * we2);   // every edge's term is owned by one rank
+        if (a.write_system && (ent & 8)) {
           // off-diagonal block H[from rows, to cols] = A^T W B
           const int64_t so = a.e_slot[k];
           TO *dst = a.hvals + (so >> 1);
@@ -259,9 +268,10 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<TO, T> a) {
     for (int t = 0; t < 6; t++) hd[t] = group_sum8(hd[t]);
 #pragma unroll
     for (int t = 0; t < 3; t++) bv[t] = group_sum8(bv[t]);
-    if (node < a.n_nodes && sub == 0) {
+    if (node >= 0 && sub == 0) {
       T add = a.lambda;
       if (node == a.anchor) add += (T)10000000.0;
+      if (a.adds_diag && !a.adds_diag[node]) add = 0;
       TO *d = a.hvals + a.diag_off[node];
       if (nd == 3) {
         d[0] = (TO)(hd[0] + add); d[1] = (TO)hd[1];         d[2] = (TO)hd[3];
@@ -294,7 +304,8 @@ template <typename T, typename TC = T> struct LinArgs3 {
   const typename VecT<TC>::V4 *e_meas;  // 2 per edge, same packing
   const TC *e_info;                     // 21 per edge, row-major upper triangle
   const int64_t *e_slot;
-  const int32_t *inc_ptr, *inc_list;    // entry = edge << 2 | role
+  const int32_t *inc_ptr, *inc_list;    // entry = edge << 4 | offdiag << 3 | owns << 2 | role
+  const int32_t *node_list;             // sharded runs: the nodes this rank linearises, else null
   const int32_t *node_offset;
   const int64_t *diag_off;
   T *hvals;
@@ -303,6 +314,7 @@ template <typename T, typename TC = T> struct LinArgs3 {
   int anchor;
   TC lambda;
   int write_system;
+  const uint8_t *adds_diag;             // sharded runs: per node, 1 = this rank adds prior / lambda
 };
 
 template <typename T> __device__ __forceinline__ void q_mul(const T a[4], const T b[4], T r[4]) {
@@ -387,20 +399,23 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize_se3(LinArgs3<TO, T> a
   using V4 = typename VecT<T>::V4;
   __shared__ double red[LIN_THREADS / 64];
   const int gid = blockIdx.x * LIN_THREADS + threadIdx.x;
-  const int node = gid / LIN_GROUP, sub = gid % LIN_GROUP;
+  const int slot = gid / LIN_GROUP, sub = gid % LIN_GROUP;
+  const int node = slot < a.n_nodes ? (a.node_list ? a.node_list[slot] : slot) : -1;
   double chi = 0.0;
   T hd[21], bv[6];   // lower triangle of the 6 x 6 diagonal block, row-major: (0,0),(1,0),(1,1),...
 #pragma unroll
   for (int t = 0; t < 21; t++) hd[t] = 0;
 #pragma unroll
   for (int t = 0; t < 6; t++) bv[t] = 0;
-  if (node < a.n_nodes) {
+  if (node >= 0) {
     const V4 st = a.pose[2 * node], sq = a.pose[2 * node + 1];
     const T ts[3] = {st.x, st.y, st.z}, qs[4] = {sq.x, sq.y, sq.z, sq.w};
     const int q1 = a.inc_ptr[node + 1];
     for (int q = a.inc_ptr[node] + sub; q < q1; q += LIN_GROUP) {
       const int ent = a.inc_list[q];
-      const int k = ent >> 2, role = ent & 1;
+      if (!(ent & 12)) continue;   // sharded runs: see k_linearize
+      const bool owns = ent & 4;
+      const int k = ent >> 4, role = ent & 1;
       const int2 ft = a.e_idx[k];
       const int other = role ? ft.x : ft.y;
       const V4 ot = a.pose[2 * other], oq = a.pose[2 * other + 1];
@@ -429,7 +444,7 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize_se3(LinArgs3<TO, T> a
           for (int r = 0; r < 6; r++) sacc += J[r][i] * W[r][j];
           JW[i][j] = sacc;
         }
-      if (a.write_system) {
+      if (a.write_system && owns) {
         int t = 0;
 #pragma unroll
         for (int i = 0; i < 6; i++)
@@ -457,8 +472,8 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize_se3(LinArgs3<TO, T> a
           for (int r = 0; r < 6; r++) we += W[i][r] * e[r];
           c2 += e[i] * we;
         }
-        chi += (double)c2;
-        if (a.write_system) {
+        if (owns) chi += (double)c2;
+        if (a.write_system && (ent & 8)) {
           // off-diagonal block H[from rows, to cols] = A^T W B: B of the same edge
           T e2[6], Bm[6][6];
           edge_linearize_3d<T>(1, ts, qs, to, qo, tz, qz, e2, Bm);
@@ -483,9 +498,10 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize_se3(LinArgs3<TO, T> a
     for (int t = 0; t < 21; t++) hd[t] = group_sum8(hd[t]);
 #pragma unroll
     for (int t = 0; t < 6; t++) bv[t] = group_sum8(bv[t]);
-    if (node < a.n_nodes && sub == 0) {
+    if (node >= 0 && sub == 0) {
       T add = a.lambda;
       if (node == a.anchor) add += (T)10000000.0;
+      if (a.adds_diag && !a.adds_diag[node]) add = 0;
       TO *d = a.hvals + a.diag_off[node];
       int t = 0;
 #pragma unroll
@@ -515,16 +531,19 @@ template <typename T, typename TC = T> struct UpdArgs3 {
   double *norm_partial;
   int export_only;     // 1: only write dx_ref_out
   const int *err;      // sticky device error flag: a failed factorisation must not touch the state
+  const int32_t *node_list;    // sharded runs: the nodes this rank updates (own + shared), n_nodes = its length
+  const uint8_t *norm_counts;  // sharded runs: per node, 1 = this rank adds the node's |dx|^2 (every node counted once)
 };
 
 // X <- X * (dt, Exp(dw)):  t += R dt ;  q <- normalise( q (x) exp(dw) )
 template <typename TO, typename T>
 __global__ void __launch_bounds__(UPD_THREADS) k_update_se3(UpdArgs3<TO, T> a) {
   __shared__ double red[UPD_THREADS / 64];
-  const int node = blockIdx.x * UPD_THREADS + threadIdx.x;
+  const int slot = blockIdx.x * UPD_THREADS + threadIdx.x;
+  const int node = slot < a.n_nodes ? (a.node_list ? a.node_list[slot] : slot) : -1;
   double nrm = 0.0;
   const bool failed = a.err && *a.err != 0;
-  if (node < a.n_nodes && !failed) {
+  if (node >= 0 && !failed) {
     T d[6];
     const TO *src = a.dx_ref_in ? a.dx_ref_in + a.node_offset[node] : a.x + a.node_pcol[node];
 #pragma unroll
@@ -537,6 +556,7 @@ __global__ void __launch_bounds__(UPD_THREADS) k_update_se3(UpdArgs3<TO, T> a) {
     if (a.export_only) return;
 #pragma unroll
     for (int t = 0; t < 6; t++) { nrm += (double)d[t] * (double)d[t]; d[t] *= a.sign; }
+    if (a.norm_counts && !a.norm_counts[node]) nrm = 0.0;
     auto pt = a.pose[2 * node], pq = a.pose[2 * node + 1];
     const T q[4] = {pq.x, pq.y, pq.z, pq.w};
     T rt[3];
@@ -2692,14 +2712,24 @@ template <typename T> __global__ void __launch_bounds__(256) k_pack_boundary(Fac
   }
 }
 
-// Before the all-reduce of the solution: keep the columns this rank owns (rank 0 also keeps the
-// shared ones, which every rank computed identically), zero the rest.
-template <typename T> __global__ void k_mask_x(int n, T *x, const int8_t *col_owner, int rank) {
+// The shared nodes' diagonal blocks and right-hand-side entries are sums over edges of ALL ranks: every rank
+// publishes its partial sums behind its update matrices (k_pack_shared, list = (source offset in hvals or
+// ~offset in b, length) per shared node, packed back to back at `off` of the rank's chunk); after the
+// all-gather every rank adds the P partials in rank order (k_sum_shared): identical bits everywhere.
+template <typename T> __global__ void __launch_bounds__(256) k_pack_shared(const int64_t *src_off, int n, const T *hvals, const T *b, T *dst) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) {
-    const int o = col_owner[i];
-    if (!(o == rank || (o < 0 && rank == 0))) x[i] = 0;
-  }
+  if (i >= n) return;
+  const int64_t so = src_off[i];
+  dst[i] = so >= 0 ? hvals[so] : b[~so];
+}
+template <typename T> __global__ void __launch_bounds__(256) k_sum_shared(const int64_t *src_off, int n, T *hvals, T *b, const T *xch, int64_t chunk, int64_t off, int P) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  T s = 0;
+  for (int r = 0; r < P; r++) s += xch[(int64_t)r * chunk + off + i];
+  const int64_t so = src_off[i];
+  if (so >= 0) hvals[so] = s;
+  else b[~so] = s;
 }
 
 // ------------------------------------------------------------------ gauge transfer (single-precision factor)
@@ -2761,6 +2791,8 @@ template <typename T, typename TC = T> struct UpdArgs {
   int gauge_anchor;    // >= 0: x is a solution in the root-separator gauge; transfer it to the anchor gauge first
   int export_only;     // 1: only write dx_ref_out (rr_pgo_linearize_solve), the state stays as it is
   const int *err;      // sticky device error flag: a failed factorisation must not touch the state
+  const int32_t *node_list;    // sharded runs: the nodes this rank updates (own + shared), n_nodes = its length
+  const uint8_t *norm_counts;  // sharded runs: per node, 1 = this rank adds the node's |dx|^2 (every node counted once)
 };
 
 // update_nodes (:229-245) + |dx|^2 (:273).  The step of a failed factorisation (non-positive pivot) is NOT
@@ -2768,10 +2800,11 @@ template <typename T, typename TC = T> struct UpdArgs {
 template <typename TO, typename T>
 __global__ void __launch_bounds__(UPD_THREADS) k_update(UpdArgs<TO, T> a) {
   __shared__ double red[UPD_THREADS / 64];
-  const int node = blockIdx.x * UPD_THREADS + threadIdx.x;
+  const int slot = blockIdx.x * UPD_THREADS + threadIdx.x;
+  const int node = slot < a.n_nodes ? (a.node_list ? a.node_list[slot] : slot) : -1;
   double nrm = 0.0;
   const bool failed = a.err && *a.err != 0;
-  if (node < a.n_nodes && !failed) {
+  if (node >= 0 && !failed) {
     const int nd = a.node_dim[node];
     T d[3] = {0, 0, 0};
     const TO *src = a.dx_ref_in ? a.dx_ref_in + a.node_offset[node] : a.x + a.node_pcol[node];
@@ -2793,7 +2826,8 @@ __global__ void __launch_bounds__(UPD_THREADS) k_update(UpdArgs<TO, T> a) {
       for (int t = 0; t < nd; t++) dst[t] = (TO)d[t];
     }
     if (!a.export_only && !(regauge && node == a.gauge_anchor)) {
-      for (int t = 0; t < nd; t++) nrm += (double)d[t] * (double)d[t];
+      if (!a.norm_counts || a.norm_counts[node])
+        for (int t = 0; t < nd; t++) nrm += (double)d[t] * (double)d[t];
       p.x += a.sign * d[0];
       p.y += a.sign * d[1];
       if (nd == 3) {  // rotation *= UnitComplex::from_angle(dtheta), no renormalisation (:236)

@@ -95,6 +95,36 @@ struct StreamPool {
 };
 static StreamPool &stream_pool() { static StreamPool *p = new StreamPool; return *p; }   // leaked on purpose: outlives the runtime's teardown order
 
+// RAII holders: an Engine constructor that throws (hipMalloc failure, RR_PGO_EUNSUPPORTED) still releases these
+struct PooledStream {
+  hipStream_t s = nullptr;
+  PooledStream() = default;
+  PooledStream(const PooledStream &) = delete;
+  PooledStream &operator=(const PooledStream &) = delete;
+  ~PooledStream() { if (s) stream_pool().put(s); }
+  void acquire() { if (!s) s = stream_pool().get(); }
+  operator hipStream_t() const { return s; }
+};
+struct EventHolder {
+  hipEvent_t e = nullptr;
+  EventHolder() = default;
+  EventHolder(const EventHolder &) = delete;
+  EventHolder &operator=(const EventHolder &) = delete;
+  ~EventHolder() { if (e) (void)hipEventDestroy(e); }
+  void create(unsigned flags) { if (!e) HIPCHK(hipEventCreateWithFlags(&e, flags)); }
+  operator hipEvent_t() const { return e; }
+};
+template <typename U> struct PinnedBuf {
+  U *p = nullptr;
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf &) = delete;
+  PinnedBuf &operator=(const PinnedBuf &) = delete;
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+  void alloc(size_t n) { HIPCHK(hipHostMalloc((void **)&p, n * sizeof(U))); }
+  U &operator[](size_t i) const { return p[i]; }
+  operator U *() const { return p; }
+};
+
 template <typename U> struct DevBuf {
   U *p = nullptr;
   size_t n = 0;
@@ -163,6 +193,20 @@ __global__ void k_finalize_slot(const double *chi_partial, int n_chi, const doub
   }
 }
 
+// sharded runs: this rank's partial sums (chi2, |dx|^2) for the caller's sum all-reduce; `which` bit 0 = chi2, bit 1 = |dx|^2
+__global__ void k_finalize_partial(const double *chi_partial, int n_chi, const double *norm_partial, int n_norm, double *scal) {
+  __shared__ double red[4];
+  double c = 0.0, n = 0.0;
+  for (int i = threadIdx.x; i < n_chi; i += 256) c += chi_partial[i];
+  for (int i = threadIdx.x; i < n_norm; i += 256) n += norm_partial[i];
+  double ct = block_sum<double, 256>(c, red);
+  double nt = block_sum<double, 256>(n, red);
+  if (threadIdx.x == 0) {
+    if (n_chi > 0) scal[0] = ct;
+    scal[1] = n_norm > 0 ? nt : 0.0;
+  }
+}
+
 // T: type of H, b, L, x (factor + solve).  S: type of the state, the measurements and the
 // linearisation arithmetic (S == T, or S = double with T = float: "mixed" mode).
 template <typename T, typename S = T> class Engine final : public EngineBase {
@@ -171,7 +215,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   const HostGraph &g_;
   const Symbolic &sym_;
   DeviceArena arena_;   // declared before every DevBuf: destroyed after them
-  hipStream_t stream_ = nullptr;
+  PooledStream stream_;
   hipGraphExec_t gn_exec_ = nullptr;
   // graph data
   DevBuf<V4> pose_, e_meas_, e_info_a_;
@@ -184,7 +228,17 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   bool is3d_ = false;
   // sharding over ranks
   int rank_ = 0, world_ = 1;
-  DevBuf<T> xch_own_;               // exchange buffer (boundary update matrices) unless the caller binds one
+  bool sharded_ = false;            // driven by rr_pgo_stage (world_size > 1, or opt.sharded with one rank)
+  int64_t xch_n_ = 0;               // elements of exchange buffer 0: world * chunk
+  DevBuf<int32_t> node_list_;       // nodes this rank linearises and updates: own + shared (null: all)
+  DevBuf<uint8_t> norm_counts_;     // per node: this rank adds its |dx|^2 to the partial sum (and prior / lambda to its diagonal)
+  DevBuf<int64_t> shared_src_;      // scalars of the shared nodes' diagonal blocks and rhs (k_pack_shared / k_sum_shared)
+  int n_shared_ = 0;
+  int n_list_ = 0;
+  DevBuf<double> scal_own_;         // exchange buffer 1: partial (chi2, |dx|^2) unless the caller binds one
+  double *scal_ = nullptr;
+  hipGraphExec_t stage_exec_[2] = {nullptr, nullptr};
+  DevBuf<T> xch_own_;               // exchange buffer 0 (boundary update matrices) unless the caller binds one
   T *xch_ = nullptr, *x_ptr_ = nullptr;
   bool left_looking_ = true;        // RR_PGO_RIGHT_LOOKING=1: the older diag / trsm / K=32 update launches
   int small_tile_below_ = 1 << 30;  // trailing updates of fewer 128 x 128 tiles than this use 64 x 64 tiles: measured best on EVERY
@@ -198,9 +252,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   bool overlap_ = false;            // RR_PGO_OVERLAP=1: the far part of a trailing update on a second stream, beside the next panel chain (measured neutral so far)
   int overlap_max_nf_ = 1 << 30;    // RR_PGO_OVERLAP=<n>: only on levels with at most n fronts
   bool rest_pending_ = false;       // a rest-update is in flight on stream2_ (ev_rest_ marks its end)
-  hipStream_t stream2_ = nullptr;
-  hipEvent_t ev_chain_ = nullptr, ev_rest_ = nullptr;
-  DevBuf<int8_t> col_owner_;
+  PooledStream stream2_;
+  EventHolder ev_chain_, ev_rest_;
   // gauge transfer (single-precision factor, Gauss-Newton; kernels.hip.h "gauge transfer")
   bool gauge_ok_ = false;            // the root front is a big front with an SE2 pivot node
   bool gauge_now_ = false;           // the system being factored was linearised without the anchor prior
@@ -226,20 +279,21 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   bool head_done_ = false;           // this factorisation has already zeroed and assembled every big front
   DevBuf<ChildMeta> child_meta_;
   std::vector<int> step_solve_lds_;  // scalars of LDS the back-solve of each step needs
-  double *host_pair_ = nullptr;      // pinned: chi2, |dx|, and (as an int in slot 2) the device error flag
+  PinnedBuf<double> host_pair_;      // pinned: chi2, |dx|, and (as an int in slot 2) the device error flag
   int n_lin_blocks_ = 0, n_upd_blocks_ = 0;
   int host_counter_ = 0;             // mirrors the device slot counter
 
  public:
-  Engine(const HostGraph &g, const Symbolic &sym, int rank, int world) : g_(g), sym_(sym), rank_(rank), world_(world) {
+  Engine(const HostGraph &g, const Symbolic &sym, int rank, int world, bool sharded)
+      : g_(g), sym_(sym), rank_(rank), world_(world), sharded_(sharded || world > 1) {
     struct ArenaScope {   // every DevBuf::alloc of this constructor draws from arena_
       explicit ArenaScope(DeviceArena *a) { t_arena = a; }
       ~ArenaScope() { t_arena = nullptr; }
     } scope(&arena_);
     // the factor storage dominates: one chunk sized for it and the value arrays, tables follow in 8 MB chunks
     arena_.reserve((size_t)(sym.l_elems + sym.u_elems + sym.n_hvals + 8 * (int64_t)g.dim + sym.xch_elems) * sizeof(T) + (4u << 20));
-    stream_ = stream_pool().get();
-    HIPCHK(hipHostMalloc((void **)&host_pair_, 3 * sizeof(double)));
+    stream_.acquire();
+    host_pair_.alloc(3);
     const int N = g.n_nodes(), E = g.n_edges();
     // ---- graph arrays
     is3d_ = g.has_se3;
@@ -300,9 +354,17 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       e_info3_.upload(einfo);
     }
     std::vector<int32_t> inc(sym.inc_list.size());
+    if (E >= (1 << 27)) throw ApiError(RR_PGO_EUNSUPPORTED, "more than 2^27 edges");
     for (size_t q = 0; q < inc.size(); q++) {
       int k = sym.inc_list[q] >> 1, role = sym.inc_list[q] & 1;
-      inc[q] = (k << 2) | ((g.edge_kind[k] == EDGE_SE2_XY ? 1 : 0) << 1) | role;
+      // Sharded runs: an edge's contributions to diagonal blocks, right-hand side and chi2 are computed by ONE
+      // rank, its owner = the rank of its from-node, else of its to-node, else (both shared) rank 0 -- only
+      // the owner is sure to hold current poses of both endpoints.  The off-diagonal block of an edge between
+      // two shared nodes is needed (and computable) on every rank.
+      const int pf = world_ > 1 ? sym.node_part[g.edge_from[k]] : 0, pt = world_ > 1 ? sym.node_part[g.edge_to[k]] : 0;
+      const int owns = (pf >= 0 ? pf : pt >= 0 ? pt : 0) == rank_ ? 1 : 0;
+      const int offd = role == 0 && (owns || (pf < 0 && pt < 0)) ? 1 : 0;
+      inc[q] = (k << 4) | (offd << 3) | (owns << 2) | ((g.edge_kind[k] == EDGE_SE2_XY ? 1 : 0) << 1) | role;
     }
     inc_ptr_.upload(sym.inc_ptr);
     inc_list_.upload(inc);
@@ -317,11 +379,36 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     dx_ref_.alloc((size_t)g.dim);
     b_.zero(); x_.zero(); dx_ref_.zero();
     x_ptr_ = x_.p;
-    if (world_ > 1) {
-      xch_own_.alloc((size_t)sym.xch_elems + 4);
+    n_list_ = N;
+    if (sharded_) {
+      xch_n_ = std::max<int64_t>(sym.xch_elems, 64 * (int64_t)world_);
+      xch_own_.alloc((size_t)xch_n_ + 4);
       xch_own_.zero();
       xch_ = xch_own_.p;
-      col_owner_.upload(sym.col_owner);
+      scal_own_.alloc(2);
+      scal_own_.zero();
+      scal_ = scal_own_.p;
+    }
+    if (world_ > 1) {
+      std::vector<int32_t> nl;
+      std::vector<uint8_t> nc(N);
+      std::vector<int64_t> sh;   // the shared nodes' diagonal blocks (offset in hvals) and rhs entries (~offset in b)
+      for (int i = 0; i < N; i++) {
+        const int pt = sym.node_part[i];
+        if (pt == rank_ || pt < 0) nl.push_back(i);
+        nc[i] = (pt == rank_ || (pt < 0 && rank_ == 0)) ? 1 : 0;
+        if (pt < 0) {
+          const int d = node_dim(g.node_kind[i]);
+          for (int t = 0; t < d * d; t++) sh.push_back(sym.diag_off[i] + t);
+          for (int t = 0; t < d; t++) sh.push_back(~(int64_t)(g.node_offset[i] + t));
+        }
+      }
+      n_list_ = (int)nl.size();
+      node_list_.upload(nl);
+      norm_counts_.upload(nc);
+      n_shared_ = (int)sh.size();
+      if (sym.xch_shared_off + n_shared_ > sym.xch_chunk) throw ApiError(RR_PGO_EINVAL, "internal: exchange chunk too small");
+      shared_src_.upload(sh);
       std::vector<int64_t> pl;
       for (int f = 0; f < sym.S; f++)
         if (sym.sn_xch_off[f] >= 0 && sym.sn_big[f] && sym.sn_owner[f] == rank_) {
@@ -344,9 +431,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     left_looking_ = getenv("RR_PGO_RIGHT_LOOKING") == nullptr;
     overlap_ = getenv("RR_PGO_OVERLAP") != nullptr;
     if (overlap_) {   // the second stream and its events only exist for this experiment
-      stream2_ = stream_pool().get();
-      HIPCHK(hipEventCreateWithFlags(&ev_chain_, hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&ev_rest_, hipEventDisableTiming));
+      stream2_.acquire();
+      ev_chain_.create(hipEventDisableTiming);
+      ev_rest_.create(hipEventDisableTiming);
     }
     if (overlap_ && std::atoi(getenv("RR_PGO_OVERLAP")) > 1) overlap_max_nf_ = std::atoi(getenv("RR_PGO_OVERLAP"));
     panel128_ = getenv("RR_PGO_PANEL128") != nullptr;
@@ -354,8 +441,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     factor_threads_max_ = getenv("RR_PGO_FACTOR_512") ? 512 : 1024;
     if (const char *e = getenv("RR_PGO_SOLVE_THREADS")) solve_threads_max_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_SMALL_TILE")) small_tile_below_ = std::atoi(e);
-    n_lin_blocks_ = (int)(((int64_t)N * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
-    n_upd_blocks_ = (N + UPD_THREADS - 1) / UPD_THREADS;
+    n_lin_blocks_ = (int)(((int64_t)n_list_ * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
+    n_upd_blocks_ = (n_list_ + UPD_THREADS - 1) / UPD_THREADS;
     chi_partial_.alloc((size_t)n_lin_blocks_);
     norm_partial_.alloc((size_t)n_upd_blocks_);
     hist_.alloc(2 * HIST);
@@ -431,7 +518,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         double big_bytes = 0.0;
         for (const SnMeta &bm : ba) big_bytes += (double)(bm.nc + bm.nr + 1) * (bm.nc + bm.nr + 1) * sizeof(T);
         big_all_small_ = n_big_all_ > 0 && big_bytes <= 192.0 * 1024 * 1024;
-        merged_head_ = world_ == 1 && big_all_small_ && getenv("RR_PGO_SERIAL_ASSEMBLY") == nullptr;
+        merged_head_ = !sharded_ && big_all_small_ && getenv("RR_PGO_SERIAL_ASSEMBLY") == nullptr;
       }
       if (wblk_total > 0x7fffff00LL) throw ApiError(RR_PGO_EUNSUPPORTED, "too many diagonal blocks");
       winv_.alloc((size_t)wblk_total * 256 + 4);
@@ -475,12 +562,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   }
 
   ~Engine() override {
-    if (gn_exec_) (void)hipGraphExecDestroy(gn_exec_);
-    if (host_pair_) (void)hipHostFree(host_pair_);
-    if (ev_chain_) (void)hipEventDestroy(ev_chain_);
-    if (ev_rest_) (void)hipEventDestroy(ev_rest_);
-    if (stream2_) stream_pool().put(stream2_);
-    if (stream_) stream_pool().put(stream_);
+    if (gn_exec_) (void)hipGraphExecDestroy(gn_exec_);   // streams, events and the pinned buffer release themselves
+    for (hipGraphExec_t e : stage_exec_) if (e) (void)hipGraphExecDestroy(e);
   }
 
   hipStream_t stream() override { return stream_; }
@@ -565,7 +648,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     // Gauss-Newton with a single-precision factor: no anchor prior, the root front carries the gauge term
     if (write_system) gauge_now_ = gauge_ok_ && !lm && !reference_prior;
     LinArgs<T, S> a;
-    a.n_nodes = g_.n_nodes();
+    a.n_nodes = n_list_;
+    a.node_list = node_list_.p;
     a.pose = pose_.p;
     a.e_idx = e_idx_.p;
     a.e_meas = e_meas_.p;
@@ -583,6 +667,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     a.anchor = (write_system && gauge_now_) ? -1 : g_.anchor_node;
     a.lambda = lm ? (S)lambda : (S)0;
     a.write_system = write_system;
+    a.adds_diag = norm_counts_.p;
     return a;
   }
 
@@ -650,7 +735,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
                          lin_args(lambda, lm, write_system, reference_prior));
     } else {
       LinArgs3<T, S> a;
-      a.n_nodes = g_.n_nodes();
+      a.n_nodes = n_list_;
+      a.node_list = node_list_.p;
       a.pose = pose_.p;
       a.e_idx = e_idx_.p;
       a.e_meas = e_meas_.p;
@@ -666,6 +752,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       a.anchor = g_.anchor_node;
       a.lambda = lm ? (S)lambda : (S)0;
       a.write_system = write_system;
+      a.adds_diag = norm_counts_.p;
       hipLaunchKernelGGL((k_linearize_se3<T, S>), dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_, a);
     }
     check_launch("k_linearize");
@@ -920,7 +1007,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     pbegin();
     if (!is3d_) {
       UpdArgs<T, S> u;
-      u.n_nodes = g_.n_nodes();
+      u.n_nodes = n_list_;
+      u.node_list = node_list_.p;
+      u.norm_counts = norm_counts_.p;
       u.pose = pose_.p;
       u.node_dim = node_dim_.p;
       u.node_pcol = node_pcol_.p;
@@ -936,7 +1025,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       hipLaunchKernelGGL((k_update<T, S>), dim3(n_upd_blocks_), dim3(UPD_THREADS), 0, stream_, u);
     } else {
       UpdArgs3<T, S> u;
-      u.n_nodes = g_.n_nodes();
+      u.n_nodes = n_list_;
+      u.node_list = node_list_.p;
+      u.norm_counts = norm_counts_.p;
       u.pose = pose_.p;
       u.node_pcol = node_pcol_.p;
       u.node_offset = node_offset_.p;
@@ -973,17 +1064,25 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (gn_exec_) return;
     hipGraph_t graph = nullptr;
     HIPCHK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-    enqueue_gn_iteration();
+    try {
+      enqueue_gn_iteration();
+    } catch (...) {
+      // a failed launch must not leave the (pooled) stream in capture mode
+      (void)hipStreamEndCapture(stream_, &graph);
+      if (graph) (void)hipGraphDestroy(graph);
+      throw;
+    }
     HIPCHK(hipStreamEndCapture(stream_, &graph));
-    HIPCHK(hipGraphInstantiate(&gn_exec_, graph, nullptr, nullptr, 0));
-    HIPCHK(hipGraphDestroy(graph));
+    const hipError_t ie = hipGraphInstantiate(&gn_exec_, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) { gn_exec_ = nullptr; throw ApiError(RR_PGO_ENODEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
   }
 
   // One host round trip per iteration: the two scalars and the device error flag come back in
   // two async copies behind a single stream synchronisation.
   void read_slot(int slot, double *chi, double *norm) {
-    int *eflag = reinterpret_cast<int *>(host_pair_ + 2);
-    HIPCHK(hipMemcpyAsync(host_pair_, hist_.p + 2 * (slot % HIST), 2 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    int *eflag = reinterpret_cast<int *>(host_pair_.p + 2);
+    HIPCHK(hipMemcpyAsync(host_pair_.p, hist_.p + 2 * (slot % HIST), 2 * sizeof(double), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipMemcpyAsync(eflag, err_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     if (chi) *chi = host_pair_[0];
@@ -999,7 +1098,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   }
 
   void check_device_error() {
-    int *eflag = reinterpret_cast<int *>(host_pair_ + 2);
+    int *eflag = reinterpret_cast<int *>(host_pair_.p + 2);
     HIPCHK(hipMemcpyAsync(eflag, err_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
     throw_on_flag(*eflag);
@@ -1023,7 +1122,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   void chi2(double *out) override { *out = chi2_now(); }
 
   void linearize_solve(double lambda, int lm, double *dx_out) override {
-    if (world_ > 1) throw ApiError(RR_PGO_EUNSUPPORTED, "sharded handle: drive it with rr_pgo_stage + all-reduces");
+    if (sharded_) throw ApiError(RR_PGO_EUNSUPPORTED, "sharded handle: drive it with rr_pgo_stage + the two collectives");
     launch_linearize(lambda, lm, 1);
     launch_factor();
     launch_solve();
@@ -1045,7 +1144,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
 
   // optimize(), pose_graph_optimization.rs:247-303
   void optimize(int solver, int iters, double *errors, int *n_errors, double *norms) override {
-    if (world_ > 1) throw ApiError(RR_PGO_EUNSUPPORTED, "sharded handle: drive it with rr_pgo_stage + all-reduces");
+    if (sharded_) throw ApiError(RR_PGO_EUNSUPPORTED, "sharded handle: drive it with rr_pgo_stage + the two collectives");
     const double tolerance = 1e-4;  // :253
     int ne = 0;
     if (solver == RR_PGO_GAUSS_NEWTON) {
@@ -1147,7 +1246,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   }
 
   void iterate_async(int iters) override {
-    if (world_ > 1) throw ApiError(RR_PGO_EUNSUPPORTED, "sharded handle: drive it with rr_pgo_stage + all-reduces");
+    if (sharded_) throw ApiError(RR_PGO_EUNSUPPORTED, "sharded handle: drive it with rr_pgo_stage + the two collectives");
     // RR_PGO_NO_GRAPH=1: plain launches (rocprofv3 --kernel-trace crashes on replays of graphs
     // with thousands of nodes; profiling runs of the large workloads use this switch)
     static const bool no_graph = std::getenv("RR_PGO_NO_GRAPH") != nullptr;
@@ -1169,54 +1268,88 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (stamps_.n) HIPCHK(hipMemcpy(out.data(), stamps_.p, stamps_.n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   }
 
-  // ---- sharded execution (world_size > 1): one GN iteration in three stages, the host all-reduces
-  // (sum) buffer 0 between stage 0 and 1 and buffer 1 between stage 1 and 2.
+  // ---- sharded execution: one GN iteration = stage 0, all-gather of exchange buffer 0, stage 1, sum all-reduce
+  // of exchange buffer 1 (two doubles).  Both collectives are the caller's (RCCL), issued on this stream.
   void exchange_buffer(int which, void **ptr, int64_t *n, int32_t *esize) override {
-    if (world_ <= 1) throw ApiError(RR_PGO_EINVAL, "handle is not sharded (world_size <= 1)");
-    if (which == 0) { *ptr = xch_; *n = sym_.xch_elems; }
-    else if (which == 1) { *ptr = x_ptr_; *n = g_.dim; }
+    if (!sharded_) throw ApiError(RR_PGO_EINVAL, "handle is not sharded");
+    if (which == 0) { *ptr = xch_; *n = xch_n_; *esize = (int32_t)sizeof(T); }
+    else if (which == 1) { *ptr = scal_; *n = 2; *esize = (int32_t)sizeof(double); }
     else throw ApiError(RR_PGO_EINVAL, "exchange buffer index must be 0 or 1");
-    *esize = (int32_t)sizeof(T);
   }
   void set_exchange_buffer(int which, void *ptr, int64_t n) override {
-    if (world_ <= 1) throw ApiError(RR_PGO_EINVAL, "handle is not sharded (world_size <= 1)");
-    if (which == 0 && n >= sym_.xch_elems) xch_ = (T *)ptr;
-    else if (which == 1 && n >= g_.dim) x_ptr_ = (T *)ptr;
+    if (!sharded_) throw ApiError(RR_PGO_EINVAL, "handle is not sharded");
+    for (hipGraphExec_t &e : stage_exec_) if (e) { (void)hipGraphExecDestroy(e); e = nullptr; }   // captured pointers
+    if (which == 0 && n >= xch_n_) xch_ = (T *)ptr;
+    else if (which == 1 && n >= 2) scal_ = (double *)ptr;
     else throw ApiError(RR_PGO_EINVAL, "exchange buffer index / size mismatch");
   }
-  void stage(int stg, double lambda, int lm) override {
-    if (world_ <= 1) throw ApiError(RR_PGO_EINVAL, "handle is not sharded (world_size <= 1)");
+  void enqueue_stage(int stg, double lambda, int lm) {
+    const size_t n_local = world_ > 1 ? (size_t)sym_.n_local_steps : sym_.steps.size();
     if (stg == 0) {
-      // linearise everything (every rank holds the full state; 1M edges cost < 0.1 ms), factor this
-      // rank's subtrees, publish the boundary update matrices
-      if (sym_.xch_elems) HIPCHK(hipMemsetAsync(xch_, 0, (size_t)sym_.xch_elems * sizeof(T), stream_));
+      // linearise this rank's nodes (own + shared top separators), factor its own subtrees, publish the
+      // boundary fronts' update matrices in this rank's chunk of buffer 0
       launch_linearize(lambda, lm, 1);
-      launch_factor_range(0, (size_t)sym_.n_local_steps);
+      if (n_shared_ > 0)   // this rank's partial sums of the shared nodes' diagonal blocks and rhs, behind its update matrices
+        hipLaunchKernelGGL(k_pack_shared<T>, dim3((n_shared_ + 255) / 256), dim3(256), 0, stream_, shared_src_.p, n_shared_,
+                           (const T *)hvals_.p, (const T *)b_.p, xch_ + (int64_t)rank_ * sym_.xch_chunk + sym_.xch_shared_off);
+      launch_factor_range(0, n_local);
       if (n_pack_ > 0) {
         hipLaunchKernelGGL(k_pack_boundary<T>, dim3(std::min(pack_max_nu_, 1024), n_pack_), dim3(256), 0, stream_,
                            factor_args(0), pack_list_.p);
         check_launch("k_pack_boundary");
       }
     } else if (stg == 1) {
-      // after the all-reduce of buffer 0: the shared top fronts (redundantly), the whole back
-      // substitution this rank can do, then mask the solution for the all-reduce of buffer 1
-      launch_factor_range((size_t)sym_.n_local_steps, sym_.steps.size());
+      // after the all-gather: the shared top fronts (every rank, identical), the back substitution of the top
+      // and of this rank's subtrees, the update of this rank's nodes, its partial chi2 / |dx|^2
+      if (n_shared_ > 0)   // the shared nodes' diagonal blocks and rhs: the P partial sums, added in rank order
+        hipLaunchKernelGGL(k_sum_shared<T>, dim3((n_shared_ + 255) / 256), dim3(256), 0, stream_, shared_src_.p, n_shared_, hvals_.p, b_.p,
+                           (const T *)xch_, sym_.xch_chunk, sym_.xch_shared_off, world_);
+      launch_factor_range(n_local, sym_.steps.size());
       launch_solve();
-      hipLaunchKernelGGL(k_mask_x<T>, dim3((g_.dim + 255) / 256), dim3(256), 0, stream_, g_.dim, x_ptr_, col_owner_.p, rank_);
-      check_launch("k_mask_x");
-    } else if (stg == 2) {
-      // after the all-reduce of buffer 1: every rank applies the full step and reduces chi2 / |dx|
       launch_update(nullptr, 1.0, true);
-      launch_finalize(true, true, false);
+      hipLaunchKernelGGL(k_finalize_partial, dim3(1), dim3(256), 0, stream_, chi_partial_.p, n_lin_blocks_, norm_partial_.p,
+                         n_upd_blocks_, scal_);
     } else {
-      throw ApiError(RR_PGO_EINVAL, "stage must be 0, 1 or 2");
+      // chi2 of the current state only (the last entry of optimize()'s error list): partial sum -> buffer 1
+      launch_linearize(0.0, 0, 0);
+      hipLaunchKernelGGL(k_finalize_partial, dim3(1), dim3(256), 0, stream_, chi_partial_.p, n_lin_blocks_, norm_partial_.p, 0, scal_);
     }
+    check_launch("stage");
   }
+  void stage(int stg, double lambda, int lm) override {
+    if (!sharded_) throw ApiError(RR_PGO_EINVAL, "handle is not sharded");
+    if (stg < 0 || stg > 2) throw ApiError(RR_PGO_EINVAL, "stage must be 0, 1 or 2");
+    static const bool no_graph = std::getenv("RR_PGO_NO_GRAPH") != nullptr;
+    if (stg == 2 || lm || no_graph) { enqueue_stage(stg, lambda, lm); return; }
+    if (!stage_exec_[stg]) {   // Gauss-Newton stages replay a captured graph like the unsharded iteration
+      hipGraph_t graph = nullptr;
+      if (stg == 1) gauge_now_ = gauge_ok_;   // what stage 0 (lm == 0) set; the capture must not depend on call order
+      HIPCHK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+      try {
+        enqueue_stage(stg, 0.0, 0);
+      } catch (...) {
+        (void)hipStreamEndCapture(stream_, &graph);
+        if (graph) (void)hipGraphDestroy(graph);
+        throw;
+      }
+      HIPCHK(hipStreamEndCapture(stream_, &graph));
+      const hipError_t ie = hipGraphInstantiate(&stage_exec_[stg], graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (ie != hipSuccess) { stage_exec_[stg] = nullptr; throw ApiError(RR_PGO_ENODEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+    }
+    if (stg == 0) gauge_now_ = gauge_ok_;
+    HIPCHK(hipGraphLaunch(stage_exec_[stg], stream_));
+  }
+  // (chi2, |dx|) of the last stage-1 / stage-2 call, valid once the caller has all-reduced buffer 1
   void read_last_scalars(double *chi, double *norm) override {
-    int c = 0;
-    HIPCHK(hipMemcpyAsync(&c, counter_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    if (!sharded_) throw ApiError(RR_PGO_EINVAL, "handle is not sharded");
+    int *eflag = reinterpret_cast<int *>(host_pair_.p + 2);
+    HIPCHK(hipMemcpyAsync(host_pair_.p, scal_, 2 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipMemcpyAsync(eflag, err_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
     HIPCHK(hipStreamSynchronize(stream_));
-    read_slot(c, chi, norm);
+    *chi = host_pair_[0];
+    *norm = std::sqrt(host_pair_[1]);
+    throw_on_flag(*eflag);
   }
 
   void profile(int iters, double *ms, int64_t *launches) override {
@@ -1297,6 +1430,7 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
     throw ApiError(RR_PGO_EINVAL, "bad precision");
   if (opt.world_size > 1) {
     if (opt.world_size & (opt.world_size - 1)) throw ApiError(RR_PGO_EINVAL, "world_size must be a power of two");
+    if (opt.world_size > 64) throw ApiError(RR_PGO_EINVAL, "world_size must be at most 64");
     if (opt.rank < 0 || opt.rank >= opt.world_size) throw ApiError(RR_PGO_EINVAL, "rank out of range");
   }
   // symbolic analysis (host only)
@@ -1308,6 +1442,7 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
     so.n_parts = opt.world_size;
     so.my_part = opt.rank;
     so.nd_leaf = 64;
+    so.pin_node = h->g.anchor_node;   // every rank needs the anchor's entries of the solution (gauge transfer)
   }
   if (const char *e = std::getenv("RR_PGO_MID_MAX")) so.mid_max_front = std::atoi(e);   // tuning knobs
   if (const char *e = std::getenv("RR_PGO_TASK_US")) so.task_us = std::atof(e);
@@ -1317,7 +1452,7 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
   if (const char *e = std::getenv("RR_PGO_ND_LEAF")) so.nd_leaf = std::atoi(e);
   double t0 = now_ms();
   std::string err;
-  if (h->g.n_nodes() >= 2400 && h->g.n_nodes() <= 6000 && opt.world_size <= 1 && !std::getenv("RR_PGO_ND_LEAF")) {
+  if (h->g.n_nodes() >= 2400 && h->g.n_nodes() <= 6000 && opt.world_size <= 1 && !opt.sharded && !std::getenv("RR_PGO_ND_LEAF")) {
     // Small graphs are bound by the critical path through the supernode tree, not by flops: a few
     // nested-dissection cuts above minimum-degree leaves shorten that path on the larger ones (M3500, dlr,
     // sphere2500: +20..26 % measured) and lengthen it on intel.  The front cost model ranks the candidates
@@ -1349,9 +1484,10 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
     HIPCHK(hipSetDevice(opt.device));
   }
   const int wr = opt.world_size > 1 ? opt.rank : 0, ww = opt.world_size > 1 ? opt.world_size : 1;
-  if (opt.precision == RR_PGO_F64) h->engine = std::make_unique<Engine<double>>(h->g, h->sym, wr, ww);
-  else if (opt.precision == RR_PGO_F32) h->engine = std::make_unique<Engine<float>>(h->g, h->sym, wr, ww);
-  else h->engine = std::make_unique<Engine<float, double>>(h->g, h->sym, wr, ww);
+  const bool shd = opt.sharded != 0;
+  if (opt.precision == RR_PGO_F64) h->engine = std::make_unique<Engine<double>>(h->g, h->sym, wr, ww, shd);
+  else if (opt.precision == RR_PGO_F32) h->engine = std::make_unique<Engine<float>>(h->g, h->sym, wr, ww, shd);
+  else h->engine = std::make_unique<Engine<float, double>>(h->g, h->sym, wr, ww, shd);
   // stats
   rr_pgo_stats &s = h->stats;
   std::memset(&s, 0, sizeof s);
@@ -1434,6 +1570,9 @@ int rr_pgo_create(const rr_pgo_graph_desc *d, const rr_pgo_options *opt, rr_pgo 
     auto h = std::make_unique<rr_pgo>();
     HostGraph &g = h->g;
     if (d->n_nodes < 0 || d->n_edges < 0) throw ApiError(RR_PGO_EINVAL, "negative counts");
+    if (d->n_nodes > 0 && (!d->node_kind || !d->node_state)) throw ApiError(RR_PGO_EINVAL, "null node arrays");
+    if (d->n_edges > 0 && (!d->edge_kind || !d->edge_from || !d->edge_to || !d->edge_meas || !d->edge_info))
+      throw ApiError(RR_PGO_EINVAL, "null edge arrays");
     g.node_kind.assign(d->node_kind, d->node_kind + d->n_nodes);
     g.node_id.resize(d->n_nodes);
     for (int i = 0; i < d->n_nodes; i++) g.node_id[i] = d->node_id ? d->node_id[i] : (uint32_t)i;
@@ -1630,5 +1769,12 @@ int rr_pgo_debug_stamps(rr_pgo *h, double *out, int32_t *n_sn) {
 #endif
 
 void *rr_pgo_stream(rr_pgo *h) { return h && h->engine ? (void *)h->engine->stream() : nullptr; }
+
+int rr_pgo_node_owner(const rr_pgo *h, int32_t *owner) {
+  if (!h || !owner) { g_last_error = "null argument"; return RR_PGO_EINVAL; }
+  const int ws = h->opt.world_size > 1 ? h->opt.world_size : 1;
+  for (int i = 0; i < h->g.n_nodes(); i++) owner[i] = ws > 1 ? h->sym.node_part[i] : 0;
+  return RR_PGO_OK;
+}
 
 }  // extern "C"

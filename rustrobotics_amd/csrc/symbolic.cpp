@@ -391,6 +391,16 @@ struct NestedDissection {
         if (gscore >= 0 && gscore < bfs_score) { left.swap(gl); right.swap(gr); sep.swap(gs); }
       }
     }
+    if (depth == 0 && opt.pin_node >= 0 && part_depth > 0) {
+      // sharded runs: the anchor joins the top separator, so that every rank holds its solution entries
+      // (the gauge transfer of the single-precision factor needs them on every rank before the update)
+      auto drop = [&](std::vector<int32_t> &v) {
+        for (size_t i = 0; i < v.size(); i++)
+          if (v[i] == opt.pin_node) { v.erase(v.begin() + (long)i); return true; }
+        return false;
+      };
+      if (drop(left) || drop(right)) sep.push_back(opt.pin_node);
+    }
     if (depth < part_depth)
       for (int v : sep) part[v] = -1;
     const int lid = next_set++, rid = next_set++, zid = next_set++;
@@ -819,13 +829,35 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
   // ---- 6b. sharding: boundary fronts and column owners
   sym.sn_xch_off.assign(S, -1);
   sym.col_owner.assign(g.dim, 0);
+  sym.xch_chunk = 0;
   if (opt.n_parts > 1) {
-    int64_t xo = 0;
+    // The boundary fronts' update matrices are exchanged by an ALL-GATHER: rank r writes chunk r of the
+    // buffer (its own boundary fronts, packed), so offsets are (owner * chunk + offset inside the chunk)
+    // with one chunk size for all ranks (the largest total, rounded to 64 scalars).
+    std::vector<int64_t> used(opt.n_parts, 0);
+    for (int f = 0; f < S; f++) {
+      const int p = sym.sn_parent[f];
+      if (sym.sn_owner[f] >= 0 && p >= 0 && sym.sn_owner[p] < 0) {
+        int64_t &xo = used[sym.sn_owner[f]];
+        xo += (int64_t)(sym.sn_nrows[f] + 1) * (sym.sn_nrows[f] + 2) / 2;
+        xo = (xo + 3) & ~(int64_t)3;
+      }
+    }
+    for (int64_t u : used) sym.xch_chunk = std::max(sym.xch_chunk, u);
+    // behind the update matrices, every rank's chunk carries its PARTIAL diagonal blocks and right-hand-side
+    // entries of the shared nodes (summed over the edges the rank owns): the "Hessian border blocks"
+    sym.xch_shared_off = (sym.xch_chunk + 63) & ~(int64_t)63;
+    int64_t shared_elems = 0;
+    for (int i = 0; i < N; i++)
+      if (sym.node_part[i] < 0) shared_elems += (int64_t)w[i] * w[i] + w[i];
+    sym.xch_chunk = std::max<int64_t>((sym.xch_shared_off + shared_elems + 63) & ~(int64_t)63, 64);
+    std::fill(used.begin(), used.end(), 0);
     for (int f = 0; f < S; f++) {
       for (int c = 0; c < sym.sn_ncols[f]; c++) sym.col_owner[sym.sn_col0[f] + c] = (int8_t)sym.sn_owner[f];
       const int p = sym.sn_parent[f];
       if (sym.sn_owner[f] >= 0 && p >= 0 && sym.sn_owner[p] < 0) {
-        sym.sn_xch_off[f] = xo;
+        int64_t &xo = used[sym.sn_owner[f]];
+        sym.sn_xch_off[f] = (int64_t)sym.sn_owner[f] * sym.xch_chunk + xo;
         xo += (int64_t)(sym.sn_nrows[f] + 1) * (sym.sn_nrows[f] + 2) / 2;
         xo = (xo + 3) & ~(int64_t)3;
       }
@@ -833,7 +865,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
         return "internal: a front's parent belongs to another rank";
       if (sym.sn_owner[f] < 0 && p >= 0 && sym.sn_owner[p] >= 0) return "internal: shared front below an owned one";
     }
-    sym.xch_elems = xo;
+    sym.xch_elems = (int64_t)opt.n_parts * sym.xch_chunk;
   }
 
   ptimer.mark("layout");

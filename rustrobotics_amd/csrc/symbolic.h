@@ -27,6 +27,7 @@ struct SymbolicOptions {
   int nd_leaf = 40;         // nested dissection stops below this many nodes
   int n_parts = 1;          // >1: top ND levels are shared, subtrees owned by ranks (power of two)
   int my_part = 0;          // with n_parts > 1: the rank whose schedule is emitted (own subtrees, then shared top)
+  int pin_node = -1;        // with n_parts > 1: this node (the anchor) is made part of the top separator
   double task_us = 0.0;     // subtrees cheaper than this (model us) become one leaf task; 0 = pick by the cost model
   int mid_max_front = 0;    // fronts beyond LDS up to this size go to the one-workgroup in-place path (0: none,
                             // measured slower than the batched tiled path on the 1M-edge lattice)
@@ -107,7 +108,9 @@ struct Symbolic {
   // (owned, parent shared) publish their update matrix, packed, in the exchange buffer.
   int32_t n_local_steps = 0;
   std::vector<int64_t> sn_xch_off;   // per supernode: offset in the exchange buffer, -1 = not a boundary front
-  int64_t xch_elems = 0;
+  int64_t xch_elems = 0;             // n_parts * xch_chunk
+  int64_t xch_chunk = 0;             // scalars of one rank's chunk of the exchange buffer (all-gather)
+  int64_t xch_shared_off = 0;        // inside a chunk: the rank's partial diagonal blocks + rhs of the shared nodes
   std::vector<int8_t> col_owner;     // per permuted scalar column: owner rank, -1 = shared
   // ---- stats
   int64_t nnz_l_blocks = 0;          // node-level nonzero blocks of L (no padding)

@@ -68,7 +68,7 @@ class PoseGraph:
     @classmethod
     def from_arrays(cls, node_kind, node_state, edge_kind, edge_from, edge_to, edge_meas, edge_info,
                     solver=PoseGraphSolver.GaussNewton, precision="f64", device=-1, node_id=None,
-                    rank=0, world_size=1):
+                    rank=0, world_size=1, sharded=False):
         L = _lib.load()
         keep = [np.ascontiguousarray(node_kind, np.int32), np.ascontiguousarray(node_state, np.float64),
                 np.ascontiguousarray(edge_kind, np.int32), np.ascontiguousarray(edge_from, np.int32),
@@ -94,6 +94,7 @@ class PoseGraph:
         opt.device = device
         opt.solver = solver.value
         opt.rank, opt.world_size = rank, world_size
+        opt.sharded = 1 if sharded else 0
         h = C.c_void_p()
         _check(L.rr_pgo_create(C.byref(d), C.byref(opt), C.byref(h)))
         return cls(h, solver)
@@ -211,7 +212,7 @@ class PoseGraph:
     # -- sharding ONE graph over ranks (include/rr_pgo.h, "sharding") --------------------------------
     def exchange_info(self, which):
         """(device pointer, element count, element size) of exchange buffer `which` (0: boundary update
-        matrices, 1: the solution dx)."""
+        matrices, all-gathered; 1: the two partial sums chi2 and |dx|^2, all-reduced)."""
         ptr, n, es = C.c_void_p(), C.c_int64(), C.c_int32()
         _check(_lib.load().rr_pgo_exchange_buffer(self._h, which, C.byref(ptr), C.byref(n), C.byref(es)))
         return ptr.value, n.value, es.value
@@ -226,6 +227,16 @@ class PoseGraph:
         chi, nrm = C.c_double(), C.c_double()
         _check(_lib.load().rr_pgo_stage_scalars(self._h, C.byref(chi), C.byref(nrm)))
         return chi.value, nrm.value
+
+    def node_owner(self):
+        """rank owning every node, -1 = shared (top separators, anchor); zeros on an unsharded handle"""
+        out = np.zeros(self.num_nodes, np.int32)
+        _check(_lib.load().rr_pgo_node_owner(self._h, _ip(out)))
+        return out
+
+    def stream_ptr(self):
+        """hipStream_t of the handle as an integer (torch.cuda.ExternalStream takes it)"""
+        return int(_lib.load().rr_pgo_stream(self._h) or 0)
 
     def iterate_async(self, iters):
         _check(_lib.load().rr_pgo_iterate_async(self._h, iters))
@@ -245,33 +256,10 @@ class PoseGraph:
         return {name: (float(ms[i]), int(n[i])) for i, name in enumerate(_lib.KCLASS_NAMES)}
 
 
-def sharded_gauss_newton(shards, num_iterations, allreduce, tolerance=1e-4):
-    """`PoseGraph::optimize` (GN) on ONE graph sharded over ranks.
-
-    shards    : the handles this process drives -- [own handle] under torch.distributed (one rank per
-                GPU), or all P handles when P ranks are emulated in one process (tests).
-    allreduce : callable(which) doing the SUM all-reduce of exchange buffer `which` over all ranks
-                (RCCL through torch.distributed in production); called after every shard has been
-                synchronised.
-    Returns the chi2 list with the reference's semantics (1 + iterations entries)."""
-    errors = []
-    for _ in range(num_iterations):
-        for stage in (0, 1):
-            for g in shards:
-                g.stage(stage)
-            for g in shards:
-                g.sync()
-            allreduce(stage)
-        for g in shards:
-            g.stage(2)
-        chi, nrm = shards[0].stage_scalars()
-        for g in shards[1:]:
-            g.sync()
-        errors.append(chi)
-        if nrm < tolerance:
-            break
-    errors.append(shards[0].global_error())
-    return errors
+def parse_g2o_arrays(file_path):
+    """parse_g2o (g2o.rs:35-143) through the library's loader, returned as the flat arrays `from_arrays` takes
+    (needs a device: the loader entry point builds a handle)."""
+    return PoseGraph.new(file_path).graph_arrays()
 
 
 def synthetic_grid_arrays(width, height, n_edges=0, seed_meas=42, seed_init=43):

@@ -114,7 +114,9 @@ def mfcheck(tmp_path_factory):
     ([g2o_path("dlr")], {"LEAF": "1000000"}),
     ([g2o_path("input_M3500_g2o")], {"LEAF": "64", "LDS": "38000"}),
     (["grid", "40", "25"], {"LEAF": "64"}),
-    (["grid", "60", "40"], {"LEAF": "64", "PARTS": "4"}),           # rank-owned subtrees + shared top
+    (["grid", "60", "40"], {"LEAF": "64", "PARTS": "2"}),           # rank-owned subtrees + shared top
+    (["grid", "60", "40"], {"LEAF": "64", "PARTS": "4"}),
+    (["grid", "100", "100"], {"LEAF": "64", "PARTS": "8"}),
 ])
 def test_symbolic_tables_drive_a_correct_factorization(mfcheck, args, env):
     out = subprocess.run([mfcheck, *args], env={**os.environ, **env}, capture_output=True, text=True)

@@ -59,58 +59,72 @@ def test_timed_steps_world2_gloo():
 
 
 # ---- the sharded Gauss-Newton driver over 2 gloo ranks (fake shards: the numerics are the GPU tests'
-# business; this covers the stage / sync / all-reduce protocol of rustrobotics_amd.sharded_gauss_newton)
+# business; this covers the stage / all-gather / all-reduce protocol of rustrobotics_amd.sharding.gauss_newton
+# with REAL torch.distributed collectives, world_size 2)
 
 class _FakeShard:
-    """A 'graph' whose chi2 is sum_i (target_i - x_i)^2 over 8 entries, 4 owned by each rank.  Stage 0
-    publishes the owned residuals (buffer 0), stage 1 turns the all-reduced residuals into the owned
-    part of the step (buffer 1), stage 2 applies the all-reduced step."""
+    """A 'graph' whose chi2 is sum_i (target_i - x_i)^2 over 8 entries, 4 owned by each rank, with the protocol
+    of include/rr_pgo.h: stage 0 publishes the owned residuals in the rank's chunk of buffer 0 (all-gathered),
+    stage 1 needs the GATHERED buffer (its step is the mean residual of the other rank's chunk added to its own
+    residuals -- nonsense numerically, but it makes a missing all-gather visible), applies the owned step and
+    leaves the partial (chi2, |dx|^2) in buffer 1 (all-reduced); stage 2 leaves the partial chi2 only."""
 
     def __init__(self, rank, world):
         self.rank, self.world = rank, world
         self.x = torch.zeros(8, dtype=torch.float64)
         self.target = torch.arange(8, dtype=torch.float64)
-        self.buf = [torch.zeros(8, dtype=torch.float64), torch.zeros(8, dtype=torch.float64)]
+        self.xch = torch.zeros(8, dtype=torch.float64)
+        self.scal = torch.zeros(2, dtype=torch.float64)
         self.log, self.own = [], slice(4 * rank, 4 * rank + 4)
-        self._chi = self._nrm = 0.0
+        self.other = slice(4 * (1 - rank), 4 * (1 - rank) + 4)
 
     def stage(self, k):
         self.log.append(("stage", k))
         if k == 0:
-            self.buf[0].zero_()
-            self.buf[0][self.own] = (self.target - self.x)[self.own]
+            self.xch.zero_()
+            self.xch[self.own] = (self.target - self.x)[self.own]
         elif k == 1:
-            self._chi = float((self.buf[0] ** 2).sum())          # needs the REDUCED buffer 0
-            self.buf[1].zero_()
-            self.buf[1][self.own] = self.buf[0][self.own]
+            self.seen_other = getattr(self, 'seen_other', []) + [float(self.xch[self.other].abs().sum())]   # non-zero only after the all-gather
+            step = self.xch[self.own].clone()
+            self.scal[0] = float((self.xch[self.own] ** 2).sum())
+            self.scal[1] = float((step ** 2).sum())
+            self.x[self.own] += step
         else:
-            self._nrm = float(self.buf[1].norm())                # needs the REDUCED buffer 1
-            self.x += self.buf[1]
+            self.scal[0] = float(((self.target - self.x)[self.own] ** 2).sum())
+            self.scal[1] = 0.0
 
     def sync(self):
         self.log.append(("sync",))
 
     def stage_scalars(self):
-        return self._chi, self._nrm
+        return float(self.scal[0]), float(self.scal[1]) ** 0.5
 
-    def global_error(self):
-        return float(((self.target - self.x) ** 2).sum())
+
+class _GlooCollectives:
+    def __init__(self, g):
+        self.g, self.calls = g, []
+
+    def all_gather_boundary(self):
+        self.calls.append("all_gather")
+        g = self.g
+        parts = [torch.zeros(4, dtype=torch.float64) for _ in range(g.world)]
+        dist.all_gather(parts, g.xch[g.own].clone())
+        g.xch.copy_(torch.cat(parts))
+
+    def all_reduce_scalars(self):
+        self.calls.append("all_reduce")
+        dist.all_reduce(self.g.scal, op=dist.ReduceOp.SUM)
 
 
 def _sharded_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
-    from rustrobotics_amd.mapping import sharded_gauss_newton
+    from rustrobotics_amd.sharding import gauss_newton
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = _FakeShard(rank, world)
-    calls = []
-
-    def allreduce(which):
-        calls.append(which)
-        dist.all_reduce(g.buf[which], op=dist.ReduceOp.SUM)
-
-    errors = sharded_gauss_newton([g], 5, allreduce)
-    q.put((rank, errors, calls, g.log[:8], g.x.tolist()))
+    coll = _GlooCollectives(g)
+    errors, norms = gauss_newton([g], 5, coll)
+    q.put((rank, errors, norms, coll.calls, g.log[:6], g.x.tolist(), g.seen_other))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -126,9 +140,12 @@ def test_sharded_driver_world2_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, e0, c0, log0, x0), (_, e1, c1, log1, x1) = res
+    (_, e0, n0, c0, log0, x0, s0), (_, e1, n1, c1, log1, x1, s1) = res
     expected0 = float(sum(i * i for i in range(8)))
-    assert e0 == e1 == [expected0, 0.0, 0.0]        # one full step solves it; 2nd iteration sees |dx| = 0 and stops
-    assert c0 == c1 == [0, 1, 0, 1]                  # two all-reduces per iteration, in order
-    assert log0[:6] == [("stage", 0), ("sync",), ("stage", 1), ("sync",), ("stage", 2), ("stage", 0)]
-    assert x0 == x1 == [float(i) for i in range(8)]  # both ranks hold the full, identical state
+    assert e0 == e1 == [expected0, 0.0, 0.0]        # one full step solves it; the 2nd iteration sees |dx| = 0 and stops
+    assert n0 == n1 and abs(n0[0] - expected0 ** 0.5) < 1e-12 and n0[1] == 0.0     # |dx| summed over BOTH ranks
+    # per iteration: all-gather then all-reduce; one more all-reduce for the final chi2 (stage 2)
+    assert c0 == c1 == ["all_gather", "all_reduce", "all_gather", "all_reduce", "all_reduce"]
+    assert log0[:4] == [("stage", 0), ("stage", 1), ("stage", 0), ("stage", 1)]
+    assert x0 == [0.0, 1.0, 2.0, 3.0, 0.0, 0.0, 0.0, 0.0] and x1 == [0.0, 0.0, 0.0, 0.0, 4.0, 5.0, 6.0, 7.0]   # owned parts only
+    assert s0 == [22.0, 0.0] and s1 == [6.0, 0.0]   # stage 1 saw the OTHER rank's chunk: the all-gather ran before it
