@@ -502,9 +502,9 @@ static void se2xy_jacobians(const double *x, const double *l, double A[6], doubl
 /* ------------------------------------------------------------- SE(3) maths
  * NOT reference behaviour (the reference's SE(3) path is todo!()).
  * Build-defined, g2o file convention: E = Z^-1 * Xi^-1 * Xj,
- * e = [t_E ; 2*vec(q_E) with w>=0]... see se3_error below; Jacobians are taken
- * w.r.t. the update  X <- X * Exp([dt ; dw])  by central differences in the
- * oracle (it is the checker, speed is irrelevant). */
+ * e = [t_E ; sign(w_E) vec(q_E)], see se3_error below; Jacobians w.r.t. the update
+ * X <- X * (dt, Exp(dw)) in closed form (se3_jacobians), pinned to 50-digit central
+ * differences by tests/golden/se3_jacobians.json. */
 
 typedef struct { double t[3]; double q[4]; /* x y z w */ } iso3;
 
@@ -572,22 +572,61 @@ static void se3_retract(const double *x, const double d[6], double out[7]) {
   double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   for (int i = 0; i < 4; i++) out[3 + i] = q[i] / n;
 }
+/* Jacobians of se3_error w.r.t. the right increments of Xi (A) and Xj (B), row-major 6 x 6, in closed form
+ * through the 4 x 4 left / right quaternion product matrices (q (x) p = Lq(q) p = Rq(p) q, order x y z w):
+ *   Xj <- Xj * (dt, Exp(dw)):  E' = E * (dt, Exp(dw))
+ *        t_E' = t_E + R_E dt                                   B[0:3,0:3] = R_E
+ *        q_E' = q_E (x) (dw/2, 1) = Lq(q_E) (dw/2, 1)           B[3:6,3:6] = (s/2) Lq(q_E)[0:3,0:3]
+ *   Xi <- Xi * (dt, Exp(dw)):  E' = Z^-1 * (dt, Exp(dw))^-1 * C ,  C = Xi^-1 Xj ,  (dt, Exp(dw))^-1 ~ (-dt, Exp(-dw))
+ *        t_E' = Rz^T (t_C - dt - dw x t_C - t_z)               A[0:3,0:3] = -Rz^T ,  A[0:3,3:6] = Rz^T [t_C]x
+ *        q_E' = qz^-1 (x) (-dw/2, 1) (x) q_C = Lq(qz^-1) Rq(q_C) (-dw/2, 1)
+ *                                                              A[3:6,3:6] = -(s/2) (Lq(qz^-1) Rq(q_C))[0:3,0:3]
+ * with s = sign(w_E).  Derived for this oracle independently of the device code; both are pinned by
+ * tests/golden/se3_jacobians.json (50-digit central differences, scripts/gen_se3_golden.py) -- the reference pins
+ * nothing here (its linearize_pose3D_pose3D_constraint, :488-514, is never called). */
+static void quat_left(const double q[4], double L[4][4]) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double m[4][4] = { { w, -z, y, x }, { z, w, -x, y }, { -y, x, w, z }, { -x, -y, -z, w } };
+  memcpy(L, m, sizeof m);
+}
+static void quat_right(const double p[4], double R[4][4]) {
+  const double x = p[0], y = p[1], z = p[2], w = p[3];
+  const double m[4][4] = { { w, z, -y, x }, { -z, w, x, y }, { y, -x, w, z }, { -x, -y, -z, w } };
+  memcpy(R, m, sizeof m);
+}
+static void quat_rotmat(const double q[4], double R[3][3]) {   /* columns = images of the basis vectors */
+  for (int c = 0; c < 3; c++) {
+    double v[3] = { c == 0, c == 1, c == 2 }, r[3];
+    quat_rot(q, v, r);
+    for (int i = 0; i < 3; i++) R[i][c] = r[i];
+  }
+}
 static void se3_jacobians(const double *x1, const double *x2, const double *z,
                           double A[36], double B[36]) {
-  const double h = 1e-6;
-  for (int c = 0; c < 6; c++) {
-    double d[6] = { 0, 0, 0, 0, 0, 0 }, xp[7], xm[7], ep[6], em[6];
-    d[c] = h;  se3_retract(x1, d, xp);
-    d[c] = -h; se3_retract(x1, d, xm);
-    se3_error(xp, x2, z, ep);
-    se3_error(xm, x2, z, em);
-    for (int r = 0; r < 6; r++) A[r * 6 + c] = (ep[r] - em[r]) / (2 * h);
-    d[c] = h;  se3_retract(x2, d, xp);
-    d[c] = -h; se3_retract(x2, d, xm);
-    se3_error(x1, xp, z, ep);
-    se3_error(x1, xm, z, em);
-    for (int r = 0; r < 6; r++) B[r * 6 + c] = (ep[r] - em[r]) / (2 * h);
-  }
+  const iso3 Zi = iso3_inverse(iso3_of(z));
+  const iso3 Cm = iso3_mul(iso3_inverse(iso3_of(x1)), iso3_of(x2));
+  const iso3 E = iso3_mul(Zi, Cm);
+  const double s = E.q[3] < 0 ? -1.0 : 1.0;
+  double RE[3][3], RZt[3][3], LE[4][4], LZ[4][4], RC[4][4];
+  quat_rotmat(E.q, RE);
+  quat_rotmat(Zi.q, RZt);
+  quat_left(E.q, LE);
+  quat_left(Zi.q, LZ);
+  quat_right(Cm.q, RC);
+  for (int i = 0; i < 36; i++) A[i] = B[i] = 0.0;
+  const double *tc = Cm.t;
+  const double skew[3][3] = { { 0, -tc[2], tc[1] }, { tc[2], 0, -tc[0] }, { -tc[1], tc[0], 0 } };
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      B[r * 6 + c] = RE[r][c];
+      B[(3 + r) * 6 + 3 + c] = 0.5 * s * LE[r][c];
+      A[r * 6 + c] = -RZt[r][c];
+      double acc = 0.0, m = 0.0;
+      for (int k = 0; k < 3; k++) acc += RZt[r][k] * skew[k][c];
+      A[r * 6 + 3 + c] = acc;
+      for (int k = 0; k < 4; k++) m += LZ[r][k] * RC[k][c];
+      A[(3 + r) * 6 + 3 + c] = -0.5 * s * m;
+    }
 }
 
 /* ----------------------------------------------------------- global error */
