@@ -274,9 +274,7 @@ def secondary_entry(ctx, workload, precision, steps, warmup, sharded):
             g, state0, dt = measure_single(ctx, workload, precision, steps, warmup)
             drv = None
     except Exception as e:   # noqa: BLE001 -- a secondary config must never take the headline line down
-        if ctx.dist:
-            raise
-        return {"workload": workload, "dtype": precision, "error": f"{type(e).__name__}: {e}"}
+        return {"workload": workload, "dtype": precision, "sharded": bool(sharded), "error": f"{type(e).__name__}: {e}"}
     value = steps / dt * (1 if sharded else ctx.world)
     rec = {"workload": f"{workload} ({g.num_nodes} poses / {g.num_edges} edges / dim {g.len})", "dtype": precision,
            "n_gpus": ctx.world, "parallelism": (f"sharded{ctx.world}" if sharded else "single" if ctx.world == 1 else "replicas (no communication)"),
@@ -326,6 +324,12 @@ def main():
                     help="shard ONE graph (--workload) over the ranks as the headline line (strong scaling); with one rank "
                          "the collectives still run, over a one-rank RCCL group")
     args = ap.parse_args()
+
+    # The contract is ONE JSON line on stdout.  RCCL / HIP libraries print banners through C stdio, which no Python
+    # redirection catches: from here on file descriptor 1 IS stderr, the JSON line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -454,13 +458,15 @@ def main():
                 rec = secondary_entry(ctx, workload, precision, args.steps, args.warmup, sharded)
             if rec is not None:
                 sec.append(rec)
+            if rec is not None and "error" in rec and world > 1:
+                break   # the ranks may be out of step after a failure: no further collective legs
         if out is not None:
             out["secondary"] = sec
     if ctx.dist:
         ctx.dist.barrier()
         ctx.dist.destroy_process_group()
     if out is not None:
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":
