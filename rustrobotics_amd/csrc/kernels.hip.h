@@ -1998,33 +1998,25 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_trsm128(Facto
 // NT = MFMA tiles per wave and dimension: 4 -> 64 x 64 per wave, 128 x 128 per workgroup; 2 -> 32 x 32 per wave,
 // 64 x 64 per workgroup, for launches that would not fill the chip with the large tile (the top levels of
 // the tree: a quarter of the MFMA work per wave on the critical path of the launch).
-template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_update(FactorArgs<T> a, int kb, int mode, int diag_tail) {
+template <typename T, int NT> struct UpdTile {
+  static constexpr int KC = 16;   // k-chunk staged in LDS: 36.9 KB in fp32 (three workgroups per CU), 73.7 KB in fp64 (two)
+  static constexpr int TILE = 32 * NT, WTILE = 16 * NT;  // workgroup tile, wave tile
+  static constexpr int KSTEP = 256 / TILE;               // k-rows of a chunk loaded per pass of the 256 threads
+  static constexpr int LDT = TILE + 16;                  // padded row: the four k-rows a wave reads hit disjoint banks
+  static constexpr int NLD = KC / KSTEP;                 // global loads per operand per thread per chunk
+  static constexpr int SMEM = 2 * 2 * KC * LDT;          // scalars of LDS: As[2][KC][LDT] | Bs[2][KC][LDT]
+};
+// One tile of a rank update by the 256 threads of a workgroup: C(I0.., J0..) -= F(I0.., ka:ke) F(J0.., ka:ke)^T,
+// restricted to i < M, j < jmax, i >= j.  smem: UpdTile::SMEM scalars.  Returns whether this wave holds part of the
+// tile; acc keeps the wave's (updated) part of C for a caller that goes on with it.
+template <typename T, int NT>
+__device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int jmax, int I0, int J0, T *smem,
+                                                typename Mfma16<T>::Acc (&acc)[NT][NT]) {
   using MM = Mfma16<T>;
-  constexpr int KC = 16;   // k-chunk staged in LDS: 36.9 KB in fp32 (three workgroups per CU), 73.7 KB in fp64 (two)
-  constexpr int TILE = 32 * NT, WTILE = 16 * NT;  // workgroup tile, wave tile
-  constexpr int KSTEP = 256 / TILE;               // k-rows of a chunk loaded per pass of the 256 threads
-  constexpr int LDT = TILE + 16;                  // padded row: the four k-rows a wave reads hit disjoint banks
-  constexpr int NLD = KC / KSTEP;                 // global loads per operand per thread per chunk
-  __shared__ T As[2][KC][LDT];                   // As[buf][k][i] =  F(I0 + i, k)
-  __shared__ T Bs[2][KC][LDT];                   // Bs[buf][k][j] = -F(J0 + j, k)
-  RRPGO_TRACE_MARK(a, 100 + mode);
-  if (blockIdx.x < blockIdx.y) return;           // lower triangle of tiles only
-  const SnMeta m = a.task_meta[a.task_begin + blockIdx.z];
-  if (kb >= m.nc) return;
-  const int M = m.nc + m.nr + 1;
-  const int super_end = min((kb / BIG_SUPER) * BIG_SUPER + BIG_SUPER, m.nc);
-  const int ka = kb;
-  const int ke = mode == 0 ? min(kb + BIG_NB, m.nc) : super_end;
-  const int t0 = ke;
-  // mode 2 / 3 split the trailing update by column: the 128 columns right of the super-panel (the next
-  // super-panel's own columns, needed by its panel chain) and everything after them (which can run
-  // beside that chain on a second stream)
-  const int jmax = mode == 0 ? super_end : mode == 2 ? min(t0 + 128, M) : M;
-  static_assert(NT == 4 || NT == 2, "tile shapes");
-  const int toff = mode == 3 ? 128 / TILE : 0;   // mode 3 starts one 128-column strip further right
-  const int I0 = t0 + (blockIdx.x + toff) * TILE, J0 = t0 + (blockIdx.y + toff) * TILE;
-  if (t0 >= jmax || I0 >= M || J0 >= jmax) return;   // uniform over the workgroup
-  T *F = a.lvals + m.loff;
+  using UT = UpdTile<T, NT>;
+  constexpr int KC = UT::KC, TILE = UT::TILE, WTILE = UT::WTILE, KSTEP = UT::KSTEP, LDT = UT::LDT, NLD = UT::NLD;
+  T (*As)[KC][LDT] = reinterpret_cast<T (*)[KC][LDT]>(smem);                    // As[buf][k][i] =  F(I0 + i, k)
+  T (*Bs)[KC][LDT] = reinterpret_cast<T (*)[KC][LDT]>(smem + 2 * KC * LDT);     // Bs[buf][k][j] = -F(J0 + j, k)
   const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int wi = (wave & 1) * WTILE, wj = (wave >> 1) * WTILE;
@@ -2034,10 +2026,7 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
   // load goes to a CLAMPED address (no branch per load: out-of-range rows only feed entries that are
   // never stored) and only the stores are predicated.
   const bool interior = I0 + TILE <= M && J0 + TILE <= jmax && I0 >= J0 + TILE;
-  [[maybe_unused]] const bool pm = blockIdx.x == 2 && blockIdx.y == 0 && blockIdx.z == 0;
-  RRPGO_PHASE_MARK(a, pm, 600);
   // ---- accumulators = current C tile
-  typename MM::Acc acc[NT][NT];
   if (wave_active) {
 #pragma unroll
     for (int jb = 0; jb < NT; jb++)
@@ -2077,7 +2066,6 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
   fetch(0);
   stash(0);
   __syncthreads();
-  RRPGO_PHASE_MARK(a, pm, 601);
   for (int c = 0; c < nchunks; c++) {
     const int buf = c & 1;
     if (c + 1 < nchunks) fetch(c + 1);
@@ -2099,12 +2087,7 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
     if (c + 1 < nchunks) stash(buf ^ 1);
     __syncthreads();
   }
-  RRPGO_PHASE_MARK(a, pm, 602);
-  if (!wave_active) return;
-  // The first wave of the first tile holds the next super-panel's first diagonal block (rows = columns
-  // = t0 .. t0+31) in acc[0..1][0..1]: after the tile is stored it factors and inverts that block here,
-  // which saves the k_big_diag32 launch that would otherwise open the next super-panel's chain.
-  const bool next_diag = diag_tail && (mode == 1 || mode == 2) && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && t0 < m.nc;
+  if (!wave_active) return false;
   if (interior) {
 #pragma unroll
     for (int jb = 0; jb < NT; jb++)
@@ -2125,11 +2108,42 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
           if (i < M && j < jmax && i >= j) F[(int64_t)j * M + i] = acc[ib][jb][r];
         }
   }
-  RRPGO_PHASE_MARK(a, pm, 603);
+  return true;
+}
+
+template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_update(FactorArgs<T> a, int kb, int mode, int diag_tail) {
+  using MM = Mfma16<T>;
+  using UT = UpdTile<T, NT>;
+  constexpr int TILE = UT::TILE;
+  __shared__ T smem[UT::SMEM];
+  RRPGO_TRACE_MARK(a, 100 + mode);
+  if (blockIdx.x < blockIdx.y) return;           // lower triangle of tiles only
+  const SnMeta m = a.task_meta[a.task_begin + blockIdx.z];
+  if (kb >= m.nc) return;
+  const int M = m.nc + m.nr + 1;
+  const int super_end = min((kb / BIG_SUPER) * BIG_SUPER + BIG_SUPER, m.nc);
+  const int ka = kb;
+  const int ke = mode == 0 ? min(kb + BIG_NB, m.nc) : super_end;
+  const int t0 = ke;
+  // mode 2 / 3 split the trailing update by column: the 128 columns right of the super-panel (the next
+  // super-panel's own columns, needed by its panel chain) and everything after them (which can run
+  // beside that chain: on a second stream, or inside the chain's own launches -- k_big_chain)
+  const int jmax = mode == 0 ? super_end : mode == 2 ? min(t0 + 128, M) : M;
+  static_assert(NT == 4 || NT == 2, "tile shapes");
+  const int toff = mode == 3 ? 128 / TILE : 0;   // mode 3 starts one 128-column strip further right
+  const int I0 = t0 + (blockIdx.x + toff) * TILE, J0 = t0 + (blockIdx.y + toff) * TILE;
+  if (t0 >= jmax || I0 >= M || J0 >= jmax) return;   // uniform over the workgroup
+  T *F = a.lvals + m.loff;
+  typename MM::Acc acc[NT][NT];
+  if (!big_update_tile<T, NT>(F, M, ka, ke, jmax, I0, J0, smem, acc)) return;
+  // The first wave of the first tile holds the next super-panel's first diagonal block (rows = columns
+  // = t0 .. t0+31) in acc[0..1][0..1]: after the tile is stored it factors and inverts that block here,
+  // which saves the k_big_diag32 launch that would otherwise open the next super-panel's chain.
+  const bool next_diag = diag_tail && (mode == 1 || mode == 2) && blockIdx.x == 0 && blockIdx.y == 0 && wave_index() == 0 && t0 < m.nc;
   if (next_diag) {
-    T *Sh = &As[0][0][0];   // the staging buffers are idle now (every wave passed the last barrier of the k loop)
+    T *Sh = smem;   // the staging buffers are idle now (every wave passed the last barrier of the k loop)
     const int nbn = min(BIG_NB, m.nc - t0);
-    static_assert(DIAG32_LDS <= 2 * KC * LDT, "the diagonal-block images fit the first operand strip");
+    static_assert(DIAG32_LDS <= UT::SMEM / 2, "the diagonal-block images fit the first operand strip");
     if constexpr (NT == 2) sh_image_from_acc<T>(Sh, acc, nbn);
     else {
       const typename MM::Acc corner[2][2] = {{acc[0][0], acc[0][1]}, {acc[1][0], acc[1][1]}};
@@ -2141,6 +2155,244 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     diag32_factor_invert<T, false>(Sh, nbn, F + (int64_t)t0 * M + t0, M, a.winv + (int64_t)m.wblk * 256 + (int64_t)(t0 / BIG_NB) * 1024, a.err);
   }
+}
+
+// ---- the panel chain with the PREVIOUS super-panel's far update riding along -------------------------------
+// At the top of the tree a level has a handful of fronts: its launches fill a fraction of the chip and the step is
+// a chain of latencies -- four k_big_panel32 launches and one trailing update per 128 columns, one after the other.
+// Only the next 128 columns of that update are needed by the next chain (k_big_update mode 2); everything further
+// right (mode 3: columns >= K0 + 256 of super-panel K0's update) touches nothing the next chain reads or writes.
+// k_big_chain is one launch per 32 columns like k_big_panel32, with two kinds of workgroups:
+//   blockIdx.x <  n_panel : 32 rows below the block at kb on the workgroup's first wave, the same arithmetic as a
+//                           k_big_panel32 workgroup (first workgroup: also the next diagonal block)
+//   blockIdx.x >= n_panel : 64 x 64 tiles of the far update of the super-panel at rest_K0 (= K0 - 128), tile
+//                           t = rest_part + rest_parts * (blockIdx.x - n_panel) of the front's lower triangle of
+//                           tiles: the four launches of a chain share the tiles out between them.
+// Results are bit-identical to the separate launches (same products, same order).
+template <typename T>
+__device__ __forceinline__ void chain_panel_wave(const FactorArgs<T> &a, const SnMeta &m, int kb, int K0, int first, int rowblk,
+                                                 bool lookwave, T *Sh) {
+  static_assert(BIG_NB == 32, "the left-looking panel kernels are written for 32-column blocks");
+  using MM = Mfma16<T>;
+  const int nb = min(BIG_NB, m.nc - kb);
+  const int M = m.nc + m.nr + 1;
+  const int R0 = kb + nb + rowblk * 32;
+  const bool active = R0 < M;   // an inactive wave only takes part in the barriers of the `first` block
+  T *F = a.lvals + m.loff;
+  const T *Wt = a.winv + (int64_t)m.wblk * 256 + (kb / BIG_NB) * 1024;
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  const int wave = wave_index();
+  const int super_end = min(K0 + BIG_SUPER, m.nc);
+  const int kn = kb + BIG_NB;
+  const bool look = lookwave && kn < super_end && active;
+  T wv[3][4];
+  if (!first) {
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int cb = t == 0 ? 0 : 1, jb = t == 2 ? 1 : 0;
+        wv[t][r] = Wt[(16 * jb + MM::row(lane, r)) * 32 + 16 * cb + li];
+      }
+  }
+  T dv[16];
+  if (first && wave == 0) {
+    const T *Fblk = F + (int64_t)kb * M + kb;
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      const int e = t * 64 + lane, c = e >> 5, r = e & 31;
+      dv[t] = Fblk[(int64_t)min(c, nb - 1) * M + min(r, nb - 1)];
+    }
+  }
+  int irow[2];
+  irow[0] = min(R0 + li, M - 1);
+  irow[1] = min(R0 + 16 + li, M - 1);
+  constexpr int PRE = sizeof(T) == 4 ? 3 : 2;
+  const int nblk = (kb - K0) / BIG_NB;
+  const int arow0 = kb + min(li, nb - 1), arow1 = kb + min(16 + li, nb - 1);
+  const T am0 = li < nb ? (T)-1 : (T)0, am1 = 16 + li < nb ? (T)-1 : (T)0;
+  T av[PRE][8][2], bv[PRE][8][2];
+  const char *Fb = reinterpret_cast<const char *>(F);
+  const uint32_t colb = (uint32_t)((K0 + lk) * M) * (uint32_t)sizeof(T);
+  const uint32_t oa0 = colb + (uint32_t)arow0 * (uint32_t)sizeof(T), oa1 = colb + (uint32_t)arow1 * (uint32_t)sizeof(T);
+  const uint32_t ob0 = colb + (uint32_t)irow[0] * (uint32_t)sizeof(T), ob1 = colb + (uint32_t)irow[1] * (uint32_t)sizeof(T);
+  const uint32_t kstep = (uint32_t)(4 * M) * (uint32_t)sizeof(T);
+  auto ld = [&](uint32_t off) { return *reinterpret_cast<const T *>(Fb + off); };
+  auto fetch = [&](int blk, T (*xa)[2], T (*xb)[2]) {
+    uint32_t d = (uint32_t)(blk * 8) * kstep;
+#pragma unroll
+    for (int s4 = 0; s4 < 8; s4++) {
+      xa[s4][0] = ld(oa0 + d) * am0;
+      xa[s4][1] = ld(oa1 + d) * am1;
+      xb[s4][0] = ld(ob0 + d);
+      xb[s4][1] = ld(ob1 + d);
+      d += kstep;
+    }
+  };
+  typename MM::Acc acc[2][2], nxt[2][2];
+#pragma unroll
+  for (int jb = 0; jb < 2; jb++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int j = 16 * jb + MM::row(lane, r);
+      const T *ccol = F + (int64_t)(kb + min(j, nb - 1)) * M;
+#pragma unroll
+      for (int ib = 0; ib < 2; ib++) acc[ib][jb][r] = ccol[irow[ib]];
+    }
+#pragma unroll
+  for (int p = 0; p < PRE; p++)
+    if (p < nblk) fetch(p, av[p], bv[p]);
+  if (look) {
+#pragma unroll
+    for (int jb = 0; jb < 2; jb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const T *ccol = F + (int64_t)min(kn + 16 * jb + MM::row(lane, r), M - 1) * M;
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++) nxt[ib][jb][r] = ccol[irow[ib]];
+      }
+  }
+#pragma unroll
+  for (int jb = 0; jb < 2; jb++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int j = 16 * jb + MM::row(lane, r);
+#pragma unroll
+      for (int ib = 0; ib < 2; ib++) {
+        const T v = pin(acc[ib][jb][r]);
+        acc[ib][jb][r] = j < nb ? v : (T)0;
+      }
+    }
+  if (first) {
+    // the level's very first block: the first wave of every workgroup factors and inverts it for its workgroup
+    // (the block stays as assembled in F: see k_big_panel32), all four waves read W from the LDS image
+    if (wave == 0) {
+#pragma unroll
+      for (int t = 0; t < 16; t++) {
+        const int e = t * 64 + lane, c = e >> 5, r = e & 31;
+        Sh[c * 33 + r] = (r < nb && c < nb && r >= c) ? dv[t] : ((r == c && r >= nb) ? (T)1 : (T)0);
+      }
+      diag32_init_tables<T>(Sh);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      diag32_factor_invert<T, false>(Sh, nb, F + (int64_t)kb * M + kb, M, const_cast<T *>(Wt), a.err, false, blockIdx.x == 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int cb = t == 0 ? 0 : 1, jb = t == 2 ? 1 : 0;
+        wv[t][r] = Sh[32 * 33 + (16 * jb + MM::row(lane, r)) * 33 + 16 * cb + li];
+      }
+    __syncthreads();   // Sh is free again for the next diagonal block's image
+  }
+  if (!active) return;
+#pragma unroll
+  for (int blk = 0; blk < BIG_SUPER / BIG_NB - 1; blk++) {
+    if (blk < nblk) {
+      const int slot = blk % PRE;
+#pragma unroll
+      for (int s4 = 0; s4 < 8; s4++) {
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+          for (int jb = 0; jb < 2; jb++) acc[ib][jb] = MM::mma(av[slot][s4][jb], bv[slot][s4][ib], acc[ib][jb]);
+        if (look) {
+#pragma unroll
+          for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+            for (int jb = 0; jb <= ib; jb++) nxt[ib][jb] = MM::mma(-bv[slot][s4][jb], bv[slot][s4][ib], nxt[ib][jb]);
+        }
+      }
+      if (PRE < BIG_SUPER / BIG_NB - 1 && blk + PRE < nblk) fetch(blk + PRE, av[slot], bv[slot]);
+    }
+  }
+  typename MM::Acc out[2][2];
+#pragma unroll
+  for (int ib = 0; ib < 2; ib++) {
+    out[ib][0] = typename MM::Acc{0, 0, 0, 0};
+    out[ib][1] = typename MM::Acc{0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      out[ib][0] = MM::mma(wv[0][r], acc[ib][0][r], out[ib][0]);
+      out[ib][1] = MM::mma(wv[1][r], acc[ib][0][r], out[ib][1]);
+      out[ib][1] = MM::mma(wv[2][r], acc[ib][1][r], out[ib][1]);
+    }
+  }
+  if (nb == BIG_NB && R0 + 32 <= M) {
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        T *ccol = F + (int64_t)(kb + 16 * cb + MM::row(lane, r)) * M + R0 + li;
+        ccol[0] = out[0][cb][r];
+        ccol[16] = out[1][cb][r];
+      }
+  } else {
+#pragma unroll
+    for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+      for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int c = 16 * cb + MM::row(lane, r), i = R0 + 16 * ib + li;
+          if (i < M && c < nb) F[(int64_t)(kb + c) * M + i] = out[ib][cb][r];
+        }
+  }
+  if (!look) return;
+#pragma unroll
+  for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+        for (int jb = 0; jb <= ib; jb++) nxt[ib][jb] = MM::mma(-out[jb][cb][r], out[ib][cb][r], nxt[ib][jb]);
+  const int nbn = min(BIG_NB, m.nc - kn);
+  sh_image_from_acc<T>(Sh, nxt, nbn);
+  diag32_init_tables<T>(Sh);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  diag32_factor_invert<T, false>(Sh, nbn, F + (int64_t)kn * M + kn, M, a.winv + (int64_t)m.wblk * 256 + (kn / BIG_NB) * 1024, a.err);
+}
+
+template <typename T> __global__ void __launch_bounds__(256) k_big_chain(FactorArgs<T> a, int kb, int K0, int first, int n_panel,
+                                                                       int rest_K0, int rest_part, int rest_parts) {
+  using UT = UpdTile<T, 2>;
+  static_assert(UT::SMEM >= DIAG32_LDS, "one LDS region serves both roles");
+  __shared__ T smem[UT::SMEM];
+  RRPGO_TRACE_MARK(a, 200);
+  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
+  if ((int)blockIdx.x < n_panel) {
+    if (kb >= m.nc) return;
+    const int nb = min(BIG_NB, m.nc - kb);
+    const int M = m.nc + m.nr + 1;
+    // ONE wave per workgroup works in this role (32 rows, like a k_big_panel32 workgroup): four row blocks on the
+    // four SIMDs of one CU were measured ~2 us slower per launch -- their ~560 loads queue on one CU's memory
+    // pipeline, the critical wave's among them -- than spread over four CUs
+    if (wave_index() != 0 || kb + nb + (int)blockIdx.x * 32 >= M) return;
+    chain_panel_wave<T>(a, m, kb, K0, first, (int)blockIdx.x, blockIdx.x == 0, smem);
+    return;
+  }
+  // ---- far update of the previous super-panel: rows and columns >= rest_K0 + 256
+  if (rest_K0 < 0 || rest_K0 >= m.nc) return;
+  const int M = m.nc + m.nr + 1;
+  const int ke = min(rest_K0 + BIG_SUPER, m.nc);
+  const int t0 = ke + 128;
+  if (t0 >= M) return;
+  const int nt = (M - t0 + 63) / 64;
+  const int t = rest_part + rest_parts * ((int)blockIdx.x - n_panel);
+  if (t >= nt * (nt + 1) / 2) return;
+  // tile t of the lower triangle, row by row: ib (ib + 1) / 2 <= t
+  int ib = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while (ib * (ib + 1) / 2 > t) ib--;
+  while ((ib + 1) * (ib + 2) / 2 <= t) ib++;
+  const int jb = t - ib * (ib + 1) / 2;
+  typename Mfma16<T>::Acc acc[2][2];
+  big_update_tile<T, 2>(a.lvals + m.loff, M, rest_K0, ke, M, t0 + 64 * ib, t0 + 64 * jb, smem, acc);
 }
 
 // Back substitution for one supernode:

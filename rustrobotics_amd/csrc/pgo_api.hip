@@ -246,6 +246,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
                                     // RR_PGO_SMALL_TILE=0 brings the 128 x 128 tiles back
   int solve_threads_max_ = 512;     // RR_PGO_SOLVE_THREADS=<n>: cap of the back-substitution workgroup size
   int factor_threads_max_ = 1024;   // 16-wave workgroups for steps whose fronts exceed 128 rows (RR_PGO_FACTOR_512=1: 8 waves)
+  int lookahead_max_nf_ = 16;       // RR_PGO_LOOKAHEAD=<n>: levels of at most n big fronts run the k_big_chain sequence (0: none)
   bool separate_diag32_ = false;    // RR_PGO_SEPARATE_DIAG32=1: a k_big_diag32 launch for the first block of every level
   bool panel128_ = false;           // RR_PGO_PANEL128=1: two launches per 128-column super-panel (diagonal block in LDS by one
                                     // workgroup, then all rows at once) instead of one per 32 columns; measured 10 % slower
@@ -441,6 +442,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     factor_threads_max_ = getenv("RR_PGO_FACTOR_512") ? 512 : 1024;
     if (const char *e = getenv("RR_PGO_SOLVE_THREADS")) solve_threads_max_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_SMALL_TILE")) small_tile_below_ = std::atoi(e);
+    if (const char *e = getenv("RR_PGO_LOOKAHEAD")) lookahead_max_nf_ = std::atoi(e);
+    if (const char *e = getenv("RR_PGO_MANY_TASKS")) many_tasks_ = std::atoi(e);
+    if (const char *e = getenv("RR_PGO_MANY_THREADS")) many_threads_ = std::atoi(e);
     n_lin_blocks_ = (int)(((int64_t)n_list_ * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
     n_upd_blocks_ = (n_list_ + UPD_THREADS - 1) / UPD_THREADS;
     chi_partial_.alloc((size_t)n_lin_blocks_);
@@ -772,10 +776,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         const int nt = st.task_end - st.task_begin;
         const size_t lds = (size_t)st.max_lds_elems * sizeof(T);
         FactorArgs<T> a = factor_args(st.task_begin);
-        if (st.threads == 64) launch_factor_tasks<64>(nt, lds, a);
-        else if (st.threads == 128) launch_factor_tasks<128>(nt, lds, a);
-        else if (st.threads == 256) launch_factor_tasks<256>(nt, lds, a);
-        else if (st.threads <= 512 || factor_threads_max_ < 1024) launch_factor_tasks<512>(nt, lds, a);
+        const int fth = step_threads(st, nt, factor_threads_max_);
+        if (fth == 64) launch_factor_tasks<64>(nt, lds, a);
+        else if (fth == 128) launch_factor_tasks<128>(nt, lds, a);
+        else if (fth == 256) launch_factor_tasks<256>(nt, lds, a);
+        else if (fth <= 512) launch_factor_tasks<512>(nt, lds, a);
         else launch_factor_tasks<1024>(nt, lds, a);
         pend(RR_PGO_K_FACTOR);
       } else if (st.kind == STEP_MID) {
@@ -787,6 +792,18 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         pend(RR_PGO_K_BIGFRONT);
       }
     }
+  }
+
+  // Workgroup size of an LDS-front step.  The symbolic phase sizes it for the latency of ONE task (a 16-wave
+  // workgroup per front of > 128 rows).  A level with many more tasks than the chip has CUs is bound by task
+  // THROUGHPUT instead: smaller workgroups let several tasks share a CU (a 1024-thread workgroup at 128 VGPRs
+  // owns the whole CU), which hides each task's dependent chains behind the others.
+  int many_tasks_ = 1 << 30, many_threads_ = 256;   // RR_PGO_MANY_TASKS / RR_PGO_MANY_THREADS: measured SLOWER on the lattice
+                                                    // (5244 tasks: 690 us with 1024 threads, 873 with 512, 1045 with 256), off by default
+  int step_threads(const Step &st, int nt, int cap) const {
+    int th = std::min(st.threads, cap);
+    if (nt >= many_tasks_) th = std::min(th, many_threads_);
+    return th;
   }
 
   const Step *first_big_step() const {
@@ -864,6 +881,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       }
     }
     if (do_launch) pend(RR_PGO_K_BIGFRONT);   // closes the zero / assemble / extend-add segment
+    // look-ahead (k_big_chain) on levels with few fronts, where launches are latency- rather than throughput-bound
+    const bool lookahead = left_looking_ && !panel128_ && !separate_diag32_ && !overlap_ && nf <= lookahead_max_nf_;
+    int la_rest_K0 = -1;   // super-panel whose far update is still owed (rides with the next chain)
     for (int K0 = 0; K0 < max_nc; K0 += BIG_SUPER) {
       if (left_looking_ && panel128_) {
         // the whole super-panel in two launches: its diagonal block in LDS (one workgroup per front), then
@@ -878,7 +898,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           pend(RR_PGO_K_BIG_PANEL, 2);
         }
         n += 2;
-      } else if (left_looking_) {
+      } else if (left_looking_ && !lookahead) {
         // left-looking inside the super-panel: the first diagonal block, then ONE launch per 32 columns
         // (update from the columns K0..kb, multiply by the inverse diagonal block, next diagonal block)
         // the first diagonal block of a later super-panel comes out of the previous trailing update
@@ -902,6 +922,34 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           n++;
         }
         if (do_launch) pend(RR_PGO_K_BIG_PANEL, (sep_diag ? 1 : 0) + (std::min(K0 + BIG_SUPER, max_nc) - K0 + BIG_NB - 1) / BIG_NB);
+      } else if (left_looking_ && lookahead) {
+        // top of the tree (few fronts per level): k_big_chain -- the panel rows and, riding along, the far part of
+        // the PREVIOUS super-panel's trailing update; only the next 128 columns of an update stay on the chain
+        if (do_launch) pbegin();
+        const int k_end = std::min(K0 + BIG_SUPER, max_nc);
+        const int n_steps = (k_end - K0 + BIG_NB - 1) / BIG_NB;
+        int64_t rest_tiles = 0;
+        if (la_rest_K0 >= 0)
+          for (int s : fr)
+            if (sym_.sn_ncols[s] > la_rest_K0) {
+              const int Ms = sym_.sn_ncols[s] + sym_.sn_nrows[s] + 1;
+              const int nrem = Ms - (std::min(la_rest_K0 + BIG_SUPER, sym_.sn_ncols[s]) + 128);
+              if (nrem > 0) { const int64_t nt = (nrem + 63) / 64; rest_tiles = std::max(rest_tiles, nt * (nt + 1) / 2); }
+            }
+        const int n_rest = (int)((rest_tiles + n_steps - 1) / n_steps);
+        int step_i = 0;
+        for (int kb = K0; kb < k_end; kb += BIG_NB, step_i++) {
+          const int rb = rows_max(kb) - 1;
+          const int n_panel = (std::max(rb, 1) + 31) / 32;
+          if (do_launch) {
+            hipLaunchKernelGGL(k_big_chain<T>, dim3(n_panel + n_rest, nf), dim3(256), 0, stream_, a, kb, K0, kb == 0 ? 1 : 0, n_panel,
+                               la_rest_K0, step_i, n_steps);
+            check_launch("k_big_chain");
+          }
+          n++;
+        }
+        la_rest_K0 = -1;
+        if (do_launch) pend(RR_PGO_K_BIG_PANEL, n_steps);
       } else
       for (int kb = K0; kb < std::min(K0 + BIG_SUPER, max_nc); kb += BIG_NB) {
         const int rb = rows_max(kb) - 1;   // rows below a 1..32 wide block, at least the rhs row
@@ -925,7 +973,18 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       const int rt = rows_max(K0);   // rows from K0 on; the trailing part starts after the super-panel
       const int nti = (std::max(rt, 1) + 127) / 128;
       const bool overlap = left_looking_ && overlap_ && !prof_.on && nti > 2 && nf <= overlap_max_nf_;
-      if (!overlap) {
+      if (lookahead && K0 + BIG_SUPER < max_nc) {
+        // the next super-panel's own columns now, the rest under its chain
+        if (do_launch) {
+          pbegin();
+          const int nt64 = (std::max(rt, 1) + 63) / 64;
+          hipLaunchKernelGGL((k_big_update<T, 2>), dim3(nt64, 2, nf), dim3(256), 0, stream_, a, K0, 2, diag_tail);
+          check_launch("k_big_update/2");
+          pend(RR_PGO_K_BIG_UPDATE);
+        }
+        la_rest_K0 = K0;
+        n++;
+      } else if (!overlap) {
         if (do_launch) {
           if (rest_pending_) { HIPCHK(hipStreamWaitEvent(stream_, ev_rest_, 0)); rest_pending_ = false; }
           pbegin();
@@ -972,7 +1031,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       if (st.kind == STEP_TASKS) {
         const int nt = st.task_end - st.task_begin;
         FactorArgs<T> a = factor_args(st.task_begin);
-        const int sth = std::min(st.threads, solve_threads_max_);
+        const int sth = step_threads(st, nt, solve_threads_max_);
         if (sth <= 64) launch_solve_tasks<64>(nt, lds, a);
         else if (sth <= 128) launch_solve_tasks<128>(nt, lds, a);
         else if (sth <= 256) launch_solve_tasks<256>(nt, lds, a);

@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include "host_graph.h"
 #include "symbolic.h"
 using namespace rrpgo;
@@ -50,6 +51,27 @@ int main(int argc, char **argv) {
     printf("  steps: %d task launches, %d big-front steps\n", nsteps_tasks, nsteps_big);
     return 0;
   }
+  if (getenv("TASKHIST"))
+    for (auto &st : s.steps) {
+      if (st.kind != STEP_TASKS) continue;
+      // per task: largest LDS need, largest M, fronts, model cost
+      const long long le[] = {2400, 4800, 9600, 19000, 38000, 1 << 30};
+      long long cnt[6] = {0}, fr[6] = {0}, mM[6] = {0};
+      for (int t = st.task_begin; t < st.task_end; t++) {
+        long long lds = 0, M = 0;
+        for (int q = s.task_ptr[t]; q < s.task_ptr[t + 1]; q++) {
+          int f = s.task_sn[q], nc = s.sn_ncols[f], nr = s.sn_nrows[f];
+          lds = std::max<long long>(lds, (long long)(nc + nr + 1) * nc + (long long)(nr + 1) * (nr + 2) / 2);
+          M = std::max<long long>(M, nc + nr + 1);
+        }
+        int b = 0;
+        while (lds > le[b]) b++;
+        cnt[b]++; fr[b] += s.task_ptr[t + 1] - s.task_ptr[t]; mM[b] = std::max(mM[b], M);
+      }
+      printf("  step: %d tasks;", st.task_end - st.task_begin);
+      for (int b = 0; b < 6; b++) printf(" lds<=%lld: %lld tasks %lld fronts maxM %lld |", le[b], cnt[b], fr[b], mM[b]);
+      printf("\n");
+    }
   for (auto &st : s.steps) {
     printf("  %s %d (threads %d, maxM %d, lds %d)\n", st.kind == STEP_TASKS ? "tasks" : st.kind == STEP_MID ? "mid" : "HUGE",
            st.task_end - st.task_begin, st.threads, st.max_front, st.max_lds_elems);
