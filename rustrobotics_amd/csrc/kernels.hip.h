@@ -178,6 +178,41 @@ template <typename T, int THREADS> __device__ __forceinline__ T block_sum(T v, T
   return r;
 }
 
+// The last workgroup of an update launch also does the fixed-order reduction of the chi2 / |dx|^2 partials into
+// the (chi2, |dx|) ring slot (what k_finalize_slot does in a launch of its own): one launch less per iteration.
+struct FinArgs {
+  int enabled;                 // 0: the caller launches k_finalize_slot itself
+  const double *chi_partial;   // written by the linearisation of this iteration (an earlier launch)
+  int n_chi;
+  double *hist;                // ring of (chi2, |dx|) pairs
+  int *counter;                // slot counter, advanced when `advance`
+  int advance, ring;
+  int *blocks_done;            // zero between launches
+};
+template <int THREADS>
+__device__ __forceinline__ void finalize_in_last_block(const FinArgs &f, const double *norm_partial, int n_norm, double *red) {
+  __shared__ int is_last;
+  if (threadIdx.x == 0) {
+    __threadfence();                                  // this block's partial is out before it is counted
+    is_last = atomicAdd(f.blocks_done, 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();                                    // the other blocks' partials are visible
+  double c = 0.0, n = 0.0;
+  for (int i = threadIdx.x; i < f.n_chi; i += THREADS) c += f.chi_partial[i];
+  for (int i = threadIdx.x; i < n_norm; i += THREADS) n += norm_partial[i];
+  const double ct = block_sum<double, THREADS>(c, red);
+  const double nt = block_sum<double, THREADS>(n, red);
+  if (threadIdx.x == 0) {
+    const int slot = *f.counter % f.ring;
+    if (f.n_chi > 0) f.hist[2 * slot] = ct;
+    f.hist[2 * slot + 1] = sqrt(nt);
+    if (f.advance) *f.counter = *f.counter + 1;
+    *f.blocks_done = 0;
+  }
+}
+
 // One group of LIN_GROUP lanes per node pulls the node's incident edges
 // (deterministic: no atomics, fixed summation order), builds the node's
 // diagonal block and right-hand side; the lane holding an edge in its `from`
@@ -533,6 +568,7 @@ template <typename T, typename TC = T> struct UpdArgs3 {
   const int *err;      // sticky device error flag: a failed factorisation must not touch the state
   const int32_t *node_list;    // sharded runs: the nodes this rank updates (own + shared), n_nodes = its length
   const uint8_t *norm_counts;  // sharded runs: per node, 1 = this rank adds the node's |dx|^2 (every node counted once)
+  FinArgs fin;
 };
 
 // X <- X * (dt, Exp(dw)):  t += R dt ;  q <- normalise( q (x) exp(dw) )
@@ -580,6 +616,7 @@ __global__ void __launch_bounds__(UPD_THREADS) k_update_se3(UpdArgs3<TO, T> a) {
   if (a.export_only) return;
   double tot = block_sum<double, UPD_THREADS>(nrm, red);
   if (threadIdx.x == 0) a.norm_partial[blockIdx.x] = tot;
+  if (a.fin.enabled) finalize_in_last_block<UPD_THREADS>(a.fin, a.norm_partial, (int)gridDim.x, red);
 }
 
 // ------------------------------------------------------------ multifrontal
@@ -2009,9 +2046,15 @@ template <typename T, int NT> struct UpdTile {
 // One tile of a rank update by the 256 threads of a workgroup: C(I0.., J0..) -= F(I0.., ka:ke) F(J0.., ka:ke)^T,
 // restricted to i < M, j < jmax, i >= j.  smem: UpdTile::SMEM scalars.  Returns whether this wave holds part of the
 // tile; acc keeps the wave's (updated) part of C for a caller that goes on with it.
-template <typename T, int NT>
+// DEPTH = k-chunks whose global loads are in flight ahead of the MFMAs.  1: the chunk after the current one -- the
+// throughput shape (few registers, three workgroups per CU).  8: the whole K = 128 strip is requested up front -- for
+// launches of a few hundred tiles at the top of the tree, where a tile is a chain of memory round trips (data of the
+// previous launch comes back from HBM in ~1.3 us) and nothing else runs on the CU to hide them.
+template <typename T, int NT, int DEPTH = 1>
 __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int jmax, int I0, int J0, T *smem,
-                                                typename Mfma16<T>::Acc (&acc)[NT][NT]) {
+                                                typename Mfma16<T>::Acc (&acc)[NT][NT], unsigned long long *trace = nullptr, bool pm = false) {
+  struct { unsigned long long *trace; } a{trace};   // for RRPGO_PHASE_MARK (diagnostic builds)
+  (void)a; (void)pm;
   using MM = Mfma16<T>;
   using UT = UpdTile<T, NT>;
   constexpr int KC = UT::KC, TILE = UT::TILE, WTILE = UT::WTILE, KSTEP = UT::KSTEP, LDT = UT::LDT, NLD = UT::NLD;
@@ -2043,32 +2086,39 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
   const T *pb = F + (int64_t)(ka + sk) * M + min(J0 + sr, M - 1);
   const int64_t M2 = KSTEP * (int64_t)M;
   const int nk = ke - ka;
-  T ra[NLD], rb[NLD];
-  auto fetch = [&](int c) {   // columns past ke are re-read from a valid column and zeroed by a select
+  T ra[DEPTH][NLD], rb[DEPTH][NLD];
+  auto fetch = [&](int c, T (&xa)[NLD], T (&xb)[NLD]) {   // columns past ke are re-read from a valid column and zeroed by a select
     const T *qa = pa + (int64_t)c * KC * M, *qb = pb + (int64_t)c * KC * M;
 #pragma unroll
     for (int q = 0; q < NLD; q++) {
       const bool kok = c * KC + sk + KSTEP * q < nk;
       const int64_t off = kok ? q * M2 : 0;
       const T va = qa[off], vb = qb[off];
-      ra[q] = kok ? va : (T)0;
-      rb[q] = kok ? -vb : (T)0;
+      xa[q] = kok ? va : (T)0;
+      xb[q] = kok ? -vb : (T)0;
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, const T (&xa)[NLD], const T (&xb)[NLD]) {
 #pragma unroll
     for (int q = 0; q < NLD; q++) {
-      As[buf][sk + KSTEP * q][sr] = ra[q];
-      Bs[buf][sk + KSTEP * q][sr] = rb[q];
+      As[buf][sk + KSTEP * q][sr] = xa[q];
+      Bs[buf][sk + KSTEP * q][sr] = xb[q];
     }
   };
   const int nchunks = (nk + KC - 1) / KC;
-  fetch(0);
-  stash(0);
+  constexpr int MAXCH = BIG_SUPER / KC;   // K <= 128
+#pragma unroll
+  for (int d = 0; d < DEPTH; d++)
+    if (d < nchunks) fetch(d, ra[d], rb[d]);
+  RRPGO_PHASE_MARK(a, pm, 604);
+  stash(0, ra[0], rb[0]);
+  if (DEPTH < nchunks) fetch(DEPTH, ra[0], rb[0]);
   __syncthreads();
-  for (int c = 0; c < nchunks; c++) {
+  RRPGO_PHASE_MARK(a, pm, 601);
+#pragma unroll
+  for (int c = 0; c < MAXCH; c++) {
+    if (c >= nchunks) break;
     const int buf = c & 1;
-    if (c + 1 < nchunks) fetch(c + 1);
     if (wave_active) {
 #pragma unroll
       for (int s4 = 0; s4 < KC / 4; s4++) {
@@ -2084,9 +2134,15 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
           for (int jb = 0; jb < NT; jb++) acc[ib][jb] = MM::mma(av[jb], bv[ib], acc[ib][jb]);
       }
     }
-    if (c + 1 < nchunks) stash(buf ^ 1);
+    if (c + 1 < nchunks) {
+      constexpr int dummy = 0; (void)dummy;
+      const int set = (c + 1) % DEPTH;   // compile-time after unrolling
+      stash(buf ^ 1, ra[set], rb[set]);
+      if (c + 1 + DEPTH < nchunks) fetch(c + 1 + DEPTH, ra[set], rb[set]);
+    }
     __syncthreads();
   }
+  RRPGO_PHASE_MARK(a, pm, 602);
   if (!wave_active) return false;
   if (interior) {
 #pragma unroll
@@ -2111,7 +2167,7 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
   return true;
 }
 
-template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_update(FactorArgs<T> a, int kb, int mode, int diag_tail) {
+template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(256, (DEPTH > 1 ? 1 : sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_update(FactorArgs<T> a, int kb, int mode, int diag_tail) {
   using MM = Mfma16<T>;
   using UT = UpdTile<T, NT>;
   constexpr int TILE = UT::TILE;
@@ -2135,7 +2191,10 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
   if (t0 >= jmax || I0 >= M || J0 >= jmax) return;   // uniform over the workgroup
   T *F = a.lvals + m.loff;
   typename MM::Acc acc[NT][NT];
-  if (!big_update_tile<T, NT>(F, M, ka, ke, jmax, I0, J0, smem, acc)) return;
+  [[maybe_unused]] const bool pm = blockIdx.x == 2 && blockIdx.y == 0 && blockIdx.z == 0;
+  RRPGO_PHASE_MARK(a, pm, 600);
+  if (!big_update_tile<T, NT, DEPTH>(F, M, ka, ke, jmax, I0, J0, smem, acc, a.trace, pm)) return;
+  RRPGO_PHASE_MARK(a, pm, 603);
   // The first wave of the first tile holds the next super-panel's first diagonal block (rows = columns
   // = t0 .. t0+31) in acc[0..1][0..1]: after the tile is stored it factors and inverts that block here,
   // which saves the k_big_diag32 launch that would otherwise open the next super-panel's chain.
@@ -3045,6 +3104,7 @@ template <typename T, typename TC = T> struct UpdArgs {
   const int *err;      // sticky device error flag: a failed factorisation must not touch the state
   const int32_t *node_list;    // sharded runs: the nodes this rank updates (own + shared), n_nodes = its length
   const uint8_t *norm_counts;  // sharded runs: per node, 1 = this rank adds the node's |dx|^2 (every node counted once)
+  FinArgs fin;
 };
 
 // update_nodes (:229-245) + |dx|^2 (:273).  The step of a failed factorisation (non-positive pivot) is NOT
@@ -3094,6 +3154,7 @@ __global__ void __launch_bounds__(UPD_THREADS) k_update(UpdArgs<TO, T> a) {
   if (a.export_only) return;
   double tot = block_sum<double, UPD_THREADS>(nrm, red);
   if (threadIdx.x == 0) a.norm_partial[blockIdx.x] = tot;
+  if (a.fin.enabled) finalize_in_last_block<UPD_THREADS>(a.fin, a.norm_partial, (int)gridDim.x, red);
 }
 
 }  // namespace rrpgo

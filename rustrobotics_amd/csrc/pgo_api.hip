@@ -246,7 +246,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
                                     // RR_PGO_SMALL_TILE=0 brings the 128 x 128 tiles back
   int solve_threads_max_ = 512;     // RR_PGO_SOLVE_THREADS=<n>: cap of the back-substitution workgroup size
   int factor_threads_max_ = 1024;   // 16-wave workgroups for steps whose fronts exceed 128 rows (RR_PGO_FACTOR_512=1: 8 waves)
-  int lookahead_max_nf_ = 16;       // RR_PGO_LOOKAHEAD=<n>: levels of at most n big fronts run the k_big_chain sequence (0: none)
+  int64_t deep_below_ = 2048;       // RR_PGO_DEEP_BELOW=<n>: trailing updates of at most n 64 x 64 tiles request their whole K strip up front
+  int lookahead_max_nf_ = 0;        // RR_PGO_LOOKAHEAD=<n>: levels of at most n big fronts run the k_big_chain sequence (0: none)
   bool separate_diag32_ = false;    // RR_PGO_SEPARATE_DIAG32=1: a k_big_diag32 launch for the first block of every level
   bool panel128_ = false;           // RR_PGO_PANEL128=1: two launches per 128-column super-panel (diagonal block in LDS by one
                                     // workgroup, then all rows at once) instead of one per 32 columns; measured 10 % slower
@@ -268,7 +269,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<T> hvals_, b_, x_, dx_ref_, lvals_, uvals_, winv_, gemv_part_;
   static constexpr int kGemvSlices = 16;   // row slices of the multi-workgroup L21^T x product
   DevBuf<double> chi_partial_, norm_partial_, hist_;
-  DevBuf<int> counter_, err_;
+  DevBuf<int> counter_, err_, blocks_done_;
   DevBuf<unsigned long long> stamps_;  // diagnostic builds only
   // symbolic tables
   DevBuf<int32_t> task_ptr_, task_sn_, fasm_src_, fasm_dst_, fdup_src_, fdup_dst_, scat_, rel_, perm_, sn_rows_;
@@ -443,6 +444,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (const char *e = getenv("RR_PGO_SOLVE_THREADS")) solve_threads_max_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_SMALL_TILE")) small_tile_below_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_LOOKAHEAD")) lookahead_max_nf_ = std::atoi(e);
+    if (const char *e = getenv("RR_PGO_DEEP_BELOW")) deep_below_ = std::atoll(e);
     if (const char *e = getenv("RR_PGO_MANY_TASKS")) many_tasks_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_MANY_THREADS")) many_threads_ = std::atoi(e);
     n_lin_blocks_ = (int)(((int64_t)n_list_ * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
@@ -455,6 +457,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     counter_.zero();
     err_.alloc(1);
     err_.zero();
+    blocks_done_.alloc(1);
+    blocks_done_.zero();
     // ---- symbolic tables
     task_ptr_.upload(sym.task_ptr);
     task_sn_.upload(sym.task_sn);
@@ -560,7 +564,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     stamps_.zero();
 #endif
     configure_kernels();
-    n_launches_per_iter = 3;
+    n_launches_per_iter = 2;
     for (const Step &st : sym.steps)
       n_launches_per_iter += st.kind == STEP_BIG ? count_big_launches(st) + (left_looking_ ? 2 : 3) : st.kind == STEP_MID ? 4 : 2;
   }
@@ -990,7 +994,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           pbegin();
           if ((int64_t)nf * nti * (nti + 1) / 2 < small_tile_below_) {
             const int nt64 = (std::max(rt, 1) + 63) / 64;
-            hipLaunchKernelGGL((k_big_update<T, 2>), dim3(nt64, nt64, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail);
+            // a launch of at most a few rounds of tiles is a chain of memory round trips per tile: deep prefetch
+            if ((int64_t)nf * nt64 * (nt64 + 1) / 2 <= deep_below_)
+              hipLaunchKernelGGL((k_big_update<T, 2, 8>), dim3(nt64, nt64, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail);
+            else
+              hipLaunchKernelGGL((k_big_update<T, 2>), dim3(nt64, nt64, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail);
           } else {
             hipLaunchKernelGGL((k_big_update<T, 4>), dim3(nti, nti, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail);
           }
@@ -1062,7 +1070,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     }
   }
 
-  void launch_update(const T *dx_ref_in, double sign, bool write_ref, bool export_only = false) {
+  void launch_update(const T *dx_ref_in, double sign, bool write_ref, bool export_only = false, bool fused_finalize = false) {
+    FinArgs fin{};
+    if (fused_finalize) {
+      fin.enabled = 1; fin.chi_partial = chi_partial_.p; fin.n_chi = n_lin_blocks_; fin.hist = hist_.p; fin.counter = counter_.p;
+      fin.advance = 1; fin.ring = HIST; fin.blocks_done = blocks_done_.p;
+    }
     pbegin();
     if (!is3d_) {
       UpdArgs<T, S> u;
@@ -1081,6 +1094,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       u.gauge_anchor = (!dx_ref_in && gauge_now_) ? g_.anchor_node : -1;
       u.export_only = export_only ? 1 : 0;
       u.err = dx_ref_in ? nullptr : err_.p;
+      u.fin = fin;
       hipLaunchKernelGGL((k_update<T, S>), dim3(n_upd_blocks_), dim3(UPD_THREADS), 0, stream_, u);
     } else {
       UpdArgs3<T, S> u;
@@ -1097,6 +1111,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       u.norm_partial = norm_partial_.p;
       u.export_only = export_only ? 1 : 0;
       u.err = dx_ref_in ? nullptr : err_.p;
+      u.fin = fin;
       hipLaunchKernelGGL((k_update_se3<T, S>), dim3(n_upd_blocks_), dim3(UPD_THREADS), 0, stream_, u);
     }
     check_launch("k_update");
@@ -1115,8 +1130,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     launch_linearize(0.0, 0, 1);
     launch_factor();
     launch_solve();
-    launch_update(nullptr, 1.0, true);
-    launch_finalize(true, true, true);
+    launch_update(nullptr, 1.0, true, false, true);   // + the reduction of the chi2 / |dx|^2 partials in its last workgroup
   }
 
   void ensure_gn_graph() {
@@ -1822,6 +1836,7 @@ int rr_pgo_debug_stamps(rr_pgo *h, double *out, int32_t *n_sn) {
       o[0] = step_of[s]; o[1] = task_of[s]; o[2] = y.sn_ncols[s]; o[3] = y.sn_nrows[s];
       o[4] = y.child_ptr[s + 1] - y.child_ptr[s];
       for (int q = 0; q < 10; q++) o[5 + q] = (double)st[(size_t)s * 12 + q];
+      o[15] = y.sn_parent[s];
     }
   });
 }

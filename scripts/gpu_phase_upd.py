@@ -20,10 +20,12 @@ sel = (tags >= 600) & (tags < 700)
 tags, ts = tags[sel], ts[sel]
 rows = []; i = 0
 while i + 3 < len(tags):
-    if list(tags[i:i + 4]) == [600, 601, 602, 603]: rows.append(np.diff(ts[i:i + 4])); i += 4
+    if list(tags[i:i + 5]) == [600, 604, 601, 602, 603]: rows.append(np.diff(ts[i:i + 5])); i += 5
     else: i += 1
 rows = np.array(rows)
-names = ['C tile load + first chunk staged', 'k loop (4 chunks)', 'C tile store']
+names = ['C tile + first operand loads back', 'first chunk staged + barrier', 'k loop', 'C tile store']
 print(len(rows), 'launches sampled; mean / median / max us per phase of tile (2,0):')
+last = rows[-12:]
+print('last 12 launches (the root level), us:'); print(np.round(last / 2400, 2))
 for n, col in zip(names, rows.T): print(f'  {n:34s} {col.mean()/2400:7.2f} {np.median(col)/2400:7.2f} {col.max()/2400:7.2f}')
 print('  total', rows.sum(1).mean() / 2400)
