@@ -1274,6 +1274,14 @@ constexpr int BIG_SUPER = RRPGO_BIG_SUPER;  // super-panel width = K of the big 
 constexpr int BIG_PANEL_ROWS = 256;         // rows below the diagonal block handled by one workgroup
 constexpr int BIG_NB2_PER_THREAD = (BIG_NB * BIG_NB + 255) / 256;
 
+// columns [0, big_built_cols) of a front are written by k_big_build when the first trailing update gathers the rest
+// from the children: the pivot columns, rounded up to the tile grid of that update (tiles start at column 128 when
+// nc > 128 and are 64 or 128 wide)
+__device__ __host__ __forceinline__ int big_built_cols(int nc, int M) {
+  const int r = ((nc + 127) / 128) * 128;
+  return nc <= BIG_SUPER ? nc : (r < M ? r : M);
+}
+
 template <typename T> __device__ __forceinline__ int big_front(const FactorArgs<T> &a, int slot) {
   return a.task_sn[a.task_ptr[a.task_begin + slot]];
 }
@@ -1296,14 +1304,80 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_zero(FactorAr
   }
 }
 
-template <typename T> __global__ void __launch_bounds__(256) k_big_assemble(FactorArgs<T> a) {
+// add == 0: plain stores into the zeroed front (before the extend-adds); add == 1: on top of what k_big_build
+// gathered from the children (every destination appears once in the list, so neither form needs atomics)
+template <typename T> __global__ void __launch_bounds__(256) k_big_assemble(FactorArgs<T> a, int add) {
   const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
   T *F = a.lvals + m.loff;
   const int M = m.nc + m.nr + 1;
   const int gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
   const int32_t *src = a.fasm_src + m.asm_begin, *dst = a.fasm_dst + m.asm_begin;
-  for (int t = gid; t < m.asm_count; t += gsz) F[dst[t]] = a.hvals[src[t]];
-  for (int j = gid; j < m.nc; j += gsz) F[(int64_t)j * M + (M - 1)] = a.b[a.perm[m.col0 + j]];
+  if (add) {
+    for (int t = gid; t < m.asm_count; t += gsz) F[dst[t]] += a.hvals[src[t]];
+    for (int j = gid; j < m.nc; j += gsz) F[(int64_t)j * M + (M - 1)] += a.b[a.perm[m.col0 + j]];
+  } else {
+    for (int t = gid; t < m.asm_count; t += gsz) F[dst[t]] = a.hvals[src[t]];
+    for (int j = gid; j < m.nc; j += gsz) F[(int64_t)j * M + (M - 1)] = a.b[a.perm[m.col0 + j]];
+  }
+}
+
+// Zeroing + every extend-add of a level in ONE pass: a wave per column of the parent, lanes over its rows; each
+// entry is the sum, in child order, of what the children hold for it (inverse maps: ChildMeta::scat_ptr), written
+// once.  The front is never read here: against k_big_zero + one read-modify-write launch per child this moves
+// (parent once + children once) instead of (parent 1 + 2 x children-that-touch-it) times.  Rows (J & ~63)..J-1 of
+// column J are cleared like k_big_zero does (the diagonal-block kernels read whole squares).
+// QB children per batch: all their index loads are requested before the first value load, so a batch pays two
+// dependent round trips; a child without this column (jq < 0) is read at a clamped address and masked.
+template <typename T, int QB>
+__device__ __forceinline__ void big_build_column(const FactorArgs<T> &a, const ChildMeta *cm, int nkids, int M, int J, T *col, int lane) {
+  for (int r0 = (J & ~63) + lane; r0 < M; r0 += 256) {
+    T acc[4] = {0, 0, 0, 0};
+    for (int q0 = 0; q0 < nkids; q0 += QB) {
+      int jq[QB], last[QB], iq[QB][4];
+      const T *ucol[QB];
+#pragma unroll
+      for (int qq = 0; qq < QB; qq++) {
+        const ChildMeta c = cm[min(q0 + qq, nkids - 1)];
+        const int32_t *inv = a.scat + c.scat_ptr;
+        const int j = __builtin_amdgcn_readfirstlane(inv[J]);   // the child's column for this parent column (wave-uniform)
+        jq[qq] = q0 + qq < nkids ? j : -1;
+        const int jc = max(jq[qq], 0);
+        const T *Uc = (c.uld > 0 ? a.lvals : c.uld < 0 ? a.xch : a.uvals) + c.uoff;
+        ucol[qq] = Uc + (c.uld > 0 ? (int64_t)jc * c.uld : (int64_t)jc * c.ncu - (int64_t)jc * (jc - 1) / 2 - jc);
+        last[qq] = c.ncu - 1;       // the (rhs, rhs) corner is never used (and never written by an LDS child)
+#pragma unroll
+        for (int u = 0; u < 4; u++) iq[qq][u] = inv[min(r0 + 64 * u, M - 1)];
+      }
+      T uv[QB][4];
+#pragma unroll
+      for (int qq = 0; qq < QB; qq++)
+#pragma unroll
+        for (int u = 0; u < 4; u++) uv[qq][u] = ucol[qq][max(iq[qq][u], max(jq[qq], 0))];   // rows above the column map below jq
+#pragma unroll
+      for (int qq = 0; qq < QB; qq++)
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          acc[u] += (jq[qq] >= 0 && iq[qq][u] >= jq[qq] && !(iq[qq][u] == last[qq] && jq[qq] == last[qq])) ? uv[qq][u] : (T)0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (r0 + 64 * u < M) col[r0 + 64 * u] = acc[u];
+  }
+}
+
+// pivot_only: columns [0, big_built_cols) only -- the first trailing update forms the rest (k_big_update, gather).
+template <typename T> __global__ void __launch_bounds__(256) k_big_build(FactorArgs<T> a, int pivot_only) {
+  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
+  const int M = m.nc + m.nr + 1;
+  T *F = a.lvals + m.loff;
+  const int wave = wave_index(), lane = threadIdx.x & 63;
+  const ChildMeta *cm = a.child_meta + m.child_begin;
+  const int Jend = pivot_only ? big_built_cols(m.nc, M) : M;
+  for (int J = blockIdx.x * 4 + wave; J < Jend; J += gridDim.x * 4) {
+    T *col = F + (int64_t)J * M;
+    if (m.child_count <= 2) big_build_column<T, 2>(a, cm, m.child_count, M, J, col, lane);
+    else big_build_column<T, 4>(a, cm, m.child_count, M, J, col, lane);
+  }
 }
 
 // blocks of parallel edges (rare): serial, after the plain stores
@@ -2050,9 +2124,19 @@ template <typename T, int NT> struct UpdTile {
 // throughput shape (few registers, three workgroups per CU).  8: the whole K = 128 strip is requested up front -- for
 // launches of a few hundred tiles at the top of the tree, where a tile is a chain of memory round trips (data of the
 // previous launch comes back from HBM in ~1.3 us) and nothing else runs on the CU to hide them.
+// Where the C tile of a front's FIRST trailing update comes from when its columns were left out of k_big_build
+// (n > 0): the children's update matrices, gathered through the inverse maps -- the trailing part of a front is
+// then written once, fully formed, instead of built (written), read, updated and written again.
+template <typename T> struct TileGather {
+  const ChildMeta *cm;
+  int n;                       // children to gather from (a front without children starts from zeros); -1 = load the tile from F
+  const int32_t *scat;
+  const T *lvals, *uvals, *xch;
+};
 template <typename T, int NT, int DEPTH = 1>
 __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int jmax, int I0, int J0, T *smem,
-                                                typename Mfma16<T>::Acc (&acc)[NT][NT], unsigned long long *trace = nullptr, bool pm = false) {
+                                                typename Mfma16<T>::Acc (&acc)[NT][NT], unsigned long long *trace = nullptr, bool pm = false,
+                                                const TileGather<T> gather = TileGather<T>{nullptr, -1, nullptr, nullptr, nullptr, nullptr}) {
   struct { unsigned long long *trace; } a{trace};   // for RRPGO_PHASE_MARK (diagnostic builds)
   (void)a; (void)pm;
   using MM = Mfma16<T>;
@@ -2070,7 +2154,61 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
   // never stored) and only the stores are predicated.
   const bool interior = I0 + TILE <= M && J0 + TILE <= jmax && I0 >= J0 + TILE;
   // ---- accumulators = current C tile
-  if (wave_active) {
+  if (gather.n >= 0) {   // uniform over the workgroup
+    // the sum, in child order, of what the children hold for every entry (rows and columns the child does not have
+    // map to -1; the maps are monotone, so row >= column implies iq >= jq wherever both exist).  The index vectors of
+    // up to four children are staged in LDS by all threads (one coalesced load each), so a tile pays two dependent
+    // global round trips (indices, values) however many children it has.
+#pragma unroll
+    for (int ib = 0; ib < NT; ib++)
+#pragma unroll
+      for (int jb = 0; jb < NT; jb++) acc[ib][jb] = typename MM::Acc{0, 0, 0, 0};
+    int32_t *sidx = reinterpret_cast<int32_t *>(smem);
+    for (int q0 = 0; q0 < gather.n; q0 += 4) {
+      const int nb = min(4, gather.n - q0);
+      if (q0 > 0) __syncthreads();
+      for (int e = tid; e < nb * 2 * TILE; e += 256) {
+        const int qq = e / (2 * TILE), w = e - qq * 2 * TILE;
+        const int p = w < TILE ? min(I0 + w, M - 1) : min(J0 + w - TILE, jmax - 1);
+        sidx[e] = (gather.scat + gather.cm[q0 + qq].scat_ptr)[p];
+      }
+      __syncthreads();
+      if (wave_active) {
+        for (int qq = 0; qq < nb; qq++) {
+          const ChildMeta c = gather.cm[q0 + qq];
+          const int32_t *si = sidx + qq * 2 * TILE;
+          const T *Uc = (c.uld > 0 ? gather.lvals : c.uld < 0 ? gather.xch : gather.uvals) + c.uoff;
+          const int last = c.ncu - 1;
+          int iq[NT];
+#pragma unroll
+          for (int ib = 0; ib < NT; ib++) iq[ib] = si[wi + 16 * ib + li];
+#pragma unroll
+          for (int jb = 0; jb < NT; jb++) {
+            int jq[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) jq[r] = si[TILE + wj + 16 * jb + MM::row(lane, r)];
+            T v[4][NT];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int jc = max(jq[r], 0);
+              // column jc of the child: plain column-major square (uld > 0) or packed lower triangle
+              const int coff = c.uld > 0 ? jc * c.uld : jc * c.ncu - ((jc * (jc - 1)) >> 1) - jc;
+#pragma unroll
+              for (int ib = 0; ib < NT; ib++) v[r][ib] = Uc[coff + max(iq[ib], jc)];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+              for (int ib = 0; ib < NT; ib++) {
+                const bool ok = jq[r] >= 0 && iq[ib] >= jq[r] && !(iq[ib] == last && jq[r] == last);
+                acc[ib][jb][r] += ok ? v[r][ib] : (T)0;
+              }
+          }
+        }
+      }
+    }
+    __syncthreads();   // the index vectors share the operand staging buffers
+  } else if (wave_active) {
 #pragma unroll
     for (int jb = 0; jb < NT; jb++)
 #pragma unroll
@@ -2167,7 +2305,9 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
   return true;
 }
 
-template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(256, (DEPTH > 1 ? 1 : sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_update(FactorArgs<T> a, int kb, int mode, int diag_tail) {
+// gather: the launch for the FIRST super-panel (kb == 0, mode 1) forms the tiles right of big_built_cols from the
+// children instead of loading them (k_big_build was told to leave them out)
+template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(256, (DEPTH > 1 ? 1 : sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_update(FactorArgs<T> a, int kb, int mode, int diag_tail, int gather = 0) {
   using MM = Mfma16<T>;
   using UT = UpdTile<T, NT>;
   constexpr int TILE = UT::TILE;
@@ -2193,7 +2333,9 @@ template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(2
   typename MM::Acc acc[NT][NT];
   [[maybe_unused]] const bool pm = blockIdx.x == 2 && blockIdx.y == 0 && blockIdx.z == 0;
   RRPGO_PHASE_MARK(a, pm, 600);
-  if (!big_update_tile<T, NT, DEPTH>(F, M, ka, ke, jmax, I0, J0, smem, acc, a.trace, pm)) return;
+  TileGather<T> tg{nullptr, -1, nullptr, nullptr, nullptr, nullptr};
+  if (gather && J0 >= big_built_cols(m.nc, M)) tg = TileGather<T>{a.child_meta + m.child_begin, m.child_count, a.scat, a.lvals, a.uvals, a.xch};
+  if (!big_update_tile<T, NT, DEPTH>(F, M, ka, ke, jmax, I0, J0, smem, acc, a.trace, pm, tg)) return;
   RRPGO_PHASE_MARK(a, pm, 603);
   // The first wave of the first tile holds the next super-panel's first diagonal block (rows = columns
   // = t0 .. t0+31) in acc[0..1][0..1]: after the tile is stored it factors and inverts that block here,

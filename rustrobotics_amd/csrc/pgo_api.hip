@@ -248,6 +248,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   int factor_threads_max_ = 1024;   // 16-wave workgroups for steps whose fronts exceed 128 rows (RR_PGO_FACTOR_512=1: 8 waves)
   int64_t deep_below_ = 2048;       // RR_PGO_DEEP_BELOW=<n>: trailing updates of at most n 64 x 64 tiles request their whole K strip up front
   int lookahead_max_nf_ = 0;        // RR_PGO_LOOKAHEAD=<n>: levels of at most n big fronts run the k_big_chain sequence (0: none)
+  bool gather_update_ = true;       // ... and only for the pivot columns: a front's first trailing update gathers its tiles from the children (RR_PGO_NO_GATHER_UPDATE=1)
+  bool fused_build_ = true;         // big fronts: k_big_build (one gather pass) instead of zero + extend-add per child (RR_PGO_SPLIT_ASSEMBLY=1)
   bool separate_diag32_ = false;    // RR_PGO_SEPARATE_DIAG32=1: a k_big_diag32 launch for the first block of every level
   bool panel128_ = false;           // RR_PGO_PANEL128=1: two launches per 128-column super-panel (diagonal block in LDS by one
                                     // workgroup, then all rows at once) instead of one per 32 columns; measured 10 % slower
@@ -439,12 +441,15 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     }
     if (overlap_ && std::atoi(getenv("RR_PGO_OVERLAP")) > 1) overlap_max_nf_ = std::atoi(getenv("RR_PGO_OVERLAP"));
     panel128_ = getenv("RR_PGO_PANEL128") != nullptr;
+    fused_build_ = getenv("RR_PGO_SPLIT_ASSEMBLY") == nullptr && getenv("RR_PGO_SERIAL_ASSEMBLY") == nullptr;
     separate_diag32_ = getenv("RR_PGO_SEPARATE_DIAG32") != nullptr;
     factor_threads_max_ = getenv("RR_PGO_FACTOR_512") ? 512 : 1024;
     if (const char *e = getenv("RR_PGO_SOLVE_THREADS")) solve_threads_max_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_SMALL_TILE")) small_tile_below_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_LOOKAHEAD")) lookahead_max_nf_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_DEEP_BELOW")) deep_below_ = std::atoll(e);
+    gather_update_ = fused_build_ && left_looking_ && !panel128_ && !overlap_ && lookahead_max_nf_ == 0 &&
+                     getenv("RR_PGO_NO_GATHER_UPDATE") == nullptr;
     if (const char *e = getenv("RR_PGO_MANY_TASKS")) many_tasks_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_MANY_THREADS")) many_threads_ = std::atoi(e);
     n_lin_blocks_ = (int)(((int64_t)n_list_ * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
@@ -843,7 +848,18 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         if (sym_.sn_ncols[s] > from) r = std::max(r, sym_.sn_ncols[s] + sym_.sn_nrows[s] + 1 - from);
       return r;
     };
-    if (merged_head_) {
+    if (fused_build_) {
+      // one pass writes every entry of the level's fronts once: the sum of the children's contributions (gathered
+      // through inverse maps), zeros elsewhere; the H entries and the rhs are added on top
+      if (do_launch) {
+        hipLaunchKernelGGL(k_big_build<T>, dim3((unsigned)std::min(std::max(((gather_update_ ? std::min(maxM, ((max_nc + 127) / 128) * 128) : maxM) + 3) / 4, 1), 8192), nf), dim3(256), 0, stream_, a, gather_update_ ? 1 : 0);
+        check_launch("k_big_build");
+        hipLaunchKernelGGL(k_big_assemble<T>, dim3((unsigned)std::min<int64_t>((max_asm + 255) / 256, 2048), nf), dim3(256), 0, stream_, a, 1);
+        check_launch("k_big_assemble");
+        if (any_dup) hipLaunchKernelGGL(k_big_assemble_dup<T>, dim3(1, nf), dim3(64), 0, stream_, a);
+      }
+      n += 2 + (any_dup ? 1 : 0);
+    } else if (merged_head_) {
       // every big front of every level in one zero and one assemble launch, at the first big level
       const bool first_big = &st == first_big_step();
       if (do_launch && !head_done_) {
@@ -853,7 +869,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         const unsigned znb = (unsigned)std::min(std::max((big_all_maxM_ + 3) / 4, 1), 8192);
         hipLaunchKernelGGL(k_big_zero<T>, dim3(znb, n_big_all_), dim3(256), 0, stream_, all);
         check_launch("k_big_zero");
-        hipLaunchKernelGGL(k_big_assemble<T>, dim3((unsigned)std::min<int64_t>((big_all_max_asm_ + 255) / 256, 2048), n_big_all_), dim3(256), 0, stream_, all);
+        hipLaunchKernelGGL(k_big_assemble<T>, dim3((unsigned)std::min<int64_t>((big_all_max_asm_ + 255) / 256, 2048), n_big_all_), dim3(256), 0, stream_, all, 0);
         check_launch("k_big_assemble");
         if (big_all_dup_) hipLaunchKernelGGL(k_big_assemble_dup<T>, dim3(1, n_big_all_), dim3(64), 0, stream_, all);
         head_done_ = true;
@@ -863,7 +879,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       const unsigned znb = (unsigned)std::min(std::max((maxM + 3) / 4, 1), 8192);   // a wave per column, four per workgroup
       if (do_launch) { hipLaunchKernelGGL(k_big_zero<T>, dim3(znb, nf), dim3(256), 0, stream_, a); check_launch("k_big_zero"); }
       n++;
-      if (do_launch) hipLaunchKernelGGL(k_big_assemble<T>, dim3((unsigned)std::min<int64_t>((max_asm + 255) / 256, 2048), nf), dim3(256), 0, stream_, a);
+      if (do_launch) hipLaunchKernelGGL(k_big_assemble<T>, dim3((unsigned)std::min<int64_t>((max_asm + 255) / 256, 2048), nf), dim3(256), 0, stream_, a, 0);
       if (do_launch) check_launch("k_big_assemble");
       n++;
       if (any_dup) {
@@ -871,7 +887,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         n++;
       }
     }
-    for (int q = 0; q < max_kids; q++) {
+    for (int q = 0; q < (fused_build_ ? 0 : max_kids); q++) {
       if (do_launch) hipLaunchKernelGGL(k_big_extend_add<T>, dim3((unsigned)std::min<int64_t>((max_ncu + 3) / 4, 2048), nf), dim3(256), 0, stream_, a, q);
       if (do_launch) check_launch("k_big_extend_add");
       n++;
@@ -992,15 +1008,16 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         if (do_launch) {
           if (rest_pending_) { HIPCHK(hipStreamWaitEvent(stream_, ev_rest_, 0)); rest_pending_ = false; }
           pbegin();
+          const int gu = (gather_update_ && K0 == 0) ? 1 : 0;
           if ((int64_t)nf * nti * (nti + 1) / 2 < small_tile_below_) {
             const int nt64 = (std::max(rt, 1) + 63) / 64;
             // a launch of at most a few rounds of tiles is a chain of memory round trips per tile: deep prefetch
             if ((int64_t)nf * nt64 * (nt64 + 1) / 2 <= deep_below_)
-              hipLaunchKernelGGL((k_big_update<T, 2, 8>), dim3(nt64, nt64, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail);
+              hipLaunchKernelGGL((k_big_update<T, 2, 8>), dim3(nt64, nt64, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail, gu);
             else
-              hipLaunchKernelGGL((k_big_update<T, 2>), dim3(nt64, nt64, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail);
+              hipLaunchKernelGGL((k_big_update<T, 2>), dim3(nt64, nt64, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail, gu);
           } else {
-            hipLaunchKernelGGL((k_big_update<T, 4>), dim3(nti, nti, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail);
+            hipLaunchKernelGGL((k_big_update<T, 4>), dim3(nti, nti, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail, gu);
           }
           check_launch("k_big_update/1");
           pend(RR_PGO_K_BIG_UPDATE);

@@ -1036,6 +1036,32 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
       }
       out[-1] = -1;   // the (rhs, rhs) corner is never used
     }
+    // children of a front beyond LDS: the INVERSE of rel (parent local index -> child local index, -1 where the
+    // child has no such row), so that k_big_build can gather every entry of the parent from its children and write
+    // it exactly once -- no zeroing pass, no read-modify-write per child.  rel is strictly increasing (both row
+    // lists are in elimination order), so the inverse is monotone too and a column's gather is a near-contiguous read.
+    int64_t inv_base = total;
+    for (int c = 0; c < S; c++) {
+      const int p = sym.sn_parent[c];
+      if (p < 0 || !sym.sn_huge[p]) continue;
+      sym.scat_ptr[c] = total;
+      total += sym.sn_ncols[p] + sym.sn_nrows[p] + 1;
+    }
+    if (total > inv_base) {
+      sym.scat.resize(total, -1);
+      for (int c = 0; c < S; c++) {
+        const int p = sym.sn_parent[c];
+        if (p < 0 || !sym.sn_huge[p]) continue;
+        const int ncu = sym.sn_nrows[c] + 1, Mp = sym.sn_ncols[p] + sym.sn_nrows[p] + 1;
+        const int32_t *rel = sym.rel.data() + sym.rel_ptr[c];
+        int32_t *inv = sym.scat.data() + sym.scat_ptr[c];
+        for (int r = 0; r < Mp; r++) inv[r] = -1;
+        for (int i = 0; i < ncu; i++) {
+          if (i > 0 && rel[i] <= rel[i - 1]) return "internal: child rows not in the parent's order";
+          inv[rel[i]] = i;
+        }
+      }
+    }
   }
 
   ptimer.mark("asm lists");

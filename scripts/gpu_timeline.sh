@@ -18,7 +18,7 @@ out = []
 t0 = int(rows[last]["Start_Timestamp"])
 for r in rows[last:]:
     n = r["Kernel_Name"]
-    short = n.split("rrpgo::")[-1].split("(")[0]
+    short = n.split("(")[0].split("rrpgo::")[-1]
     out.append([short, int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
                 int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0), int(r.get("Grid_Size_Y", 0) or 0), int(r.get("Grid_Size_Z", 0) or 0),
                 int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 0)) or 0)])

@@ -21,6 +21,11 @@ int main(int argc, char **argv) {
   if (getenv("PARTS")) opt.n_parts = atoi(getenv("PARTS"));
   if (getenv("LDS")) opt.lds_budget_elems = atoll(getenv("LDS"));
   if (getenv("TASKUS")) opt.task_us = atof(getenv("TASKUS"));
+  if (getenv("API")) {   // the options rr_pgo_create uses for a graph of this size (pgo_api.hip, build_handle), fp32 budget
+    opt.lds_budget_elems = getenv("F64") ? 19000 : 38000;
+    opt.nd_leaf = g.n_nodes() <= 6000 ? (1 << 30) : 64;
+    opt.split_separators = g.n_nodes() > 6000;
+  }
   Symbolic s;
   auto t0 = std::chrono::steady_clock::now();
   std::string e = analyze(g, opt, s);
@@ -71,6 +76,19 @@ int main(int argc, char **argv) {
       printf("  step: %d tasks;", st.task_end - st.task_begin);
       for (int b = 0; b < 6; b++) printf(" lds<=%lld: %lld tasks %lld fronts maxM %lld |", le[b], cnt[b], fr[b], mM[b]);
       printf("\n");
+    }
+  if (getenv("FRONTS"))   // every front of every big step: pivot columns x front order
+    for (auto &st : s.steps) {
+      if (st.kind != STEP_BIG) continue;
+      printf("  big step, %d fronts:", st.task_end - st.task_begin);
+      long long fl = 0, st_bytes = 0;
+      int shown = 0;
+      for (int t = st.task_begin; t < st.task_end; t++) {
+        const int f = s.task_sn[s.task_ptr[t]], nc = s.sn_ncols[f], M = nc + s.sn_nrows[f] + 1;
+        fl += (long long)nc * M * M; st_bytes += (long long)M * M;
+        if (shown++ < 6) printf(" %dx%d(kids %d)", nc, M, s.child_ptr[f + 1] - s.child_ptr[f]);
+      }
+      printf(" ... nc*M^2 = %.2f G, storage %.1f M elems\n", fl * 1e-9, st_bytes * 1e-6);
     }
   for (auto &st : s.steps) {
     printf("  %s %d (threads %d, maxM %d, lds %d)\n", st.kind == STEP_TASKS ? "tasks" : st.kind == STEP_MID ? "mid" : "HUGE",

@@ -312,13 +312,16 @@ def test_fronts_beyond_lds_match_oracle_f64(api, oracle):
     assert _state_diff_se2(g.state(), o.state()) <= 1e-8
 
 
-@pytest.mark.parametrize("env", ["RR_PGO_RIGHT_LOOKING", "RR_PGO_OVERLAP", "RR_PGO_PANEL128", "RR_PGO_SEPARATE_DIAG32", "RR_PGO_SERIAL_ASSEMBLY"])
+@pytest.mark.parametrize("env", ["RR_PGO_RIGHT_LOOKING", "RR_PGO_OVERLAP", "RR_PGO_PANEL128", "RR_PGO_SEPARATE_DIAG32", "RR_PGO_SERIAL_ASSEMBLY",
+                                 "RR_PGO_SPLIT_ASSEMBLY"])
 def test_alternate_big_front_launch_sequences_agree(api, env, monkeypatch):
     """The big-front path has switches read when a handle is created: the older right-looking launch
     sequence (diag / trsm / K=32 update), the two-stream trailing update, whole 128-column
     super-panels per chain step (diagonal block in LDS + one row launch), and a launch of its own for
-    the first diagonal block of a level (the default factors it inside the first row launch), and zeroing +
-    assembly of the big fronts level by level (the default does all levels in one launch each).
+    the first diagonal block of a level (the default factors it inside the first row launch), and the older
+    assembly of the big fronts (zero, assemble, one read-modify-write extend-add launch per child -- level by level
+    with RR_PGO_SERIAL_ASSEMBLY, all levels' zero/assemble at once with RR_PGO_SPLIT_ASSEMBLY alone; the default is
+    k_big_build, one gather pass per level).
     Each must give the default path's answer on the 100 x 100 lattice (same
     arithmetic up to the order of the block operations)."""
     from rustrobotics_amd import synthetic_grid_arrays
