@@ -191,7 +191,7 @@ enum {
   RR_PGO_K_BIGFRONT = 5,    /* huge fronts: k_big_zero / k_big_assemble / k_big_extend_add */
   RR_PGO_K_BIG_PANEL = 6,   /* k_big_diag + k_big_trsm (huge fronts: 32-column panels)  */
   RR_PGO_K_BIG_UPDATE = 7,  /* k_big_update (huge fronts: MFMA rank-32 / rank-128 updates) */
-  RR_PGO_K_MID_FACTOR = 8,  /* k_factor_mid (fronts beyond LDS, one workgroup each)    */
+  RR_PGO_K_MID_FACTOR = 8,  /* k_factor_panel (panel-in-LDS fronts, one workgroup each) */
   RR_PGO_K_BIG_SOLVE = 9,   /* k_solve_mid  (back substitution of fronts beyond LDS)   */
   RR_PGO_NUM_KCLASS = 10
 };

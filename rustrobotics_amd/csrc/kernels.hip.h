@@ -5,7 +5,7 @@
 //   k_solve_tasks    back substitution down the supernode tree         (replaces umfpack.solve, :141)
 //   k_update         update_nodes + |dx|^2                             (reference :229-245,273)
 //   k_finalize_slot  fixed-order reduction of the chi2 / |dx|^2 partials (pgo_api.hip)
-//   k_big_* / k_solve_mid / k_factor_mid   fronts beyond LDS (see "huge fronts" below)
+//   k_big_* / k_solve_mid / k_factor_panel fronts beyond LDS (see "huge fronts" below)
 //   k_linearize_se3 / k_update_se3, k_pack_boundary / k_mask_x   SE(3), sharding over ranks
 //
 // Wavefront = 64 lanes.  All cross-workgroup dependencies are kernel boundaries
@@ -1237,16 +1237,210 @@ __global__ void __launch_bounds__(THREADS) k_factor_tasks(FactorArgs<T> a) {
   }
 }
 
-// Mid-size fronts (beyond LDS, small enough for one workgroup): the same front code working in
-// place in HBM (L storage holds the whole M x M front), one workgroup per front, batched per level.
+// Panel class (STEP_MID): fronts whose panel + update matrix exceed LDS but whose pivot PANEL (M x nc) fits.
+// One workgroup per front, batched per level.  The front lives in place in L storage like the huge fronts
+// (M x M, ld M), but only its final contents ever travel: the panel is assembled (H entries + the children's
+// contributions, gathered through the inverse maps) and factored in LDS and stored once; every 32 x 32 tile of
+// the update matrix is formed in registers -- the children's sum minus L21 L21^T, operands read from the LDS
+// panel -- and stored once.  Nothing is zeroed, nothing is read-modify-written in HBM.
 template <typename T, int THREADS>
-__global__ void __launch_bounds__(THREADS) k_factor_mid(FactorArgs<T> a) {
+__global__ void __launch_bounds__(THREADS) k_factor_panel(FactorArgs<T> a) {
+  using MM = Mfma16<T>;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
   __shared__ T dinv[W16_SCR];
-  init_w16_identity<T>(dinv, threadIdx.x, THREADS);
-  const int task = a.task_begin + blockIdx.x;
-  const int s = a.task_sn[a.task_ptr[task]];
-  const SnMeta m = a.sn_meta[s];
-  process_front<T, THREADS, true>(a, s, m, a.lvals + m.loff, a.lvals + m.uoff, m.nc + m.nr + 1, dinv);
+  T *P = reinterpret_cast<T *>(smem_raw);
+  const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63;
+  constexpr int NW = THREADS / 64;
+  init_w16_identity<T>(dinv, tid, THREADS);
+  const SnMeta m = a.task_meta[a.task_begin + blockIdx.x];
+  const int nc = m.nc, M = nc + m.nr + 1, nu = m.nr + 1, psize = M * nc;
+  const ChildMeta *cm = a.child_meta + m.child_begin;
+  // the inverse maps (parent row -> child row) of the first PQ children are staged behind the panel
+  constexpr int PQ = 4;
+  int32_t *invs = reinterpret_cast<int32_t *>(P + ((psize + 3) & ~3));
+  // ---- H entries of the pivot columns and the rhs row (index, then value: requested before the zeroing pass)
+  constexpr int APRE = 2;
+  const int32_t *asrc = a.fasm_src + m.asm_begin, *adst = a.fasm_dst + m.asm_begin;
+  int pd[APRE];
+  T pv[APRE], pb = 0;
+#pragma unroll
+  for (int u = 0; u < APRE; u++) {
+    const int t = tid + u * THREADS;
+    pd[u] = -1;
+    pv[u] = 0;
+    if (t < m.asm_count) { pd[u] = adst[t]; pv[u] = a.hvals[asrc[t]]; }
+  }
+  if (tid < nc) pb = a.b[a.perm[m.col0 + tid]];
+  for (int q = 0; q < min(m.child_count, PQ); q++) {
+    const int32_t *ginv = a.scat + cm[q].scat_ptr;
+    for (int t = tid; t < M; t += THREADS) invs[q * M + t] = ginv[t];
+  }
+  for (int t = tid; t < psize; t += THREADS) P[t] = 0;
+  lds_barrier();
+#pragma unroll
+  for (int u = 0; u < APRE; u++)
+    if (pd[u] >= 0) P[pd[u]] = pv[u];
+  for (int t = tid + APRE * THREADS; t < m.asm_count; t += THREADS) P[adst[t]] = a.hvals[asrc[t]];
+  if (tid < nc) P[tid * M + (M - 1)] = pb;
+  for (int j = tid + THREADS; j < nc; j += THREADS) P[j * M + (M - 1)] = a.b[a.perm[m.col0 + j]];
+  __syncthreads();
+  if (m.dup_count > 0) {  // blocks of parallel edges (rare): serial, fixed order
+    if (tid == 0)
+      for (int t = 0; t < m.dup_count; t++) P[a.fdup_dst[m.dup_begin + t]] += a.hvals[a.fdup_src[m.dup_begin + t]];
+    __syncthreads();
+  }
+  // ---- the children's contributions to the pivot columns.  The inverse maps of the first PQ children were staged
+  // in LDS (one coalesced load each), so an entry costs ONE global round trip (its values), and a thread's four
+  // entries x all children are requested together.
+  const int nkq = min(m.child_count, PQ);
+  for (int e0 = tid; e0 < psize; e0 += 4 * THREADS) {
+    int J[4], r[4];
+    T acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = min(e0 + u * THREADS, psize - 1);
+      J[u] = e / M;
+      r[u] = e - J[u] * M;
+    }
+    for (int q = 0; q < m.child_count; q++) {
+      const ChildMeta c = cm[q];
+      const int32_t *ginv = a.scat + c.scat_ptr;
+      const int32_t *sinv = invs + q * M;
+      const T *Uc = (c.uld > 0 ? a.lvals : c.uld < 0 ? a.xch : a.uvals) + c.uoff;
+      int iq[4], jq[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        iq[u] = q < nkq ? sinv[r[u]] : ginv[r[u]];
+        jq[u] = q < nkq ? sinv[J[u]] : ginv[J[u]];
+      }
+      T uv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int jc = max(jq[u], 0);
+        const int coff = c.uld > 0 ? jc * c.uld : jc * c.ncu - ((jc * (jc - 1)) >> 1) - jc;
+        uv[u] = Uc[coff + max(iq[u], jc)];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) acc[u] += (jq[u] >= 0 && iq[u] >= jq[u]) ? uv[u] : (T)0;   // J < nc <= M - 1: never the (rhs, rhs) corner
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (e0 + u * THREADS < psize && r[u] >= J[u]) P[e0 + u * THREADS] += acc[u];
+  }
+  __syncthreads();
+  // ---- partial factorisation of the panel (16 x 16 inverse diagonal blocks kept for the back substitution)
+  panel_factor<T, THREADS, true>(P, M, nc, a.err, dinv, a.winv + (int64_t)m.wblk * 256);
+  __syncthreads();
+  // ---- panel -> the front's first nc columns (same layout: column-major, ld M)
+  T *F = a.lvals + m.loff;
+  for (int t = tid; t < psize; t += THREADS) F[t] = P[t];
+  // ---- update matrix: U(i, j) = children(i, j) - sum_k L21(i, k) L21(j, k), 32 x 32 tiles, one per wave at a time.
+  // The children's values of the NEXT tile are requested before the MFMAs of the current one.
+  const int li = lane & 15, lk = lane >> 4;
+  const int nt = (nu + 31) >> 5, ntiles = nt * (nt + 1) / 2;
+  const T *L21 = P + nc;   // row i of the update matrix = row nc + i of the panel
+  auto tile_origin = [&](int t, int &i0, int &j0) {
+    int jb = 0, rem = t;
+    while (rem >= nt - jb) { rem -= nt - jb; jb++; }
+    i0 = 32 * (jb + rem);
+    j0 = 32 * jb;
+  };
+  // values of children [q0, q0 + 2) for the tile at (i0, j0): v[qq][y][r][x], masked to zero where the child has no entry
+  auto fetch2 = [&](int q0, int i0, int j0, T (&v)[2][2][4][2]) {
+#pragma unroll
+    for (int qq = 0; qq < 2; qq++) {
+      const int q = min(q0 + qq, m.child_count - 1);
+      const ChildMeta c = cm[q];
+      const int32_t *ginv = a.scat + c.scat_ptr;
+      const int32_t *sinv = invs + q * M;
+      const bool staged = q < nkq, have = q0 + qq < m.child_count;
+      const T *Uc = (c.uld > 0 ? a.lvals : c.uld < 0 ? a.xch : a.uvals) + c.uoff;
+      const int last = c.ncu - 1;
+      int iq[2];
+#pragma unroll
+      for (int x = 0; x < 2; x++) {
+        const int pr = nc + min(i0 + 16 * x + li, nu - 1);
+        iq[x] = staged ? sinv[pr] : ginv[pr];
+      }
+#pragma unroll
+      for (int y = 0; y < 2; y++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int pc = nc + min(j0 + 16 * y + MM::row(lane, r), nu - 1);
+          const int jq = staged ? sinv[pc] : ginv[pc];
+          const int jc = max(jq, 0);
+          const int coff = c.uld > 0 ? jc * c.uld : jc * c.ncu - ((jc * (jc - 1)) >> 1) - jc;
+#pragma unroll
+          for (int x = 0; x < 2; x++) {
+            const T val = Uc[coff + max(iq[x], jc)];
+            const bool ok = have && jq >= 0 && iq[x] >= jq && !(iq[x] == last && jq == last);
+            v[qq][y][r][x] = ok ? val : (T)0;
+          }
+        }
+    }
+  };
+  T vnext[2][2][4][2];
+  int i0 = 0, j0 = 0;
+  if (wave < ntiles) {
+    tile_origin(wave, i0, j0);
+    if (m.child_count > 0) fetch2(0, i0, j0, vnext);
+  }
+  for (int t = wave; t < ntiles; t += NW) {
+    typename MM::Acc acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+      for (int y = 0; y < 2; y++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[x][y][r] = m.child_count > 0 ? vnext[0][y][r][x] + vnext[1][y][r][x] : (T)0;
+    for (int q0 = 2; q0 < m.child_count; q0 += 2) {   // more than two children (rare): no prefetch
+      fetch2(q0, i0, j0, vnext);
+#pragma unroll
+      for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int y = 0; y < 2; y++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) acc[x][y][r] += vnext[0][y][r][x] + vnext[1][y][r][x];
+    }
+    const int ci0 = i0, cj0 = j0;
+    if (t + NW < ntiles) {
+      tile_origin(t + NW, i0, j0);
+      if (m.child_count > 0) fetch2(0, i0, j0, vnext);
+    }
+    // rank-nc update from the LDS panel: D = (-X_j) X_i^T, so a lane's four results are four columns j of one row i
+    const T *xi0 = L21 + min(ci0 + li, nu - 1), *xi1 = L21 + min(ci0 + 16 + li, nu - 1);
+    const T *xj0 = L21 + min(cj0 + li, nu - 1), *xj1 = L21 + min(cj0 + 16 + li, nu - 1);
+    const int nfull = nc >> 2;
+    int kk = lk * M;
+#pragma unroll 4
+    for (int k4 = 0; k4 < nfull; k4++, kk += 4 * M) {
+      const T b0 = xi0[kk], b1 = xi1[kk];
+      const T a0 = -xj0[kk], a1 = -xj1[kk];
+      acc[0][0] = MM::mma(a0, b0, acc[0][0]);
+      acc[0][1] = MM::mma(a1, b0, acc[0][1]);
+      acc[1][0] = MM::mma(a0, b1, acc[1][0]);
+      acc[1][1] = MM::mma(a1, b1, acc[1][1]);
+    }
+    if (nc & 3) {
+      const bool kok = 4 * nfull + lk < nc;
+      const int kc = min(4 * nfull + lk, nc - 1) * M;
+      const T b0 = xi0[kc], b1 = xi1[kc];
+      const T a0 = kok ? -xj0[kc] : (T)0, a1 = kok ? -xj1[kc] : (T)0;
+      acc[0][0] = MM::mma(a0, b0, acc[0][0]);
+      acc[0][1] = MM::mma(a1, b0, acc[0][1]);
+      acc[1][0] = MM::mma(a0, b1, acc[1][0]);
+      acc[1][1] = MM::mma(a1, b1, acc[1][1]);
+    }
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+      for (int y = 0; y < 2; y++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int i = ci0 + 16 * x + li, j = cj0 + 16 * y + MM::row(lane, r);
+          if (i < nu && j < nu && i >= j) F[(int64_t)(nc + j) * M + nc + i] = acc[x][y][r];
+        }
+  }
 }
 
 // ---- huge fronts: many workgroups per front, one launch per phase, the huge fronts of one

@@ -648,6 +648,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     set_lds_attr<512>();
     HIPCHK(hipFuncSetAttribute((const void *)k_factor_tasks<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
     HIPCHK(hipFuncSetAttribute((const void *)k_solve_mid<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void *)k_factor_panel<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
   }
 
   template <int TH> void launch_factor_tasks(int nt, size_t lds, const FactorArgs<T> &a) {
@@ -793,8 +794,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         else launch_factor_tasks<1024>(nt, lds, a);
         pend(RR_PGO_K_FACTOR);
       } else if (st.kind == STEP_MID) {
-        hipLaunchKernelGGL((k_factor_mid<T, 1024>), dim3(st.task_end - st.task_begin), dim3(1024), 0, stream_,
+        hipLaunchKernelGGL((k_factor_panel<T, 1024>), dim3(st.task_end - st.task_begin), dim3(1024), (size_t)st.max_lds_elems * sizeof(T), stream_,
                            factor_args(st.task_begin));
+        check_launch("k_factor_panel");
         pend(RR_PGO_K_MID_FACTOR);
       } else {
         launch_big_level(st, true);
@@ -1534,7 +1536,10 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
     so.nd_leaf = 64;
     so.pin_node = h->g.anchor_node;   // every rank needs the anchor's entries of the solution (gauge transfer)
   }
-  if (const char *e = std::getenv("RR_PGO_MID_MAX")) so.mid_max_front = std::atoi(e);   // tuning knobs
+  // experiment knob: fronts beyond LDS whose pivot panel (M x nc scalars) fits this budget get one workgroup each with
+  // the panel in LDS (k_factor_panel).  Measured on the 1M-edge lattice (fp32): 6.56 ms per step with 36000, 6.50 with
+  // 10000, against 6.44 without -- a lone CU spends 75..140 us on such a front, the batched tiled path wins.  Off.
+  if (const char *e = std::getenv("RR_PGO_PANEL_BUDGET")) so.panel_budget_elems = std::atoll(e);   // tuning knobs
   if (const char *e = std::getenv("RR_PGO_TASK_US")) so.task_us = std::atof(e);
   if (const char *e = std::getenv("RR_PGO_THREADS_SHIFT")) so.threads_shift = std::atoi(e);
   if (std::getenv("RR_PGO_NO_GEO")) so.geo_nd = false;

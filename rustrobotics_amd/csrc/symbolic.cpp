@@ -799,7 +799,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
       const int nc = sym.sn_ncols[f], nr = sym.sn_nrows[f], M = nc + nr + 1;
       const bool big = lds_elems(nc, nr) > lds_budget;
       sym.sn_big[f] = big;
-      sym.sn_huge[f] = big && M > opt.mid_max_front;
+      sym.sn_huge[f] = big && (int64_t)M * nc > opt.panel_budget_elems;
       sym.n_big += big;
       sym.max_front = std::max(sym.max_front, nc + nr);
       sym.max_pivot_cols = std::max(sym.max_pivot_cols, nc);
@@ -1043,7 +1043,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     int64_t inv_base = total;
     for (int c = 0; c < S; c++) {
       const int p = sym.sn_parent[c];
-      if (p < 0 || !sym.sn_huge[p]) continue;
+      if (p < 0 || !sym.sn_big[p]) continue;
       sym.scat_ptr[c] = total;
       total += sym.sn_ncols[p] + sym.sn_nrows[p] + 1;
     }
@@ -1051,7 +1051,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
       sym.scat.resize(total, -1);
       for (int c = 0; c < S; c++) {
         const int p = sym.sn_parent[c];
-        if (p < 0 || !sym.sn_huge[p]) continue;
+        if (p < 0 || !sym.sn_big[p]) continue;
         const int ncu = sym.sn_nrows[c] + 1, Mp = sym.sn_ncols[p] + sym.sn_nrows[p] + 1;
         const int32_t *rel = sym.rel.data() + sym.rel_ptr[c];
         int32_t *inv = sym.scat.data() + sym.scat_ptr[c];
@@ -1181,6 +1181,8 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
               sym.task_sn.push_back(f);
               sym.task_ptr.push_back((int)sym.task_sn.size());
               b.max_front = std::max(b.max_front, sym.sn_ncols[f] + sym.sn_nrows[f] + 1);
+              if (cls == 0)   // the panel class keeps M x nc in LDS
+                b.max_lds_elems = std::max<int64_t>(b.max_lds_elems, (int64_t)(sym.sn_ncols[f] + sym.sn_nrows[f] + 1) * (sym.sn_ncols[f] + 4) + 4);  // + four staged inverse maps (4-byte entries)
               w2 = std::max(w2, cost[f]);
             }
           b.task_end = (int)sym.task_ptr.size() - 1;

@@ -29,8 +29,9 @@ struct SymbolicOptions {
   int my_part = 0;          // with n_parts > 1: the rank whose schedule is emitted (own subtrees, then shared top)
   int pin_node = -1;        // with n_parts > 1: this node (the anchor) is made part of the top separator
   double task_us = 0.0;     // subtrees cheaper than this (model us) become one leaf task; 0 = pick by the cost model
-  int mid_max_front = 0;    // fronts beyond LDS up to this size go to the one-workgroup in-place path (0: none,
-                            // measured slower than the batched tiled path on the 1M-edge lattice)
+  int64_t panel_budget_elems = 0;  // fronts beyond LDS whose pivot PANEL (M x nc) still fits this many LDS scalars go to
+                                   // the one-workgroup panel class (STEP_MID: panel factored in LDS, Schur complement
+                                   // streamed to the in-place front); 0: none
 };
 
 // One (block) entry of H that has to be added into a front.
@@ -42,8 +43,8 @@ struct AsmItem {
   int32_t diag;   // 1: symmetric diagonal block (only i >= j is used)
 };
 
-// STEP_TASKS: LDS fronts, one workgroup per task.  STEP_MID: fronts beyond LDS but small enough for one
-// workgroup working in place in HBM, batched (task list of single fronts).  STEP_BIG: the huge fronts of
+// STEP_TASKS: LDS fronts, one workgroup per task.  STEP_MID: fronts beyond LDS whose pivot panel fits LDS, one
+// workgroup each (k_factor_panel), batched (task list of single fronts).  STEP_BIG: the huge fronts of
 // one level (task list of single fronts), tiled over many workgroups, a sequence of batched launches.
 enum StepKind : int32_t { STEP_TASKS = 0, STEP_BIG = 1, STEP_MID = 2 };
 struct Step {

@@ -313,7 +313,7 @@ def test_fronts_beyond_lds_match_oracle_f64(api, oracle):
 
 
 @pytest.mark.parametrize("env", ["RR_PGO_RIGHT_LOOKING", "RR_PGO_OVERLAP", "RR_PGO_PANEL128", "RR_PGO_SEPARATE_DIAG32", "RR_PGO_SERIAL_ASSEMBLY",
-                                 "RR_PGO_SPLIT_ASSEMBLY"])
+                                 "RR_PGO_SPLIT_ASSEMBLY", "RR_PGO_NO_GATHER_UPDATE", "RR_PGO_PANEL_BUDGET=18000"])
 def test_alternate_big_front_launch_sequences_agree(api, env, monkeypatch):
     """The big-front path has switches read when a handle is created: the older right-looking launch
     sequence (diag / trsm / K=32 update), the two-stream trailing update, whole 128-column
@@ -321,14 +321,16 @@ def test_alternate_big_front_launch_sequences_agree(api, env, monkeypatch):
     the first diagonal block of a level (the default factors it inside the first row launch), and the older
     assembly of the big fronts (zero, assemble, one read-modify-write extend-add launch per child -- level by level
     with RR_PGO_SERIAL_ASSEMBLY, all levels' zero/assemble at once with RR_PGO_SPLIT_ASSEMBLY alone; the default is
-    k_big_build, one gather pass per level).
+    k_big_build, one gather pass per level, pivot columns only -- RR_PGO_NO_GATHER_UPDATE builds whole fronts), and the
+    one-workgroup panel class (RR_PGO_PANEL_BUDGET: pivot panel factored in LDS, k_factor_panel; off by default).
     Each must give the default path's answer on the 100 x 100 lattice (same
     arithmetic up to the order of the block operations)."""
     from rustrobotics_amd import synthetic_grid_arrays
     arrays = synthetic_grid_arrays(100, 100)
     ref = api[0].from_arrays(*arrays)
     eref = ref.optimize(3)
-    monkeypatch.setenv(env, "1")
+    env, _, val = env.partition("=")
+    monkeypatch.setenv(env, val or "1")
     alt = api[0].from_arrays(*arrays)
     monkeypatch.delenv(env)
     ealt = alt.optimize(3)
