@@ -3334,6 +3334,142 @@ __device__ void solve_big_front(const FactorArgs<T> &a, const SnMeta &m, T *work
   __syncthreads();
 }
 
+// Back substitution of WIDE pivot blocks (the top separators: 600 .. 1500 columns), one launch per 128-column
+// super-panel, right to left.  k_solve_mid walks a front's whole L11 through one CU (4.5 MB for the root of the
+// 1M-edge lattice, 4.6 us per 32 columns); here launch ell handles super-panel s = S - 1 - ell of every front:
+//   workgroup 0       folds x of super-panel s + 1 (solved by the previous launch) into its own 128 columns
+//                     (a 128 x 128 block of L), then solves them: four chain steps with the kept inverses
+//   workgroups 1..    fold the same x into the columns further left, 64 columns each (the whole chip reads L11)
+// The running right-hand side lives in x[col0 ..]; launch 0 (no super-panel to the right yet) initialises it:
+// t = y1 - sum of the row slices of k_big_gemv_partial.  Every column is owned by one workgroup per launch and
+// the launches are ordered: plain read-modify-write, fixed summation order.
+template <typename T> __global__ void __launch_bounds__(1024) k_big_solve_sp(FactorArgs<T> a, int ell, const T *part, int64_t N, int R) {
+  __shared__ T xf[BIG_SUPER];              // this super-panel: t, then x
+  __shared__ T xr[BIG_SUPER];              // x of the super-panel to the right
+  __shared__ T Ws[4 * 32 * 33];            // the super-panel's four W_b, staged transposed
+  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
+  const int nc = m.nc, M = nc + m.nr + 1;
+  const int S = (nc + BIG_SUPER - 1) / BIG_SUPER, sp = S - 1 - ell;
+  if (sp < 0) return;
+  const int K0 = BIG_SUPER * sp, K1 = min(nc, K0 + BIG_SUPER), K2 = min(nc, K1 + BIG_SUPER);
+  const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+  constexpr int NW = 16;
+  const T *Lg = a.lvals + m.loff;
+  T *xg = a.x + m.col0;
+  auto t_init = [&](int j) {   // y1 - L21^T x[rows], slices subtracted in slice order
+    T t = Lg[(int64_t)j * M + (M - 1)];
+    if (m.nr > 0)
+      for (int r = 0; r < R; r++) t -= part[(int64_t)r * N + m.col0 + j];
+    return t;
+  };
+  const bool have_right = sp + 1 < S;
+  const int nright = K2 - K1;   // 1..128 rows of the super-panel to the right
+  // x of the super-panel to the right, two rows per lane: rows lane and lane + 64
+  T xa = 0, xb = 0;
+  if (have_right) {
+    const T va = xg[K1 + min(lane, nright - 1)], vb = xg[K1 + min(lane + 64, nright - 1)];
+    xa = lane < nright ? va : (T)0;
+    xb = lane + 64 < nright ? vb : (T)0;
+  }
+  // column i: sum over the rows of the right super-panel of L(K1 + j, i) x_j, by one wave
+  auto fold_column = [&](int i) {
+    const T *col = Lg + (int64_t)i * M + K1;
+    const T la = col[min(lane, nright - 1)], lb = col[min(lane + 64, nright - 1)];
+    return wave_sum63<T>(la * xa + lb * xb);   // valid in lane 63
+  };
+  if (blockIdx.x > 0) {
+    // ---- columns further left: 64 per workgroup, 4 per wave
+    const int c_lo = 64 * (blockIdx.x - 1);
+    if (c_lo >= K0) return;
+    const int c_hi = min(K0, c_lo + 64);
+    if (ell == 0) {   // nothing to the right of this front's last super-panel: initialise the running rhs
+      for (int j = c_lo + tid; j < c_hi; j += 1024) xg[j] = t_init(j);
+      return;
+    }
+    for (int i = c_lo + wave; i < c_hi; i += NW) {
+      const T sum = fold_column(i);
+      if (lane == 63) xg[i] -= sum;
+    }
+    return;
+  }
+  // ---- workgroup 0: this super-panel.  Every load whose address does not depend on a solution is requested up
+  // front (the fold operands, the four inverse diagonal blocks, the in-panel fold operands): the chain below then
+  // runs out of registers and LDS.
+  const int w = K1 - K0;
+  const int b_hi = (K1 + 31) / 32 - 1, b_lo = K0 / 32;
+  T fa_[8], fb_[8];
+  if (have_right) {
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const T *col = Lg + (int64_t)(K0 + min(wave + NW * c, w - 1)) * M + K1;
+      fa_[c] = col[min(lane, nright - 1)];
+      fb_[c] = col[min(lane + 64, nright - 1)];
+    }
+  }
+  const T *Wb = a.winv + (int64_t)m.wblk * 256;
+  T wreg[4], lv[4][3];
+#pragma unroll
+  for (int bb = 0; bb < 4; bb++) {
+    const int b = max(b_hi - bb, b_lo);
+    wreg[bb] = Wb[(int64_t)b * 1024 + tid];   // Wb[b][c * 32 + j] = W_b(j, c)
+    // L(c0 + l32, i) for the columns i in [K0, c0): half a wave per column
+    const int c0 = 32 * b, cw = min(32, nc - c0), ncols = c0 - K0;
+    const T *base = Lg + c0 + min(l32, cw - 1);
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int i = 2 * (wave + NW * q) + half;
+      lv[bb][q] = base[(int64_t)(K0 + min(i, max(ncols - 1, 0))) * M];
+    }
+  }
+  if (tid < w) xf[tid] = ell == 0 ? t_init(K0 + tid) : xg[K0 + tid];
+#pragma unroll
+  for (int bb = 0; bb < 4; bb++) {   // -> Ws[bb][j * 33 + c]
+    const int c = tid >> 5, j = tid & 31;
+    Ws[bb * (32 * 33) + j * 33 + c] = wreg[bb];
+  }
+  __syncthreads();
+  if (have_right) {
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const int i = wave + NW * c;
+      const T sum = wave_sum63<T>(fa_[c] * xa + fb_[c] * xb);
+      if (lane == 63 && i < w) xf[i] -= sum;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int bb = 0; bb < 4; bb++) {
+    const int b = b_hi - bb;
+    if (b < b_lo) break;   // uniform
+    const int c0 = 32 * b, cw = min(32, nc - c0), o = c0 - K0, ncols = c0 - K0;
+    if (tid < 64) {   // x_b = W_b^T t_b (W is padded with an identity past cw)
+      const T *ws = Ws + bb * (32 * 33) + l32;
+      const T tv = pin(xf[o + min(l32, cw - 1)]);
+      const T v = l32 < cw ? tv : (T)0;
+      T wv[32];
+#pragma unroll
+      for (int j = 0; j < 32; j++) wv[j] = ws[j * 33];
+      T x = 0;
+#pragma unroll
+      for (int j = 0; j < 32; j++) x += wv[j] * lane_bcast(v, j);
+      if (lane < cw) xf[o + lane] = x;
+    }
+    __syncthreads();
+    if (ncols > 0) {   // uniform
+      const T xv = pin(xf[o + min(l32, cw - 1)]);
+      const T xj = l32 < cw ? xv : (T)0;
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int i = 2 * (wave + NW * q) + half;
+        const T sum = half_wave_sum<T>(lv[bb][q] * xj);
+        if (l32 == 31 && i < ncols) xf[i] -= sum;
+      }
+      __syncthreads();
+    }
+  }
+  if (tid < w) xg[K0 + tid] = xf[tid];
+}
+
 template <typename T, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_solve_mid(FactorArgs<T> a, int w32, const T *part, int64_t N, int R) {
   extern __shared__ __align__(16) unsigned char smem_raw[];

@@ -248,6 +248,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   int factor_threads_max_ = 1024;   // 16-wave workgroups for steps whose fronts exceed 128 rows (RR_PGO_FACTOR_512=1: 8 waves)
   int64_t deep_below_ = 2048;       // RR_PGO_DEEP_BELOW=<n>: trailing updates of at most n 64 x 64 tiles request their whole K strip up front
   int lookahead_max_nf_ = 0;        // RR_PGO_LOOKAHEAD=<n>: levels of at most n big fronts run the k_big_chain sequence (0: none)
+  int sp_solve_min_nc_ = 256;       // back substitution: levels whose widest pivot block has at least this many columns run k_big_solve_sp (RR_PGO_SP_SOLVE_MIN)
   bool gather_update_ = true;       // ... and only for the pivot columns: a front's first trailing update gathers its tiles from the children (RR_PGO_NO_GATHER_UPDATE=1)
   bool fused_build_ = true;         // big fronts: k_big_build (one gather pass) instead of zero + extend-add per child (RR_PGO_SPLIT_ASSEMBLY=1)
   bool separate_diag32_ = false;    // RR_PGO_SEPARATE_DIAG32=1: a k_big_diag32 launch for the first block of every level
@@ -448,6 +449,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (const char *e = getenv("RR_PGO_SMALL_TILE")) small_tile_below_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_LOOKAHEAD")) lookahead_max_nf_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_DEEP_BELOW")) deep_below_ = std::atoll(e);
+    if (const char *e = getenv("RR_PGO_SP_SOLVE_MIN")) sp_solve_min_nc_ = std::atoi(e);
     gather_update_ = fused_build_ && left_looking_ && !panel128_ && !overlap_ && lookahead_max_nf_ == 0 &&
                      getenv("RR_PGO_NO_GATHER_UPDATE") == nullptr;
     if (const char *e = getenv("RR_PGO_MANY_TASKS")) many_tasks_ = std::atoi(e);
@@ -571,7 +573,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     configure_kernels();
     n_launches_per_iter = 2;
     for (const Step &st : sym.steps)
-      n_launches_per_iter += st.kind == STEP_BIG ? count_big_launches(st) + (left_looking_ ? 2 : 3) : st.kind == STEP_MID ? 4 : 2;
+      n_launches_per_iter += st.kind == STEP_BIG ? count_big_launches(st) + count_big_solve_launches(st) : st.kind == STEP_MID ? 4 : 2;
   }
 
   ~Engine() override {
@@ -1034,11 +1036,18 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           HIPCHK(hipEventRecord(ev_chain_, stream_));
           HIPCHK(hipStreamWaitEvent(stream2_, ev_chain_, 0));
           if (rest_pending_) HIPCHK(hipStreamWaitEvent(stream_, ev_rest_, 0));
-          hipLaunchKernelGGL((k_big_update<T, 4>), dim3(nti - 1, nti - 1, nf), dim3(256), 0, stream2_, a, K0, 3, 0);
+          const int nt64 = (std::max(rt, 1) + 63) / 64;
+          if ((int64_t)nf * nti * (nti + 1) / 2 < small_tile_below_)
+            hipLaunchKernelGGL((k_big_update<T, 2>), dim3(std::max(nt64 - 2, 1), std::max(nt64 - 2, 1), nf), dim3(256), 0, stream2_, a, K0, 3, 0);
+          else
+            hipLaunchKernelGGL((k_big_update<T, 4>), dim3(nti - 1, nti - 1, nf), dim3(256), 0, stream2_, a, K0, 3, 0);
           check_launch("k_big_update/3");
           HIPCHK(hipEventRecord(ev_rest_, stream2_));
           rest_pending_ = true;
-          hipLaunchKernelGGL((k_big_update<T, 4>), dim3(nti, 1, nf), dim3(256), 0, stream_, a, K0, 2, diag_tail);
+          if ((int64_t)nf * nti * (nti + 1) / 2 < small_tile_below_)
+            hipLaunchKernelGGL((k_big_update<T, 2>), dim3(nt64, 2, nf), dim3(256), 0, stream_, a, K0, 2, diag_tail);
+          else
+            hipLaunchKernelGGL((k_big_update<T, 4>), dim3(nti, 1, nf), dim3(256), 0, stream_, a, K0, 2, diag_tail);
           check_launch("k_big_update/2");
         }
         n += 2;
@@ -1049,6 +1058,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     return n;
   }
   int count_big_launches(const Step &st) { return launch_big_level(st, false); }
+  int count_big_solve_launches(const Step &st) const {
+    int max_nc = 1;
+    for (int t = st.task_begin; t < st.task_end; t++) max_nc = std::max(max_nc, sym_.sn_ncols[sym_.task_sn[sym_.task_ptr[t]]]);
+    if (left_looking_ && max_nc >= sp_solve_min_nc_) return 1 + (max_nc + BIG_SUPER - 1) / BIG_SUPER;
+    return left_looking_ ? 2 : 3;
+  }
 
   void launch_solve() {
     for (int i = (int)sym_.steps.size() - 1; i >= 0; i--) {   // shared top fronts first, then this rank's subtrees
@@ -1079,6 +1094,16 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         hipLaunchKernelGGL(k_big_gemv_partial<T>, dim3(cb, R, nf), dim3(256), 0, stream_, fa, gemv_part_.p, (int64_t)g_.dim, R);
         check_launch("k_big_gemv_partial");
         const int w32 = (st.kind == STEP_BIG && left_looking_) ? 1 : 0;
+        if (w32 && max_nc >= sp_solve_min_nc_) {
+          // wide pivot blocks: one launch per 128-column super-panel, L11 read by the whole chip
+          const int nsp = (max_nc + BIG_SUPER - 1) / BIG_SUPER;
+          for (int ell = 0; ell < nsp; ell++) {
+            hipLaunchKernelGGL(k_big_solve_sp<T>, dim3(1 + (max_nc + 63) / 64, nf), dim3(1024), 0, stream_, fa, ell, (const T *)gemv_part_.p, (int64_t)g_.dim, R);
+            check_launch("k_big_solve_sp");
+          }
+          pend(RR_PGO_K_BIG_SOLVE, 1 + nsp);
+          continue;
+        }
         if (!w32) {
           hipLaunchKernelGGL(k_big_gemv_finish<T>, dim3((max_nc + 255) / 256, nf), dim3(256), 0, stream_, fa, (const T *)gemv_part_.p, (int64_t)g_.dim, R);
           check_launch("k_big_gemv_finish");
