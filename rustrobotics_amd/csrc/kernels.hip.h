@@ -324,6 +324,145 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<TO, T> a) {
   if (threadIdx.x == 0) a.chi2_partial[blockIdx.x] = tot;
 }
 
+// ---- the EDGE-PARALLEL form of the same linearisation (the north star's wording; RR_PGO_EDGE_LINEARIZE=1) ----
+// Kept as the measured alternative to k_linearize, not as the default: see DESIGN.md "Linearisation: pull vs
+// edge-parallel".  One thread per edge evaluates the factor ONCE (the pull form evaluates it from both ends):
+//   off-diagonal block   stored directly (one writer per block)
+//   from-node terms      edges of one `from` node are consecutive in file order on the lattice: a segmented scan over
+//                        the wave (head flags, fixed order) adds them up and the last lane of a run issues ONE set of
+//                        atomic adds per run
+//   to-node terms        atomic adds, one set per edge (the far endpoints of a wave's edges are all different)
+//   chi2                 workgroup sum in f64, like the pull form
+// k_lin_init clears diagonal blocks and rhs first (and places prior / lambda), k_lin_finish mirrors the lower
+// triangles.  Floating-point atomics make the summation order -- hence the last bits of H, b and every later
+// iterate -- vary from run to run; the pull form is bit-reproducible.
+template <typename TO, typename T>
+__global__ void __launch_bounds__(256) k_lin_init(LinArgs<TO, T> a) {
+  const int node = blockIdx.x * 256 + threadIdx.x;
+  if (node >= a.n_nodes) return;
+  const int nd = a.node_dim[node];
+  T add = a.lambda;
+  if (node == a.anchor) add += (T)10000000.0;
+  TO *d = a.hvals + a.diag_off[node];
+  for (int t = 0; t < nd * nd; t++) d[t] = (t / nd == t % nd) ? (TO)add : (TO)0;
+  TO *bo = a.b + a.node_offset[node];
+  for (int t = 0; t < nd; t++) bo[t] = 0;
+}
+template <typename TO, typename T>
+__global__ void __launch_bounds__(256) k_lin_finish(LinArgs<TO, T> a) {
+  const int node = blockIdx.x * 256 + threadIdx.x;
+  if (node >= a.n_nodes) return;
+  const int nd = a.node_dim[node];
+  TO *d = a.hvals + a.diag_off[node];
+  for (int i = 0; i < nd; i++)
+    for (int j = i + 1; j < nd; j++) d[i * nd + j] = d[j * nd + i];
+}
+template <typename TO, typename T>
+__global__ void __launch_bounds__(LIN_THREADS) k_linearize_edges(LinArgs<TO, T> a, int n_edges) {
+  using V4 = typename VecT<T>::V4;
+  using V2 = typename VecT<T>::V2;
+  __shared__ double red[LIN_THREADS / 64];
+  const int k = blockIdx.x * LIN_THREADS + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool live = k < n_edges;
+  const int kc = live ? k : n_edges - 1;
+  const int2 ft = a.e_idx[kc];
+  const int kind = a.node_dim[ft.y] == 2 ? 1 : 0;   // an XY landmark is always the `to` end (g2o.rs:98-115)
+  const V4 x1 = a.pose[ft.x], x2 = a.pose[ft.y];
+  const V4 z = a.e_meas[kc];
+  const V4 wa = a.e_info_a[kc];
+  const V2 wb = a.e_info_b[kc];
+  const T W[3][3] = {{wa.x, wa.y, wa.z}, {wa.y, wa.w, wb.x}, {wa.z, wb.x, wb.y}};
+  T e[3], A[3][3], B[3][3];
+  edge_linearize_2d<T>(kind, x1, x2, z, e, A, B);
+  const T we0 = W[0][0] * e[0] + W[0][1] * e[1] + W[0][2] * e[2];
+  const T we1 = W[1][0] * e[0] + W[1][1] * e[1] + W[1][2] * e[2];
+  const T we2 = W[2][0] * e[0] + W[2][1] * e[1] + W[2][2] * e[2];
+  double chi = live ? (double)(e[0] * we0 + e[1] * we1 + e[2] * we2) : 0.0;
+  if (a.write_system) {
+    T AW[3][3], BW[3][3];   // J^T W
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        T sa = 0, sb = 0;
+#pragma unroll
+        for (int r = 0; r < 3; r++) { sa += A[r][i] * W[r][j]; sb += B[r][i] * W[r][j]; }
+        AW[i][j] = sa;
+        BW[i][j] = sb;
+      }
+    // nine terms per end: lower triangle of J^T W J (00 10 11 20 21 22) and -J^T W e
+    T fa[9], fb[9];
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) {
+        T sa = 0, sb = 0;
+#pragma unroll
+        for (int r = 0; r < 3; r++) { sa += AW[i][r] * A[r][j]; sb += BW[i][r] * B[r][j]; }
+        fa[t] = live ? sa : (T)0;
+        fb[t] = live ? sb : (T)0;
+        t++;
+      }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      fa[6 + i] = live ? -(AW[i][0] * e[0] + AW[i][1] * e[1] + AW[i][2] * e[2]) : (T)0;
+      fb[6 + i] = live ? -(BW[i][0] * e[0] + BW[i][1] * e[1] + BW[i][2] * e[2]) : (T)0;
+    }
+    if (live) {
+      // off-diagonal block H[from rows, to cols] = A^T W B
+      const int64_t so = a.e_slot[k];
+      TO *dst = a.hvals + (so >> 1);
+      const bool tr = so & 1;
+      const int d2 = kind ? 2 : 3;
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          if (j >= d2) continue;
+          const T sv = AW[i][0] * B[0][j] + AW[i][1] * B[1][j] + AW[i][2] * B[2][j];
+          dst[tr ? j * 3 + i : i * d2 + j] = (TO)sv;
+        }
+    }
+    // from-node terms: segmented inclusive scan over the wave (head flag = first lane of a run of equal `from`)
+    const int key = live ? ft.x : -1;
+    const int kprev = __shfl_up(key, 1);
+    bool head = lane == 0 || kprev != key;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      T other[9];
+#pragma unroll
+      for (int q = 0; q < 9; q++) other[q] = __shfl_up(fa[q], o);
+      const bool ohead = __shfl_up((int)head, o) != 0;
+      if (lane >= o && !head) {
+#pragma unroll
+        for (int q = 0; q < 9; q++) fa[q] += other[q];
+        head = ohead;
+      }
+    }
+    const int knext = __shfl_down(key, 1);
+    const bool tail = live && (lane == 63 || knext != key);
+    auto add_node = [&](int node, const T (&f)[9]) {
+      const int nd = a.node_dim[node];
+      TO *d = a.hvals + a.diag_off[node];
+      TO *bo = a.b + a.node_offset[node];
+      if (nd == 3) {
+        unsafeAtomicAdd(d + 0, (TO)f[0]); unsafeAtomicAdd(d + 3, (TO)f[1]); unsafeAtomicAdd(d + 4, (TO)f[2]);
+        unsafeAtomicAdd(d + 6, (TO)f[3]); unsafeAtomicAdd(d + 7, (TO)f[4]); unsafeAtomicAdd(d + 8, (TO)f[5]);
+        unsafeAtomicAdd(bo + 0, (TO)f[6]); unsafeAtomicAdd(bo + 1, (TO)f[7]); unsafeAtomicAdd(bo + 2, (TO)f[8]);
+      } else {
+        unsafeAtomicAdd(d + 0, (TO)f[0]); unsafeAtomicAdd(d + 2, (TO)f[1]); unsafeAtomicAdd(d + 3, (TO)f[2]);
+        unsafeAtomicAdd(bo + 0, (TO)f[6]); unsafeAtomicAdd(bo + 1, (TO)f[7]);
+      }
+    };
+    if (tail) add_node(ft.x, fa);
+    if (live) add_node(ft.y, fb);
+  }
+  const double tot = block_sum<double, LIN_THREADS>(chi, red);
+  if (threadIdx.x == 0) a.chi2_partial[blockIdx.x] = tot;
+}
+
 // ------------------------------------------------------------------ SE(3)
 // NOT reference behaviour: the reference's SE(3) path is todo!() (pose_graph_optimization.rs:241,
 // 357,570).  Build-defined, g2o file convention, identical to the oracle's definition:

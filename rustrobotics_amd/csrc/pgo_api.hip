@@ -286,6 +286,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   std::vector<int> step_solve_lds_;  // scalars of LDS the back-solve of each step needs
   PinnedBuf<double> host_pair_;      // pinned: chi2, |dx|, and (as an int in slot 2) the device error flag
   int n_lin_blocks_ = 0, n_upd_blocks_ = 0;
+  bool edge_lin_ = false;           // RR_PGO_EDGE_LINEARIZE=1: k_linearize_edges (one thread per edge, atomics) instead of the pull form
   int host_counter_ = 0;             // mirrors the device slot counter
 
  public:
@@ -455,6 +456,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (const char *e = getenv("RR_PGO_MANY_TASKS")) many_tasks_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_MANY_THREADS")) many_threads_ = std::atoi(e);
     n_lin_blocks_ = (int)(((int64_t)n_list_ * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
+    edge_lin_ = getenv("RR_PGO_EDGE_LINEARIZE") != nullptr && !is3d_ && !sharded_ && g_.n_edges() > 0;
+    if (edge_lin_) n_lin_blocks_ = std::max(1, (g_.n_edges() + LIN_THREADS - 1) / LIN_THREADS);
     n_upd_blocks_ = (n_list_ + UPD_THREADS - 1) / UPD_THREADS;
     chi_partial_.alloc((size_t)n_lin_blocks_);
     norm_partial_.alloc((size_t)n_upd_blocks_);
@@ -746,7 +749,14 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
 
   void launch_linearize(double lambda, int lm, int write_system, bool reference_prior = false) {
     pbegin();
-    if (!is3d_) {
+    if (!is3d_ && edge_lin_) {
+      // the edge-parallel form (experiment knob RR_PGO_EDGE_LINEARIZE): clear + prior, one thread per edge, mirror
+      const LinArgs<T, S> la = lin_args(lambda, lm, write_system, reference_prior);
+      const unsigned nb = (unsigned)((g_.n_nodes() + 255) / 256);
+      if (write_system) hipLaunchKernelGGL((k_lin_init<T, S>), dim3(nb), dim3(256), 0, stream_, la);
+      hipLaunchKernelGGL((k_linearize_edges<T, S>), dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_, la, g_.n_edges());
+      if (write_system) hipLaunchKernelGGL((k_lin_finish<T, S>), dim3(nb), dim3(256), 0, stream_, la);
+    } else if (!is3d_) {
       hipLaunchKernelGGL((k_linearize<T, S>), dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_,
                          lin_args(lambda, lm, write_system, reference_prior));
     } else {

@@ -7,13 +7,13 @@ python __graft_entry__.py smoke 2>&1 | tail -1 | tee gpurun_out/smoke_$TAG.log
 export TMPDIR=/tmp
 # --- intel.g2o fp64 (BASELINE configs[1])
 python bench.py > gpurun_out/bench_intel_$TAG.json 2> gpurun_out/bench_intel_$TAG.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_intel_$TAG -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_intel_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_intel_$TAG -- python3 bench.py --no-cpu-baseline --no-secondary > gpurun_out/prof_intel_$TAG.log 2>&1
 cp $(find gpurun_out/prof_intel_$TAG -name "*kernel_stats.csv" | head -1) gpurun_out/kernel_stats_intel_$TAG.csv
 # --- M3500 + sphere2500 bench lines (no profile)
-python bench.py --workload m3500 --no-cpu-baseline > gpurun_out/bench_m3500_$TAG.json 2>/dev/null
-python bench.py --workload sphere2500 --no-cpu-baseline > gpurun_out/bench_sphere2500_$TAG.json 2>/dev/null
-python bench.py --workload dlr --no-cpu-baseline > gpurun_out/bench_dlr_$TAG.json 2>/dev/null
-python bench.py --precision mixed --no-cpu-baseline > gpurun_out/bench_intelmixed_$TAG.json 2>/dev/null
+python bench.py --workload m3500 --no-cpu-baseline --no-secondary > gpurun_out/bench_m3500_$TAG.json 2>/dev/null
+python bench.py --workload sphere2500 --no-cpu-baseline --no-secondary > gpurun_out/bench_sphere2500_$TAG.json 2>/dev/null
+python bench.py --workload dlr --no-cpu-baseline --no-secondary > gpurun_out/bench_dlr_$TAG.json 2>/dev/null
+python bench.py --precision mixed --no-cpu-baseline --no-secondary > gpurun_out/bench_intelmixed_$TAG.json 2>/dev/null
 # --- 1M-edge lattice fp32 (BASELINE configs[3]); rocprof needs plain launches (graph replay of 800 nodes crashes it)
 python bench.py --workload grid:400x250:1000000 --precision f32 --steps 50 --warmup 5 > gpurun_out/bench_grid_$TAG.json 2> gpurun_out/bench_grid_$TAG.err
 RR_PGO_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_grid_$TAG -- python3 scripts/gpu_grid_prof.py 400 250 1000000 f32 5 > gpurun_out/prof_grid_$TAG.log 2>&1

@@ -313,7 +313,8 @@ def test_fronts_beyond_lds_match_oracle_f64(api, oracle):
 
 
 @pytest.mark.parametrize("env", ["RR_PGO_RIGHT_LOOKING", "RR_PGO_OVERLAP", "RR_PGO_PANEL128", "RR_PGO_SEPARATE_DIAG32", "RR_PGO_SERIAL_ASSEMBLY",
-                                 "RR_PGO_SPLIT_ASSEMBLY", "RR_PGO_NO_GATHER_UPDATE", "RR_PGO_PANEL_BUDGET=18000"])
+                                 "RR_PGO_SPLIT_ASSEMBLY", "RR_PGO_NO_GATHER_UPDATE", "RR_PGO_PANEL_BUDGET=18000",
+                                 "RR_PGO_EDGE_LINEARIZE"])
 def test_alternate_big_front_launch_sequences_agree(api, env, monkeypatch):
     """The big-front path has switches read when a handle is created: the older right-looking launch
     sequence (diag / trsm / K=32 update), the two-stream trailing update, whole 128-column
@@ -336,6 +337,22 @@ def test_alternate_big_front_launch_sequences_agree(api, env, monkeypatch):
     ealt = alt.optimize(3)
     np.testing.assert_allclose(ealt, eref, rtol=1e-9)
     assert _state_diff_se2(alt.state(), ref.state()) <= 1e-8
+
+
+@pytest.mark.parametrize("name", ["intel", "dlr", "simulation-pose-landmark"])
+def test_edge_parallel_linearisation_agrees_with_the_pull_form(api, name, monkeypatch):
+    """RR_PGO_EDGE_LINEARIZE=1 swaps k_linearize (pull form, bit-reproducible) for k_linearize_edges (one thread per
+    edge, floating-point atomics): same H, b and chi2 up to the order of the sums, on pose-pose and pose-landmark
+    factors (reference maths: pose_graph_optimization.rs:434-486,516-535)."""
+    ref = api[0].new(g2o_path(name))
+    monkeypatch.setenv("RR_PGO_EDGE_LINEARIZE", "1")
+    alt = api[0].new(g2o_path(name))
+    monkeypatch.delenv("RR_PGO_EDGE_LINEARIZE")
+    assert alt.global_error() == pytest.approx(ref.global_error(), rel=1e-13)
+    # the order of the atomic sums differs from run to run: dlr's Gauss-Newton excursion (3.7e8 -> 6.4e7 -> 1.8e8)
+    # amplifies the last bits of the first step to ~1e-8 of chi2 by the fourth
+    np.testing.assert_allclose(alt.optimize(4), ref.optimize(4), rtol=1e-6)
+    assert _state_diff_se2(alt.state(), ref.state()) <= 1e-5
 
 
 def test_fronts_beyond_lds_f32_reaches_the_f64_minimum(api):
