@@ -1563,12 +1563,16 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
   // symbolic analysis (host only)
   SymbolicOptions so;
   so.lds_budget_elems = opt.precision == RR_PGO_F64 ? 19000 : 38000;
-  so.nd_leaf = h->g.n_nodes() <= 6000 ? (1 << 30) : 64;
+  // nested dissection down to leaves of this many nodes on large graphs (measured on the 400 x 250 lattice, r02:
+  // fp32 6.05 ms per step with 48, 6.09 with 40, 6.12 with 56, 6.21 with 64; fp64 -- half the LDS budget per front --
+  // 9.78 with 32, 10.41 with 48 or 64)
+  const int big_leaf = opt.precision == RR_PGO_F64 ? 32 : 48;
+  so.nd_leaf = h->g.n_nodes() <= 6000 ? (1 << 30) : big_leaf;
   so.split_separators = h->g.n_nodes() > 6000;   // wide top fronts: see symbolic.cpp, supernode pass
   if (opt.world_size > 1) {   // sharding needs the nested-dissection top levels
     so.n_parts = opt.world_size;
     so.my_part = opt.rank;
-    so.nd_leaf = 64;
+    so.nd_leaf = big_leaf;
     so.pin_node = h->g.anchor_node;   // every rank needs the anchor's entries of the solution (gauge transfer)
   }
   // experiment knob: fronts beyond LDS whose pivot panel (M x nc scalars) fits this budget get one workgroup each with

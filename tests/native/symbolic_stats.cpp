@@ -23,7 +23,7 @@ int main(int argc, char **argv) {
   if (getenv("TASKUS")) opt.task_us = atof(getenv("TASKUS"));
   if (getenv("API")) {   // the options rr_pgo_create uses for a graph of this size (pgo_api.hip, build_handle), fp32 budget
     opt.lds_budget_elems = getenv("F64") ? 19000 : 38000;
-    opt.nd_leaf = g.n_nodes() <= 6000 ? (1 << 30) : 64;
+    opt.nd_leaf = g.n_nodes() <= 6000 ? (1 << 30) : (getenv("F64") ? 32 : 48);
     opt.split_separators = g.n_nodes() > 6000;
     opt.panel_budget_elems = getenv("F64") ? 18000 : 36000;
   }
