@@ -2486,6 +2486,36 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
   // load goes to a CLAMPED address (no branch per load: out-of-range rows only feed entries that are
   // never stored) and only the stores are predicated.
   const bool interior = I0 + TILE <= M && J0 + TILE <= jmax && I0 >= J0 + TILE;
+  // ---- operand staging: thread t loads row (t % TILE) of every KSTEP-th k of the chunk
+  const int sr = tid % TILE, sk = tid / TILE;
+  const T *pa = F + (int64_t)(ka + sk) * M + min(I0 + sr, M - 1);
+  const T *pb = F + (int64_t)(ka + sk) * M + min(J0 + sr, M - 1);
+  const int64_t M2 = KSTEP * (int64_t)M;
+  const int nk = ke - ka;
+  T ra[DEPTH][NLD], rb[DEPTH][NLD];
+  auto fetch = [&](int c, T (&xa)[NLD], T (&xb)[NLD]) {   // columns past ke are re-read from a valid column and zeroed by a select
+    const T *qa = pa + (int64_t)c * KC * M, *qb = pb + (int64_t)c * KC * M;
+#pragma unroll
+    for (int q = 0; q < NLD; q++) {
+      const bool kok = c * KC + sk + KSTEP * q < nk;
+      const int64_t off = kok ? q * M2 : 0;
+      const T va = qa[off], vb = qb[off];
+      xa[q] = kok ? va : (T)0;
+      xb[q] = kok ? -vb : (T)0;
+    }
+  };
+  auto stash = [&](int buf, const T (&xa)[NLD], const T (&xb)[NLD]) {
+#pragma unroll
+    for (int q = 0; q < NLD; q++) {
+      As[buf][sk + KSTEP * q][sr] = xa[q];
+      Bs[buf][sk + KSTEP * q][sr] = xb[q];
+    }
+  };
+  const int nchunks = (nk + KC - 1) / KC;
+  constexpr int MAXCH = BIG_SUPER / KC;   // K <= 128
+#pragma unroll
+  for (int d = 0; d < DEPTH; d++)
+    if (d < nchunks) fetch(d, ra[d], rb[d]);   // requested BEFORE the C tile: a gathered tile pays two dependent round trips of its own
   // ---- accumulators = current C tile
   if (gather.n >= 0) {   // uniform over the workgroup
     // the sum, in child order, of what the children hold for every entry (rows and columns the child does not have
@@ -2551,36 +2581,6 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
         for (int ib = 0; ib < NT; ib++) acc[ib][jb][r] = ccol[min(i0 + 16 * ib + li, M - 1)];
       }
   }
-  // ---- operand staging: thread t loads row (t % TILE) of every KSTEP-th k of the chunk
-  const int sr = tid % TILE, sk = tid / TILE;
-  const T *pa = F + (int64_t)(ka + sk) * M + min(I0 + sr, M - 1);
-  const T *pb = F + (int64_t)(ka + sk) * M + min(J0 + sr, M - 1);
-  const int64_t M2 = KSTEP * (int64_t)M;
-  const int nk = ke - ka;
-  T ra[DEPTH][NLD], rb[DEPTH][NLD];
-  auto fetch = [&](int c, T (&xa)[NLD], T (&xb)[NLD]) {   // columns past ke are re-read from a valid column and zeroed by a select
-    const T *qa = pa + (int64_t)c * KC * M, *qb = pb + (int64_t)c * KC * M;
-#pragma unroll
-    for (int q = 0; q < NLD; q++) {
-      const bool kok = c * KC + sk + KSTEP * q < nk;
-      const int64_t off = kok ? q * M2 : 0;
-      const T va = qa[off], vb = qb[off];
-      xa[q] = kok ? va : (T)0;
-      xb[q] = kok ? -vb : (T)0;
-    }
-  };
-  auto stash = [&](int buf, const T (&xa)[NLD], const T (&xb)[NLD]) {
-#pragma unroll
-    for (int q = 0; q < NLD; q++) {
-      As[buf][sk + KSTEP * q][sr] = xa[q];
-      Bs[buf][sk + KSTEP * q][sr] = xb[q];
-    }
-  };
-  const int nchunks = (nk + KC - 1) / KC;
-  constexpr int MAXCH = BIG_SUPER / KC;   // K <= 128
-#pragma unroll
-  for (int d = 0; d < DEPTH; d++)
-    if (d < nchunks) fetch(d, ra[d], rb[d]);
   RRPGO_PHASE_MARK(a, pm, 604);
   stash(0, ra[0], rb[0]);
   if (DEPTH < nchunks) fetch(DEPTH, ra[0], rb[0]);

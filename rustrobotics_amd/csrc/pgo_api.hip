@@ -246,7 +246,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
                                     // RR_PGO_SMALL_TILE=0 brings the 128 x 128 tiles back
   int solve_threads_max_ = 512;     // RR_PGO_SOLVE_THREADS=<n>: cap of the back-substitution workgroup size
   int factor_threads_max_ = 1024;   // 16-wave workgroups for steps whose fronts exceed 128 rows (RR_PGO_FACTOR_512=1: 8 waves)
-  int64_t deep_below_ = 2048;       // RR_PGO_DEEP_BELOW=<n>: trailing updates of at most n 64 x 64 tiles request their whole K strip up front
+  int64_t deep_below_ = 0;          // RR_PGO_DEEP_BELOW=<n>: trailing updates of at most n 64 x 64 tiles request their whole K strip up front (measured r02: 6.02 ms per lattice step with 2048, 5.95 with 0; sphere2500 1 % slower with it: off)
   int lookahead_max_nf_ = 0;        // RR_PGO_LOOKAHEAD=<n>: levels of at most n big fronts run the k_big_chain sequence (0: none)
   int sp_solve_min_nc_ = 256;       // back substitution: levels whose widest pivot block has at least this many columns run k_big_solve_sp (RR_PGO_SP_SOLVE_MIN)
   bool gather_update_ = true;       // ... and only for the pivot columns: a front's first trailing update gathers its tiles from the children (RR_PGO_NO_GATHER_UPDATE=1)
