@@ -2442,8 +2442,11 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_trsm128(Facto
 // NT = MFMA tiles per wave and dimension: 4 -> 64 x 64 per wave, 128 x 128 per workgroup; 2 -> 32 x 32 per wave,
 // 64 x 64 per workgroup, for launches that would not fill the chip with the large tile (the top levels of
 // the tree: a quarter of the MFMA work per wave on the critical path of the launch).
+#ifndef RRPGO_UPD_KC
+#define RRPGO_UPD_KC 16
+#endif
 template <typename T, int NT> struct UpdTile {
-  static constexpr int KC = 16;   // k-chunk staged in LDS: 36.9 KB in fp32 (three workgroups per CU), 73.7 KB in fp64 (two)
+  static constexpr int KC = RRPGO_UPD_KC;   // k-chunk staged in LDS: 36.9 KB in fp32 (three workgroups per CU), 73.7 KB in fp64 (two)
   static constexpr int TILE = 32 * NT, WTILE = 16 * NT;  // workgroup tile, wave tile
   static constexpr int KSTEP = 256 / TILE;               // k-rows of a chunk loaded per pass of the 256 threads
   static constexpr int LDT = TILE + 16;                  // padded row: the four k-rows a wave reads hit disjoint banks
