@@ -4,7 +4,7 @@ Each of the P emulated ranks runs its stage 0 and stage 1 alone on the GPU (HIP 
 synchronised stage); the collectives are costed, not measured: the all-gather by bytes / per-link bandwidth
 (every rank sends its chunk to P-1 peers over separate xGMI links, MI355X_MICROARCH.md: 153.6 GB/s per link per
 direction peak, ~50 GB/s achieved per link is the planning number used here) plus a launch latency, the two-double
-all-reduce by latency only.  usage: python scripts/gpu_shard_emul.py [WxH[:E]] [precision] [P ...]"""
+all-reduce by latency only (150 us each: measured through torch.distributed on a one-rank group).  usage: python scripts/gpu_shard_emul.py [WxH[:E]] [precision] [P ...]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -16,7 +16,7 @@ Ps = [int(x) for x in sys.argv[3:]] or [2, 4, 8]
 parts = spec.split(":")
 w, h = (int(x) for x in parts[0].split("x"))
 arrays = synthetic_grid_arrays(w, h, int(parts[1]) if len(parts) > 1 else 0)
-LINK_GBPS, COLL_LAT_US = 50.0, 25.0
+LINK_GBPS, COLL_LAT_US = 50.0, 150.0   # 150 us per RCCL collective: what the one-rank nccl leg of bench.py costs over the emulated P = 1 run (r02: 6.41 against 6.11 ms per step, two collectives)
 
 g = PoseGraph.from_arrays(*arrays, precision=prec)
 g.iterate_async(3); g.sync()
