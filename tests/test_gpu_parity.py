@@ -339,6 +339,28 @@ def test_alternate_big_front_launch_sequences_agree(api, env, monkeypatch):
     assert _state_diff_se2(alt.state(), ref.state()) <= 1e-8
 
 
+@pytest.mark.parametrize("case", ["intel", "dlr", "sphere2500", "lattice-f32", "lattice-mixed"])
+def test_results_are_bit_reproducible(api, case):
+    """No atomics on floating-point data, fixed summation orders everywhere (pull-form linearisation, fixed child
+    order in the front assembly, ordered slices in the back substitution, fixed-order chi2 / |dx| reductions): two
+    handles on the same graph must produce the same BITS -- errors and state -- whatever the dispatch order was.
+    (The reference is deterministic too apart from rayon's update_nodes, which has no cross-node arithmetic.)"""
+    from rustrobotics_amd import synthetic_grid_arrays
+
+    def run():
+        if case.startswith("lattice"):
+            g = api[0].from_arrays(*synthetic_grid_arrays(100, 100), precision=case.split("-")[1])
+        else:
+            g = api[0].new(g2o_path(case))
+        e = np.array(g.optimize(5))
+        return e, np.array(g.state())
+
+    e1, s1 = run()
+    e2, s2 = run()
+    assert np.array_equal(e1, e2), (e1, e2)
+    assert np.array_equal(s1, s2)
+
+
 @pytest.mark.parametrize("name", ["intel", "dlr", "simulation-pose-landmark"])
 def test_edge_parallel_linearisation_agrees_with_the_pull_form(api, name, monkeypatch):
     """RR_PGO_EDGE_LINEARIZE=1 swaps k_linearize (pull form, bit-reproducible) for k_linearize_edges (one thread per
