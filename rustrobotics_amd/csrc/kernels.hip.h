@@ -1883,7 +1883,7 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
   // orders this wave's LDS writes before its later reads: a workgroup barrier where the workgroup IS the
   // wave, a wave-level fence where other waves of the workgroup have already left
   auto sync = [] {
-    if (WG_IS_ONE_WAVE) __syncthreads();
+    if (WG_IS_ONE_WAVE) lds_barrier();   // LDS traffic only: __syncthreads() would also wait for the caller's global stores (~1 us on the chain)
     else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
   };
   using MM = Mfma16<T>;
@@ -2001,7 +2001,7 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_diag32(FactorA
     Sh[c * 33 + r] = v[t];
   }
   diag32_init_tables<T>(Sh);
-  __syncthreads();
+  lds_barrier();
   diag32_factor_invert<T>(Sh, nb, Fblk, M, a.winv + (int64_t)m.wblk * 256 + (kb / BIG_NB) * 1024, a.err);
 }
 
@@ -2137,9 +2137,9 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
       Sh[c * 33 + r] = (r < nb && c < nb && r >= c) ? dv[t] : ((r == c && r >= nb) ? (T)1 : (T)0);
     }
     diag32_init_tables<T>(Sh);
-    __syncthreads();
+    lds_barrier();
     diag32_factor_invert<T>(Sh, nb, F + (int64_t)kb * M + kb, M, const_cast<T *>(Wt), a.err, false, blockIdx.x == 0);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int t = 0; t < 3; t++)
 #pragma unroll
@@ -2147,7 +2147,7 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
         const int cb = t == 0 ? 0 : 1, jb = t == 2 ? 1 : 0;
         wv[t][r] = Sh[32 * 33 + (16 * jb + MM::row(lane, r)) * 33 + 16 * cb + li];   // the LDS image of W
       }
-    __syncthreads();   // Sh is free again for the next diagonal block's image
+    lds_barrier();   // Sh is free again for the next diagonal block's image
   }
   RRPGO_PHASE_MARK(a, look, 501);
 #pragma unroll
@@ -2219,7 +2219,7 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
   const int nbn = min(BIG_NB, m.nc - kn);
   sh_image_from_acc<T>(Sh, nxt, nbn);
   diag32_init_tables<T>(Sh);
-  __syncthreads();
+  lds_barrier();   // not __syncthreads(): the X stores above need not have landed before the next block is factored
   RRPGO_PHASE_MARK(a, look, 504);
   diag32_factor_invert<T>(Sh, nbn, F + (int64_t)kn * M + kn, M, a.winv + (int64_t)m.wblk * 256 + (kn / BIG_NB) * 1024, a.err);
   RRPGO_PHASE_MARK(a, look, 505);
