@@ -312,6 +312,23 @@ def test_fronts_beyond_lds_match_oracle_f64(api, oracle):
     assert _state_diff_se2(g.state(), o.state()) <= 1e-8
 
 
+def test_levenberg_marquardt_through_the_big_front_path(api, oracle):
+    """The LM branch (:275-286, :362-366: lambda on every diagonal entry, reject -> update_nodes(-dx), lambda x 2) on
+    a graph whose top fronts live beyond LDS (60 x 40 lattice: k_big_build / k_big_panel32 / gathered k_big_update /
+    k_big_solve_sp), fp64 against the oracle; the reference's formulation is kept (anchor prior, no gauge transfer)."""
+    from oracle.oracle import LEVENBERG_MARQUARDT
+    from rustrobotics_amd import synthetic_grid_arrays
+    arrays = synthetic_grid_arrays(60, 40)
+    g = api[0].from_arrays(*arrays, solver=api[1].LevenbergMarquardt)
+    o = oracle.from_arrays(*arrays)
+    assert g.stats()["n_big_fronts"] > 0
+    eg = g.optimize(6)
+    eo = o.optimize(6, LEVENBERG_MARQUARDT)
+    assert len(eg) == len(eo)
+    np.testing.assert_allclose(eg, eo, rtol=1e-8)
+    assert _state_diff_se2(g.state(), o.state()) <= 1e-6
+
+
 @pytest.mark.parametrize("env", ["RR_PGO_RIGHT_LOOKING", "RR_PGO_OVERLAP", "RR_PGO_PANEL128", "RR_PGO_SEPARATE_DIAG32", "RR_PGO_SERIAL_ASSEMBLY",
                                  "RR_PGO_SPLIT_ASSEMBLY", "RR_PGO_NO_GATHER_UPDATE", "RR_PGO_PANEL_BUDGET=18000",
                                  "RR_PGO_EDGE_LINEARIZE"])
