@@ -2490,21 +2490,33 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
   // never stored) and only the stores are predicated.
   const bool interior = I0 + TILE <= M && J0 + TILE <= jmax && I0 >= J0 + TILE;
   // ---- operand staging: thread t loads row (t % TILE) of every KSTEP-th k of the chunk
+  // 32-bit byte offsets from the (uniform) front base: one VALU add per load instead of 64-bit pointer arithmetic and
+  // selects (a front is a few tens of MB).  The PMC instruction mix of this kernel was 6 VALU + 3 SALU per MFMA.
   const int sr = tid % TILE, sk = tid / TILE;
-  const T *pa = F + (int64_t)(ka + sk) * M + min(I0 + sr, M - 1);
-  const T *pb = F + (int64_t)(ka + sk) * M + min(J0 + sr, M - 1);
-  const int64_t M2 = KSTEP * (int64_t)M;
+  const char *Fb = reinterpret_cast<const char *>(F);
+  const uint32_t oa = (uint32_t)((ka + sk) * M + min(I0 + sr, M - 1)) * (uint32_t)sizeof(T);
+  const uint32_t ob = (uint32_t)((ka + sk) * M + min(J0 + sr, M - 1)) * (uint32_t)sizeof(T);
+  const uint32_t qstep = (uint32_t)(KSTEP * M) * (uint32_t)sizeof(T), cstep = (uint32_t)(KC * M) * (uint32_t)sizeof(T);
+  auto ldo = [&](uint32_t off) { return *reinterpret_cast<const T *>(Fb + off); };
   const int nk = ke - ka;
   T ra[DEPTH][NLD], rb[DEPTH][NLD];
-  auto fetch = [&](int c, T (&xa)[NLD], T (&xb)[NLD]) {   // columns past ke are re-read from a valid column and zeroed by a select
-    const T *qa = pa + (int64_t)c * KC * M, *qb = pb + (int64_t)c * KC * M;
+  auto fetch = [&](int c, T (&xa)[NLD], T (&xb)[NLD]) {
+    const uint32_t ca = oa + (uint32_t)c * cstep, cb = ob + (uint32_t)c * cstep;
+    if ((c + 1) * KC <= nk) {   // uniform: a whole chunk, no masks
 #pragma unroll
-    for (int q = 0; q < NLD; q++) {
-      const bool kok = c * KC + sk + KSTEP * q < nk;
-      const int64_t off = kok ? q * M2 : 0;
-      const T va = qa[off], vb = qb[off];
-      xa[q] = kok ? va : (T)0;
-      xb[q] = kok ? -vb : (T)0;
+      for (int q = 0; q < NLD; q++) {
+        xa[q] = ldo(ca + (uint32_t)q * qstep);
+        xb[q] = -ldo(cb + (uint32_t)q * qstep);
+      }
+    } else {   // columns past ke are re-read from a valid column and zeroed by a select
+#pragma unroll
+      for (int q = 0; q < NLD; q++) {
+        const bool kok = c * KC + sk + KSTEP * q < nk;
+        const uint32_t off = kok ? (uint32_t)q * qstep : 0u;
+        const T va = ldo(ca + off), vb = ldo(cb + off);
+        xa[q] = kok ? va : (T)0;
+        xb[q] = kok ? -vb : (T)0;
+      }
     }
   };
   auto stash = [&](int buf, const T (&xa)[NLD], const T (&xb)[NLD]) {
@@ -2574,6 +2586,15 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
       }
     }
     __syncthreads();   // the index vectors share the operand staging buffers
+  } else if (wave_active && interior) {
+#pragma unroll
+    for (int jb = 0; jb < NT; jb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t co = (uint32_t)((j0 + 16 * jb + MM::row(lane, r)) * M + i0 + li) * (uint32_t)sizeof(T);
+#pragma unroll
+        for (int ib = 0; ib < NT; ib++) acc[ib][jb][r] = ldo(co + (uint32_t)(16 * ib) * (uint32_t)sizeof(T));
+      }
   } else if (wave_active) {
 #pragma unroll
     for (int jb = 0; jb < NT; jb++)
@@ -2619,13 +2640,14 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
   RRPGO_PHASE_MARK(a, pm, 602);
   if (!wave_active) return false;
   if (interior) {
+    char *Fw = reinterpret_cast<char *>(F);
 #pragma unroll
     for (int jb = 0; jb < NT; jb++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        T *ccol = F + (int64_t)(j0 + 16 * jb + MM::row(lane, r)) * M + i0 + li;
+        const uint32_t co = (uint32_t)((j0 + 16 * jb + MM::row(lane, r)) * M + i0 + li) * (uint32_t)sizeof(T);
 #pragma unroll
-        for (int ib = 0; ib < NT; ib++) ccol[16 * ib] = acc[ib][jb][r];
+        for (int ib = 0; ib < NT; ib++) *reinterpret_cast<T *>(Fw + co + (uint32_t)(16 * ib) * (uint32_t)sizeof(T)) = acc[ib][jb][r];
       }
   } else {
 #pragma unroll
