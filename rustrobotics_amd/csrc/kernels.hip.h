@@ -2665,13 +2665,23 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
 
 // gather: the launch for the FIRST super-panel (kb == 0, mode 1) forms the tiles right of big_built_cols from the
 // children instead of loading them (k_big_build was told to leave them out)
-template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(256, (DEPTH > 1 ? 1 : sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_update(FactorArgs<T> a, int kb, int mode, int diag_tail, int gather = 0) {
+template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(256, (DEPTH > 1 ? 1 : sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_update(FactorArgs<T> a, int kb, int mode, int diag_tail, int gather = 0, int tri = 0) {
   using MM = Mfma16<T>;
   using UT = UpdTile<T, NT>;
   constexpr int TILE = UT::TILE;
   __shared__ T smem[UT::SMEM];
   RRPGO_TRACE_MARK(a, 100 + mode);
-  if (blockIdx.x < blockIdx.y) return;           // lower triangle of tiles only
+  // tri: the grid's x dimension enumerates the lower triangle of tiles, t = bx (bx + 1) / 2 + by -- a square grid
+  // launches as many workgroups again only to have them exit
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (tri) {
+    const int t = blockIdx.x;
+    bx = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while (bx * (bx + 1) / 2 > t) bx--;
+    while ((bx + 1) * (bx + 2) / 2 <= t) bx++;
+    by = t - bx * (bx + 1) / 2;
+  }
+  if (bx < by) return;           // lower triangle of tiles only
   const SnMeta m = a.task_meta[a.task_begin + blockIdx.z];
   if (kb >= m.nc) return;
   const int M = m.nc + m.nr + 1;
@@ -2685,11 +2695,11 @@ template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(2
   const int jmax = mode == 0 ? super_end : mode == 2 ? min(t0 + 128, M) : M;
   static_assert(NT == 4 || NT == 2, "tile shapes");
   const int toff = mode == 3 ? 128 / TILE : 0;   // mode 3 starts one 128-column strip further right
-  const int I0 = t0 + (blockIdx.x + toff) * TILE, J0 = t0 + (blockIdx.y + toff) * TILE;
+  const int I0 = t0 + (bx + toff) * TILE, J0 = t0 + (by + toff) * TILE;
   if (t0 >= jmax || I0 >= M || J0 >= jmax) return;   // uniform over the workgroup
   T *F = a.lvals + m.loff;
   typename MM::Acc acc[NT][NT];
-  [[maybe_unused]] const bool pm = blockIdx.x == 2 && blockIdx.y == 0 && blockIdx.z == 0;
+  [[maybe_unused]] const bool pm = bx == 2 && by == 0 && blockIdx.z == 0;
   RRPGO_PHASE_MARK(a, pm, 600);
   TileGather<T> tg{nullptr, -1, nullptr, nullptr, nullptr, nullptr};
   if (gather && J0 >= big_built_cols(m.nc, M)) tg = TileGather<T>{a.child_meta + m.child_begin, m.child_count, a.scat, a.lvals, a.uvals, a.xch};
@@ -2698,7 +2708,7 @@ template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(2
   // The first wave of the first tile holds the next super-panel's first diagonal block (rows = columns
   // = t0 .. t0+31) in acc[0..1][0..1]: after the tile is stored it factors and inverts that block here,
   // which saves the k_big_diag32 launch that would otherwise open the next super-panel's chain.
-  const bool next_diag = diag_tail && (mode == 1 || mode == 2) && blockIdx.x == 0 && blockIdx.y == 0 && wave_index() == 0 && t0 < m.nc;
+  const bool next_diag = diag_tail && (mode == 1 || mode == 2) && bx == 0 && by == 0 && wave_index() == 0 && t0 < m.nc;
   if (next_diag) {
     T *Sh = smem;   // the staging buffers are idle now (every wave passed the last barrier of the k loop)
     const int nbn = min(BIG_NB, m.nc - t0);

@@ -1027,9 +1027,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
             const int nt64 = (std::max(rt, 1) + 63) / 64;
             // a launch of at most a few rounds of tiles is a chain of memory round trips per tile: deep prefetch
             if ((int64_t)nf * nt64 * (nt64 + 1) / 2 <= deep_below_)
-              hipLaunchKernelGGL((k_big_update<T, 2, 8>), dim3(nt64, nt64, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail, gu);
-            else
-              hipLaunchKernelGGL((k_big_update<T, 2>), dim3(nt64, nt64, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail, gu);
+              hipLaunchKernelGGL((k_big_update<T, 2, 8>), dim3(nt64, nt64, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail, gu, 0);
+            else   // the lower triangle of 64 x 64 tiles as a one-dimensional grid
+              hipLaunchKernelGGL((k_big_update<T, 2>), dim3(nt64 * (nt64 + 1) / 2, 1, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail, gu, 1);
           } else {
             hipLaunchKernelGGL((k_big_update<T, 4>), dim3(nti, nti, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail, gu);
           }
