@@ -2665,7 +2665,7 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
 
 // gather: the launch for the FIRST super-panel (kb == 0, mode 1) forms the tiles right of big_built_cols from the
 // children instead of loading them (k_big_build was told to leave them out)
-template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(256, (DEPTH > 1 ? 1 : sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_update(FactorArgs<T> a, int kb, int mode, int diag_tail, int gather = 0, int tri = 0) {
+template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(256, (DEPTH > 4 ? 1 : sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_update(FactorArgs<T> a, int kb, int mode, int diag_tail, int gather = 0, int tri = 0) {
   using MM = Mfma16<T>;
   using UT = UpdTile<T, NT>;
   constexpr int TILE = UT::TILE;

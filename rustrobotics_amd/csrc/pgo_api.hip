@@ -22,6 +22,9 @@
 #include "kernels.hip.h"
 #include "symbolic.h"
 
+#ifndef RRPGO_UPD_DEPTH
+#define RRPGO_UPD_DEPTH 1   // k-chunks of the trailing update requested ahead of the MFMAs
+#endif
 namespace rrpgo {
 
 
@@ -1029,7 +1032,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
             if ((int64_t)nf * nt64 * (nt64 + 1) / 2 <= deep_below_)
               hipLaunchKernelGGL((k_big_update<T, 2, 8>), dim3(nt64, nt64, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail, gu, 0);
             else   // the lower triangle of 64 x 64 tiles as a one-dimensional grid
-              hipLaunchKernelGGL((k_big_update<T, 2>), dim3(nt64 * (nt64 + 1) / 2, 1, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail, gu, 1);
+              hipLaunchKernelGGL((k_big_update<T, 2, RRPGO_UPD_DEPTH>), dim3(nt64 * (nt64 + 1) / 2, 1, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail, gu, 1);
           } else {
             hipLaunchKernelGGL((k_big_update<T, 4>), dim3(nti, nti, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail, gu);
           }
