@@ -2541,46 +2541,55 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
     for (int ib = 0; ib < NT; ib++)
 #pragma unroll
       for (int jb = 0; jb < NT; jb++) acc[ib][jb] = typename MM::Acc{0, 0, 0, 0};
+    // staged per child: TILE row indices | TILE column indices | TILE column OFFSETS (the column's start in the child's
+    // packed or square storage: two integer multiplies, done once per column here instead of by every lane)
     int32_t *sidx = reinterpret_cast<int32_t *>(smem);
     for (int q0 = 0; q0 < gather.n; q0 += 4) {
       const int nb = min(4, gather.n - q0);
       if (q0 > 0) __syncthreads();
       for (int e = tid; e < nb * 2 * TILE; e += 256) {
         const int qq = e / (2 * TILE), w = e - qq * 2 * TILE;
+        const ChildMeta c = gather.cm[q0 + qq];
         const int p = w < TILE ? min(I0 + w, M - 1) : min(J0 + w - TILE, jmax - 1);
-        sidx[e] = (gather.scat + gather.cm[q0 + qq].scat_ptr)[p];
+        const int v = (gather.scat + c.scat_ptr)[p];
+        sidx[qq * 3 * TILE + w] = v;
+        if (w >= TILE) {
+          const int jc = max(v, 0);
+          sidx[qq * 3 * TILE + TILE + w] = c.uld > 0 ? jc * c.uld : jc * c.ncu - ((jc * (jc - 1)) >> 1) - jc;
+        }
       }
       __syncthreads();
       if (wave_active) {
         for (int qq = 0; qq < nb; qq++) {
           const ChildMeta c = gather.cm[q0 + qq];
-          const int32_t *si = sidx + qq * 2 * TILE;
+          const int32_t *si = sidx + qq * 3 * TILE;
           const T *Uc = (c.uld > 0 ? gather.lvals : c.uld < 0 ? gather.xch : gather.uvals) + c.uoff;
-          const int last = c.ncu - 1;
           int iq[NT];
 #pragma unroll
           for (int ib = 0; ib < NT; ib++) iq[ib] = si[wi + 16 * ib + li];
 #pragma unroll
           for (int jb = 0; jb < NT; jb++) {
-            int jq[4];
+            int jq[4], co[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) jq[r] = si[TILE + wj + 16 * jb + MM::row(lane, r)];
+            for (int r = 0; r < 4; r++) {
+              jq[r] = si[TILE + wj + 16 * jb + MM::row(lane, r)];
+              co[r] = si[2 * TILE + wj + 16 * jb + MM::row(lane, r)];
+            }
             T v[4][NT];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
               const int jc = max(jq[r], 0);
-              // column jc of the child: plain column-major square (uld > 0) or packed lower triangle
-              const int coff = c.uld > 0 ? jc * c.uld : jc * c.ncu - ((jc * (jc - 1)) >> 1) - jc;
 #pragma unroll
-              for (int ib = 0; ib < NT; ib++) v[r][ib] = Uc[coff + max(iq[ib], jc)];
+              for (int ib = 0; ib < NT; ib++) v[r][ib] = Uc[co[r] + max(iq[ib], jc)];   // clamped into the column
             }
+            // an entry of the lower triangle exists in the child iff its row AND its column do (monotone maps);
+            // entries above the diagonal of a diagonal tile take whatever falls out, they are never stored.  The
+            // (rhs, rhs) corner is read like any other entry: it is finite (zero in an LDS child's packed storage,
+            // which is never written there) and never used.
 #pragma unroll
             for (int r = 0; r < 4; r++)
 #pragma unroll
-              for (int ib = 0; ib < NT; ib++) {
-                const bool ok = jq[r] >= 0 && iq[ib] >= jq[r] && !(iq[ib] == last && jq[r] == last);
-                acc[ib][jb][r] += ok ? v[r][ib] : (T)0;
-              }
+              for (int ib = 0; ib < NT; ib++) acc[ib][jb][r] += (iq[ib] | jq[r]) >= 0 ? v[r][ib] : (T)0;
           }
         }
       }
