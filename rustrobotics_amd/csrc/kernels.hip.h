@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 namespace rrpgo {
 
@@ -2615,37 +2616,56 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
       }
   }
   RRPGO_PHASE_MARK(a, pm, 604);
-  stash(0, ra[0], rb[0]);
-  if (DEPTH < nchunks) fetch(DEPTH, ra[0], rb[0]);
-  __syncthreads();
-  RRPGO_PHASE_MARK(a, pm, 601);
+  // The chunk loop twice: FULL = a whole super-panel (K = 128, every launch above the lowest levels) with all of its
+  // conditions resolved at compile time -- the general form pays eight scalar compare-and-branch pairs per chunk
+  // (SQ_ACTIVE_INST_SCA read 20-27 % on this kernel).
+  auto chunks = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    auto fetch_c = [&](int c, T (&xa)[NLD], T (&xb)[NLD]) {
+      if constexpr (FULL) {
+        const uint32_t ca = oa + (uint32_t)c * cstep, cb = ob + (uint32_t)c * cstep;
 #pragma unroll
-  for (int c = 0; c < MAXCH; c++) {
-    if (c >= nchunks) break;
-    const int buf = c & 1;
-    if (wave_active) {
-#pragma unroll
-      for (int s4 = 0; s4 < KC / 4; s4++) {
-        T av[NT], bv[NT];
-#pragma unroll
-        for (int q = 0; q < NT; q++) {
-          bv[q] = As[buf][4 * s4 + lk][wi + 16 * q + li];
-          av[q] = Bs[buf][4 * s4 + lk][wj + 16 * q + li];
+        for (int q = 0; q < NLD; q++) {
+          xa[q] = ldo(ca + (uint32_t)q * qstep);
+          xb[q] = -ldo(cb + (uint32_t)q * qstep);
         }
-#pragma unroll
-        for (int ib = 0; ib < NT; ib++)
-#pragma unroll
-          for (int jb = 0; jb < NT; jb++) acc[ib][jb] = MM::mma(av[jb], bv[ib], acc[ib][jb]);
+      } else {
+        fetch(c, xa, xb);
       }
-    }
-    if (c + 1 < nchunks) {
-      constexpr int dummy = 0; (void)dummy;
-      const int set = (c + 1) % DEPTH;   // compile-time after unrolling
-      stash(buf ^ 1, ra[set], rb[set]);
-      if (c + 1 + DEPTH < nchunks) fetch(c + 1 + DEPTH, ra[set], rb[set]);
-    }
+    };
+    stash(0, ra[0], rb[0]);
+    if (FULL ? DEPTH < MAXCH : DEPTH < nchunks) fetch_c(DEPTH, ra[0], rb[0]);
     __syncthreads();
-  }
+    RRPGO_PHASE_MARK(a, pm, 601);
+#pragma unroll
+    for (int c = 0; c < MAXCH; c++) {
+      if (!FULL && c >= nchunks) break;
+      const int buf = c & 1;
+      if (wave_active) {
+#pragma unroll
+        for (int s4 = 0; s4 < KC / 4; s4++) {
+          T av[NT], bv[NT];
+#pragma unroll
+          for (int q = 0; q < NT; q++) {
+            bv[q] = As[buf][4 * s4 + lk][wi + 16 * q + li];
+            av[q] = Bs[buf][4 * s4 + lk][wj + 16 * q + li];
+          }
+#pragma unroll
+          for (int ib = 0; ib < NT; ib++)
+#pragma unroll
+            for (int jb = 0; jb < NT; jb++) acc[ib][jb] = MM::mma(av[jb], bv[ib], acc[ib][jb]);
+        }
+      }
+      if (FULL ? c + 1 < MAXCH : c + 1 < nchunks) {
+        const int set = (c + 1) % DEPTH;   // compile-time after unrolling
+        stash(buf ^ 1, ra[set], rb[set]);
+        if (FULL ? c + 1 + DEPTH < MAXCH : c + 1 + DEPTH < nchunks) fetch_c(c + 1 + DEPTH, ra[set], rb[set]);
+      }
+      __syncthreads();
+    }
+  };
+  if (nk == BIG_SUPER) chunks(std::true_type{});
+  else chunks(std::false_type{});
   RRPGO_PHASE_MARK(a, pm, 602);
   if (!wave_active) return false;
   if (interior) {
