@@ -209,6 +209,10 @@ def golden_chi2(workload):
         return None
 
 
+class SetupFailed(RuntimeError):
+    """a sharded leg that every rank agreed to skip (Ctx.all_ok) before its first data-path collective"""
+
+
 class Ctx:
     """torch / torch.distributed plumbing shared by every measurement of this process."""
 
@@ -225,6 +229,14 @@ class Ctx:
     def barrier(self):
         if self.dist:
             self.dist.barrier()
+
+    def all_ok(self, ok):
+        """True iff `ok` on every rank.  A collective: call it only where every rank arrives whatever happened."""
+        if not self.dist:
+            return bool(ok)
+        t = self.torch.tensor([0 if ok else 1], dtype=self.torch.int32, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return int(t.item()) == 0
 
     def all_max(self, x):
         if not self.dist:
@@ -251,8 +263,14 @@ def measure_sharded(ctx, workload, precision, steps, warmup, force_collectives=F
     """ONE graph sharded over the ranks: rr_pgo_stage + RCCL collectives issued on the library's own stream
     (rustrobotics_amd.sharding.TorchShardDriver); no host synchronisation inside an iteration."""
     from rustrobotics_amd.sharding import TorchShardDriver
-    drv = TorchShardDriver(workload_arrays(workload), precision, ctx.local_rank, ctx.rank, ctx.world,
-                           ctx.dist, force_collectives=force_collectives)
+    drv, err = None, None
+    try:
+        drv = TorchShardDriver(workload_arrays(workload), precision, ctx.local_rank, ctx.rank, ctx.world,
+                               ctx.dist, force_collectives=force_collectives)
+    except Exception as e:   # noqa: BLE001 -- agreed on below, before any rank enters a data-path collective
+        err = e
+    if not ctx.all_ok(err is None):
+        raise SetupFailed(f"set-up of the sharded graph failed on some rank (this rank: {err!r})")
     state0 = drv.graph.state()
 
     def sync():
@@ -266,6 +284,7 @@ def measure_sharded(ctx, workload, precision, steps, warmup, force_collectives=F
 def secondary_entry(ctx, workload, precision, steps, warmup, sharded):
     """A BASELINE config other than the headline, same timing contract; rank 0 returns the record."""
     t_wall = time.perf_counter()
+    collective_leg = bool(sharded) and ctx.world > 1
     try:
         if sharded:
             drv, state0, dt = measure_sharded(ctx, workload, precision, steps, warmup, force_collectives=True)
@@ -273,7 +292,16 @@ def secondary_entry(ctx, workload, precision, steps, warmup, sharded):
         else:
             g, state0, dt = measure_single(ctx, workload, precision, steps, warmup)
             drv = None
+    except SetupFailed as e:   # every rank agreed on it before the first data-path collective: all of them skip the leg
+        return {"workload": workload, "dtype": precision, "sharded": bool(sharded), "error": str(e)}
     except Exception as e:   # noqa: BLE001 -- a secondary config must never take the headline line down
+        if collective_leg:
+            # this rank has left a sequence of collectives the other ranks are still inside: nothing it could send
+            # would reach them.  Leave with a failure status at once (the launcher tears the group down) instead of
+            # letting them wait out the watchdog and the run end with rc 0.
+            sys.stderr.write(f"bench.py rank {ctx.rank}: sharded leg {workload}/{precision} failed: {type(e).__name__}: {e}\n")
+            sys.stderr.flush()
+            os._exit(3)
         return {"workload": workload, "dtype": precision, "sharded": bool(sharded), "error": f"{type(e).__name__}: {e}"}
     value = steps / dt * (1 if sharded else ctx.world)
     rec = {"workload": f"{workload} ({g.num_nodes} poses / {g.num_edges} edges / dim {g.len})", "dtype": precision,
@@ -439,12 +467,14 @@ def main():
         import threading
 
         def _bail():
+            # a watchdog in a process that holds the GPU: the partial line is still written (the headline was
+            # measured), but the run FAILED -- every rank leaves with a non-zero status
             try:
                 if out is not None:
-                    out["secondary"] = sec + [{"error": "secondary legs exceeded %d s: abandoned" % limit_s}]
+                    out["secondary"] = sec + [{"error": "secondary legs exceeded %d s: abandoned, exit status 3" % limit_s}]
                     os.write(real_stdout, (json.dumps(out) + "\n").encode())
             finally:
-                os._exit(0)
+                os._exit(3)
         limit_s = int(os.environ.get("RR_PGO_BENCH_SECONDARY_LIMIT", "420" if world > 1 else "900"))
         watchdog = threading.Timer(limit_s, _bail)
         watchdog.daemon = True

@@ -5,7 +5,9 @@ compute entry point of the library itself fails with RR_PGO_ENODEVICE when no
 HIP device is present.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librr_pgo.so")
@@ -66,14 +68,18 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). rustrobotics_amd has no CPU fallback.")
-    # PyTorch-ROCm bundles its own libamdhip64; a process that loads /opt/rocm's copy first (through this
-    # library) and torch's later ends up with two HIP runtimes, and the second one finds no device.  Loading
-    # torch first makes both resolve to the same runtime (same SONAME).  RR_PGO_NO_TORCH_PRELOAD=1 skips this
-    # for torch-free callers.
-    if not os.environ.get("RR_PGO_NO_TORCH_PRELOAD"):
+    # PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  A process that maps /opt/rocm's copy
+    # first (through this library) and torch's later ends up with two HIP runtimes, and the second one finds no
+    # device.  So the runtime torch WOULD load is mapped first, by path and without importing torch (an import costs
+    # seconds; torch-free callers pay a dlopen): both then resolve to one runtime whichever order they come in.
+    # Nothing to do when torch is already imported.  RR_PGO_NO_TORCH_PRELOAD=1 skips this.
+    if "torch" not in sys.modules and not os.environ.get("RR_PGO_NO_TORCH_PRELOAD"):
         try:
-            import torch  # noqa: F401
-        except ImportError:
+            spec = importlib.util.find_spec("torch")
+            hip = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec and spec.origin else None
+            if hip and os.path.exists(hip):
+                C.CDLL(hip, mode=C.RTLD_GLOBAL)
+        except (ImportError, OSError, ValueError):
             pass
     L = C.CDLL(LIB_PATH)
     vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)

@@ -6,7 +6,7 @@
 //   k_update         update_nodes + |dx|^2                             (reference :229-245,273)
 //   k_finalize_slot  fixed-order reduction of the chi2 / |dx|^2 partials (pgo_api.hip)
 //   k_big_* / k_solve_mid / k_factor_panel fronts beyond LDS (see "huge fronts" below)
-//   k_linearize_se3 / k_update_se3, k_pack_boundary / k_mask_x   SE(3), sharding over ranks
+//   k_linearize_se3 / k_update_se3, k_pack_boundary / k_pack_shared / k_sum_shared   SE(3), sharding over ranks
 //
 // Wavefront = 64 lanes.  All cross-workgroup dependencies are kernel boundaries
 // on one stream; inside a launch a workgroup only reads what it wrote itself
@@ -3714,6 +3714,18 @@ template <typename T> __global__ void __launch_bounds__(256) k_pack_shared(const
   if (i >= n) return;
   const int64_t so = src_off[i];
   dst[i] = so >= 0 ? hvals[so] : b[~so];
+}
+// A rank whose own subtrees hit a non-positive pivot in stage 0 publishes that in the last scalar of its chunk
+// (k_pack_err); after the all-gather every rank folds the P flags into its own device flag (k_merge_err) BEFORE
+// stage 1's k_update tests it: either every rank applies the step or none does, and every rank reports ENOTSPD.
+template <typename T> __global__ void k_pack_err(const int *err, T *dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = (T)(*err != 0 ? 1 : 0);
+}
+template <typename T> __global__ void k_merge_err(int *err, const T *xch, int64_t chunk, int64_t off, int P) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  bool any = false;
+  for (int r = 0; r < P; r++) any = any || xch[(int64_t)r * chunk + off] != (T)0;
+  if (any) atomicOr(err, DEVERR_NOT_SPD);
 }
 template <typename T> __global__ void __launch_bounds__(256) k_sum_shared(const int64_t *src_off, int n, T *hvals, T *b, const T *xch, int64_t chunk, int64_t off, int P) {
   const int i = blockIdx.x * 256 + threadIdx.x;

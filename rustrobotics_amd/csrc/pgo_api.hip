@@ -529,6 +529,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
               const int sn = sym.task_sn[sym.task_ptr[t]];
               ba.push_back(meta[sn]);
               big_all_maxM_ = std::max(big_all_maxM_, sym.sn_ncols[sn] + sym.sn_nrows[sn] + 1);
+              // k_big_panel32 / k_big_update address a front with 32-bit BYTE offsets from its base
+              if ((int64_t)(sym.sn_ncols[sn] + sym.sn_nrows[sn] + 1) * (sym.sn_ncols[sn] + sym.sn_nrows[sn] + 1) * (int64_t)sizeof(T) >= (1LL << 32))
+                throw ApiError(RR_PGO_EUNSUPPORTED, "a front of more than 4 GiB exceeds the 32-bit addressing of the big-front kernels");
               big_all_max_asm_ = std::max<int64_t>(big_all_max_asm_, std::max<int64_t>(sym.fasm_ptr[sn + 1] - sym.fasm_ptr[sn], sym.sn_ncols[sn]));
               big_all_dup_ = big_all_dup_ || sym.fdup_ptr[sn + 1] > sym.fdup_ptr[sn];
             }
@@ -1249,7 +1252,15 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   }
 
  public:
-  void chi2(double *out) override { *out = chi2_now(); }
+  // On a handle that holds ONE RANK's share of a graph (world_size > 1) these three would return rank-partial
+  // results (chi2 of the edges this rank owns, partial diagonal blocks of the shared nodes, an update of this
+  // rank's nodes only): refused -- rr_pgo_stage(h, 2) + the sum all-reduce of exchange buffer 1 is the chi2 of a
+  // sharded graph, rr_pgo_stage(h, 0 / 1) its iteration.
+  void refuse_rank_partial(const char *what) const {
+    if (world_ > 1)
+      throw ApiError(RR_PGO_EUNSUPPORTED, std::string(what) + " on one rank of a sharded graph would be rank-partial: use rr_pgo_stage + the two collectives");
+  }
+  void chi2(double *out) override { refuse_rank_partial("rr_pgo_chi2"); *out = chi2_now(); }
 
   void linearize_solve(double lambda, int lm, double *dx_out) override {
     if (sharded_) throw ApiError(RR_PGO_EUNSUPPORTED, "sharded handle: drive it with rr_pgo_stage + the two collectives");
@@ -1265,6 +1276,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   }
 
   void update(const double *dx, double sign) override {
+    refuse_rank_partial("rr_pgo_update");
     std::vector<T> tmp((size_t)g_.dim);
     for (int i = 0; i < g_.dim; i++) tmp[i] = (T)dx[i];
     HIPCHK(hipMemcpyAsync(dx_ref_.p, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice, stream_));
@@ -1366,6 +1378,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   }
 
   void assemble(double lambda, int lm, std::vector<double> &hv, std::vector<double> &b) override {
+    refuse_rank_partial("rr_pgo_assemble");
     launch_linearize(lambda, lm, 1, true);   // always the reference's system (anchor prior), whatever the factor's gauge
     std::vector<T> th((size_t)sym_.n_hvals), tb((size_t)g_.dim);
     HIPCHK(hipMemcpyAsync(th.data(), hvals_.p, th.size() * sizeof(T), hipMemcpyDeviceToHost, stream_));
@@ -1428,12 +1441,17 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
                            factor_args(0), pack_list_.p);
         check_launch("k_pack_boundary");
       }
+      if (world_ > 1)   // this rank's error flag travels with its chunk (the group must agree on ENOTSPD)
+        hipLaunchKernelGGL(k_pack_err<T>, dim3(1), dim3(64), 0, stream_, (const int *)err_.p,
+                           xch_ + (int64_t)rank_ * sym_.xch_chunk + sym_.xch_flag_off);
     } else if (stg == 1) {
       // after the all-gather: the shared top fronts (every rank, identical), the back substitution of the top
       // and of this rank's subtrees, the update of this rank's nodes, its partial chi2 / |dx|^2
       if (n_shared_ > 0)   // the shared nodes' diagonal blocks and rhs: the P partial sums, added in rank order
         hipLaunchKernelGGL(k_sum_shared<T>, dim3((n_shared_ + 255) / 256), dim3(256), 0, stream_, shared_src_.p, n_shared_, hvals_.p, b_.p,
                            (const T *)xch_, sym_.xch_chunk, sym_.xch_shared_off, world_);
+      if (world_ > 1)
+        hipLaunchKernelGGL(k_merge_err<T>, dim3(1), dim3(64), 0, stream_, err_.p, (const T *)xch_, sym_.xch_chunk, sym_.xch_flag_off, world_);
       launch_factor_range(n_local, sym_.steps.size());
       launch_solve();
       launch_update(nullptr, 1.0, true);

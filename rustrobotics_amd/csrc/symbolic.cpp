@@ -850,7 +850,10 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     int64_t shared_elems = 0;
     for (int i = 0; i < N; i++)
       if (sym.node_part[i] < 0) shared_elems += (int64_t)w[i] * w[i] + w[i];
-    sym.xch_chunk = std::max<int64_t>((sym.xch_shared_off + shared_elems + 63) & ~(int64_t)63, 64);
+    // ... and, last, ONE scalar: the rank's device error flag after stage 0 (a non-positive pivot in a rank's own
+    // subtree must stop the update on EVERY rank: the state stays untouched across the whole group)
+    sym.xch_flag_off = sym.xch_shared_off + shared_elems;
+    sym.xch_chunk = std::max<int64_t>((sym.xch_flag_off + 1 + 63) & ~(int64_t)63, 64);
     std::fill(used.begin(), used.end(), 0);
     for (int f = 0; f < S; f++) {
       for (int c = 0; c < sym.sn_ncols[f]; c++) sym.col_owner[sym.sn_col0[f] + c] = (int8_t)sym.sn_owner[f];

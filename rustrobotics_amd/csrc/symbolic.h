@@ -112,6 +112,7 @@ struct Symbolic {
   int64_t xch_elems = 0;             // n_parts * xch_chunk
   int64_t xch_chunk = 0;             // scalars of one rank's chunk of the exchange buffer (all-gather)
   int64_t xch_shared_off = 0;        // inside a chunk: the rank's partial diagonal blocks + rhs of the shared nodes
+  int64_t xch_flag_off = 0;          // inside a chunk: the rank's device error flag after stage 0 (one scalar)
   std::vector<int8_t> col_owner;     // per permuted scalar column: owner rank, -1 = shared
   // ---- stats
   int64_t nnz_l_blocks = 0;          // node-level nonzero blocks of L (no padding)
