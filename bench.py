@@ -45,7 +45,7 @@ LATTICE = "grid:400x250:1000000"   # BASELINE configs[3]
 KERNEL_OF = {"linearize": "k_linearize", "factor": "k_factor_tasks", "solve": "k_solve_tasks",
              "update": "k_update", "reduce": "k_finalize_slot", "big_assembly": "k_big_build+k_big_assemble",
              "big_panel": "k_big_diag32+k_big_panel32", "big_update": "k_big_update", "mid_factor": "k_factor_panel",
-             "big_solve": "k_big_gemv_partial+k_big_solve_sp+k_solve_mid"}
+             "big_solve": "k_big_gemv_partial+k_big_solve_sp+k_solve_mid", "big_flow": "k_big_flow"}
 
 
 def g2o_file(name):

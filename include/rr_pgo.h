@@ -193,7 +193,8 @@ enum {
   RR_PGO_K_BIG_UPDATE = 7,  /* k_big_update (huge fronts: MFMA rank-128 trailing updates) */
   RR_PGO_K_MID_FACTOR = 8,  /* k_factor_panel (panel-in-LDS fronts, one workgroup each) */
   RR_PGO_K_BIG_SOLVE = 9,   /* k_big_gemv_partial + k_big_solve_sp / k_solve_mid        */
-  RR_PGO_NUM_KCLASS = 10
+  RR_PGO_K_BIG_FLOW = 10,   /* k_big_flow (huge fronts of a level of few fronts: panels + updates as one dataflow launch) */
+  RR_PGO_NUM_KCLASS = 11
 };
 int rr_pgo_profile(rr_pgo *h, int32_t iters, double *ms_total /*[NUM_KCLASS]*/,
                    int64_t *launches /*[NUM_KCLASS]*/);

@@ -15,9 +15,9 @@ LIB_PATH = os.path.join(_HERE, "librr_pgo.so")
 OK, EINVAL, EIO, EPARSE, ENODEVICE, ENOTSPD, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7
 F64, F32, MIXED = 0, 1, 2
 PRECISIONS = {"f64": F64, "f32": F32, "mixed": MIXED}
-NUM_KCLASS = 10
+NUM_KCLASS = 11
 KCLASS_NAMES = ("linearize", "factor", "solve", "update", "reduce", "big_assembly", "big_panel", "big_update",
-                "mid_factor", "big_solve")
+                "mid_factor", "big_solve", "big_flow")
 
 # every symbol include/rr_pgo.h declares (tests check that the .so exports exactly these)
 EXPORTS = (

@@ -1,0 +1,450 @@
+// flow.hip.h -- k_big_flow: the fronts beyond LDS of ONE tree level as ONE launch of ticket-ordered tile tasks.
+//
+// The launch sequence of kernels.hip.h ("huge fronts") is level-synchronous twice over: every 32-column step of
+// the panel chain and every 128-column trailing update is a launch of its own, so a level of few fronts is a chain
+// of ~8 us launches that leave most of the chip idle (r02: the six top levels of the 1M-edge lattice took 3.4 of
+// 5.8 ms at MfmaUtil 1.8 %).  Here the same arithmetic (same device functions, same order of every sum: results
+// are bit-identical to the launch sequence) runs as a dataflow:
+//
+//   task PANEL(front, kb, row-block group)   four waves = four 32-row blocks below the 32-column block at kb:
+//        left-looking update inside the super-panel, X = A W^T; the wave that owns rows kb+32..kb+63 then forms,
+//        factors and inverts the NEXT diagonal block (the chain) -- the body of k_big_panel32
+//   task UPDATE(front, K0, tile)             one 64 x 64 tile of the K = 128 trailing update of super-panel K0
+//        (the first one of a front gathers its tile from the children); tile (0, 0) also factors and inverts the
+//        next super-panel's first diagonal block -- the body of k_big_update
+//
+// Workgroups draw tasks from ONE atomic ticket; the task list is in a topological order (sorted by the earliest
+// start time of a cost model, host side), so a task only ever waits for tasks with smaller tickets, which are
+// finished or held by a running workgroup: no deadlock whatever the grid size or the dispatch order.  Completion is
+// published per unit (W of a block, X of a row block, a tile) in flag words; payload moves with sc1 (write-through /
+// L1-bypassing) accesses, flags with agent-scope relaxed atomics after the storing wave's s_waitcnt vmcnt(0)
+// (MI355X_MICROARCH.md, inter-workgroup visibility; scripts/handoff_probe.hip measured this form stale-free with
+// lines shared by two producers, 0.8 us per hop against ~1.5-2 us per kernel boundary).  Every spin is bounded:
+// a wait that runs out sets DEVERR_FLOW_TIMEOUT, after which every wait returns at once and the launch drains.
+// Replaces the reference's umfpack.factorize (src/mapping/pose_graph_optimization.rs:138) for those fronts.
+#pragma once
+
+namespace rrpgo {
+
+struct FlowFront {       // one front of a flow level: where its flags live (indices into FlowArgs::flags)
+  int32_t wf;            // wf[b]: W of 32-column block b is in winv (and every row the chain read for it is in F)
+  int32_t pf, pstride;   // pf[b * pstride + rb]: X of row block rb of block b is in F
+  int32_t uf, ustride;   // uf[sp * ustride + bx (bx + 1) / 2 + by]: tile (bx, by) of super-panel sp's update is in F
+  int32_t pad[3];
+};
+static_assert(sizeof(FlowFront) == 32, "FlowFront is one 32-byte record");
+
+struct FlowTask {        // 16 bytes, one scalar load
+  int32_t kind_front;    // kind << 24 | front slot of the level
+  int32_t p0, p1, p2;    // PANEL: kb, first row block, K0;  UPDATE: K0, bx, by;  DIAG0: -
+};
+constexpr int FLOW_PANEL = 0, FLOW_UPDATE = 1, FLOW_DIAG0 = 2;
+constexpr int FLOW_GROUP = 4;   // row blocks per PANEL task (one per wave)
+
+template <typename T> struct FlowArgs {   // everything the launch reads: a slim kernel-argument block (the ticket loop keeps all of it in SGPRs)
+  const FlowTask *tasks;
+  const FlowFront *fronts;
+  unsigned *ticket;
+  unsigned *flags;
+  int n_tasks;
+  int gather;   // the first trailing update of a front gathers its tiles right of big_built_cols from the children
+  int exact;    // 1: the next super-panel's first diagonal block comes out of tile (0, 0) of the trailing update, exactly as
+                // in the launch sequence (bit-identical results); 0: the chain wave forms it itself, left-looking over the
+                // whole super-panel like every other diagonal block -- same sums in another order, and no tile on the chain
+  const SnMeta *front_meta;      // task_meta of the level's first front (slot 0)
+  const ChildMeta *child_meta;
+  const int32_t *scat;
+  T *lvals, *uvals, *xch, *winv;
+  int *err;
+  unsigned long long *trace;   // diagnostic build (-DRRPGO_FLOW_TRACE): [ticket][wave][4] wall-clock stamps, else null
+};
+
+// stamps of a task's wave: 0 = ticket drawn, 1 = dependencies met, 2 = X / tile stored, 3 = flags set (100 MHz wall clock)
+#ifdef RRPGO_FLOW_TRACE
+#define RRPGO_FLOW_MARK(fa, t, wv, slot)                                                                     \
+  do {                                                                                                        \
+    if ((fa).trace && (lane) == 0) (fa).trace[((size_t)(t) * 4 + (size_t)(wv)) * 4 + (slot)] = wall_clock64(); \
+  } while (0)
+#else
+#define RRPGO_FLOW_MARK(fa, t, wv, slot) do { } while (0)
+#endif
+
+#ifndef RRPGO_FLOW_SPIN_MAX
+#define RRPGO_FLOW_SPIN_MAX (1u << 22)   // polls of one wait before it gives up (seconds: a poll is a memory round trip)
+#endif
+
+__device__ __forceinline__ unsigned flow_flag_ld(const unsigned *p) { return __hip_atomic_load(const_cast<unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void flow_flag_set(unsigned *p) { __hip_atomic_store(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// One wave waits until every flag its lanes name (nullptr = none) is set.  Bounded; false = gave up or the launch
+// is draining after an error (the caller goes on: addresses never depend on data, the results are reported invalid).
+__device__ __forceinline__ bool flow_wait(const unsigned *p, int *err) {
+  bool ok = true;
+  for (unsigned spins = 0;; spins++) {
+    const unsigned v = p ? flow_flag_ld(p) : 1u;
+    if (__all(v != 0u)) break;
+    if ((spins & 63u) == 63u) {
+      const int e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e != 0 || spins >= RRPGO_FLOW_SPIN_MAX) {
+        if (e == 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicOr(err, DEVERR_FLOW_TIMEOUT);
+        ok = false;
+        break;
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the payload loads below the poll
+  return ok;
+}
+// after this wave's payload stores: drain them, then the caller sets its flags
+__device__ __forceinline__ void flow_drain() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ int flow_tri(int bx, int by) { return bx * (bx + 1) / 2 + by; }
+
+// ---- DIAG0: the very first diagonal block of a front, by one wave (k_big_diag32's arithmetic).  The block stays as
+// assembled in F: nothing reads a diagonal block of L once its W exists (the back substitution works with the inverses).
+template <typename T>
+__device__ __forceinline__ void flow_diag0_wave(const FlowArgs<T> &fa, const FlowFront &ff, const SnMeta &m, T *Sh, int tid) {
+  const int nb = min(BIG_NB, m.nc);
+  const int M = m.nc + m.nr + 1;
+  T *F = fa.lvals + m.loff;
+  const int lane = tid & 63;
+  const Sc1Buf<T> fbuf(F, (uint32_t)((int64_t)M * M * (int64_t)sizeof(T)));
+  T dv[16];
+#pragma unroll
+  for (int t = 0; t < 16; t++) {
+    const int e = t * 64 + lane, c = e >> 5, r = e & 31;
+    dv[t] = fbuf.ld((uint32_t)(min(c, nb - 1) * M + min(r, nb - 1)) * (uint32_t)sizeof(T));
+  }
+#pragma unroll
+  for (int t = 0; t < 16; t++) {
+    const int e = t * 64 + lane, c = e >> 5, r = e & 31;
+    Sh[c * 33 + r] = (r < nb && c < nb && r >= c) ? dv[t] : ((r == c && r >= nb) ? (T)1 : (T)0);
+  }
+  diag32_init_tables<T>(Sh);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  diag32_factor_invert<T, false, true>(Sh, nb, F, M, fa.winv + (int64_t)m.wblk * 256, fa.err, false, true);
+  flow_drain();
+  if (lane == 0) flow_flag_set(fa.flags + ff.wf);
+}
+
+// ---- PANEL: one wave = 32 rows below the block at kb (k_big_panel32's arithmetic, sc1 accesses, flags).
+// The order of work is the chain's schedule.  Everything that does not depend on the diagonal block being factored
+// right now comes first -- the left-looking update from the super-panel's earlier blocks, oldest first, each block's
+// operands requested one block ahead (two register sets); only the NEWEST block waits for its X (published one
+// step ago, by the chain wave BEFORE it factors).  Then the wave waits for W, multiplies, stores and publishes its X;
+// the wave that owns the next diagonal block's rows goes on: last term of that block, factor and invert, publish W.
+// So one step of the chain costs: hop + newest block's loads and MFMAs + hop + W load + X + factor-and-invert,
+// with the first half running under the previous step's factor-and-invert.
+template <typename T>
+__device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const FlowFront &ff, const SnMeta &m, int kb,
+                                                int K0, int rowblk, T *Sh, int tid, int ticket) {
+  static_assert(BIG_NB == 32 && BIG_SUPER == 128, "written for 32-column blocks in 128-column super-panels");
+  using MM = Mfma16<T>;
+  const int nb = min(BIG_NB, m.nc - kb);
+  const int M = m.nc + m.nr + 1;
+  const int R0 = kb + nb + rowblk * 32;
+  if (R0 >= M) return;
+  T *F = fa.lvals + m.loff;
+  T *Wt = fa.winv + (int64_t)m.wblk * 256 + (kb / BIG_NB) * 1024;
+  const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int super_end = min(K0 + BIG_SUPER, m.nc);
+  const int kn = kb + BIG_NB;
+  const int blk = kb / BIG_NB, q = (kb - K0) / BIG_NB, sp = K0 / BIG_SUPER;
+  // this wave also prepares the next diagonal block (nb == 32 then); across the super-panel's end only in the fast mode
+  const bool look = rowblk == 0 && kn < (fa.exact ? super_end : m.nc);
+  // flags of block (blk - j) that block's term of the update needs: my rows there (a partial last block is not
+  // aligned with the whole blocks' row blocks and straddles two) and the rows of the diagonal block (row block j - 1)
+  auto block_flag = [&](int j, int which) -> const unsigned * {   // which: 0, 1 = my rows; 2 = the diagonal block's rows
+    if (which == 2) return fa.flags + ff.pf + (blk - j) * ff.pstride + (j - 1);
+    const int r0p = kb - 32 * j + 32;
+    const int rb = (R0 - r0p) / 32 + which;
+    return rb <= (min(R0 + 31, M - 1) - r0p) / 32 ? fa.flags + ff.pf + (blk - j) * ff.pstride + rb : nullptr;
+  };
+  {
+    // ---- first wait: the C tiles (previous super-panel's trailing update) and every block but the newest
+    const unsigned *fp = nullptr;
+    if (lane < 6) {
+      const int j = lane / 3 + 2;   // blocks blk - 2, blk - 3
+      if (j <= q) fp = block_flag(j, lane % 3);
+    } else if (lane <= 7) {
+      const int bx = (R0 - K0) / 64 + (lane - 6), bxe = (min(R0 + 31, M - 1) - K0) / 64;
+      if (sp > 0 && bx <= bxe) fp = fa.flags + ff.uf + (sp - 1) * ff.ustride + flow_tri(bx, (kb - K0) / 64);
+    } else if (lane == 8) {
+      const int d = (kn - K0) / 64;
+      if (look && sp > 0) fp = fa.flags + ff.uf + (sp - 1) * ff.ustride + flow_tri(d, d);
+    }
+    flow_wait(fp, fa.err);
+  }
+  RRPGO_FLOW_MARK(fa, ticket, tid >> 6, 1);
+  constexpr uint32_t SZ = (uint32_t)sizeof(T);
+  const Sc1Buf<T> fbuf(F, (uint32_t)((int64_t)M * M * (int64_t)sizeof(T))), wbuf(Wt, 1024u * SZ);
+  auto ldF = [&](int col, int row) { return fbuf.ld((uint32_t)(col * M + row) * SZ); };   // element (row, col) of the front
+  int irow[2];
+  irow[0] = min(R0 + li, M - 1);
+  irow[1] = min(R0 + 16 + li, M - 1);
+  const int nblk = q;
+  const int arow0 = kb + min(li, nb - 1), arow1 = kb + min(16 + li, nb - 1);
+  const T am0 = li < nb ? (T)-1 : (T)0, am1 = 16 + li < nb ? (T)-1 : (T)0;
+  T av[2][8][2], bv[2][8][2];
+  const uint32_t colb = (uint32_t)((K0 + lk) * M) * SZ;
+  const uint32_t oa0 = colb + (uint32_t)arow0 * SZ, oa1 = colb + (uint32_t)arow1 * SZ;
+  const uint32_t ob0 = colb + (uint32_t)irow[0] * SZ, ob1 = colb + (uint32_t)irow[1] * SZ;
+  const uint32_t kstep = (uint32_t)(4 * M) * SZ;
+  auto fetch = [&](int b, T (*xa)[2], T (*xb)[2]) {
+    uint32_t d = (uint32_t)(b * 8) * kstep;
+#pragma unroll
+    for (int s4 = 0; s4 < 8; s4++) {
+      xa[s4][0] = fbuf.ld(oa0 + d) * am0;
+      xa[s4][1] = fbuf.ld(oa1 + d) * am1;
+      xb[s4][0] = fbuf.ld(ob0 + d);
+      xb[s4][1] = fbuf.ld(ob1 + d);
+      d += kstep;
+    }
+  };
+  auto wait_newest = [&] {   // X of block blk - 1: my rows and the diagonal block's rows
+    flow_wait(lane < 3 ? block_flag(1, lane) : nullptr, fa.err);
+  };
+  typename MM::Acc acc[2][2], nxt[2][2];
+#pragma unroll
+  for (int jb = 0; jb < 2; jb++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int j = 16 * jb + MM::row(lane, r);
+#pragma unroll
+      for (int ib = 0; ib < 2; ib++) acc[ib][jb][r] = ldF(kb + min(j, nb - 1), irow[ib]);
+    }
+  if (nblk == 1) wait_newest();
+  if (nblk > 0) fetch(0, av[0], bv[0]);
+  if (look) {
+#pragma unroll
+    for (int jb = 0; jb < 2; jb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int cn = min(kn + 16 * jb + MM::row(lane, r), M - 1);
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++) nxt[ib][jb][r] = ldF(cn, irow[ib]);
+      }
+  }
+#pragma unroll
+  for (int jb = 0; jb < 2; jb++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int j = 16 * jb + MM::row(lane, r);
+#pragma unroll
+      for (int ib = 0; ib < 2; ib++) {
+        const T v = pin(acc[ib][jb][r]);
+        acc[ib][jb][r] = j < nb ? v : (T)0;
+      }
+    }
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+#pragma unroll
+  for (int b = 0; b < BIG_SUPER / BIG_NB - 1; b++) {
+    if (b < nblk) {
+      const int slot = b & 1;
+      if (b + 1 < nblk) {   // the next block's operands are in flight under this block's MFMAs
+        if (b + 2 == nblk) wait_newest();
+        fetch(b + 1, av[slot ^ 1], bv[slot ^ 1]);
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 8; s4++) {
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+          for (int jb = 0; jb < 2; jb++) acc[ib][jb] = MM::mma(av[slot][s4][jb], bv[slot][s4][ib], acc[ib][jb]);
+        if (look) {
+#pragma unroll
+          for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+            for (int jb = 0; jb <= ib; jb++) nxt[ib][jb] = MM::mma(-bv[slot][s4][jb], bv[slot][s4][ib], nxt[ib][jb]);
+        }
+      }
+    }
+  }
+  // ---- now the diagonal block: wait for its inverse
+  flow_wait(lane == 0 ? fa.flags + ff.wf + blk : nullptr, fa.err);
+  RRPGO_FLOW_MARK(fa, ticket, tid >> 6, 2);
+  T wv[3][4];
+#pragma unroll
+  for (int t = 0; t < 3; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int cb = t == 0 ? 0 : 1, jb = t == 2 ? 1 : 0;
+      wv[t][r] = wbuf.ld((uint32_t)((16 * jb + MM::row(lane, r)) * 32 + 16 * cb + li) * SZ);
+    }
+  typename MM::Acc out[2][2];
+#pragma unroll
+  for (int ib = 0; ib < 2; ib++) {
+    out[ib][0] = typename MM::Acc{0, 0, 0, 0};
+    out[ib][1] = typename MM::Acc{0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      out[ib][0] = MM::mma(wv[0][r], acc[ib][0][r], out[ib][0]);
+      out[ib][1] = MM::mma(wv[1][r], acc[ib][0][r], out[ib][1]);
+      out[ib][1] = MM::mma(wv[2][r], acc[ib][1][r], out[ib][1]);
+    }
+  }
+  if (nb == BIG_NB && R0 + 32 <= M) {
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t co = (uint32_t)((kb + 16 * cb + MM::row(lane, r)) * M + R0 + li) * SZ;
+        fbuf.st(co, (T)out[0][cb][r]);
+        fbuf.st(co + 16u * SZ, (T)out[1][cb][r]);
+      }
+  } else {
+#pragma unroll
+    for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+      for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int c = 16 * cb + MM::row(lane, r), i = R0 + 16 * ib + li;
+          if (i < M && c < nb) fbuf.st((uint32_t)((kb + c) * M + i) * SZ, (T)out[ib][cb][r]);
+        }
+  }
+  unsigned *pflag = fa.flags + ff.pf + blk * ff.pstride + rowblk;
+  if (!look) {
+    flow_drain();
+    if (lane == 0) flow_flag_set(pflag);
+    RRPGO_FLOW_MARK(fa, ticket, tid >> 6, 3);
+    return;
+  }
+  // next diagonal block: the last 32 columns of its update are this wave's own X
+#pragma unroll
+  for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+        for (int jb = 0; jb <= ib; jb++) nxt[ib][jb] = MM::mma(-out[jb][cb][r], out[ib][cb][r], nxt[ib][jb]);
+  const int nbn = min(BIG_NB, m.nc - kn);
+  sh_image_from_acc<T>(Sh, nxt, nbn);
+  diag32_init_tables<T>(Sh);
+  // X of this row block is what the NEXT step's pre-work reads (these rows are its diagonal block's): publish it now,
+  // before the factorisation -- its stores have been draining under the MFMAs and LDS writes above
+  flow_drain();
+  if (lane == 0) flow_flag_set(pflag);
+  wave_sync();
+  // the factored block itself is not stored: nothing reads a diagonal block of L once its W exists (the back
+  // substitution works with the inverses), and across a super-panel's end tile (0, 0) of the update still owns it
+  diag32_factor_invert<T, false, true>(Sh, nbn, F + (int64_t)kn * M + kn, M, fa.winv + (int64_t)m.wblk * 256 + (kn / BIG_NB) * 1024, fa.err,
+                                       false, true);
+  flow_drain();   // W is in memory
+  if (lane == 0) flow_flag_set(fa.flags + ff.wf + blk + 1);
+  RRPGO_FLOW_MARK(fa, ticket, tid >> 6, 3);
+}
+
+// Tickets and completion flags are zeroed by a KERNEL at the start of every factorisation, not by a memset node: inside
+// the captured stage graphs of a sharded handle a hipMemsetAsync node was not ordered before the kernels behind it on
+// replay (r03: the second replay of a stage found the first one's flags still set -- tasks did not wait, the ticket
+// was past the end -- while eager launches and the unsharded graph, where hundreds of microseconds of other kernels
+// sit between the two, were fine).
+__global__ void __launch_bounds__(256) k_flow_reset(unsigned *words, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) words[i] = 0u;
+}
+
+#ifndef RRPGO_FLOW_WAVES
+#define RRPGO_FLOW_WAVES 2   // fp32: waves per SIMD the register allocation aims at (= workgroups per CU): the panel wave keeps ~200 values in flight;
+#endif                       // fp64 (two registers per value) runs one workgroup per CU
+
+template <typename T> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? RRPGO_FLOW_WAVES : 1)) k_big_flow(FlowArgs<T> fa) {
+  using MM = Mfma16<T>;
+  using UT = UpdTile<T, 2>;
+  static_assert(UT::SMEM >= DIAG32_LDS, "one LDS region serves the tile staging and the diagonal-block images");
+  __shared__ T smem[UT::SMEM];
+  __shared__ unsigned s_ticket;
+  for (;;) {
+    // Everything a task derives from the thread index is derived from THIS copy: the compiler would otherwise hoist
+    // the per-lane constants of both task bodies out of the ticket loop and keep them all live (k_big_flow needed
+    // more than 256 VGPRs that way; the panel wave alone needs 180, the tile 80).
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) s_ticket = atomicAdd(fa.ticket, 1u);
+    __syncthreads();
+    const int t = __builtin_amdgcn_readfirstlane((int)s_ticket);
+    __syncthreads();   // everybody has read it (and is done with smem) before the next round rewrites it
+    if (t >= fa.n_tasks) return;
+    RRPGO_FLOW_MARK(fa, t, wave, 0);
+    const FlowTask tk = fa.tasks[t];
+    const int kind = tk.kind_front >> 24, slot = tk.kind_front & 0xffffff;
+    const SnMeta m = fa.front_meta[slot];
+    const FlowFront ff = fa.fronts[slot];
+    if (kind == FLOW_PANEL) {
+      flow_panel_wave<T>(fa, ff, m, tk.p0, tk.p2, tk.p1 + wave, smem, tid, t);
+      continue;
+    }
+    if (kind == FLOW_DIAG0) {
+      if (wave == 0) flow_diag0_wave<T>(fa, ff, m, smem, tid);
+      RRPGO_FLOW_MARK(fa, t, wave, 3);
+      continue;
+    }
+    // ---- UPDATE: tile (bx, by) of the trailing update of the super-panel at K0
+    const int K0 = tk.p0, bx = tk.p1, by = tk.p2;
+    const int M = m.nc + m.nr + 1;
+    const int ke = min(K0 + BIG_SUPER, m.nc), sp = K0 / BIG_SUPER;
+    const int t0 = ke;
+    const int I0 = t0 + bx * 64, J0 = t0 + by * 64;
+    if (wave == 0) {
+      // X of the rows of both operand strips for every 32-column block of the super-panel (lanes 0..31: block,
+      // strip, up to four row blocks each), the tiles of the previous super-panel's update under this one (32..35)
+      const unsigned *fp = nullptr;
+      if (lane < 32) {
+        const int qq = lane >> 3, strip = (lane >> 2) & 1, k = lane & 3;
+        const int kb = K0 + 32 * qq;
+        if (kb < ke) {
+          const int nbq = min(BIG_NB, m.nc - kb), r0 = kb + nbq;
+          const int lo = strip ? J0 : I0, hi = min(lo + 63, M - 1);
+          const int rb = (lo - r0) / 32 + k;
+          if (rb <= (hi - r0) / 32) fp = fa.flags + ff.pf + (kb / BIG_NB) * ff.pstride + rb;
+        }
+      } else if (lane < 36 && sp > 0) {
+        const int o = K0;   // origin of the previous update's tile grid
+        const int bxl = (I0 - o) / 64, bxh = (min(I0 + 63, M - 1) - o) / 64, byl = (J0 - o) / 64, byh = (min(J0 + 63, M - 1) - o) / 64;
+        const int pbx = bxl + ((lane - 32) >> 1), pby = byl + ((lane - 32) & 1);
+        if (pbx <= bxh && pby <= byh && pby <= pbx) fp = fa.flags + ff.uf + (sp - 1) * ff.ustride + flow_tri(pbx, pby);
+      }
+      flow_wait(fp, fa.err);
+    }
+    __syncthreads();
+    RRPGO_FLOW_MARK(fa, t, wave, 1);
+    T *F = fa.lvals + m.loff;
+    typename MM::Acc acc[2][2];
+    TileGather<T> tg{nullptr, -1, nullptr, nullptr, nullptr, nullptr};
+    if (fa.gather && K0 == 0 && J0 >= big_built_cols(m.nc, M)) tg = TileGather<T>{fa.child_meta + m.child_begin, m.child_count, fa.scat, fa.lvals, fa.uvals, fa.xch};
+    const bool have = big_update_tile<T, 2, 1, true>(F, M, K0, ke, M, I0, J0, smem, acc, nullptr, false, tg, tid);
+    RRPGO_FLOW_MARK(fa, t, wave, 2);
+    flow_drain();
+    __syncthreads();   // every wave's part of the tile is in memory
+    if (tid == 64) flow_flag_set(fa.flags + ff.uf + sp * ff.ustride + flow_tri(bx, by));
+    // tile (0, 0): its first wave holds the next super-panel's first diagonal block: factor and invert it here
+    if (fa.exact && bx == 0 && by == 0 && t0 < m.nc && wave == 0 && have) {
+      T *Sh = smem;
+      const int nbn = min(BIG_NB, m.nc - t0);
+      sh_image_from_acc<T>(Sh, acc, nbn);
+      diag32_init_tables<T>(Sh);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      diag32_factor_invert<T, false, true>(Sh, nbn, F + (int64_t)t0 * M + t0, M, fa.winv + (int64_t)m.wblk * 256 + (int64_t)(t0 / BIG_NB) * 1024, fa.err,
+                                           false, true);
+      flow_drain();
+      if (lane == 0) flow_flag_set(fa.flags + ff.wf + t0 / BIG_NB);
+    }
+    RRPGO_FLOW_MARK(fa, t, wave, 3);
+  }
+}
+
+}  // namespace rrpgo

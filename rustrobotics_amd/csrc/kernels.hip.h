@@ -93,7 +93,7 @@ constexpr int UPD_THREADS = 256;
 __device__ __forceinline__ int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // device-side error flags (sticky, read by the host at sync points)
-enum : int { DEVERR_NOT_SPD = 1 };
+enum : int { DEVERR_NOT_SPD = 1, DEVERR_FLOW_TIMEOUT = 2 };
 
 
 // TC = type of the state, the measurements and all factor arithmetic; T = type H and b are stored in
@@ -911,6 +911,47 @@ template <typename T> __device__ __forceinline__ T pin(T v) {
   asm volatile("" : "+v"(v));
   return v;
 }
+
+// Memory policy of the big-front device functions.  SC1 = false: plain accesses (every dependency of the launch is
+// a kernel boundary).  SC1 = true (k_big_flow: tasks of ONE launch hand tiles to each other): agent-scope relaxed
+// atomics = global_load / global_store ... sc1 -- the store is written through to memory, the load bypasses this
+// CU's L1 and is served coherently by L2; no release / acquire fence is needed around them (MI355X_MICROARCH.md,
+// inter-workgroup visibility; measured for this path with lines shared by two producers: scripts/handoff_probe.hip,
+// profiles/r03_handoff_probe.txt).
+template <bool SC1, typename T> __device__ __forceinline__ T mem_ld(const T *p) {
+  if constexpr (SC1) return __hip_atomic_load(const_cast<T *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool SC1, typename T> __device__ __forceinline__ void mem_st(T *p, T v) {
+  if constexpr (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+// The same policy through a buffer resource (a front, a W slot): sc1 accesses by 32-bit byte offset from a uniform
+// base -- no 64-bit address arithmetic per access, immediate offsets fold into the instruction, and unlike atomics the
+// compiler may schedule them freely (relaxed atomics are "ordered" memory operations to the scheduler: every address
+// of a batch of loads stays live until its load has issued in source order, which cost k_big_flow ~100 VGPRs).
+// aux = 16 is the sc1 bit of gfx940+ buffer instructions.
+typedef unsigned rr_u2 __attribute__((ext_vector_type(2)));
+template <typename T> struct Sc1Buf {
+  __amdgpu_buffer_rsrc_t r;
+  __device__ __forceinline__ Sc1Buf(const T *base, uint32_t bytes)
+      : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(base), 0, (int)bytes, 0x00020000)) {}
+  __device__ __forceinline__ T ld(uint32_t off) const {
+    if constexpr (sizeof(T) == 4) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 16));
+    else {
+      const rr_u2 w = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 16);
+      return __hiloint2double((int)w.y, (int)w.x);
+    }
+  }
+  __device__ __forceinline__ void st(uint32_t off, T v) const {
+    if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)off, 0, 16);
+    else {
+      const rr_u2 w = {(unsigned)__double2loint(v), (unsigned)__double2hiint(v)};
+      __builtin_amdgcn_raw_buffer_store_b64(w, r, (int)off, 0, 16);
+    }
+  }
+};
 
 // value of `v` in lane `src` (wave-uniform src): v_readlane, no LDS crossbar trip
 __device__ __forceinline__ double lane_bcast(double v, int src) {
@@ -1885,7 +1926,7 @@ __device__ __forceinline__ void sh_image_from_acc(T *Sh, const typename Mfma16<T
       }
 }
 
-template <typename T, bool WG_IS_ONE_WAVE = true>
+template <typename T, bool WG_IS_ONE_WAVE = true, bool SC1 = false>
 __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int M, T *Wt, int *err, bool store_l = true,
                                                      bool store_w = true) {
   // orders this wave's LDS writes before its later reads: a workgroup barrier where the workgroup IS the
@@ -1967,20 +2008,20 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
   }
   if (store_w) {
 #pragma unroll
-    for (int t = 0; t < 16; t++) Wt[t * 64 + lane] = wo[t];
+    for (int t = 0; t < 16; t++) mem_st<SC1>(Wt + t * 64 + lane, wo[t]);
   }
   if (!store_l) return;
   if (nb == BIG_NB) {
 #pragma unroll
     for (int t = 0; t < 16; t++) {
       const int e = t * 64 + lane, c = e >> 5, r = e & 31;
-      Fblk[(int64_t)c * M + r] = lo[t];
+      mem_st<SC1>(Fblk + (int64_t)c * M + r, lo[t]);
     }
   } else {
 #pragma unroll
     for (int t = 0; t < 16; t++) {
       const int e = t * 64 + lane, c = e >> 5, r = e & 31;
-      if (r < nb && c <= r) Fblk[(int64_t)c * M + r] = lo[t];
+      if (r < nb && c <= r) mem_st<SC1>(Fblk + (int64_t)c * M + r, lo[t]);
     }
   }
 }
@@ -2477,10 +2518,11 @@ template <typename T> struct TileGather {
   const int32_t *scat;
   const T *lvals, *uvals, *xch;
 };
-template <typename T, int NT, int DEPTH = 1>
+template <typename T, int NT, int DEPTH = 1, bool SC1 = false>
 __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int jmax, int I0, int J0, T *smem,
                                                 typename Mfma16<T>::Acc (&acc)[NT][NT], unsigned long long *trace = nullptr, bool pm = false,
-                                                const TileGather<T> gather = TileGather<T>{nullptr, -1, nullptr, nullptr, nullptr, nullptr}) {
+                                                const TileGather<T> gather = TileGather<T>{nullptr, -1, nullptr, nullptr, nullptr, nullptr},
+                                                int tid_in = -1 /* k_big_flow: the caller's own copy of threadIdx.x */) {
   struct { unsigned long long *trace; } a{trace};   // for RRPGO_PHASE_MARK (diagnostic builds)
   (void)a; (void)pm;
   using MM = Mfma16<T>;
@@ -2488,7 +2530,7 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
   constexpr int KC = UT::KC, TILE = UT::TILE, WTILE = UT::WTILE, KSTEP = UT::KSTEP, LDT = UT::LDT, NLD = UT::NLD;
   T (*As)[KC][LDT] = reinterpret_cast<T (*)[KC][LDT]>(smem);                    // As[buf][k][i] =  F(I0 + i, k)
   T (*Bs)[KC][LDT] = reinterpret_cast<T (*)[KC][LDT]>(smem + 2 * KC * LDT);     // Bs[buf][k][j] = -F(J0 + j, k)
-  const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63;
+  const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, wave = tid_in >= 0 ? __builtin_amdgcn_readfirstlane(tid_in >> 6) : wave_index(), lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int wi = (wave & 1) * WTILE, wj = (wave >> 1) * WTILE;
   const int i0 = I0 + wi, j0 = J0 + wj;
@@ -2505,7 +2547,15 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
   const uint32_t oa = (uint32_t)((ka + sk) * M + min(I0 + sr, M - 1)) * (uint32_t)sizeof(T);
   const uint32_t ob = (uint32_t)((ka + sk) * M + min(J0 + sr, M - 1)) * (uint32_t)sizeof(T);
   const uint32_t qstep = (uint32_t)(KSTEP * M) * (uint32_t)sizeof(T), cstep = (uint32_t)(KC * M) * (uint32_t)sizeof(T);
-  auto ldo = [&](uint32_t off) { return *reinterpret_cast<const T *>(Fb + off); };
+  [[maybe_unused]] const Sc1Buf<T> fbuf(F, SC1 ? (uint32_t)((int64_t)M * M * (int64_t)sizeof(T)) : 0u);
+  auto ldo = [&](uint32_t off) {
+    if constexpr (SC1) return fbuf.ld(off);
+    else return *reinterpret_cast<const T *>(Fb + off);
+  };
+  auto sto = [&](uint32_t off, T v) {
+    if constexpr (SC1) fbuf.st(off, v);
+    else *reinterpret_cast<T *>(const_cast<char *>(Fb) + off) = v;
+  };
   const int nk = ke - ka;
   T ra[DEPTH][NLD], rb[DEPTH][NLD];
   auto fetch = [&](int c, T (&xa)[NLD], T (&xb)[NLD]) {
@@ -2617,9 +2667,15 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
     for (int jb = 0; jb < NT; jb++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const T *ccol = F + (int64_t)min(j0 + 16 * jb + MM::row(lane, r), jmax - 1) * M;
+        if constexpr (SC1) {
+          const uint32_t cj = (uint32_t)(min(j0 + 16 * jb + MM::row(lane, r), jmax - 1) * M);
 #pragma unroll
-        for (int ib = 0; ib < NT; ib++) acc[ib][jb][r] = ccol[min(i0 + 16 * ib + li, M - 1)];
+          for (int ib = 0; ib < NT; ib++) acc[ib][jb][r] = ldo((cj + (uint32_t)min(i0 + 16 * ib + li, M - 1)) * (uint32_t)sizeof(T));
+        } else {
+          const T *ccol = F + (int64_t)min(j0 + 16 * jb + MM::row(lane, r), jmax - 1) * M;
+#pragma unroll
+          for (int ib = 0; ib < NT; ib++) acc[ib][jb][r] = ccol[min(i0 + 16 * ib + li, M - 1)];
+        }
       }
   }
   RRPGO_PHASE_MARK(a, pm, 604);
@@ -2676,14 +2732,13 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
   RRPGO_PHASE_MARK(a, pm, 602);
   if (!wave_active) return false;
   if (interior) {
-    char *Fw = reinterpret_cast<char *>(F);
 #pragma unroll
     for (int jb = 0; jb < NT; jb++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const uint32_t co = (uint32_t)((j0 + 16 * jb + MM::row(lane, r)) * M + i0 + li) * (uint32_t)sizeof(T);
 #pragma unroll
-        for (int ib = 0; ib < NT; ib++) *reinterpret_cast<T *>(Fw + co + (uint32_t)(16 * ib) * (uint32_t)sizeof(T)) = acc[ib][jb][r];
+        for (int ib = 0; ib < NT; ib++) sto(co + (uint32_t)(16 * ib) * (uint32_t)sizeof(T), (T)acc[ib][jb][r]);
       }
   } else {
 #pragma unroll
@@ -2693,7 +2748,10 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int i = i0 + 16 * ib + li, j = j0 + 16 * jb + MM::row(lane, r);
-          if (i < M && j < jmax && i >= j) F[(int64_t)j * M + i] = acc[ib][jb][r];
+          if (i < M && j < jmax && i >= j) {
+            if constexpr (SC1) sto((uint32_t)(j * M + i) * (uint32_t)sizeof(T), (T)acc[ib][jb][r]);
+            else F[(int64_t)j * M + i] = acc[ib][jb][r];
+          }
         }
   }
   return true;
@@ -2727,7 +2785,7 @@ template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(2
   const int t0 = ke;
   // mode 2 / 3 split the trailing update by column: the 128 columns right of the super-panel (the next
   // super-panel's own columns, needed by its panel chain) and everything after them (which can run
-  // beside that chain: on a second stream, or inside the chain's own launches -- k_big_chain)
+  // beside that chain on a second stream)
   const int jmax = mode == 0 ? super_end : mode == 2 ? min(t0 + 128, M) : M;
   static_assert(NT == 4 || NT == 2, "tile shapes");
   const int toff = mode == 3 ? 128 / TILE : 0;   // mode 3 starts one 128-column strip further right
@@ -2760,244 +2818,6 @@ template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(2
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     diag32_factor_invert<T, false>(Sh, nbn, F + (int64_t)t0 * M + t0, M, a.winv + (int64_t)m.wblk * 256 + (int64_t)(t0 / BIG_NB) * 1024, a.err);
   }
-}
-
-// ---- the panel chain with the PREVIOUS super-panel's far update riding along -------------------------------
-// At the top of the tree a level has a handful of fronts: its launches fill a fraction of the chip and the step is
-// a chain of latencies -- four k_big_panel32 launches and one trailing update per 128 columns, one after the other.
-// Only the next 128 columns of that update are needed by the next chain (k_big_update mode 2); everything further
-// right (mode 3: columns >= K0 + 256 of super-panel K0's update) touches nothing the next chain reads or writes.
-// k_big_chain is one launch per 32 columns like k_big_panel32, with two kinds of workgroups:
-//   blockIdx.x <  n_panel : 32 rows below the block at kb on the workgroup's first wave, the same arithmetic as a
-//                           k_big_panel32 workgroup (first workgroup: also the next diagonal block)
-//   blockIdx.x >= n_panel : 64 x 64 tiles of the far update of the super-panel at rest_K0 (= K0 - 128), tile
-//                           t = rest_part + rest_parts * (blockIdx.x - n_panel) of the front's lower triangle of
-//                           tiles: the four launches of a chain share the tiles out between them.
-// Results are bit-identical to the separate launches (same products, same order).
-template <typename T>
-__device__ __forceinline__ void chain_panel_wave(const FactorArgs<T> &a, const SnMeta &m, int kb, int K0, int first, int rowblk,
-                                                 bool lookwave, T *Sh) {
-  static_assert(BIG_NB == 32, "the left-looking panel kernels are written for 32-column blocks");
-  using MM = Mfma16<T>;
-  const int nb = min(BIG_NB, m.nc - kb);
-  const int M = m.nc + m.nr + 1;
-  const int R0 = kb + nb + rowblk * 32;
-  const bool active = R0 < M;   // an inactive wave only takes part in the barriers of the `first` block
-  T *F = a.lvals + m.loff;
-  const T *Wt = a.winv + (int64_t)m.wblk * 256 + (kb / BIG_NB) * 1024;
-  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-  const int wave = wave_index();
-  const int super_end = min(K0 + BIG_SUPER, m.nc);
-  const int kn = kb + BIG_NB;
-  const bool look = lookwave && kn < super_end && active;
-  T wv[3][4];
-  if (!first) {
-#pragma unroll
-    for (int t = 0; t < 3; t++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int cb = t == 0 ? 0 : 1, jb = t == 2 ? 1 : 0;
-        wv[t][r] = Wt[(16 * jb + MM::row(lane, r)) * 32 + 16 * cb + li];
-      }
-  }
-  T dv[16];
-  if (first && wave == 0) {
-    const T *Fblk = F + (int64_t)kb * M + kb;
-#pragma unroll
-    for (int t = 0; t < 16; t++) {
-      const int e = t * 64 + lane, c = e >> 5, r = e & 31;
-      dv[t] = Fblk[(int64_t)min(c, nb - 1) * M + min(r, nb - 1)];
-    }
-  }
-  int irow[2];
-  irow[0] = min(R0 + li, M - 1);
-  irow[1] = min(R0 + 16 + li, M - 1);
-  constexpr int PRE = sizeof(T) == 4 ? 3 : 2;
-  const int nblk = (kb - K0) / BIG_NB;
-  const int arow0 = kb + min(li, nb - 1), arow1 = kb + min(16 + li, nb - 1);
-  const T am0 = li < nb ? (T)-1 : (T)0, am1 = 16 + li < nb ? (T)-1 : (T)0;
-  T av[PRE][8][2], bv[PRE][8][2];
-  const char *Fb = reinterpret_cast<const char *>(F);
-  const uint32_t colb = (uint32_t)((K0 + lk) * M) * (uint32_t)sizeof(T);
-  const uint32_t oa0 = colb + (uint32_t)arow0 * (uint32_t)sizeof(T), oa1 = colb + (uint32_t)arow1 * (uint32_t)sizeof(T);
-  const uint32_t ob0 = colb + (uint32_t)irow[0] * (uint32_t)sizeof(T), ob1 = colb + (uint32_t)irow[1] * (uint32_t)sizeof(T);
-  const uint32_t kstep = (uint32_t)(4 * M) * (uint32_t)sizeof(T);
-  auto ld = [&](uint32_t off) { return *reinterpret_cast<const T *>(Fb + off); };
-  auto fetch = [&](int blk, T (*xa)[2], T (*xb)[2]) {
-    uint32_t d = (uint32_t)(blk * 8) * kstep;
-#pragma unroll
-    for (int s4 = 0; s4 < 8; s4++) {
-      xa[s4][0] = ld(oa0 + d) * am0;
-      xa[s4][1] = ld(oa1 + d) * am1;
-      xb[s4][0] = ld(ob0 + d);
-      xb[s4][1] = ld(ob1 + d);
-      d += kstep;
-    }
-  };
-  typename MM::Acc acc[2][2], nxt[2][2];
-#pragma unroll
-  for (int jb = 0; jb < 2; jb++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int j = 16 * jb + MM::row(lane, r);
-      const T *ccol = F + (int64_t)(kb + min(j, nb - 1)) * M;
-#pragma unroll
-      for (int ib = 0; ib < 2; ib++) acc[ib][jb][r] = ccol[irow[ib]];
-    }
-#pragma unroll
-  for (int p = 0; p < PRE; p++)
-    if (p < nblk) fetch(p, av[p], bv[p]);
-  if (look) {
-#pragma unroll
-    for (int jb = 0; jb < 2; jb++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const T *ccol = F + (int64_t)min(kn + 16 * jb + MM::row(lane, r), M - 1) * M;
-#pragma unroll
-        for (int ib = 0; ib < 2; ib++) nxt[ib][jb][r] = ccol[irow[ib]];
-      }
-  }
-#pragma unroll
-  for (int jb = 0; jb < 2; jb++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int j = 16 * jb + MM::row(lane, r);
-#pragma unroll
-      for (int ib = 0; ib < 2; ib++) {
-        const T v = pin(acc[ib][jb][r]);
-        acc[ib][jb][r] = j < nb ? v : (T)0;
-      }
-    }
-  if (first) {
-    // the level's very first block: the first wave of every workgroup factors and inverts it for its workgroup
-    // (the block stays as assembled in F: see k_big_panel32), all four waves read W from the LDS image
-    if (wave == 0) {
-#pragma unroll
-      for (int t = 0; t < 16; t++) {
-        const int e = t * 64 + lane, c = e >> 5, r = e & 31;
-        Sh[c * 33 + r] = (r < nb && c < nb && r >= c) ? dv[t] : ((r == c && r >= nb) ? (T)1 : (T)0);
-      }
-      diag32_init_tables<T>(Sh);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      diag32_factor_invert<T, false>(Sh, nb, F + (int64_t)kb * M + kb, M, const_cast<T *>(Wt), a.err, false, blockIdx.x == 0);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 3; t++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int cb = t == 0 ? 0 : 1, jb = t == 2 ? 1 : 0;
-        wv[t][r] = Sh[32 * 33 + (16 * jb + MM::row(lane, r)) * 33 + 16 * cb + li];
-      }
-    __syncthreads();   // Sh is free again for the next diagonal block's image
-  }
-  if (!active) return;
-#pragma unroll
-  for (int blk = 0; blk < BIG_SUPER / BIG_NB - 1; blk++) {
-    if (blk < nblk) {
-      const int slot = blk % PRE;
-#pragma unroll
-      for (int s4 = 0; s4 < 8; s4++) {
-#pragma unroll
-        for (int ib = 0; ib < 2; ib++)
-#pragma unroll
-          for (int jb = 0; jb < 2; jb++) acc[ib][jb] = MM::mma(av[slot][s4][jb], bv[slot][s4][ib], acc[ib][jb]);
-        if (look) {
-#pragma unroll
-          for (int ib = 0; ib < 2; ib++)
-#pragma unroll
-            for (int jb = 0; jb <= ib; jb++) nxt[ib][jb] = MM::mma(-bv[slot][s4][jb], bv[slot][s4][ib], nxt[ib][jb]);
-        }
-      }
-      if (PRE < BIG_SUPER / BIG_NB - 1 && blk + PRE < nblk) fetch(blk + PRE, av[slot], bv[slot]);
-    }
-  }
-  typename MM::Acc out[2][2];
-#pragma unroll
-  for (int ib = 0; ib < 2; ib++) {
-    out[ib][0] = typename MM::Acc{0, 0, 0, 0};
-    out[ib][1] = typename MM::Acc{0, 0, 0, 0};
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      out[ib][0] = MM::mma(wv[0][r], acc[ib][0][r], out[ib][0]);
-      out[ib][1] = MM::mma(wv[1][r], acc[ib][0][r], out[ib][1]);
-      out[ib][1] = MM::mma(wv[2][r], acc[ib][1][r], out[ib][1]);
-    }
-  }
-  if (nb == BIG_NB && R0 + 32 <= M) {
-#pragma unroll
-    for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        T *ccol = F + (int64_t)(kb + 16 * cb + MM::row(lane, r)) * M + R0 + li;
-        ccol[0] = out[0][cb][r];
-        ccol[16] = out[1][cb][r];
-      }
-  } else {
-#pragma unroll
-    for (int ib = 0; ib < 2; ib++)
-#pragma unroll
-      for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int c = 16 * cb + MM::row(lane, r), i = R0 + 16 * ib + li;
-          if (i < M && c < nb) F[(int64_t)(kb + c) * M + i] = out[ib][cb][r];
-        }
-  }
-  if (!look) return;
-#pragma unroll
-  for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-#pragma unroll
-      for (int ib = 0; ib < 2; ib++)
-#pragma unroll
-        for (int jb = 0; jb <= ib; jb++) nxt[ib][jb] = MM::mma(-out[jb][cb][r], out[ib][cb][r], nxt[ib][jb]);
-  const int nbn = min(BIG_NB, m.nc - kn);
-  sh_image_from_acc<T>(Sh, nxt, nbn);
-  diag32_init_tables<T>(Sh);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  diag32_factor_invert<T, false>(Sh, nbn, F + (int64_t)kn * M + kn, M, a.winv + (int64_t)m.wblk * 256 + (kn / BIG_NB) * 1024, a.err);
-}
-
-template <typename T> __global__ void __launch_bounds__(256) k_big_chain(FactorArgs<T> a, int kb, int K0, int first, int n_panel,
-                                                                       int rest_K0, int rest_part, int rest_parts) {
-  using UT = UpdTile<T, 2>;
-  static_assert(UT::SMEM >= DIAG32_LDS, "one LDS region serves both roles");
-  __shared__ T smem[UT::SMEM];
-  RRPGO_TRACE_MARK(a, 200);
-  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
-  if ((int)blockIdx.x < n_panel) {
-    if (kb >= m.nc) return;
-    const int nb = min(BIG_NB, m.nc - kb);
-    const int M = m.nc + m.nr + 1;
-    // ONE wave per workgroup works in this role (32 rows, like a k_big_panel32 workgroup): four row blocks on the
-    // four SIMDs of one CU were measured ~2 us slower per launch -- their ~560 loads queue on one CU's memory
-    // pipeline, the critical wave's among them -- than spread over four CUs
-    if (wave_index() != 0 || kb + nb + (int)blockIdx.x * 32 >= M) return;
-    chain_panel_wave<T>(a, m, kb, K0, first, (int)blockIdx.x, blockIdx.x == 0, smem);
-    return;
-  }
-  // ---- far update of the previous super-panel: rows and columns >= rest_K0 + 256
-  if (rest_K0 < 0 || rest_K0 >= m.nc) return;
-  const int M = m.nc + m.nr + 1;
-  const int ke = min(rest_K0 + BIG_SUPER, m.nc);
-  const int t0 = ke + 128;
-  if (t0 >= M) return;
-  const int nt = (M - t0 + 63) / 64;
-  const int t = rest_part + rest_parts * ((int)blockIdx.x - n_panel);
-  if (t >= nt * (nt + 1) / 2) return;
-  // tile t of the lower triangle, row by row: ib (ib + 1) / 2 <= t
-  int ib = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-  while (ib * (ib + 1) / 2 > t) ib--;
-  while ((ib + 1) * (ib + 2) / 2 <= t) ib++;
-  const int jb = t - ib * (ib + 1) / 2;
-  typename Mfma16<T>::Acc acc[2][2];
-  big_update_tile<T, 2>(a.lvals + m.loff, M, rest_K0, ke, M, t0 + 64 * ib, t0 + 64 * jb, smem, acc);
 }
 
 // Back substitution for one supernode:

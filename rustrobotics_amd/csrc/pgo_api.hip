@@ -8,6 +8,7 @@
 #include <mutex>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -20,6 +21,7 @@
 #include "../../include/rr_pgo.h"
 #include "host_graph.h"
 #include "kernels.hip.h"
+#include "flow.hip.h"
 #include "symbolic.h"
 
 #ifndef RRPGO_UPD_DEPTH
@@ -170,6 +172,7 @@ struct EngineBase {
   virtual void profile(int iters, double *ms, int64_t *launches) = 0;
   virtual hipStream_t stream() = 0;
   virtual void read_stamps(std::vector<unsigned long long> &out) = 0;
+  virtual int flow_trace(int level, std::vector<int32_t> &tasks, std::vector<unsigned long long> &stamps, int *nf, double *est_us) = 0;
   // sharded runs
   virtual void exchange_buffer(int which, void **ptr, int64_t *n, int32_t *esize) = 0;
   virtual void set_exchange_buffer(int which, void *ptr, int64_t n) = 0;
@@ -250,13 +253,31 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   int solve_threads_max_ = 512;     // RR_PGO_SOLVE_THREADS=<n>: cap of the back-substitution workgroup size
   int factor_threads_max_ = 1024;   // 16-wave workgroups for steps whose fronts exceed 128 rows (RR_PGO_FACTOR_512=1: 8 waves)
   int64_t deep_below_ = 0;          // RR_PGO_DEEP_BELOW=<n>: trailing updates of at most n 64 x 64 tiles request their whole K strip up front (measured r02: 6.02 ms per lattice step with 2048, 5.95 with 0; sphere2500 1 % slower with it: off)
-  int lookahead_max_nf_ = 0;        // RR_PGO_LOOKAHEAD=<n>: levels of at most n big fronts run the k_big_chain sequence (0: none)
   int sp_solve_min_nc_ = 256;       // back substitution: levels whose widest pivot block has at least this many columns run k_big_solve_sp (RR_PGO_SP_SOLVE_MIN)
   bool gather_update_ = true;       // ... and only for the pivot columns: a front's first trailing update gathers its tiles from the children (RR_PGO_NO_GATHER_UPDATE=1)
   bool fused_build_ = true;         // big fronts: k_big_build (one gather pass) instead of zero + extend-add per child (RR_PGO_SPLIT_ASSEMBLY=1)
   bool separate_diag32_ = false;    // RR_PGO_SEPARATE_DIAG32=1: a k_big_diag32 launch for the first block of every level
   bool panel128_ = false;           // RR_PGO_PANEL128=1: two launches per 128-column super-panel (diagonal block in LDS by one
                                     // workgroup, then all rows at once) instead of one per 32 columns; measured 10 % slower
+  // k_big_flow (flow.hip.h): levels of at most flow_max_nf_ big fronts run as ONE launch of ticket-ordered tile tasks
+  struct FlowLevel {
+    DevBuf<FlowTask> tasks;
+    DevBuf<FlowFront> fronts;
+    int n_tasks = 0;
+    std::vector<FlowTask> host_tasks;   // diagnostic builds: the sorted list, for rr_pgo_debug_flow_trace
+    DevBuf<unsigned long long> trace;   // diagnostic builds only
+    int64_t ticket_word = 0;   // index of the level's ticket in flow_flags_
+    double est_us = 0;         // critical path of the cost model that orders the tasks
+  };
+  std::vector<std::unique_ptr<FlowLevel>> flow_levels_;   // per step of sym_.steps (null: launch sequence)
+  DevBuf<unsigned> flow_flags_;     // tickets + completion flags of every flow level, zeroed at the start of a factorisation
+  int flow_max_nf_ = 32;            // RR_PGO_FLOW=<n> (0: never)
+  int flow_max_tasks_ = 16384;      // RR_PGO_FLOW_TASKS=<n>: ... and of at most n tasks.  A level with more tile work than that is bound by
+                                    // tile THROUGHPUT, where the batched k_big_update launches (7 workgroups per CU) beat the flow kernel's two
+                                    // (measured on the 1M-edge lattice, r03: the levels of 1 and 2 fronts -- 1.4 k and 4.8 k tasks -- gain 25 %
+                                    // and 13 %, the level of 4 fronts -- 18 k tasks -- ties, the levels of 8..32 fronts lose 10-20 %)
+  bool flow_exact_ = false;         // RR_PGO_FLOW_EXACT=1: bit-identical to the launch sequence (tile (0, 0) forms the next super-panel's first block)
+  int flow_grid_ = 0;               // persistent workgroups of a flow launch (RR_PGO_FLOW_GRID; default CUs x RRPGO_FLOW_WAVES)
   bool overlap_ = false;            // RR_PGO_OVERLAP=1: the far part of a trailing update on a second stream, beside the next panel chain (measured neutral so far)
   int overlap_max_nf_ = 1 << 30;    // RR_PGO_OVERLAP=<n>: only on levels with at most n fronts
   bool rest_pending_ = false;       // a rest-update is in flight on stream2_ (ev_rest_ marks its end)
@@ -451,13 +472,17 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     factor_threads_max_ = getenv("RR_PGO_FACTOR_512") ? 512 : 1024;
     if (const char *e = getenv("RR_PGO_SOLVE_THREADS")) solve_threads_max_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_SMALL_TILE")) small_tile_below_ = std::atoi(e);
-    if (const char *e = getenv("RR_PGO_LOOKAHEAD")) lookahead_max_nf_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_DEEP_BELOW")) deep_below_ = std::atoll(e);
     if (const char *e = getenv("RR_PGO_SP_SOLVE_MIN")) sp_solve_min_nc_ = std::atoi(e);
-    gather_update_ = fused_build_ && left_looking_ && !panel128_ && !overlap_ && lookahead_max_nf_ == 0 &&
+    gather_update_ = fused_build_ && left_looking_ && !panel128_ && !overlap_ &&
                      getenv("RR_PGO_NO_GATHER_UPDATE") == nullptr;
     if (const char *e = getenv("RR_PGO_MANY_TASKS")) many_tasks_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_MANY_THREADS")) many_threads_ = std::atoi(e);
+    if (const char *e = getenv("RR_PGO_FLOW")) flow_max_nf_ = std::atoi(e);
+    flow_exact_ = getenv("RR_PGO_FLOW_EXACT") != nullptr;
+    if (const char *e = getenv("RR_PGO_FLOW_TASKS")) flow_max_tasks_ = std::atoi(e);
+    if (!(left_looking_ && fused_build_ && !panel128_ && !separate_diag32_ && !overlap_)) flow_max_nf_ = 0;
+    build_flow_levels();
     n_lin_blocks_ = (int)(((int64_t)n_list_ * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
     edge_lin_ = getenv("RR_PGO_EDGE_LINEARIZE") != nullptr && !is3d_ && !sharded_ && g_.n_edges() > 0;
     if (edge_lin_) n_lin_blocks_ = std::max(1, (g_.n_edges() + LIN_THREADS - 1) / LIN_THREADS);
@@ -593,6 +618,171 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   hipStream_t stream() override { return stream_; }
 
  private:
+  // ---- k_big_flow, host side: the task list of every level that runs as a dataflow launch.
+  // Tasks and their dependencies are those flow.hip.h waits for; the list is sorted by the earliest start time a
+  // task can have under a simple cost model with unlimited workgroups (us; the constants are the r02 in-kernel marks).
+  // A dependency always FINISHES (so also starts) before its dependant starts, hence the sorted list is a topological
+  // order -- all the ticket scheme needs -- and roughly the order in which tasks become ready.
+  void build_flow_levels() {
+    flow_levels_.resize(sym_.steps.size());
+    if (flow_max_nf_ <= 0) return;
+    constexpr double kDiag = 4.0, kPre = 2.5, kNewest = 1.5, kX = 1.5, kLook = 4.5, kTile = 6.0, kTail = 4.5, kHop = 0.7;
+    int64_t words = 0;
+    std::vector<std::vector<FlowTask>> all_tasks(sym_.steps.size());
+    std::vector<std::vector<FlowFront>> all_fronts(sym_.steps.size());
+    for (size_t si = 0; si < sym_.steps.size(); si++) {
+      const Step &st = sym_.steps[si];
+      const int nf = st.task_end - st.task_begin;
+      if (st.kind != STEP_BIG || nf > flow_max_nf_) continue;
+      auto lvl = std::make_unique<FlowLevel>();
+      lvl->ticket_word = words;
+      words += 32;   // the ticket on a 128-byte line of its own
+      struct Item { double start; int64_t seq; FlowTask t; };
+      std::vector<Item> items;
+      std::vector<FlowFront> fronts(nf);
+      double level_end = 0;
+      for (int z = 0; z < nf; z++) {
+        const int sn = sym_.task_sn[sym_.task_ptr[st.task_begin + z]];
+        const int nc = sym_.sn_ncols[sn], M = nc + sym_.sn_nrows[sn] + 1;
+        const int nblk = (nc + BIG_NB - 1) / BIG_NB, nsp = (nc + BIG_SUPER - 1) / BIG_SUPER;
+        const int pstride = (M + 31) / 32 + 1;
+        const int ntmax = (M + 63) / 64 + 1, ustride = ntmax * (ntmax + 1) / 2;
+        FlowFront &ff = fronts[z];
+        ff.wf = (int32_t)words; words += nblk + 1;
+        ff.pf = (int32_t)words; ff.pstride = pstride; words += (int64_t)nblk * pstride;
+        ff.uf = (int32_t)words; ff.ustride = ustride; words += (int64_t)nsp * ustride;
+        words = (words + 31) & ~(int64_t)31;
+        if (words > 0x7fffff00LL) throw ApiError(RR_PGO_EUNSUPPORTED, "too many flow flags");
+        // finish times of the cost model
+        std::vector<double> tw(nblk + 1, 0.0), tp((size_t)nblk * pstride, 0.0), tu((size_t)nsp * ustride, 0.0);
+        auto tri = [](int bx, int by) { return bx * (bx + 1) / 2 + by; };
+        items.push_back(Item{0.0, (int64_t)items.size(), FlowTask{(FLOW_DIAG0 << 24) | z, 0, 0, 0}});
+        tw[0] = kDiag;
+        for (int sp = 0; sp < nsp; sp++) {
+          const int K0 = sp * BIG_SUPER, ke = std::min(K0 + BIG_SUPER, nc);
+          // finish time of the previous update's tiles under rows [r0, r1] x columns [c0, c1]
+          auto prev_tiles = [&](int r0, int r1, int c0, int c1) {
+            double t = 0;
+            if (sp == 0) return t;
+            for (int bx = (r0 - K0) / 64; bx <= (std::min(r1, M - 1) - K0) / 64; bx++)
+              for (int by = (c0 - K0) / 64; by <= std::min((std::min(c1, M - 1) - K0) / 64, bx); by++)
+                t = std::max(t, tu[(size_t)(sp - 1) * ustride + tri(bx, by)]);
+            return t;
+          };
+          for (int kb = K0; kb < ke; kb += BIG_NB) {
+            const int blk = kb / BIG_NB, q = (kb - K0) / BIG_NB, nb = std::min(BIG_NB, nc - kb), kn = kb + BIG_NB;
+            const int nrb = (M - (kb + nb) + 31) / 32;
+            for (int g0 = 0; g0 < nrb; g0 += FLOW_GROUP) {
+              double start = 0;   // of the task = of its earliest wave; finish times per wave
+              double wstart[FLOW_GROUP];
+              for (int w = 0; w < FLOW_GROUP && g0 + w < nrb; w++) {
+                const int rb = g0 + w, R0 = kb + nb + 32 * rb;
+                const bool look = rb == 0 && kn < (flow_exact_ ? ke : nc);
+                // the step starts with everything that needs neither W nor the newest block (blocks blk - 2, blk - 3 and
+                // the C tiles), then the newest block's term, then W (hop), then X; the look wave goes on with the next block
+                double t = 0.0, tnew = 0.0;
+                for (int j = 1; j <= q; j++) {
+                  const int r0p = kb - 32 * j + 32;
+                  double tj = tp[(size_t)(blk - j) * pstride + (j - 1)] + kHop;
+                  for (int rbp = (R0 - r0p) / 32; rbp <= (std::min(R0 + 31, M - 1) - r0p) / 32; rbp++)
+                    tj = std::max(tj, tp[(size_t)(blk - j) * pstride + rbp] + kHop);
+                  if (j == 1) tnew = tj; else t = std::max(t, tj);
+                }
+                t = std::max(t, prev_tiles(R0, R0 + 31, kb, kb + nb - 1) + (sp > 0 ? kHop : 0.0));
+                if (look) t = std::max(t, prev_tiles(kn, kn + 31, kn, kn + 31) + (sp > 0 ? kHop : 0.0));
+                wstart[w] = t;
+                double fin = std::max(std::max(t + (q > 1 ? kPre : 0.5), tnew) + (q > 0 ? kNewest : 0.0), tw[blk] + kHop) + kX;
+                tp[(size_t)blk * pstride + rb] = fin;   // X is published before the look wave goes on
+                if (look) { fin += kLook; tw[blk + 1] = fin; }
+                level_end = std::max(level_end, fin);
+                start = w == 0 ? t : std::min(start, t);
+              }
+              (void)wstart;
+              items.push_back(Item{start, (int64_t)items.size(), FlowTask{(FLOW_PANEL << 24) | z, kb, g0, K0}});
+            }
+          }
+          // trailing update of the super-panel: tiles of rows / columns >= ke
+          const int t0 = ke;
+          const int nt = (M - t0 + 63) / 64;
+          for (int by = 0; by < nt; by++)       // column-major: the next super-panel's own columns first
+            for (int bx = by; bx < nt; bx++) {
+              const int I0 = t0 + 64 * bx, J0 = t0 + 64 * by;
+              double t = 0;
+              for (int kb = K0; kb < ke; kb += BIG_NB) {
+                const int nbq = std::min(BIG_NB, nc - kb), r0 = kb + nbq;
+                for (int strip = 0; strip < 2; strip++) {
+                  const int lo = strip ? J0 : I0, hi = std::min(lo + 63, M - 1);
+                  for (int rb = (lo - r0) / 32; rb <= (hi - r0) / 32; rb++) t = std::max(t, tp[(size_t)(kb / BIG_NB) * pstride + rb] + kHop);
+                }
+              }
+              t = std::max(t, prev_tiles(I0, I0 + 63, J0, J0 + 63) + (sp > 0 ? kHop : 0.0));
+              const double fin = t + kTile;
+              tu[(size_t)sp * ustride + tri(bx, by)] = fin;
+              level_end = std::max(level_end, fin);
+              if (flow_exact_ && bx == 0 && by == 0 && t0 < nc) { tw[t0 / BIG_NB] = fin + kTail; level_end = std::max(level_end, fin + kTail); }
+              items.push_back(Item{t, (int64_t)items.size(), FlowTask{(FLOW_UPDATE << 24) | z, K0, bx, by}});
+            }
+        }
+      }
+      if ((int64_t)items.size() > flow_max_tasks_) { words = lvl->ticket_word; continue; }   // throughput-bound level: launch sequence (its flag words are given back)
+      std::sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.start != y.start ? x.start < y.start : x.seq < y.seq; });
+      std::vector<FlowTask> tasks(items.size());
+      for (size_t i = 0; i < items.size(); i++) tasks[i] = items[i].t;
+      lvl->n_tasks = (int)tasks.size();
+      lvl->est_us = level_end;
+      all_tasks[si] = std::move(tasks);
+      all_fronts[si] = std::move(fronts);
+      flow_levels_[si] = std::move(lvl);
+    }
+    if (words == 0) return;
+    flow_flags_.alloc((size_t)words);
+    flow_flags_.zero();
+    for (size_t si = 0; si < sym_.steps.size(); si++)
+      if (flow_levels_[si]) {
+        flow_levels_[si]->tasks.upload(all_tasks[si]);
+        flow_levels_[si]->fronts.upload(all_fronts[si]);
+#ifdef RRPGO_FLOW_TRACE
+        flow_levels_[si]->host_tasks = all_tasks[si];
+        flow_levels_[si]->trace.alloc(all_tasks[si].size() * 16);
+        flow_levels_[si]->trace.zero();
+#endif
+      }
+    int dev = 0, cus = 256;
+    HIPCHK(hipGetDevice(&dev));
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    flow_grid_ = std::max(cus, 1) * (sizeof(T) == 4 ? RRPGO_FLOW_WAVES : 1);
+    if (const char *e = getenv("RR_PGO_FLOW_GRID")) flow_grid_ = std::max(1, std::atoi(e));
+  }
+  bool any_flow(size_t from, size_t to) const {
+    for (size_t si = from; si < to && si < flow_levels_.size(); si++) if (flow_levels_[si]) return true;
+    return false;
+  }
+  const FlowLevel *flow_of(const Step &st) const {
+    const size_t si = (size_t)(&st - sym_.steps.data());
+    return si < flow_levels_.size() ? flow_levels_[si].get() : nullptr;
+  }
+  void launch_flow(const Step &st, const FlowLevel &lvl) {
+    FlowArgs<T> fa;
+    fa.tasks = lvl.tasks.p;
+    fa.fronts = lvl.fronts.p;
+    fa.ticket = flow_flags_.p + lvl.ticket_word;
+    fa.flags = flow_flags_.p;
+    fa.n_tasks = lvl.n_tasks;
+    fa.gather = gather_update_ ? 1 : 0;
+    fa.exact = flow_exact_ ? 1 : 0;
+    fa.front_meta = task_meta_.p + st.task_begin;
+    fa.child_meta = child_meta_.p;
+    fa.scat = scat_.p;
+    fa.lvals = lvals_.p;
+    fa.uvals = uvals_.p;
+    fa.xch = xch_;
+    fa.winv = winv_.p;
+    fa.err = err_.p;
+    fa.trace = lvl.trace.p;
+    hipLaunchKernelGGL(k_big_flow<T>, dim3((unsigned)std::min(lvl.n_tasks, flow_grid_)), dim3(256), 0, stream_, fa);
+    check_launch("k_big_flow");
+  }
+
   // Gauge transfer applies to a single-precision factor (T = float) of an SE(2) graph whose root front is
   // one of the big in-place fronts; RR_PGO_GAUGE=0 keeps the reference's anchor prior (comparison runs).
   void setup_gauge() {
@@ -797,6 +987,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   }
   void launch_factor_range(size_t from, size_t to) {
     if (from == 0) head_done_ = false;
+    // tickets and completion flags of the flow levels (one small kernel per factorisation; flow.hip.h, k_flow_reset)
+    if (any_flow(from, to)) {
+      hipLaunchKernelGGL(k_flow_reset, dim3((unsigned)std::min<int64_t>(((int64_t)flow_flags_.n + 255) / 256, 1024)), dim3(256), 0, stream_,
+                         flow_flags_.p, (int64_t)flow_flags_.n);
+      check_launch("k_flow_reset");
+    }
     for (size_t si = from; si < to; si++) {
       const Step &st = sym_.steps[si];
       pbegin();
@@ -921,9 +1117,16 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       }
     }
     if (do_launch) pend(RR_PGO_K_BIGFRONT);   // closes the zero / assemble / extend-add segment
-    // look-ahead (k_big_chain) on levels with few fronts, where launches are latency- rather than throughput-bound
-    const bool lookahead = left_looking_ && !panel128_ && !separate_diag32_ && !overlap_ && nf <= lookahead_max_nf_;
-    int la_rest_K0 = -1;   // super-panel whose far update is still owed (rides with the next chain)
+    if (const FlowLevel *lvl = flow_of(st)) {
+      // the whole panel chain and every trailing update of the level: ONE launch of ticket-ordered tasks
+      if (do_launch) {
+        pbegin();
+        launch_flow(st, *lvl);
+        pend(RR_PGO_K_BIG_FLOW);
+        pbegin();   // re-arm: the caller closes the level with pend(BIGFRONT)
+      }
+      return n + 1;
+    }
     for (int K0 = 0; K0 < max_nc; K0 += BIG_SUPER) {
       if (left_looking_ && panel128_) {
         // the whole super-panel in two launches: its diagonal block in LDS (one workgroup per front), then
@@ -938,7 +1141,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           pend(RR_PGO_K_BIG_PANEL, 2);
         }
         n += 2;
-      } else if (left_looking_ && !lookahead) {
+      } else if (left_looking_) {
         // left-looking inside the super-panel: the first diagonal block, then ONE launch per 32 columns
         // (update from the columns K0..kb, multiply by the inverse diagonal block, next diagonal block)
         // the first diagonal block of a later super-panel comes out of the previous trailing update
@@ -962,34 +1165,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           n++;
         }
         if (do_launch) pend(RR_PGO_K_BIG_PANEL, (sep_diag ? 1 : 0) + (std::min(K0 + BIG_SUPER, max_nc) - K0 + BIG_NB - 1) / BIG_NB);
-      } else if (left_looking_ && lookahead) {
-        // top of the tree (few fronts per level): k_big_chain -- the panel rows and, riding along, the far part of
-        // the PREVIOUS super-panel's trailing update; only the next 128 columns of an update stay on the chain
-        if (do_launch) pbegin();
-        const int k_end = std::min(K0 + BIG_SUPER, max_nc);
-        const int n_steps = (k_end - K0 + BIG_NB - 1) / BIG_NB;
-        int64_t rest_tiles = 0;
-        if (la_rest_K0 >= 0)
-          for (int s : fr)
-            if (sym_.sn_ncols[s] > la_rest_K0) {
-              const int Ms = sym_.sn_ncols[s] + sym_.sn_nrows[s] + 1;
-              const int nrem = Ms - (std::min(la_rest_K0 + BIG_SUPER, sym_.sn_ncols[s]) + 128);
-              if (nrem > 0) { const int64_t nt = (nrem + 63) / 64; rest_tiles = std::max(rest_tiles, nt * (nt + 1) / 2); }
-            }
-        const int n_rest = (int)((rest_tiles + n_steps - 1) / n_steps);
-        int step_i = 0;
-        for (int kb = K0; kb < k_end; kb += BIG_NB, step_i++) {
-          const int rb = rows_max(kb) - 1;
-          const int n_panel = (std::max(rb, 1) + 31) / 32;
-          if (do_launch) {
-            hipLaunchKernelGGL(k_big_chain<T>, dim3(n_panel + n_rest, nf), dim3(256), 0, stream_, a, kb, K0, kb == 0 ? 1 : 0, n_panel,
-                               la_rest_K0, step_i, n_steps);
-            check_launch("k_big_chain");
-          }
-          n++;
-        }
-        la_rest_K0 = -1;
-        if (do_launch) pend(RR_PGO_K_BIG_PANEL, n_steps);
       } else
       for (int kb = K0; kb < std::min(K0 + BIG_SUPER, max_nc); kb += BIG_NB) {
         const int rb = rows_max(kb) - 1;   // rows below a 1..32 wide block, at least the rhs row
@@ -1013,18 +1188,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       const int rt = rows_max(K0);   // rows from K0 on; the trailing part starts after the super-panel
       const int nti = (std::max(rt, 1) + 127) / 128;
       const bool overlap = left_looking_ && overlap_ && !prof_.on && nti > 2 && nf <= overlap_max_nf_;
-      if (lookahead && K0 + BIG_SUPER < max_nc) {
-        // the next super-panel's own columns now, the rest under its chain
-        if (do_launch) {
-          pbegin();
-          const int nt64 = (std::max(rt, 1) + 63) / 64;
-          hipLaunchKernelGGL((k_big_update<T, 2>), dim3(nt64, 2, nf), dim3(256), 0, stream_, a, K0, 2, diag_tail);
-          check_launch("k_big_update/2");
-          pend(RR_PGO_K_BIG_UPDATE);
-        }
-        la_rest_K0 = K0;
-        n++;
-      } else if (!overlap) {
+      if (!overlap) {
         if (do_launch) {
           if (rest_pending_) { HIPCHK(hipStreamWaitEvent(stream_, ev_rest_, 0)); rest_pending_ = false; }
           pbegin();
@@ -1404,6 +1568,24 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   void sync() override {
     HIPCHK(hipStreamSynchronize(stream_));
     check_device_error();
+  }
+
+  // diagnostic builds: the task list and the stamps of the `level`-th flow level (-1: no such level)
+  int flow_trace(int level, std::vector<int32_t> &tasks, std::vector<unsigned long long> &stamps, int *nf, double *est_us) override {
+    int k = 0;
+    for (size_t si = 0; si < flow_levels_.size(); si++) {
+      if (!flow_levels_[si]) continue;
+      if (k++ != level) continue;
+      FlowLevel &l = *flow_levels_[si];
+      tasks.resize(l.host_tasks.size() * 4);
+      if (!l.host_tasks.empty()) std::memcpy(tasks.data(), l.host_tasks.data(), l.host_tasks.size() * sizeof(FlowTask));
+      stamps.resize(l.trace.n);
+      if (l.trace.n) HIPCHK(hipMemcpy(stamps.data(), l.trace.p, l.trace.n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      *nf = sym_.steps[si].task_end - sym_.steps[si].task_begin;
+      *est_us = l.est_us;
+      return l.n_tasks;
+    }
+    return -1;
   }
 
   void read_stamps(std::vector<unsigned long long> &out) override {
@@ -1881,6 +2063,23 @@ int rr_pgo_stage_scalars(rr_pgo *h, double *chi2, double *norm_dx) {
   if (!h || !chi2 || !norm_dx) { g_last_error = "null argument"; return RR_PGO_EINVAL; }
   return guarded([&] { h->engine->read_last_scalars(chi2, norm_dx); });
 }
+#ifdef RRPGO_FLOW_TRACE
+// Diagnostic build only (make ../librr_pgo_trace.so): task list (4 ints per task) and stamps (4 waves x 4 per task) of a flow level
+extern "C" int64_t rr_pgo_debug_flow_trace(rr_pgo *h, int32_t level, int32_t *tasks, unsigned long long *stamps, int64_t cap_tasks, int32_t *nf, double *est_us) {
+  if (!h) return -1;
+  int64_t n = -1;
+  guarded([&] {
+    std::vector<int32_t> t;
+    std::vector<unsigned long long> st;
+    n = h->engine->flow_trace(level, t, st, nf, est_us);
+    if (n < 0 || !tasks || !stamps) return;
+    const int64_t m = std::min<int64_t>(n, cap_tasks);
+    std::memcpy(tasks, t.data(), (size_t)m * 4 * sizeof(int32_t));
+    std::memcpy(stamps, st.data(), (size_t)m * 16 * sizeof(unsigned long long));
+  });
+  return n;
+}
+#endif
 #ifdef RRPGO_STAMPS
 // Diagnostic build only: the launch trace region behind the stamps (count, pad, then (tag, clock) pairs).
 extern "C" int64_t rr_pgo_debug_trace(rr_pgo *h, unsigned long long *out, int64_t cap) {

@@ -87,8 +87,9 @@ class EmulatedCollectives:
         self.bytes_moved = 0
 
     def _sync(self):
-        for g in self.shards:
-            g.sync()
+        # device-wide, like the stream order a real collective relies on; NOT PoseGraph.sync(), which would also
+        # report (and clear) a rank's device error flag before the stage that lets the group agree on it
+        self.torch.cuda.synchronize()
 
     def all_gather_boundary(self):
         self._sync()

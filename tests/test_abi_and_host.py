@@ -31,11 +31,111 @@ def test_exports_match_header(lib):
         assert hasattr(lib, name), name  # dlsym succeeds
 
 
-def test_struct_layouts_match_header(lib):
+@pytest.fixture(scope="session")
+def abi_client(tmp_path_factory, lib):
+    """tests/native/abi_client.c: include/rr_pgo.h compiled AS C (strict C99, warnings are errors) and linked against
+    the library -- the header is the product's contract with compiled callers (the reference's are Rust:
+    src/mapping/mod.rs:6, benches/graph_slam.rs:9-10), so it must stand without a C++ compiler or Python around it."""
     from rustrobotics_amd import _lib
-    assert C.sizeof(_lib.Options) == 16 * 4
-    assert C.sizeof(_lib.GraphDesc) == 80
-    assert C.sizeof(_lib.Stats) == 3 * 8 + 6 * 4 + 8 * 8 + 6 * 4
+    exe = tmp_path_factory.mktemp("abi") / "abi_client"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic-errors", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "native", "abi_client.c"), _lib.LIB_PATH, f"-Wl,-rpath,{libdir}",
+                           "-o", str(exe)])
+    return str(exe)
+
+
+def test_struct_layouts_match_the_c_compiler(abi_client):
+    """sizeof / offsetof of every field of the three public structs as gcc lays them out (the program also carries
+    _Static_asserts for the values INTEGRATION.md's #[repr(C)] structs rely on) against the ctypes mirror."""
+    from rustrobotics_amd import _lib
+    out = subprocess.run([abi_client, "layout"], capture_output=True, text=True, check=True).stdout
+    seen = {}
+    for line in out.splitlines():
+        struct, field, off, size = line.split()
+        seen[(struct, field)] = (int(off), int(size))
+    for cname, cls in (("rr_pgo_options", _lib.Options), ("rr_pgo_graph_desc", _lib.GraphDesc), ("rr_pgo_stats", _lib.Stats)):
+        assert seen.pop((cname, ".")) == (0, C.sizeof(cls)), cname
+        for fname, _ in cls._fields_:
+            d = getattr(cls, fname)
+            assert seen.pop((cname, fname)) == (d.offset, d.size), (cname, fname)
+    assert seen.pop(("enum", "RR_PGO_NUM_KCLASS"))[0] == _lib.NUM_KCLASS == len(_lib.KCLASS_NAMES)
+    assert not seen, f"fields the ctypes mirror does not know: {seen}"
+
+
+# ---- INTEGRATION.md's Rust binding against the header -------------------------------------------------------------
+
+_C_BASE = {"char": "c_char", "double": "f64", "int32_t": "i32", "int64_t": "i64", "uint32_t": "u32", "uint64_t": "u64",
+           "int": "c_int", "void": "c_void"}
+
+
+def _c_type(text):
+    """'const rr_pgo_options *opt' -> ('rr_pgo_options', ['const'])  (pointer levels, outermost last; [] = by value)"""
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S).strip()
+    m = re.match(r"^(const\s+)?(\w+)\s*((?:\*\s*(?:const\s*)?)*)\s*(\w+)?$", text)
+    assert m, text
+    base = _C_BASE.get(m.group(2), m.group(2))
+    stars = m.group(3).count("*")
+    levels = []
+    if stars:
+        levels = ["const" if m.group(1) else "mut"] + ["mut"] * (stars - 1)   # `const T **` does not occur in the header
+    return base, levels
+
+
+def _rust_type(text):
+    text = text.strip().replace("std::ffi::c_void", "c_void")
+    levels = []
+    while text.startswith("*"):
+        kind, text = text[1:].split(None, 1)
+        levels.append(kind)
+        text = text.strip()
+    return text, levels[::-1]   # innermost pointer first, like _c_type
+
+
+def test_integration_md_rust_binding_matches_the_header():
+    """INTEGRATION.md, section 2 (the `extern "C"` block and the #[repr(C)] structs a maintainer of the reference would
+    paste into src/mapping/): every function of include/rr_pgo.h, same name, arity, scalar types and pointer
+    mutability; every struct field in the same order with the same type."""
+    header = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", "rr_pgo.h")).read(), flags=re.S)
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    rust = md[md.index("// src/mapping/rr_pgo_sys.rs"):]
+    rust = rust[:rust.index("```")]
+    rust = re.sub(r"//[^\n]*", "", rust)
+    # functions
+    cfun = {}
+    for ret, name, args in re.findall(r"([\w\s\*]+?)\b(rr_pgo_\w+)\s*\(([^)]*)\)\s*;", header):
+        params = [] if args.strip() in ("", "void") else [_c_type(a) for a in args.split(",")]
+        ret = ret.replace("extern", "").strip()
+        cfun[name] = (_c_type(ret + " x") if ret != "void" else None, params)
+    rfun = {}
+    for name, args, ret in re.findall(r"pub fn (rr_pgo_\w+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", rust):
+        params = [_rust_type(a.split(":", 1)[1]) for a in args.split(",") if a.strip()]
+        rfun[name] = (_rust_type(ret) if ret else None, params)
+    assert set(cfun) == set(rfun), set(cfun) ^ set(rfun)
+    for name in cfun:
+        assert cfun[name] == rfun[name], (name, cfun[name], rfun[name])
+    # structs
+    for sname in ("rr_pgo_options", "rr_pgo_graph_desc", "rr_pgo_stats"):
+        cbody = re.search(r"typedef struct %s \{(.*?)\} %s;" % (sname, sname), header, flags=re.S).group(1)
+        cfields = []
+        for decl in cbody.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            m = re.match(r"^(const\s+)?(\w+)\s*(\*?)\s*(.*)$", decl)
+            base = _C_BASE.get(m.group(2), m.group(2))
+            for var in m.group(4).split(","):
+                var = var.strip()
+                arr = re.match(r"^(\*?)\s*(\w+)\[(\d+)\]$", var)
+                ptr = (m.group(3) == "*") or var.startswith("*")
+                vname = arr.group(2) if arr else var.lstrip("* ")
+                cfields.append((vname, f"[{base}; {arr.group(3)}]" if arr else base, ["const" if m.group(1) else "mut"] if ptr else []))
+        rbody = re.search(r"pub struct %s \{(.*?)\n\}" % sname, rust, flags=re.S).group(1)
+        rfields = []
+        for fname, ftype in re.findall(r"pub (\w+)\s*:\s*([^,\n]+(?:;\s*\d+\])?)", rbody):
+            t, lv = _rust_type(ftype.strip().rstrip(","))
+            rfields.append((fname, t, lv))
+        assert cfields == rfields, (sname, cfields, rfields)
 
 
 def _load(lib, path):
@@ -96,6 +196,99 @@ def test_synthetic_grid_counts(lib):
     assert abs(np.hypot(em[0::3], em[1::3]).max() - np.hypot(2, 2)) < 0.6
     nk2, *_rest = synthetic_grid_arrays(40, 25, closed_form(40, 25) + 100)
     assert len(_rest[1]) == closed_form(40, 25) + 100
+
+
+def _restated_grid(W, H, n_edges_target=0, seed_meas=42, seed_init=43):
+    """SURVEY.md 8(d), BASELINE configs[3], restated in Python from the survey's text, independently of synth_grid.cpp:
+    W x H unit lattice, pose index in boustrophedon order (x reversed on odd rows), ground-truth heading 0 on even and
+    pi on odd rows; edges cell-major in (y, x) raster order and offset-minor over the ten stencil offsets, `from` = the
+    lower pose index, then -- when more edges are asked for -- offset (-2, 2) in raster order; measurement =
+    x_from^-1 x_to of the ground truth + N(0, diag(.05, .05, .01)^2), information diag(400, 400, 10000), initial guess =
+    ground truth + N(0, diag(.1, .1, .02)^2).  Random stream: splitmix64 from the seed; a normal pair by Box-Muller from
+    u1 = ((z >> 11) + 1) / 2^53 (never 0) and u2 = (z' >> 11) / 2^53, cosine branch first, sine branch kept for the next draw."""
+    import math
+    M64 = (1 << 64) - 1
+
+    class Stream:
+        def __init__(self, seed):
+            self.s, self.spare = seed & M64, None
+
+        def u64(self):
+            self.s = (self.s + 0x9E3779B97F4A7C15) & M64
+            z = self.s
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+            return z ^ (z >> 31)
+
+        def normal(self):
+            if self.spare is not None:
+                v, self.spare = self.spare, None
+                return v
+            u1 = float((self.u64() >> 11) + 1) * (1.0 / 9007199254740992.0)
+            u2 = float(self.u64() >> 11) * (1.0 / 9007199254740992.0)
+            r, a = math.sqrt(-2.0 * math.log(u1)), 6.283185307179586476925286766559 * u2
+            self.spare = r * math.sin(a)
+            return r * math.cos(a)
+
+    def index(x, y):
+        return y * W + (W - 1 - x if y % 2 else x)
+
+    truth = {}
+    for y in range(H):
+        for x in range(W):
+            truth[index(x, y)] = (float(x), float(y), math.pi if y % 2 else 0.0)
+    init = Stream(seed_init)
+    state = []
+    for k in range(W * H):
+        gx, gy, gt = truth[k]
+        state += [gx + 0.1 * init.normal(), gy + 0.1 * init.normal(), gt + 0.02 * init.normal()]
+    meas_rng = Stream(seed_meas)
+    ef, et, em = [], [], []
+
+    def edge(a, b):
+        i, j = min(a, b), max(a, b)
+        (xi, yi, ti), (xj, yj, tj) = truth[i], truth[j]
+        c, s_ = math.cos(ti), math.sin(ti)
+        dx, dy = xj - xi, yj - yi
+        ef.append(i)
+        et.append(j)
+        em.extend([c * dx + s_ * dy + 0.05 * meas_rng.normal(), -s_ * dx + c * dy + 0.05 * meas_rng.normal(),
+                   (tj - ti) + 0.01 * meas_rng.normal()])
+
+    def full():
+        return n_edges_target > 0 and len(ef) >= n_edges_target
+
+    stencil = [(0, 1), (1, 0), (-1, 1), (1, 1), (0, 2), (2, 0), (-2, 1), (-1, 2), (1, 2), (2, 1)]
+    for y in range(H):
+        for x in range(W):
+            for ox, oy in stencil:
+                if not full() and 0 <= x + ox < W and y + oy < H:
+                    edge(index(x, y), index(x + ox, y + oy))
+    if n_edges_target > 0:
+        for y in range(H - 2):
+            for x in range(2, W):
+                if not full():
+                    edge(index(x, y), index(x - 2, y + 2))
+    return np.array(state), np.array(ef, np.int32), np.array(et, np.int32), np.array(em)
+
+
+@pytest.mark.parametrize("extra", [0, 100])
+def test_synthetic_grid_matches_an_independent_restatement_of_the_survey(lib, extra):
+    """The config-4 generator (rr_pgo_synth_grid) bit for bit against a Python restatement of SURVEY.md 8(d): node
+    states, edge lists and measurements -- the golden lattice fixtures rest on this stream."""
+    from rustrobotics_amd import synthetic_grid_arrays
+    W, H = 40, 25
+    stencil_edges = sum((W - abs(dx)) * (H - dy) for dx, dy in
+                        [(0, 1), (1, 0), (-1, 1), (1, 1), (0, 2), (2, 0), (-2, 1), (-1, 2), (1, 2), (2, 1)])
+    target = stencil_edges + extra if extra else 0
+    nk, ns, ek, ef, et, em, ei = synthetic_grid_arrays(W, H, target)
+    rs, rf, rt, rm = _restated_grid(W, H, target)
+    assert len(ef) == (target or stencil_edges)
+    assert np.array_equal(ef, rf) and np.array_equal(et, rt)
+    assert np.array_equal(ns, rs)            # bit for bit
+    assert np.array_equal(em, rm)
+    assert (nk == 0).all() and (ek == 0).all()
+    assert np.array_equal(ei.reshape(-1, 6), np.tile([400.0, 0, 0, 400.0, 0, 10000.0], (len(ef), 1)))
 
 
 @pytest.fixture(scope="session")

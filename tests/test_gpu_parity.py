@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from conftest import g2o_path
+from conftest import ROOT, g2o_path
 
 pytestmark = pytest.mark.gpu
 
@@ -266,6 +266,119 @@ def test_not_positive_definite_is_reported(api):
     assert ei_.value.code == -5
 
 
+def _two_component_graph(info_sign=1.0):
+    """nodes 0-1 and 2-3 joined pairwise: the prior reaches only the first pair, the second is singular (exactly: the
+    arithmetic of these integers is exact, the failing pivot is 0.0); info_sign = -1 makes H negative definite instead"""
+    nk = np.zeros(4, np.int32)
+    ns = np.array([0, 0, 0, 1, 0, 0, 5, 5, 0, 6, 5, 0], float)
+    ek = np.zeros(2, np.int32)
+    ef, et = np.array([0, 2], np.int32), np.array([1, 3], np.int32)
+    # the second edge has a residual (a step would move its nodes); all headings are 0 and every entry a small dyadic
+    # rational, so H is formed exactly and the unanchored pair's last pivot is exactly 0 in the very first iteration
+    em = np.array([1, 0, 0, 1.5, 0.25, 0.0], float)
+    ei = info_sign * np.tile([1, 0, 0, 1, 0, 1], 2).astype(float)
+    return nk, ns, ek, ef, et, em, ei
+
+
+@pytest.mark.parametrize("mode", ["gn", "lm", "staged"])
+def test_failed_factorisation_leaves_the_state_untouched(api, mode):
+    """include/rr_pgo.h, RR_PGO_ENOTSPD: like the reference (Err from solve() at :271 comes before update_nodes) the
+    handle's state is the one before the failed iteration.  Gauss-Newton on a graph with an unanchored component,
+    Levenberg-Marquardt on a negative definite H (lambda I cannot repair it), and the staged path of a sharded handle."""
+    PoseGraph, Solver, PoseGraphError = api
+    if mode == "lm":
+        g = PoseGraph.from_arrays(*_two_component_graph(-1.0), solver=Solver.LevenbergMarquardt)
+    else:
+        g = PoseGraph.from_arrays(*_two_component_graph(), sharded=(mode == "staged"))
+    s0 = np.array(g.state())
+    with pytest.raises(PoseGraphError) as err:
+        if mode == "staged":
+            g.stage(0)
+            g.stage(1)
+            g.stage_scalars()
+        else:
+            g.optimize(5)
+    assert err.value.code == -5
+    assert np.array_equal(np.array(g.state()), s0)
+    # the flag is sticky only until reported: the handle keeps working (chi2 of the untouched state)
+    if mode != "staged":
+        assert np.isfinite(g.global_error())
+
+
+def test_failed_factorisation_is_agreed_on_by_every_rank(api):
+    """Sharded over two (emulated) ranks, a non-positive pivot inside ONE rank's own subtree: its flag travels with
+    its chunk of the all-gather, so BOTH ranks skip the update and BOTH report RR_PGO_ENOTSPD (the
+    state-unchanged contract across the group)."""
+    from rustrobotics_amd import synthetic_grid_arrays, sharding
+    PoseGraph, _, PoseGraphError = api
+    nk, ns, ek, ef, et, em, ei = synthetic_grid_arrays(60, 40)
+    n = len(nk)
+    # a detached pair of poses next to the lattice's far corner, joined by one edge, reached by no prior: singular
+    nk2 = np.concatenate([nk, np.zeros(2, np.int32)])
+    ns2 = np.concatenate([ns, [70.0, 50.0, 0.0, 71.0, 50.0, 0.0]])
+    ek2 = np.concatenate([ek, np.zeros(1, np.int32)])
+    ef2, et2 = np.concatenate([ef, [n]]).astype(np.int32), np.concatenate([et, [n + 1]]).astype(np.int32)
+    em2 = np.concatenate([em, [1.5, 0.25, 0.0]])
+    ei2 = np.concatenate([ei, [1.0, 0, 0, 1.0, 0, 1.0]])
+    shards, coll = sharding.emulate((nk2, ns2, ek2, ef2, et2, em2, ei2), 2, "f64")
+    owner = shards[0].node_owner()
+    assert owner[n] == owner[n + 1] and owner[n] >= 0      # the pair sits in one rank's own subtree
+    s0 = [np.array(g.state()) for g in shards]
+    for g in shards:
+        g.stage(0)
+    coll.all_gather_boundary()
+    for g in shards:
+        g.stage(1)
+    coll.all_reduce_scalars()
+    for g in shards:
+        with pytest.raises(PoseGraphError) as err:
+            g.stage_scalars()
+        assert err.value.code == -5
+    for g, s in zip(shards, s0):
+        assert np.array_equal(np.array(g.state()), s)
+
+
+def test_rank_partial_calls_are_refused_on_a_sharded_rank(api):
+    """chi2 / update / assemble on ONE rank of a sharded graph would silently return that rank's share:
+    RR_PGO_EUNSUPPORTED instead; stage 2 + the all-reduce is the sharded chi2."""
+    from rustrobotics_amd import synthetic_grid_arrays, sharding
+    PoseGraph, _, PoseGraphError = api
+    arrays = synthetic_grid_arrays(60, 40)
+    shards, coll = sharding.emulate(arrays, 2, "f64")
+    g = shards[0]
+    for call in (g.global_error, lambda: g.assemble(), lambda: g.update_nodes(np.zeros(g.len))):
+        with pytest.raises(PoseGraphError) as err:
+            call()
+        assert err.value.code == -7
+    ref = PoseGraph.from_arrays(*arrays)
+    assert abs(sharding.global_error(shards, coll) - ref.global_error()) <= 1e-12 * ref.global_error()
+
+
+def test_c_client_of_the_abi_matches_the_python_mirror(api, tmp_path):
+    """tests/native/abi_client.c (strict C99, -Werror) drives rr_pgo_load_g2o -> rr_pgo_optimize(10) -> rr_pgo_get_state
+    on intel.g2o -- the reference's own bench closure (benches/graph_slam.rs:9-10) from a compiled caller -- and must
+    produce the same bits as the ctypes mirror: chi2 per iteration and the final pose vector."""
+    import shutil
+    import subprocess
+    from rustrobotics_amd import _lib
+    exe, out = tmp_path / "abi_client", tmp_path / "out.bin"
+    subprocess.check_call([shutil.which("gcc") or "gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic-errors",
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "abi_client.c"),
+                           _lib.LIB_PATH, f"-Wl,-rpath,{os.path.dirname(_lib.LIB_PATH)}", "-o", str(exe)])
+    for solver, tag in ((api[1].GaussNewton, "gn"), (api[1].LevenbergMarquardt, "lm")):
+        r = subprocess.run([str(exe), "run", g2o_path("intel"), "10", str(out), tag], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        raw = out.read_bytes()
+        ne, sl = np.frombuffer(raw[:8], np.int32)
+        errors = np.frombuffer(raw[8:8 + 8 * ne], np.float64)
+        state = np.frombuffer(raw[8 + 8 * ne:], np.float64)
+        g = api[0].new(g2o_path("intel"), solver)
+        eref = np.array(g.optimize(10))
+        assert len(state) == sl == len(g.state())
+        assert np.array_equal(errors, eref), (errors, eref)
+        assert np.array_equal(state, np.array(g.state()))
+
+
 # ---- synthetic lattice (BASELINE config 4 generator) ------------------------------------------
 
 def test_synthetic_small_matches_oracle_f64(api, oracle):
@@ -354,6 +467,44 @@ def test_alternate_big_front_launch_sequences_agree(api, env, monkeypatch):
     ealt = alt.optimize(3)
     np.testing.assert_allclose(ealt, eref, rtol=1e-9)
     assert _state_diff_se2(alt.state(), ref.state()) <= 1e-8
+
+
+@pytest.mark.parametrize("case", ["lattice100-f64", "lattice100-f32", "lattice100-mixed", "sphere2500-f64", "torus3D-f64",
+                                  "lattice400x250-f32"])
+def test_flow_launch_is_bit_identical_to_the_launch_sequence(api, case, monkeypatch):
+    """k_big_flow (levels of few big fronts as ONE launch of ticket-ordered tile tasks, flags between workgroups)
+    runs the same device functions in the same summation orders as the launch-per-step sequence it replaces
+    (RR_PGO_FLOW=0): chi2 trajectory and state must agree to the last bit -- any stale or early read of a tile
+    handed from one workgroup to another would show up here."""
+    from rustrobotics_amd import synthetic_grid_arrays
+    name, prec = case.rsplit("-", 1)
+
+    def make():
+        if name.startswith("lattice"):
+            w, h = (100, 100) if name == "lattice100" else (400, 250)
+            return api[0].from_arrays(*synthetic_grid_arrays(w, h, 1000000 if w == 400 else 0), precision=prec)
+        return api[0].new(g2o_path(name), precision=prec)
+
+    monkeypatch.setenv("RR_PGO_FLOW_TASKS", "100000000")   # every level of at most 32 big fronts, also the throughput-bound ones
+    monkeypatch.setenv("RR_PGO_FLOW_EXACT", "1")   # tile (0, 0) forms the next super-panel's first block, as the launches do
+    flow = make()
+    monkeypatch.delenv("RR_PGO_FLOW_EXACT")
+    assert flow.stats()["n_big_fronts"] > 0
+    monkeypatch.setenv("RR_PGO_FLOW", "0")
+    seq = make()
+    monkeypatch.delenv("RR_PGO_FLOW")
+    assert flow.stats()["n_launches_per_iter"] < seq.stats()["n_launches_per_iter"]   # the flow levels really are on
+    iters = 3 if name == "lattice400x250" else 4
+    ef, es = np.array(flow.optimize(iters)), np.array(seq.optimize(iters))
+    assert np.array_equal(ef, es), (ef, es)
+    assert np.array_equal(np.array(flow.state()), np.array(seq.state()))
+    # the default (the chain wave forms that block itself, left-looking: the same sums in another order) agrees to rounding
+    fast = make()
+    efa = np.array(fast.optimize(iters))
+    tol = 1e-12 if prec == "f64" else 2e-5
+    np.testing.assert_allclose(efa, es, rtol=tol)
+    if "lattice" in name:
+        assert _state_diff_se2(fast.state(), seq.state()) <= (1e-9 if prec == "f64" else 5e-3)
 
 
 @pytest.mark.parametrize("case", ["intel", "dlr", "sphere2500", "lattice-f32", "lattice-mixed"])
