@@ -8,7 +8,7 @@ src/mapping/pose_graph_optimization.rs:269-301): linearise + assemble, factor, s
 same work on the same pattern).  Headline workload = BASELINE.json configs[1]: intel.g2o, fp64.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload intel|m3500|dlr|sphere2500|torus3d|parking-garage|grid:WxH[:E]]
-                  [--precision f64|f32|mixed] [--shard] [--no-secondary] [--no-cpu-baseline]
+                  [--precision f64|f32|mixed] [--shard [--emulate P]] [--no-secondary] [--no-cpu-baseline]
 
 Prints ONE JSON line (rank 0): the contract keys for the headline workload plus
   roofline       dominant kernel class of the headline, HIP-event timing on the library's own stream
@@ -281,6 +281,52 @@ def measure_sharded(ctx, workload, precision, steps, warmup, force_collectives=F
     return drv, state0, dt
 
 
+def emulated_shard_record(ctx, args):
+    """--shard --emulate P: the record of a P-rank sharded run, produced on one GPU through
+    rustrobotics_amd.sharding.EmulatedCollectives (same stages, same exchange buffers, device copies instead of RCCL)."""
+    from rustrobotics_amd import sharding
+    P = args.emulate
+    shards, coll = sharding.emulate(workload_arrays(args.workload), P, args.precision, ctx.local_rank)
+    g = shards[0]
+    state0 = [h.state() for h in shards]
+
+    def run_steps(k):
+        for _ in range(k):
+            for h in shards:
+                h.stage(0)
+            coll.all_gather_boundary()
+            for h in shards:
+                h.stage(1)
+            coll.all_reduce_scalars()
+
+    def reset():
+        for h, s0 in zip(shards, state0):
+            h.set_state(s0)
+
+    dt = timed_steps(run_steps, ctx.torch.cuda.synchronize, ctx.barrier, ctx.all_max, args.steps, args.warmup, reset=reset)
+    reset()
+    errors, norms = sharding.gauss_newton(shards, 10, coll)
+    value = args.steps / dt
+    chunk_bytes = coll.chunk * coll.xch[0].element_size()
+    out = {"metric": "GN iterations/s", "value": value, "unit": "GN iterations/s", "n_gpus": 1, "emulated_ranks": P,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": args.precision,
+           "data": "synthetic" if args.workload.startswith("grid:") else "reference dataset file",
+           "config": {"workload": f"{args.workload} ({g.num_nodes} poses / {g.num_edges} edges / dim {g.len}), Gauss-Newton, ONE graph "
+                                  f"sharded over {P} EMULATED ranks on one GPU (the stages of the ranks run one after the other: "
+                                  f"the time is not a scaling number)", "solver": "GaussNewton", "parallelism": "sharded%d-emulated" % P},
+           "edges_iters_per_s": value * g.num_edges, "errors": [float(e) for e in errors], "norm_dx": [float(n) for n in norms],
+           "chi2_final": float(errors[-1]),
+           "exchange_bytes_per_step": {"all_gather_bytes_total": int(P * chunk_bytes),
+                                       "all_gather_bytes_contributed_per_rank": int(chunk_bytes), "all_reduce_bytes": 16},
+           "collectives": "per iteration: all-gather of the boundary update matrices + sum all-reduce of two doubles, EMULATED by device copies",
+           "roofline": None, "cpu_baseline": None}
+    gold = golden_chi2(args.workload)
+    if gold is not None:
+        out["chi2_rel_diff_vs_oracle"] = abs(min(errors) - gold) / gold
+    return out
+
+
 def secondary_entry(ctx, workload, precision, steps, warmup, sharded):
     """A BASELINE config other than the headline, same timing contract; rank 0 returns the record."""
     t_wall = time.perf_counter()
@@ -348,6 +394,10 @@ def main():
                     help="f64 (reference arithmetic), f32, or mixed = f64 state/linearisation + f32 factor/solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline workload only")
+    ap.add_argument("--emulate", type=int, default=0, metavar="P",
+                    help="with --shard on ONE GPU: P ranks emulated in this process (P handles, device copies as the two "
+                         "collectives) -- exercises the N > 1 record shape and the sharded numerics; the time is P ranks "
+                         "serialised on one GPU, not a scaling number")
     ap.add_argument("--shard", action="store_true",
                     help="shard ONE graph (--workload) over the ranks as the headline line (strong scaling); with one rank "
                          "the collectives still run, over a one-rank RCCL group")
@@ -369,7 +419,7 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if args.shard and world == 1:   # a one-rank RCCL group so that the collective path really executes
+    if args.shard and world == 1 and args.emulate <= 1:   # a one-rank RCCL group so that the collective path really executes
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
@@ -382,7 +432,11 @@ def main():
         ctx = Ctx(rank, local_rank, world)
 
     out = None
-    if args.shard:
+    if args.shard and args.emulate > 1:
+        if world != 1:
+            sys.exit("--emulate runs in ONE process on one GPU")
+        out = emulated_shard_record(ctx, args)
+    elif args.shard:
         drv, state0, dt = measure_sharded(ctx, args.workload, args.precision, args.steps, args.warmup, force_collectives=True)
         g = drv.graph
         value = args.steps / dt      # all ranks work on the SAME K iterations

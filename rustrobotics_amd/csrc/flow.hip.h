@@ -29,7 +29,7 @@ namespace rrpgo {
 struct FlowFront {       // one front of a flow level: where its flags live (indices into FlowArgs::flags)
   int32_t wf;            // wf[b]: W of 32-column block b is in winv (and every row the chain read for it is in F)
   int32_t pf, pstride;   // pf[b * pstride + rb]: X of row block rb of block b is in F
-  int32_t uf, ustride;   // uf[sp * ustride + bx (bx + 1) / 2 + by]: tile (bx, by) of super-panel sp's update is in F
+  int32_t uf, ustride;   // uf[sp * ustride + bx (bx + 1) / 2 + by]: tile (bx, by) of super-panel sp's update is in F (tiles of 64 or 128: FlowLevel::nt)
   int32_t pad[3];
 };
 static_assert(sizeof(FlowFront) == 32, "FlowFront is one 32-byte record");
@@ -141,7 +141,7 @@ __device__ __forceinline__ void flow_diag0_wave(const FlowArgs<T> &fa, const Flo
 // the wave that owns the next diagonal block's rows goes on: last term of that block, factor and invert, publish W.
 // So one step of the chain costs: hop + newest block's loads and MFMAs + hop + W load + X + factor-and-invert,
 // with the first half running under the previous step's factor-and-invert.
-template <typename T>
+template <typename T, int TS /* edge of a trailing-update tile: 64 or 128 */>
 __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const FlowFront &ff, const SnMeta &m, int kb,
                                                 int K0, int rowblk, T *Sh, int tid, int ticket) {
   static_assert(BIG_NB == 32 && BIG_SUPER == 128, "written for 32-column blocks in 128-column super-panels");
@@ -173,10 +173,10 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
       const int j = lane / 3 + 2;   // blocks blk - 2, blk - 3
       if (j <= q) fp = block_flag(j, lane % 3);
     } else if (lane <= 7) {
-      const int bx = (R0 - K0) / 64 + (lane - 6), bxe = (min(R0 + 31, M - 1) - K0) / 64;
-      if (sp > 0 && bx <= bxe) fp = fa.flags + ff.uf + (sp - 1) * ff.ustride + flow_tri(bx, (kb - K0) / 64);
+      const int bx = (R0 - K0) / TS + (lane - 6), bxe = (min(R0 + 31, M - 1) - K0) / TS;
+      if (sp > 0 && bx <= bxe) fp = fa.flags + ff.uf + (sp - 1) * ff.ustride + flow_tri(bx, (kb - K0) / TS);
     } else if (lane == 8) {
-      const int d = (kn - K0) / 64;
+      const int d = (kn - K0) / TS;
       if (look && sp > 0) fp = fa.flags + ff.uf + (sp - 1) * ff.ustride + flow_tri(d, d);
     }
     flow_wait(fp, fa.err);
@@ -355,13 +355,21 @@ __global__ void __launch_bounds__(256) k_flow_reset(unsigned *words, int64_t n) 
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) words[i] = 0u;
 }
 
+#ifndef RRPGO_FLOW_DEPTH
+#define RRPGO_FLOW_DEPTH 4   // k-chunks of a trailing-update tile requested ahead of the MFMAs (the launch sequence's k_big_update uses 1 at
+#endif                       // seven workgroups per CU; here two workgroups per CU have to cover a chunk's memory round trip themselves)
 #ifndef RRPGO_FLOW_WAVES
 #define RRPGO_FLOW_WAVES 2   // fp32: waves per SIMD the register allocation aims at (= workgroups per CU): the panel wave keeps ~200 values in flight;
 #endif                       // fp64 (two registers per value) runs one workgroup per CU
 
-template <typename T> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? RRPGO_FLOW_WAVES : 1)) k_big_flow(FlowArgs<T> fa) {
+// NT = MFMA tiles per wave and dimension of a trailing-update tile: 2 -> 64 x 64 tiles per task (levels of few tasks: more of
+// them in flight), 4 -> 128 x 128 (levels with thousands of tiles: the flow kernel runs two workgroups per CU, and at
+// that occupancy only the large tile -- sixteen accumulators per wave, four times the MFMAs per staged chunk -- keeps
+// the matrix cores fed while the next chunk is on its way)
+template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? RRPGO_FLOW_WAVES : 1)) k_big_flow(FlowArgs<T> fa) {
   using MM = Mfma16<T>;
-  using UT = UpdTile<T, 2>;
+  using UT = UpdTile<T, NT>;
+  constexpr int TS = UT::TILE;
   static_assert(UT::SMEM >= DIAG32_LDS, "one LDS region serves the tile staging and the diagonal-block images");
   __shared__ T smem[UT::SMEM];
   __shared__ unsigned s_ticket;
@@ -383,7 +391,7 @@ template <typename T> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? R
     const SnMeta m = fa.front_meta[slot];
     const FlowFront ff = fa.fronts[slot];
     if (kind == FLOW_PANEL) {
-      flow_panel_wave<T>(fa, ff, m, tk.p0, tk.p2, tk.p1 + wave, smem, tid, t);
+      flow_panel_wave<T, TS>(fa, ff, m, tk.p0, tk.p2, tk.p1 + wave, smem, tid, t);
       continue;
     }
     if (kind == FLOW_DIAG0) {
@@ -396,44 +404,53 @@ template <typename T> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? R
     const int M = m.nc + m.nr + 1;
     const int ke = min(K0 + BIG_SUPER, m.nc), sp = K0 / BIG_SUPER;
     const int t0 = ke;
-    const int I0 = t0 + bx * 64, J0 = t0 + by * 64;
+    const int I0 = t0 + bx * TS, J0 = t0 + by * TS;
     if (wave == 0) {
-      // X of the rows of both operand strips for every 32-column block of the super-panel (lanes 0..31: block,
-      // strip, up to four row blocks each), the tiles of the previous super-panel's update under this one (32..35)
-      const unsigned *fp = nullptr;
-      if (lane < 32) {
-        const int qq = lane >> 3, strip = (lane >> 2) & 1, k = lane & 3;
+      // X of the rows of both operand strips for every 32-column block of the super-panel: lane = block (4) x strip (2)
+      // x row block (up to TS / 32 + 1 = 5 of them when the strip is not aligned with the block's row blocks)
+      {
+        const unsigned *fp = nullptr;
+        const int qq = lane >> 4, strip = (lane >> 3) & 1, k = lane & 7;
         const int kb = K0 + 32 * qq;
         if (kb < ke) {
           const int nbq = min(BIG_NB, m.nc - kb), r0 = kb + nbq;
-          const int lo = strip ? J0 : I0, hi = min(lo + 63, M - 1);
+          const int lo = strip ? J0 : I0, hi = min(lo + TS - 1, M - 1);
           const int rb = (lo - r0) / 32 + k;
           if (rb <= (hi - r0) / 32) fp = fa.flags + ff.pf + (kb / BIG_NB) * ff.pstride + rb;
         }
-      } else if (lane < 36 && sp > 0) {
-        const int o = K0;   // origin of the previous update's tile grid
-        const int bxl = (I0 - o) / 64, bxh = (min(I0 + 63, M - 1) - o) / 64, byl = (J0 - o) / 64, byh = (min(J0 + 63, M - 1) - o) / 64;
-        const int pbx = bxl + ((lane - 32) >> 1), pby = byl + ((lane - 32) & 1);
-        if (pbx <= bxh && pby <= byh && pby <= pbx) fp = fa.flags + ff.uf + (sp - 1) * ff.ustride + flow_tri(pbx, pby);
+        flow_wait(fp, fa.err);
       }
-      flow_wait(fp, fa.err);
+      if (sp > 0) {   // the tiles of the previous super-panel's update under this one (its grid starts at K0)
+        const unsigned *fp = nullptr;
+        if (lane < 4) {
+          const int o = K0;
+          const int bxl = (I0 - o) / TS, bxh = (min(I0 + TS - 1, M - 1) - o) / TS, byl = (J0 - o) / TS, byh = (min(J0 + TS - 1, M - 1) - o) / TS;
+          const int pbx = bxl + (lane >> 1), pby = byl + (lane & 1);
+          if (pbx <= bxh && pby <= byh && pby <= pbx) fp = fa.flags + ff.uf + (sp - 1) * ff.ustride + flow_tri(pbx, pby);
+        }
+        flow_wait(fp, fa.err);
+      }
     }
     __syncthreads();
     RRPGO_FLOW_MARK(fa, t, wave, 1);
     T *F = fa.lvals + m.loff;
-    typename MM::Acc acc[2][2];
+    typename MM::Acc acc[NT][NT];
     TileGather<T> tg{nullptr, -1, nullptr, nullptr, nullptr, nullptr};
     if (fa.gather && K0 == 0 && J0 >= big_built_cols(m.nc, M)) tg = TileGather<T>{fa.child_meta + m.child_begin, m.child_count, fa.scat, fa.lvals, fa.uvals, fa.xch};
-    const bool have = big_update_tile<T, 2, 1, true>(F, M, K0, ke, M, I0, J0, smem, acc, nullptr, false, tg, tid);
+    const bool have = big_update_tile<T, NT, RRPGO_FLOW_DEPTH, true>(F, M, K0, ke, M, I0, J0, smem, acc, nullptr, false, tg, tid);
     RRPGO_FLOW_MARK(fa, t, wave, 2);
     flow_drain();
     __syncthreads();   // every wave's part of the tile is in memory
     if (tid == 64) flow_flag_set(fa.flags + ff.uf + sp * ff.ustride + flow_tri(bx, by));
-    // tile (0, 0): its first wave holds the next super-panel's first diagonal block: factor and invert it here
+    // exact mode, tile (0, 0): its first wave holds the next super-panel's first diagonal block: factor and invert it here
     if (fa.exact && bx == 0 && by == 0 && t0 < m.nc && wave == 0 && have) {
       T *Sh = smem;
       const int nbn = min(BIG_NB, m.nc - t0);
-      sh_image_from_acc<T>(Sh, acc, nbn);
+      if constexpr (NT == 2) sh_image_from_acc<T>(Sh, acc, nbn);
+      else {
+        const typename MM::Acc corner[2][2] = {{acc[0][0], acc[0][1]}, {acc[1][0], acc[1][1]}};
+        sh_image_from_acc<T>(Sh, corner, nbn);
+      }
       diag32_init_tables<T>(Sh);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();

@@ -264,6 +264,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     DevBuf<FlowTask> tasks;
     DevBuf<FlowFront> fronts;
     int n_tasks = 0;
+    int nt = 2;                // MFMA tiles per wave and dimension of an UPDATE task: 2 = 64 x 64 tiles, 4 = 128 x 128
     std::vector<FlowTask> host_tasks;   // diagnostic builds: the sorted list, for rr_pgo_debug_flow_trace
     DevBuf<unsigned long long> trace;   // diagnostic builds only
     int64_t ticket_word = 0;   // index of the level's ticket in flow_flags_
@@ -277,6 +278,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
                                     // (measured on the 1M-edge lattice, r03: the levels of 1 and 2 fronts -- 1.4 k and 4.8 k tasks -- gain 25 %
                                     // and 13 %, the level of 4 fronts -- 18 k tasks -- ties, the levels of 8..32 fronts lose 10-20 %)
   bool flow_exact_ = false;         // RR_PGO_FLOW_EXACT=1: bit-identical to the launch sequence (tile (0, 0) forms the next super-panel's first block)
+  int flow_tile4_min_ = 1 << 30;       // RR_PGO_FLOW_TILE4=<n>: levels with at least n tasks at 64 x 64 tiles use 128 x 128 tiles instead
   int flow_grid_ = 0;               // persistent workgroups of a flow launch (RR_PGO_FLOW_GRID; default CUs x RRPGO_FLOW_WAVES)
   bool overlap_ = false;            // RR_PGO_OVERLAP=1: the far part of a trailing update on a second stream, beside the next panel chain (measured neutral so far)
   int overlap_max_nf_ = 1 << 30;    // RR_PGO_OVERLAP=<n>: only on levels with at most n fronts
@@ -481,6 +483,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (const char *e = getenv("RR_PGO_FLOW")) flow_max_nf_ = std::atoi(e);
     flow_exact_ = getenv("RR_PGO_FLOW_EXACT") != nullptr;
     if (const char *e = getenv("RR_PGO_FLOW_TASKS")) flow_max_tasks_ = std::atoi(e);
+    if (const char *e = getenv("RR_PGO_FLOW_TILE4")) flow_tile4_min_ = std::atoi(e);
     if (!(left_looking_ && fused_build_ && !panel128_ && !separate_diag32_ && !overlap_)) flow_max_nf_ = 0;
     build_flow_levels();
     n_lin_blocks_ = (int)(((int64_t)n_list_ * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
@@ -636,17 +639,23 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       if (st.kind != STEP_BIG || nf > flow_max_nf_) continue;
       auto lvl = std::make_unique<FlowLevel>();
       lvl->ticket_word = words;
-      words += 32;   // the ticket on a 128-byte line of its own
       struct Item { double start; int64_t seq; FlowTask t; };
       std::vector<Item> items;
       std::vector<FlowFront> fronts(nf);
       double level_end = 0;
+      // 64 x 64 tiles first; a level that has thousands of them is generated again with 128 x 128 tiles
+      for (int TS = 64; TS <= 128; TS *= 2) {
+      if (TS == 128 && (int)items.size() < flow_tile4_min_) break;
+      lvl->nt = TS / 32;
+      words = lvl->ticket_word + 32;   // the ticket on a 128-byte line of its own
+      items.clear();
+      level_end = 0;
       for (int z = 0; z < nf; z++) {
         const int sn = sym_.task_sn[sym_.task_ptr[st.task_begin + z]];
         const int nc = sym_.sn_ncols[sn], M = nc + sym_.sn_nrows[sn] + 1;
         const int nblk = (nc + BIG_NB - 1) / BIG_NB, nsp = (nc + BIG_SUPER - 1) / BIG_SUPER;
         const int pstride = (M + 31) / 32 + 1;
-        const int ntmax = (M + 63) / 64 + 1, ustride = ntmax * (ntmax + 1) / 2;
+        const int ntmax = (M + TS - 1) / TS + 1, ustride = ntmax * (ntmax + 1) / 2;
         FlowFront &ff = fronts[z];
         ff.wf = (int32_t)words; words += nblk + 1;
         ff.pf = (int32_t)words; ff.pstride = pstride; words += (int64_t)nblk * pstride;
@@ -664,8 +673,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           auto prev_tiles = [&](int r0, int r1, int c0, int c1) {
             double t = 0;
             if (sp == 0) return t;
-            for (int bx = (r0 - K0) / 64; bx <= (std::min(r1, M - 1) - K0) / 64; bx++)
-              for (int by = (c0 - K0) / 64; by <= std::min((std::min(c1, M - 1) - K0) / 64, bx); by++)
+            for (int bx = (r0 - K0) / TS; bx <= (std::min(r1, M - 1) - K0) / TS; bx++)
+              for (int by = (c0 - K0) / TS; by <= std::min((std::min(c1, M - 1) - K0) / TS, bx); by++)
                 t = std::max(t, tu[(size_t)(sp - 1) * ustride + tri(bx, by)]);
             return t;
           };
@@ -703,20 +712,20 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           }
           // trailing update of the super-panel: tiles of rows / columns >= ke
           const int t0 = ke;
-          const int nt = (M - t0 + 63) / 64;
+          const int nt = (M - t0 + TS - 1) / TS;
           for (int by = 0; by < nt; by++)       // column-major: the next super-panel's own columns first
             for (int bx = by; bx < nt; bx++) {
-              const int I0 = t0 + 64 * bx, J0 = t0 + 64 * by;
+              const int I0 = t0 + TS * bx, J0 = t0 + TS * by;
               double t = 0;
               for (int kb = K0; kb < ke; kb += BIG_NB) {
                 const int nbq = std::min(BIG_NB, nc - kb), r0 = kb + nbq;
                 for (int strip = 0; strip < 2; strip++) {
-                  const int lo = strip ? J0 : I0, hi = std::min(lo + 63, M - 1);
+                  const int lo = strip ? J0 : I0, hi = std::min(lo + TS - 1, M - 1);
                   for (int rb = (lo - r0) / 32; rb <= (hi - r0) / 32; rb++) t = std::max(t, tp[(size_t)(kb / BIG_NB) * pstride + rb] + kHop);
                 }
               }
-              t = std::max(t, prev_tiles(I0, I0 + 63, J0, J0 + 63) + (sp > 0 ? kHop : 0.0));
-              const double fin = t + kTile;
+              t = std::max(t, prev_tiles(I0, I0 + TS - 1, J0, J0 + TS - 1) + (sp > 0 ? kHop : 0.0));
+              const double fin = t + (TS == 64 ? kTile : 2.5 * kTile);
               tu[(size_t)sp * ustride + tri(bx, by)] = fin;
               level_end = std::max(level_end, fin);
               if (flow_exact_ && bx == 0 && by == 0 && t0 < nc) { tw[t0 / BIG_NB] = fin + kTail; level_end = std::max(level_end, fin + kTail); }
@@ -724,6 +733,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
             }
         }
       }
+      }   // tile sizes
       if ((int64_t)items.size() > flow_max_tasks_) { words = lvl->ticket_word; continue; }   // throughput-bound level: launch sequence (its flag words are given back)
       std::sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.start != y.start ? x.start < y.start : x.seq < y.seq; });
       std::vector<FlowTask> tasks(items.size());
@@ -779,7 +789,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     fa.winv = winv_.p;
     fa.err = err_.p;
     fa.trace = lvl.trace.p;
-    hipLaunchKernelGGL(k_big_flow<T>, dim3((unsigned)std::min(lvl.n_tasks, flow_grid_)), dim3(256), 0, stream_, fa);
+    if (lvl.nt == 4) hipLaunchKernelGGL((k_big_flow<T, 4>), dim3((unsigned)std::min(lvl.n_tasks, flow_grid_)), dim3(256), 0, stream_, fa);
+    else hipLaunchKernelGGL((k_big_flow<T, 2>), dim3((unsigned)std::min(lvl.n_tasks, flow_grid_)), dim3(256), 0, stream_, fa);
     check_launch("k_big_flow");
   }
 

@@ -26,8 +26,20 @@ del g
 out = {"workload": spec, "precision": prec, "unsharded_ms": base_ms, "link_GBps_assumed": LINK_GBPS,
        "collective_latency_us_assumed": COLL_LAT_US, "P": {}}
 print("unsharded %.3f ms/step" % base_ms, flush=True)
+gold = None
+if spec == "400x250:1000000":
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "grid400x250.json")))["errors"]
 for P in Ps:
     shards, coll = sharding.emulate(arrays, P, prec)
+    # numbers of a wrong factorisation are worthless: the sharded run must first reproduce the oracle's chi2
+    s_init = [np.array(gq.state()) for gq in shards]
+    errs, _ = sharding.gauss_newton(shards, 8, coll, tolerance=0.0)
+    if gold is not None:
+        rel = abs(min(errs) - gold[-1]) / gold[-1]
+        assert rel <= (1e-8 if prec != "f32" else 1e-6), (P, errs, gold[-1])
+        print("P=%d chi2 %.6f vs oracle fixture %.6f (rel %.1e)" % (P, min(errs), gold[-1], rel), flush=True)
+    for gq, s0 in zip(shards, s_init):
+        gq.set_state(s0)
     for _ in range(2):   # warm-up: captures the stage graphs
         for gq in shards: gq.stage(0)
         coll.all_gather_boundary()

@@ -865,6 +865,45 @@ def test_sharded_se3_graph(api):
     assert _quat_state_diff(sharding.gather_state(shards), ref.state()) <= 1e-9
 
 
+@pytest.mark.parametrize("precision", ["mixed", "f32"])
+def test_config4_lattice_sharded_over_8_emulated_ranks(api, lattice_fixture, precision):
+    """BASELINE configs[3] names 1 -> 8 GPUs: the FULL 400 x 250 / 1M-edge lattice sharded over P = 8 ranks (emulated on one
+    GPU: eight handles, device copies for the two collectives) against the oracle's fixture, with the tolerances of the
+    unsharded test: mixed precision follows the f64 trajectory and stops by the reference rule, f32 reaches chi2 to 1e-6."""
+    from rustrobotics_amd import sharding
+    fx, arrays = lattice_fixture
+    nodes, gold = fx["sample_nodes"], fx["errors"][-1]
+    shards, coll = sharding.emulate(arrays, 8, precision)
+    owner = shards[0].node_owner()
+    assert set(np.unique(owner)) == set(range(-1, 8))
+    if precision == "mixed":
+        errors, norms = sharding.gauss_newton(shards, 30, coll)
+        assert len(errors) == len(fx["errors"]) and norms[-1] < 1e-4
+        np.testing.assert_allclose(errors, fx["errors"], rtol=1e-6)
+        assert abs(errors[-1] - gold) <= 1e-8 * gold
+        assert _sample_diff(_sample_state(sharding.gather_state(shards), nodes), fx["final_state_at_samples"]) <= 1e-6
+    else:
+        errors, norms = sharding.gauss_newton(shards, 8, coll, tolerance=0.0)
+        assert abs(errors[0] - fx["errors"][0]) <= 1e-6 * fx["errors"][0]
+        assert abs(min(errors) - gold) <= 1e-6 * gold and abs(errors[-1] - gold) <= 1e-6 * gold
+        assert _sample_diff(_sample_state(sharding.gather_state(shards), nodes), fx["final_state_at_samples"]) <= 1e-3
+
+
+def test_sphere2500_sharded_over_8_emulated_ranks(api, oracle):
+    """BASELINE configs[4] names 8 GPUs: sphere2500 (SE(3), 6 x 6 blocks, fp64) over P = 8 emulated ranks against the
+    oracle: chi2 trajectory, stop rule and poses."""
+    from rustrobotics_amd import sharding
+    ref = api[0].new(g2o_path("sphere2500"))
+    shards, coll = sharding.emulate(ref.graph_arrays(), 8)
+    errors, norms = sharding.gauss_newton(shards, 12, coll)
+    o = oracle.load(g2o_path("sphere2500"))
+    eo = o.optimize(12)
+    assert len(errors) == len(eo) and norms[-1] < 1e-4
+    np.testing.assert_allclose(errors, eo, rtol=1e-8)
+    assert abs(errors[-1] - 727.149667) < 1e-4
+    assert _quat_state_diff(sharding.gather_state(shards), o.state()) <= 1e-8
+
+
 def test_sharded_handle_with_one_rank(api, oracle):
     """opt.sharded with world_size 1: the same stages and collectives over a one-rank group (what bench.py runs
     over RCCL on a single-GPU box) == the plain handle."""
