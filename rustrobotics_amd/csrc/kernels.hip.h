@@ -5,7 +5,7 @@
 //   k_solve_tasks    back substitution down the supernode tree         (replaces umfpack.solve, :141)
 //   k_update         update_nodes + |dx|^2                             (reference :229-245,273)
 //   k_finalize_slot  fixed-order reduction of the chi2 / |dx|^2 partials (pgo_api.hip)
-//   k_big_* / k_solve_mid / k_factor_panel fronts beyond LDS (see "huge fronts" below)
+//   k_big_* / k_solve_mid / k_big_flow (flow.hip.h)  fronts beyond LDS (see "huge fronts" below)
 //   k_linearize_se3 / k_update_se3, k_pack_boundary / k_pack_shared / k_sum_shared   SE(3), sharding over ranks
 //
 // Wavefront = 64 lanes.  All cross-workgroup dependencies are kernel boundaries
@@ -1425,226 +1425,19 @@ __global__ void __launch_bounds__(THREADS) k_factor_tasks(FactorArgs<T> a) {
   }
 }
 
-// Panel class (STEP_MID): fronts whose panel + update matrix exceed LDS but whose pivot PANEL (M x nc) fits.
-// One workgroup per front, batched per level.  The front lives in place in L storage like the huge fronts
-// (M x M, ld M), but only its final contents ever travel: the panel is assembled (H entries + the children's
-// contributions, gathered through the inverse maps) and factored in LDS and stored once; every 32 x 32 tile of
-// the update matrix is formed in registers -- the children's sum minus L21 L21^T, operands read from the LDS
-// panel -- and stored once.  Nothing is zeroed, nothing is read-modify-written in HBM.
-template <typename T, int THREADS>
-__global__ void __launch_bounds__(THREADS) k_factor_panel(FactorArgs<T> a) {
-  using MM = Mfma16<T>;
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  __shared__ T dinv[W16_SCR];
-  T *P = reinterpret_cast<T *>(smem_raw);
-  const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63;
-  constexpr int NW = THREADS / 64;
-  init_w16_identity<T>(dinv, tid, THREADS);
-  const SnMeta m = a.task_meta[a.task_begin + blockIdx.x];
-  const int nc = m.nc, M = nc + m.nr + 1, nu = m.nr + 1, psize = M * nc;
-  const ChildMeta *cm = a.child_meta + m.child_begin;
-  // the inverse maps (parent row -> child row) of the first PQ children are staged behind the panel
-  constexpr int PQ = 4;
-  int32_t *invs = reinterpret_cast<int32_t *>(P + ((psize + 3) & ~3));
-  // ---- H entries of the pivot columns and the rhs row (index, then value: requested before the zeroing pass)
-  constexpr int APRE = 2;
-  const int32_t *asrc = a.fasm_src + m.asm_begin, *adst = a.fasm_dst + m.asm_begin;
-  int pd[APRE];
-  T pv[APRE], pb = 0;
-#pragma unroll
-  for (int u = 0; u < APRE; u++) {
-    const int t = tid + u * THREADS;
-    pd[u] = -1;
-    pv[u] = 0;
-    if (t < m.asm_count) { pd[u] = adst[t]; pv[u] = a.hvals[asrc[t]]; }
-  }
-  if (tid < nc) pb = a.b[a.perm[m.col0 + tid]];
-  for (int q = 0; q < min(m.child_count, PQ); q++) {
-    const int32_t *ginv = a.scat + cm[q].scat_ptr;
-    for (int t = tid; t < M; t += THREADS) invs[q * M + t] = ginv[t];
-  }
-  for (int t = tid; t < psize; t += THREADS) P[t] = 0;
-  lds_barrier();
-#pragma unroll
-  for (int u = 0; u < APRE; u++)
-    if (pd[u] >= 0) P[pd[u]] = pv[u];
-  for (int t = tid + APRE * THREADS; t < m.asm_count; t += THREADS) P[adst[t]] = a.hvals[asrc[t]];
-  if (tid < nc) P[tid * M + (M - 1)] = pb;
-  for (int j = tid + THREADS; j < nc; j += THREADS) P[j * M + (M - 1)] = a.b[a.perm[m.col0 + j]];
-  __syncthreads();
-  if (m.dup_count > 0) {  // blocks of parallel edges (rare): serial, fixed order
-    if (tid == 0)
-      for (int t = 0; t < m.dup_count; t++) P[a.fdup_dst[m.dup_begin + t]] += a.hvals[a.fdup_src[m.dup_begin + t]];
-    __syncthreads();
-  }
-  // ---- the children's contributions to the pivot columns.  The inverse maps of the first PQ children were staged
-  // in LDS (one coalesced load each), so an entry costs ONE global round trip (its values), and a thread's four
-  // entries x all children are requested together.
-  const int nkq = min(m.child_count, PQ);
-  for (int e0 = tid; e0 < psize; e0 += 4 * THREADS) {
-    int J[4], r[4];
-    T acc[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int e = min(e0 + u * THREADS, psize - 1);
-      J[u] = e / M;
-      r[u] = e - J[u] * M;
-    }
-    for (int q = 0; q < m.child_count; q++) {
-      const ChildMeta c = cm[q];
-      const int32_t *ginv = a.scat + c.scat_ptr;
-      const int32_t *sinv = invs + q * M;
-      const T *Uc = (c.uld > 0 ? a.lvals : c.uld < 0 ? a.xch : a.uvals) + c.uoff;
-      int iq[4], jq[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        iq[u] = q < nkq ? sinv[r[u]] : ginv[r[u]];
-        jq[u] = q < nkq ? sinv[J[u]] : ginv[J[u]];
-      }
-      T uv[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int jc = max(jq[u], 0);
-        const int coff = c.uld > 0 ? jc * c.uld : jc * c.ncu - ((jc * (jc - 1)) >> 1) - jc;
-        uv[u] = Uc[coff + max(iq[u], jc)];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) acc[u] += (jq[u] >= 0 && iq[u] >= jq[u]) ? uv[u] : (T)0;   // J < nc <= M - 1: never the (rhs, rhs) corner
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-      if (e0 + u * THREADS < psize && r[u] >= J[u]) P[e0 + u * THREADS] += acc[u];
-  }
-  __syncthreads();
-  // ---- partial factorisation of the panel (16 x 16 inverse diagonal blocks kept for the back substitution)
-  panel_factor<T, THREADS, true>(P, M, nc, a.err, dinv, a.winv + (int64_t)m.wblk * 256);
-  __syncthreads();
-  // ---- panel -> the front's first nc columns (same layout: column-major, ld M)
-  T *F = a.lvals + m.loff;
-  for (int t = tid; t < psize; t += THREADS) F[t] = P[t];
-  // ---- update matrix: U(i, j) = children(i, j) - sum_k L21(i, k) L21(j, k), 32 x 32 tiles, one per wave at a time.
-  // The children's values of the NEXT tile are requested before the MFMAs of the current one.
-  const int li = lane & 15, lk = lane >> 4;
-  const int nt = (nu + 31) >> 5, ntiles = nt * (nt + 1) / 2;
-  const T *L21 = P + nc;   // row i of the update matrix = row nc + i of the panel
-  auto tile_origin = [&](int t, int &i0, int &j0) {
-    int jb = 0, rem = t;
-    while (rem >= nt - jb) { rem -= nt - jb; jb++; }
-    i0 = 32 * (jb + rem);
-    j0 = 32 * jb;
-  };
-  // values of children [q0, q0 + 2) for the tile at (i0, j0): v[qq][y][r][x], masked to zero where the child has no entry
-  auto fetch2 = [&](int q0, int i0, int j0, T (&v)[2][2][4][2]) {
-#pragma unroll
-    for (int qq = 0; qq < 2; qq++) {
-      const int q = min(q0 + qq, m.child_count - 1);
-      const ChildMeta c = cm[q];
-      const int32_t *ginv = a.scat + c.scat_ptr;
-      const int32_t *sinv = invs + q * M;
-      const bool staged = q < nkq, have = q0 + qq < m.child_count;
-      const T *Uc = (c.uld > 0 ? a.lvals : c.uld < 0 ? a.xch : a.uvals) + c.uoff;
-      const int last = c.ncu - 1;
-      int iq[2];
-#pragma unroll
-      for (int x = 0; x < 2; x++) {
-        const int pr = nc + min(i0 + 16 * x + li, nu - 1);
-        iq[x] = staged ? sinv[pr] : ginv[pr];
-      }
-#pragma unroll
-      for (int y = 0; y < 2; y++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int pc = nc + min(j0 + 16 * y + MM::row(lane, r), nu - 1);
-          const int jq = staged ? sinv[pc] : ginv[pc];
-          const int jc = max(jq, 0);
-          const int coff = c.uld > 0 ? jc * c.uld : jc * c.ncu - ((jc * (jc - 1)) >> 1) - jc;
-#pragma unroll
-          for (int x = 0; x < 2; x++) {
-            const T val = Uc[coff + max(iq[x], jc)];
-            const bool ok = have && jq >= 0 && iq[x] >= jq && !(iq[x] == last && jq == last);
-            v[qq][y][r][x] = ok ? val : (T)0;
-          }
-        }
-    }
-  };
-  T vnext[2][2][4][2];
-  int i0 = 0, j0 = 0;
-  if (wave < ntiles) {
-    tile_origin(wave, i0, j0);
-    if (m.child_count > 0) fetch2(0, i0, j0, vnext);
-  }
-  for (int t = wave; t < ntiles; t += NW) {
-    typename MM::Acc acc[2][2];
-#pragma unroll
-    for (int x = 0; x < 2; x++)
-#pragma unroll
-      for (int y = 0; y < 2; y++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) acc[x][y][r] = m.child_count > 0 ? vnext[0][y][r][x] + vnext[1][y][r][x] : (T)0;
-    for (int q0 = 2; q0 < m.child_count; q0 += 2) {   // more than two children (rare): no prefetch
-      fetch2(q0, i0, j0, vnext);
-#pragma unroll
-      for (int x = 0; x < 2; x++)
-#pragma unroll
-        for (int y = 0; y < 2; y++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) acc[x][y][r] += vnext[0][y][r][x] + vnext[1][y][r][x];
-    }
-    const int ci0 = i0, cj0 = j0;
-    if (t + NW < ntiles) {
-      tile_origin(t + NW, i0, j0);
-      if (m.child_count > 0) fetch2(0, i0, j0, vnext);
-    }
-    // rank-nc update from the LDS panel: D = (-X_j) X_i^T, so a lane's four results are four columns j of one row i
-    const T *xi0 = L21 + min(ci0 + li, nu - 1), *xi1 = L21 + min(ci0 + 16 + li, nu - 1);
-    const T *xj0 = L21 + min(cj0 + li, nu - 1), *xj1 = L21 + min(cj0 + 16 + li, nu - 1);
-    const int nfull = nc >> 2;
-    int kk = lk * M;
-#pragma unroll 4
-    for (int k4 = 0; k4 < nfull; k4++, kk += 4 * M) {
-      const T b0 = xi0[kk], b1 = xi1[kk];
-      const T a0 = -xj0[kk], a1 = -xj1[kk];
-      acc[0][0] = MM::mma(a0, b0, acc[0][0]);
-      acc[0][1] = MM::mma(a1, b0, acc[0][1]);
-      acc[1][0] = MM::mma(a0, b1, acc[1][0]);
-      acc[1][1] = MM::mma(a1, b1, acc[1][1]);
-    }
-    if (nc & 3) {
-      const bool kok = 4 * nfull + lk < nc;
-      const int kc = min(4 * nfull + lk, nc - 1) * M;
-      const T b0 = xi0[kc], b1 = xi1[kc];
-      const T a0 = kok ? -xj0[kc] : (T)0, a1 = kok ? -xj1[kc] : (T)0;
-      acc[0][0] = MM::mma(a0, b0, acc[0][0]);
-      acc[0][1] = MM::mma(a1, b0, acc[0][1]);
-      acc[1][0] = MM::mma(a0, b1, acc[1][0]);
-      acc[1][1] = MM::mma(a1, b1, acc[1][1]);
-    }
-#pragma unroll
-    for (int x = 0; x < 2; x++)
-#pragma unroll
-      for (int y = 0; y < 2; y++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int i = ci0 + 16 * x + li, j = cj0 + 16 * y + MM::row(lane, r);
-          if (i < nu && j < nu && i >= j) F[(int64_t)(nc + j) * M + nc + i] = acc[x][y][r];
-        }
-  }
-}
-
 // ---- huge fronts: many workgroups per front, one launch per phase, the huge fronts of one
 // level batched in the launch (grid y or z = front slot; the level's fronts are the single-front
 // tasks task_begin, task_begin+1, ...).  Each M x M front lies in L storage (column-major, ld M).
-//   k_big_zero / k_big_assemble / k_big_extend_add (one launch per child rank: fixed order)
-//   per 128-column super-panel (default, left-looking):
-//       the first diagonal block: inside the level's first k_big_panel32 launch (every workgroup for itself),
-//       or the tail of the previous trailing update; k_big_diag32 is the stand-alone launch (RR_PGO_SEPARATE_DIAG32)
+//   k_big_build + k_big_assemble          ONE gather pass builds the pivot columns, then the H entries and the rhs
+//   per 128-column super-panel (left-looking inside it):
 //       4 x k_big_panel32   rows below a 32-column block: update from the super-panel's earlier columns,
 //                           multiply by the inverse diagonal block; its first wave prepares the next block
-//       k_big_update mode 1 everything right of the super-panel (K = 128, the dense MFMA contraction)
-//   alternatives kept for comparison: k_big_diag / k_big_trsm / k_big_update mode 0 (right-looking, K = 32),
-//   k_big_diag128 / k_big_trsm128 (a whole super-panel per chain step), k_big_update modes 2 / 3 (two streams)
-//   back substitution: k_big_gemv_partial (L21^T x over the chip, row slices), k_solve_mid (sums the slices, L11);
-//   k_big_gemv_finish sums them in a launch of its own for the right-looking alternative
+//                           (the level's very first block: inside its first launch, every workgroup for itself)
+//       k_big_update        everything right of the super-panel (K = 128, the dense MFMA contraction); its tile (0, 0)
+//                           factors and inverts the next super-panel's first diagonal block
+//   levels of few fronts and few tasks: k_big_flow (flow.hip.h) runs all of that as ONE launch of ticket-ordered tasks
+//   back substitution: k_big_gemv_partial (L21^T x over the chip, row slices), then k_big_solve_sp (wide pivot blocks,
+//   per 128 columns over the chip) or k_solve_mid (one workgroup per front; sums the slices, L11)
 #ifndef RRPGO_BIG_NB
 #define RRPGO_BIG_NB 32
 #endif
@@ -1653,8 +1446,6 @@ __global__ void __launch_bounds__(THREADS) k_factor_panel(FactorArgs<T> a) {
 #endif
 constexpr int BIG_NB = RRPGO_BIG_NB;        // pivot block width
 constexpr int BIG_SUPER = RRPGO_BIG_SUPER;  // super-panel width = K of the big trailing update
-constexpr int BIG_PANEL_ROWS = 256;         // rows below the diagonal block handled by one workgroup
-constexpr int BIG_NB2_PER_THREAD = (BIG_NB * BIG_NB + 255) / 256;
 
 // columns [0, big_built_cols) of a front are written by k_big_build when the first trailing update gathers the rest
 // from the children: the pivot columns, rounded up to the tile grid of that update (tiles start at column 128 when
@@ -1662,28 +1453,6 @@ constexpr int BIG_NB2_PER_THREAD = (BIG_NB * BIG_NB + 255) / 256;
 __device__ __host__ __forceinline__ int big_built_cols(int nc, int M) {
   const int r = ((nc + 127) / 128) * 128;
   return nc <= BIG_SUPER ? nc : (r < M ? r : M);
-}
-
-template <typename T> __device__ __forceinline__ int big_front(const FactorArgs<T> &a, int slot) {
-  return a.task_sn[a.task_ptr[a.task_begin + slot]];
-}
-
-template <typename T> __global__ void __launch_bounds__(256) k_big_zero(FactorArgs<T> a) {
-  // only the lower triangle is ever read: column j is cleared from row j down (rounded down to a
-  // 64-row boundary of the column so that every wave stores whole contiguous runs)
-  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
-  const int M = m.nc + m.nr + 1;
-  T *F = a.lvals + m.loff;
-  const int wave = wave_index(), lane = threadIdx.x & 63;
-  for (int j = blockIdx.x * 4 + wave; j < M; j += gridDim.x * 4) {
-    T *col = F + (int64_t)j * M;
-    for (int i = (j & ~63) + lane; i < M; i += 256) {
-      col[i] = 0;
-      if (i + 64 < M) col[i + 64] = 0;
-      if (i + 128 < M) col[i + 128] = 0;
-      if (i + 192 < M) col[i + 192] = 0;
-    }
-  }
 }
 
 // add == 0: plain stores into the zeroed front (before the extend-adds); add == 1: on top of what k_big_build
@@ -1705,9 +1474,9 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_assemble(Fact
 
 // Zeroing + every extend-add of a level in ONE pass: a wave per column of the parent, lanes over its rows; each
 // entry is the sum, in child order, of what the children hold for it (inverse maps: ChildMeta::scat_ptr), written
-// once.  The front is never read here: against k_big_zero + one read-modify-write launch per child this moves
+// once.  The front is never read here: against a zeroing pass + one read-modify-write launch per child (r01) this moves
 // (parent once + children once) instead of (parent 1 + 2 x children-that-touch-it) times.  Rows (J & ~63)..J-1 of
-// column J are cleared like k_big_zero does (the diagonal-block kernels read whole squares).
+// column J are cleared too (the diagonal-block kernels read whole squares).
 // QB children per batch: all their index loads are requested before the first value load, so a batch pays two
 // dependent round trips; a child without this column (jq < 0) is read at a clamped address and masked.
 template <typename T, int QB>
@@ -1768,115 +1537,6 @@ template <typename T> __global__ void k_big_assemble_dup(FactorArgs<T> a) {
   T *F = a.lvals + m.loff;
   if (blockIdx.x == 0 && threadIdx.x == 0)
     for (int t = 0; t < m.dup_count; t++) F[a.fdup_dst[m.dup_begin + t]] += a.hvals[a.fdup_src[m.dup_begin + t]];
-}
-
-template <typename T> __global__ void __launch_bounds__(256) k_big_extend_add(FactorArgs<T> a, int q) {
-  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
-  if (q >= m.child_count) return;
-  const ChildMeta c = a.child_meta[m.child_begin + q];
-  T *F = a.lvals + m.loff;
-  const int M = m.nc + m.nr + 1;
-  const T *Uc = (c.uld > 0 ? a.lvals : c.uld < 0 ? a.xch : a.uvals) + c.uoff;
-  const int32_t *rel = a.rel + c.rel_ptr;
-  const int ncu = c.ncu;
-  // one column of the child's update matrix per WAVE pass (four columns per workgroup in flight), lanes
-  // over its rows, four rows per lane in flight (index, source and destination loads are independent)
-  const int wave = wave_index(), lane = threadIdx.x & 63;
-  for (int j = blockIdx.x * 4 + wave; j < ncu; j += gridDim.x * 4) {
-    T *dcol = F + (int64_t)rel[j] * M;
-    // column j of the child: packed lower triangle (uld == 0) or a plain column-major square
-    const T *ucol = Uc + (c.uld > 0 ? (int64_t)j * c.uld : (int64_t)j * ncu - (int64_t)j * (j - 1) / 2 - j);
-    const int iend = j == ncu - 1 ? ncu - 1 : ncu;   // the (rhs, rhs) corner is never used
-    for (int i0 = j + lane; i0 < iend; i0 += 256) {
-      int ri[4];
-      T uv[4], fv[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int i = min(i0 + 64 * u, iend - 1);
-        ri[u] = rel[i];
-        uv[u] = ucol[i];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) fv[u] = dcol[ri[u]];
-      // the in-place front stores panel and update matrix in one M x M array: both land at (li, lj)
-#pragma unroll
-      for (int u = 0; u < 4; u++)
-        if (i0 + 64 * u < iend) dcol[ri[u]] = fv[u] + uv[u];
-    }
-  }
-}
-
-// The nb x nb diagonal block of the current 32-column panel: one workgroup per front, in LDS.
-// (A separate launch: workgroups of a big grid are not co-resident, so nobody may read the block
-// in the launch that rewrites it.)
-template <typename T> __global__ void __launch_bounds__(256) k_big_diag(FactorArgs<T> a, int kb) {
-  __shared__ T Pl[BIG_NB * BIG_NB];
-  __shared__ T dinv[16 * 17];
-  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
-  if (kb >= m.nc) return;
-  const int nb = min(BIG_NB, m.nc - kb);
-  T *F = a.lvals + m.loff;
-  const int M = m.nc + m.nr + 1;
-  const int tid = threadIdx.x;
-  T dv[BIG_NB2_PER_THREAD];
-#pragma unroll
-  for (int q = 0; q < BIG_NB2_PER_THREAD; q++) {
-    const int t = tid + 256 * q, c = t / nb, r = t - c * nb;
-    dv[q] = t < nb * nb ? F[(int64_t)(kb + c) * M + kb + r] : (T)0;
-  }
-#pragma unroll
-  for (int q = 0; q < BIG_NB2_PER_THREAD; q++)
-    if (tid + 256 * q < nb * nb) Pl[tid + 256 * q] = dv[q];
-  __syncthreads();
-  panel_factor<T, 256>(Pl, nb, nb, a.err, dinv, (T *)nullptr);
-#pragma unroll
-  for (int q = 0; q < BIG_NB2_PER_THREAD; q++) {
-    const int t = tid + 256 * q, c = t / nb, r = t - c * nb;
-    if (t < nb * nb && r >= c) F[(int64_t)(kb + c) * M + kb + r] = Pl[t];
-  }
-}
-
-// Rows below the diagonal block:  X * L11^T = A, one thread per row (BIG_PANEL_ROWS rows per
-// workgroup), L11 broadcast from LDS with its diagonal stored as reciprocals.
-template <typename T> __global__ void __launch_bounds__(256) k_big_trsm(FactorArgs<T> a, int kb) {
-  __shared__ T L11[BIG_NB * (BIG_NB + 1)];
-  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
-  if (kb >= m.nc) return;
-  const int nb = min(BIG_NB, m.nc - kb);
-  T *F = a.lvals + m.loff;
-  const int M = m.nc + m.nr + 1;
-  const int tid = threadIdx.x;
-  const int r0 = kb + nb + blockIdx.x * BIG_PANEL_ROWS;
-  if (r0 >= M) return;
-  const int row = r0 + tid;
-  const bool active = row < M;
-  T *src = F + (int64_t)kb * M;
-  T xr[BIG_NB];
-#pragma unroll
-  for (int c = 0; c < BIG_NB; c++) xr[c] = (c < nb && active) ? src[(int64_t)c * M + row] : (T)0;
-#pragma unroll
-  for (int q = 0; q < BIG_NB2_PER_THREAD; q++) {
-    // L11(r, c), r >= c, stored at [c * (BIG_NB+1) + r]; diagonal as reciprocal
-    const int t = tid + 256 * q, c = t / nb, r = t - c * nb;
-    if (t < nb * nb && r >= c) {
-      const T v = src[(int64_t)c * M + kb + r];
-      L11[c * (BIG_NB + 1) + r] = r == c ? (T)1 / v : v;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < BIG_NB; k++) {
-    if (k < nb) {
-      T sacc = xr[k];
-#pragma unroll
-      for (int q = 0; q < BIG_NB; q++)
-        if (q < k) sacc -= xr[q] * L11[q * (BIG_NB + 1) + k];
-      xr[k] = sacc * L11[k * (BIG_NB + 1) + k];
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < BIG_NB; c++)
-    if (c < nb && active) src[(int64_t)c * M + row] = xr[c];
 }
 
 // ---- left-looking 32-column blocks inside a 128-column super-panel -------------------------------
@@ -2026,37 +1686,9 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
   }
 }
 
-// First diagonal block of a super-panel (everything left of it has been applied by the trailing
-// update): one wave per front.
-template <typename T> __global__ void __launch_bounds__(64) k_big_diag32(FactorArgs<T> a, int kb) {
-  __shared__ T Sh[DIAG32_LDS];
-  RRPGO_TRACE_MARK(a, 300);
-  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
-  if (kb >= m.nc) return;
-  const int nb = min(BIG_NB, m.nc - kb);
-  const int M = m.nc + m.nr + 1;
-  T *Fblk = a.lvals + m.loff + (int64_t)kb * M + kb;
-  const int lane = threadIdx.x;
-  T v[16];
-#pragma unroll
-  for (int t = 0; t < 16; t++) {   // all 16 loads in flight together, clamped into the block
-    const int e = t * 64 + lane, c = e >> 5, r = e & 31;
-    const T f = pin(Fblk[(int64_t)min(c, nb - 1) * M + min(r, nb - 1)]);
-    v[t] = (r < nb && c < nb && r >= c) ? f : ((r == c && r >= nb) ? (T)1 : (T)0);   // identity padding, zeros above the diagonal
-  }
-#pragma unroll
-  for (int t = 0; t < 16; t++) {
-    const int e = t * 64 + lane, c = e >> 5, r = e & 31;
-    Sh[c * 33 + r] = v[t];
-  }
-  diag32_init_tables<T>(Sh);
-  lds_barrier();
-  diag32_factor_invert<T>(Sh, nb, Fblk, M, a.winv + (int64_t)m.wblk * 256 + (kb / BIG_NB) * 1024, a.err);
-}
-
 // Rows below the 32-column block at kb, one wave per 32 rows, everything on the matrix cores:
 //   A  = F[rows, kb:kb+nb] - F[rows, K0:kb] * F[kb:kb+nb, K0:kb]^T     (left-looking update, K <= 96)
-//   X  = A * W^T,  W = inverse of the diagonal block (k_big_diag32 or the previous launch)
+//   X  = A * W^T,  W = inverse of the diagonal block (left behind by the previous launch)
 // The accumulators hold the transposed tile (MFMA rows = panel columns j, MFMA columns = rows i, the
 // contiguous direction).  A k-slot of the second product is whatever panel column the accumulator
 // register already holds, so A goes from result to operand without leaving its registers.
@@ -2096,7 +1728,7 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
       }
   }
   // first: the very first block of a level.  No trailing update came before it to leave W behind, and a
-  // k_big_diag32 launch for it would sit alone on the chain: every workgroup of this launch factors and inverts
+  // launch of its own for it would sit alone on the chain: every workgroup of this launch factors and inverts
   // the block for itself instead (same arithmetic, same bits), the first one keeps W for the solve.  The block
   // itself stays as assembled in F -- nothing reads a diagonal block of L once its W exists, and storing it
   // here would race with the other workgroups that are still reading it.
@@ -2272,209 +1904,6 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
   RRPGO_PHASE_MARK(a, look, 504);
   diag32_factor_invert<T>(Sh, nbn, F + (int64_t)kn * M + kn, M, a.winv + (int64_t)m.wblk * 256 + (kn / BIG_NB) * 1024, a.err);
   RRPGO_PHASE_MARK(a, look, 505);
-}
-
-// ---- a whole 128-column super-panel per step of the chain ------------------------------------------
-// k_big_diag128: one workgroup per front factors the (<= 128)^2 diagonal block of the super-panel in LDS
-// with the workgroup-wide panel_factor (16-column blocks, look-ahead, MFMA), then pairs its 16 x 16
-// inverse diagonal blocks into the 32 x 32 inverses W_b the row kernels and the back substitution use:
-//   W32 = [Wa 0; -Wb L21 Wa, Wb].
-// The block is held with an odd leading dimension (129: one dummy zero row) so that the MFMA operand
-// reads of four k-columns fall into different LDS banks.
-template <typename T> __global__ void __launch_bounds__(512) k_big_diag128(FactorArgs<T> a, int K0) {
-  static_assert(BIG_NB == 32, "written for 32-column blocks");   // and for 128-column super-panels: the launcher only uses it then
-  using MM = Mfma16<T>;
-  constexpr int LD = 129;
-  __shared__ T P[LD * 128];
-  __shared__ T w16[8 * 256];     // W16 blocks of panel_factor: [blk][c * 16 + q] = W(c, q)
-  __shared__ T w21s[4 * 256];    // W21 of the four pairs: [b][p * 16 + j]
-  __shared__ T wscr[16 * 17];
-  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
-  if (K0 >= m.nc) return;
-  const int nbk = min(BIG_SUPER, m.nc - K0);
-  const int M = m.nc + m.nr + 1;
-  T *Fb = a.lvals + m.loff + (int64_t)K0 * M + K0;
-  const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63, li = lane & 15;
-  // lower triangle in, zeros elsewhere (the dummy row 128 and the rows of a partial super-panel too)
-  for (int c = wave; c < 128; c += 8) {
-    const T *col = Fb + (int64_t)min(c, nbk - 1) * M;
-    for (int r = lane; r < LD; r += 64) {
-      const T v = pin(col[min(r, nbk - 1)]);
-      P[c * LD + r] = (r < nbk && c < nbk && r >= c) ? v : (T)0;
-    }
-  }
-  for (int t = tid; t < 8 * 256; t += 512) w16[t] = ((t & 255) >> 4) == (t & 15) ? (T)1 : (T)0;   // identity where no block exists
-  __syncthreads();
-  panel_factor<T, 512>(P, LD, nbk, a.err, wscr, w16);
-  __syncthreads();
-  const int nb32 = (nbk + 31) >> 5;
-  if (wave < nb32) {
-    // T1(i, j) = sum_c L21(i, c) Wa(c, j);  W21(p, j) = -sum_i Wb(p, i) T1(i, j)   (k-slots = accumulator rows)
-    const int b = wave, o = 32 * b;
-    const T *Wa = w16 + (2 * b) * 256, *Wb = w16 + (2 * b + 1) * 256;
-    typename MM::Acc t1 = {0, 0, 0, 0}, w21 = {0, 0, 0, 0};
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int c = MM::row(lane, r);
-      t1 = MM::mma(P[(o + c) * LD + o + 16 + li], Wa[c * 16 + li], t1);   // L21(i = li, c) (zero past the panel)
-    }
-#pragma unroll
-    for (int r = 0; r < 4; r++) w21 = MM::mma(-Wb[li * 16 + MM::row(lane, r)], t1[r], w21);
-#pragma unroll
-    for (int r = 0; r < 4; r++) w21s[b * 256 + MM::row(lane, r) * 16 + li] = w21[r];   // W21(p = row, j = li)
-  }
-  __syncthreads();
-  // W32 blocks out: Wt[j * 32 + c] = W32(c, j)
-  T *Wt = a.winv + (int64_t)m.wblk * 256 + (int64_t)(K0 / BIG_NB) * 1024;
-  for (int e = tid; e < nb32 * 1024; e += 512) {
-    const int b = e >> 10, j = (e >> 5) & 31, c = e & 31;
-    const T *Wa = w16 + (2 * b) * 256, *Wb = w16 + (2 * b + 1) * 256;
-    T v = 0;
-    if (c < 16 && j < 16) v = Wa[c * 16 + j];
-    else if (c >= 16 && j >= 16) v = Wb[(c - 16) * 16 + (j - 16)];
-    else if (c >= 16) v = w21s[b * 256 + (c - 16) * 16 + j];
-    Wt[e] = v;
-  }
-  // L back in place (lower part of the block)
-  for (int c = wave; c < nbk; c += 8) {
-    T *col = Fb + (int64_t)c * M;
-    for (int r = c + lane; r < nbk; r += 64) col[r] = P[c * LD + r];
-  }
-}
-
-// k_big_trsm128: the rows below the super-panel, one wave per 32 rows, ONE launch for all four 32-column
-// blocks: with L of the diagonal block and the four W_b known there is no dependency between workgroups,
-//   for b = 0..3:  A_b -= sum_{b' < b} X_b' L(b, b')^T ;  X_b = A_b W_b^T
-// all on the matrix cores with X_b' staying in its accumulator registers (k-slot = accumulator row).
-template <typename T> __global__ void __launch_bounds__(256) k_big_trsm128(FactorArgs<T> a, int K0) {
-  using MM = Mfma16<T>;
-  constexpr int LS = 36;                 // padded row of a staged 32 x 32 block: the four k-slot groups of a wave
-                                         // read from different banks
-  __shared__ T Ls[6 * 32 * LS];          // -L(b, b') of the diagonal block, b > b': [pair][c * LS + j]
-  __shared__ T Ws[4 * 32 * LS];          // W_b: [b][j * LS + c] = W_b(c, j)
-  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
-  if (K0 >= m.nc) return;
-  const int nbk = min(BIG_SUPER, m.nc - K0);
-  const int M = m.nc + m.nr + 1;
-  const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63, li = lane & 15;
-  if (K0 + nbk + 128 * (int)blockIdx.x >= M) return;   // uniform over the workgroup
-  T *F = a.lvals + m.loff;
-  const T *Wt = a.winv + (int64_t)m.wblk * 256 + (int64_t)(K0 / BIG_NB) * 1024;
-  const int nb32 = (nbk + 31) >> 5;
-  // ---- stage the six off-diagonal L blocks (negated) and the four W blocks: every load of the
-  // workgroup is issued at once, one memory round trip for all operands
-  {
-    T lv[6][4], wv[4][4];
-#pragma unroll
-    for (int pr = 0; pr < 6; pr++) {
-      const int b = pr < 1 ? 1 : pr < 3 ? 2 : 3, bp = pr - (b * (b - 1)) / 2;
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int e = tid + 256 * u, c = e >> 5, j = e & 31;
-        const T v = pin(F[(int64_t)(K0 + min(32 * bp + c, nbk - 1)) * M + K0 + min(32 * b + j, nbk - 1)]);
-        lv[pr][u] = (32 * b + j < nbk) ? -v : (T)0;
-      }
-    }
-#pragma unroll
-    for (int b = 0; b < 4; b++)
-#pragma unroll
-      for (int u = 0; u < 4; u++) wv[b][u] = Wt[min(b, nb32 - 1) * 1024 + tid + 256 * u];
-#pragma unroll
-    for (int pr = 0; pr < 6; pr++)
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int e = tid + 256 * u;
-        Ls[pr * 32 * LS + (e >> 5) * LS + (e & 31)] = lv[pr][u];
-      }
-#pragma unroll
-    for (int b = 0; b < 4; b++)
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int e = tid + 256 * u;
-        Ws[b * 32 * LS + (e >> 5) * LS + (e & 31)] = wv[b][u];
-      }
-  }
-  const int R0 = K0 + nbk + 128 * blockIdx.x + 32 * wave;
-  int irow[2];
-  irow[0] = min(R0 + li, M - 1);
-  irow[1] = min(R0 + 16 + li, M - 1);
-  typename MM::Acc x[4][2][2];   // [block][ib][jb]: A_b, then X_b; tile rows = columns of the block, tile columns = rows i
-#pragma unroll
-  for (int b = 0; b < 4; b++)
-#pragma unroll
-    for (int jb = 0; jb < 2; jb++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int j = 32 * b + 16 * jb + MM::row(lane, r);
-        const T *ccol = F + (int64_t)(K0 + min(j, nbk - 1)) * M;
-#pragma unroll
-        for (int ib = 0; ib < 2; ib++) {
-          const T v = pin(ccol[irow[ib]]);
-          x[b][ib][jb][r] = (b < nb32 && j < nbk) ? v : (T)0;
-        }
-      }
-  __syncthreads();
-  if (R0 >= M) return;   // no barriers below
-#pragma unroll
-  for (int b = 0; b < 4; b++) {
-    if (b < nb32) {   // uniform
-#pragma unroll
-      for (int bp = 0; bp < b; bp++) {
-        const T *lb = Ls + ((b * (b - 1)) / 2 + bp) * 32 * LS;
-#pragma unroll
-        for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const T *lrow = lb + (16 * cb + MM::row(lane, r)) * LS + li;
-            const T la0 = lrow[0], la1 = lrow[16];
-#pragma unroll
-            for (int ib = 0; ib < 2; ib++) {
-              x[b][ib][0] = MM::mma(la0, x[bp][ib][cb][r], x[b][ib][0]);
-              x[b][ib][1] = MM::mma(la1, x[bp][ib][cb][r], x[b][ib][1]);
-            }
-          }
-      }
-      // X_b = A_b W_b^T; W tiles (cb, jb) = (0,0), (1,0), (1,1)
-      const T *wb = Ws + b * 32 * LS;
-      T wv[3][4];
-#pragma unroll
-      for (int t = 0; t < 3; t++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int cb = t == 0 ? 0 : 1, jb = t == 2 ? 1 : 0;
-          wv[t][r] = wb[(16 * jb + MM::row(lane, r)) * LS + 16 * cb + li];
-        }
-#pragma unroll
-      for (int ib = 0; ib < 2; ib++) {
-        typename MM::Acc o0 = {0, 0, 0, 0}, o1 = {0, 0, 0, 0};
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          o0 = MM::mma(wv[0][r], x[b][ib][0][r], o0);
-          o1 = MM::mma(wv[1][r], x[b][ib][0][r], o1);
-          o1 = MM::mma(wv[2][r], x[b][ib][1][r], o1);
-        }
-        x[b][ib][0] = o0;
-        x[b][ib][1] = o1;
-      }
-    }
-  }
-  const bool full = nbk == BIG_SUPER && R0 + 32 <= M;
-#pragma unroll
-  for (int b = 0; b < 4; b++)
-#pragma unroll
-    for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int c = 32 * b + 16 * cb + MM::row(lane, r);
-        T *ccol = F + (int64_t)(K0 + min(c, nbk - 1)) * M;
-        if (full) {
-          ccol[R0 + li] = x[b][0][cb][r];
-          ccol[R0 + 16 + li] = x[b][1][cb][r];
-        } else if (c < nbk) {
-          if (R0 + li < M) ccol[R0 + li] = x[b][0][cb][r];
-          if (R0 + 16 + li < M) ccol[R0 + 16 + li] = x[b][1][cb][r];
-        }
-      }
 }
 
 #ifndef RRPGO_UPD_WAVES
@@ -2757,53 +2186,41 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
   return true;
 }
 
-// gather: the launch for the FIRST super-panel (kb == 0, mode 1) forms the tiles right of big_built_cols from the
-// children instead of loading them (k_big_build was told to leave them out)
-template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(256, (DEPTH > 4 ? 1 : sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_update(FactorArgs<T> a, int kb, int mode, int diag_tail, int gather = 0, int tri = 0) {
+// k_big_update: everything right of the super-panel at kb, Schur complement included (K <= 128), one 64 x 64 tile per
+// workgroup; the grid's x dimension enumerates the lower triangle of tiles, t = bx (bx + 1) / 2 + by (a square grid
+// launches as many workgroups again only to have them exit).  gather: the launch for a front's FIRST super-panel forms the
+// tiles right of big_built_cols from the children instead of loading them (k_big_build was told to leave them out).
+template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_update(FactorArgs<T> a, int kb, int gather) {
   using MM = Mfma16<T>;
   using UT = UpdTile<T, NT>;
   constexpr int TILE = UT::TILE;
   __shared__ T smem[UT::SMEM];
-  RRPGO_TRACE_MARK(a, 100 + mode);
-  // tri: the grid's x dimension enumerates the lower triangle of tiles, t = bx (bx + 1) / 2 + by -- a square grid
-  // launches as many workgroups again only to have them exit
-  int bx = blockIdx.x, by = blockIdx.y;
-  if (tri) {
-    const int t = blockIdx.x;
-    bx = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-    while (bx * (bx + 1) / 2 > t) bx--;
-    while ((bx + 1) * (bx + 2) / 2 <= t) bx++;
-    by = t - bx * (bx + 1) / 2;
-  }
-  if (bx < by) return;           // lower triangle of tiles only
+  RRPGO_TRACE_MARK(a, 101);
+  const int t = blockIdx.x;
+  int bx = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while (bx * (bx + 1) / 2 > t) bx--;
+  while ((bx + 1) * (bx + 2) / 2 <= t) bx++;
+  const int by = t - bx * (bx + 1) / 2;
   const SnMeta m = a.task_meta[a.task_begin + blockIdx.z];
   if (kb >= m.nc) return;
   const int M = m.nc + m.nr + 1;
-  const int super_end = min((kb / BIG_SUPER) * BIG_SUPER + BIG_SUPER, m.nc);
-  const int ka = kb;
-  const int ke = mode == 0 ? min(kb + BIG_NB, m.nc) : super_end;
+  const int ke = min((kb / BIG_SUPER) * BIG_SUPER + BIG_SUPER, m.nc);
   const int t0 = ke;
-  // mode 2 / 3 split the trailing update by column: the 128 columns right of the super-panel (the next
-  // super-panel's own columns, needed by its panel chain) and everything after them (which can run
-  // beside that chain on a second stream)
-  const int jmax = mode == 0 ? super_end : mode == 2 ? min(t0 + 128, M) : M;
   static_assert(NT == 4 || NT == 2, "tile shapes");
-  const int toff = mode == 3 ? 128 / TILE : 0;   // mode 3 starts one 128-column strip further right
-  const int I0 = t0 + (bx + toff) * TILE, J0 = t0 + (by + toff) * TILE;
-  if (t0 >= jmax || I0 >= M || J0 >= jmax) return;   // uniform over the workgroup
+  const int I0 = t0 + bx * TILE, J0 = t0 + by * TILE;
+  if (I0 >= M || J0 >= M) return;   // uniform over the workgroup
   T *F = a.lvals + m.loff;
   typename MM::Acc acc[NT][NT];
   [[maybe_unused]] const bool pm = bx == 2 && by == 0 && blockIdx.z == 0;
   RRPGO_PHASE_MARK(a, pm, 600);
   TileGather<T> tg{nullptr, -1, nullptr, nullptr, nullptr, nullptr};
   if (gather && J0 >= big_built_cols(m.nc, M)) tg = TileGather<T>{a.child_meta + m.child_begin, m.child_count, a.scat, a.lvals, a.uvals, a.xch};
-  if (!big_update_tile<T, NT, DEPTH>(F, M, ka, ke, jmax, I0, J0, smem, acc, a.trace, pm, tg)) return;
+  if (!big_update_tile<T, NT, DEPTH>(F, M, kb, ke, M, I0, J0, smem, acc, a.trace, pm, tg)) return;
   RRPGO_PHASE_MARK(a, pm, 603);
   // The first wave of the first tile holds the next super-panel's first diagonal block (rows = columns
   // = t0 .. t0+31) in acc[0..1][0..1]: after the tile is stored it factors and inverts that block here,
-  // which saves the k_big_diag32 launch that would otherwise open the next super-panel's chain.
-  const bool next_diag = diag_tail && (mode == 1 || mode == 2) && bx == 0 && by == 0 && wave_index() == 0 && t0 < m.nc;
-  if (next_diag) {
+  // which saves a launch of its own at the head of the next super-panel's chain.
+  if (bx == 0 && by == 0 && wave_index() == 0 && t0 < m.nc) {
     T *Sh = smem;   // the staging buffers are idle now (every wave passed the last barrier of the k loop)
     const int nbn = min(BIG_NB, m.nc - t0);
     static_assert(DIAG32_LDS <= UT::SMEM / 2, "the diagonal-block images fit the first operand strip");
@@ -3130,7 +2547,7 @@ __global__ void __launch_bounds__(THREADS) k_solve_tasks(FactorArgs<T> a) {
 // Back substitution of the fronts beyond LDS, first part:  t = y1 - L21^T x[rows]  for every such front
 // of a level, spread over the whole chip: workgroup (bx, by, front) takes 64 columns and the by-th of
 // R row slices, lanes along the rows (coalesced), a wave 4 columns at a time.  Partial sums go to
-// part[by][col0 + j] (fixed slots, summed in order by k_big_gemv_finish: deterministic).
+// part[by][col0 + j] (fixed slots, summed in order by the solve kernels: deterministic).
 template <typename T> __global__ void __launch_bounds__(256) k_big_gemv_partial(FactorArgs<T> a, T *part, int64_t N, int R) {
   __shared__ T xs[1024];
   const SnMeta m = a.task_meta[a.task_begin + blockIdx.z];
@@ -3188,27 +2605,6 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_gemv_partial(
     }
 }
 
-// second part: t[j] = y1[j] - sum over the R slices, in slice order, left in x[col0 + j] for k_solve_mid
-template <typename T> __global__ void __launch_bounds__(256) k_big_gemv_finish(FactorArgs<T> a, const T *part, int64_t N, int R) {
-  const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= m.nc) return;
-  const int M = m.nc + m.nr + 1;
-  T t = a.lvals[m.loff + (int64_t)j * M + (M - 1)];
-  if (m.nr > 0)
-    for (int r = 0; r < R; r++) t -= part[(int64_t)r * N + m.col0 + j];
-  a.x[m.col0 + j] = t;
-}
-
-// Back substitution of one big front (pivot block only: t = y1 - L21^T x[rows] arrives in x[col0..]),
-// by 32-column blocks with the inverse diagonal blocks the factorisation kept:
-//   x_b = W_b^T t_b            on the first wave (32 v_readlane + FMA pairs, W_b staged in LDS a block ahead)
-//   t_i -= sum_j L(c0+j, i) x_j  for every column i left of the block: half a wave per column, lane = j, so
-//                              the 32 values of a column are one 128-byte line (coalesced), each lane
-//                              multiplies by the x_j it holds and a DPP row reduction forms the sum.
-// The loads of a block step do not depend on x_b and are issued before the first wave starts on W_b.
-// (16-byte loads with 8 lanes per column were tried: the column segments are not 16-byte aligned and
-// the kernel got slower.)
 template <typename T> __device__ __forceinline__ T half_wave_sum(T v) {   // sums of lanes 0..31 / 32..63 in lanes 31 / 63
   v += dpp_get<0x111, 0xf>(v);
   v += dpp_get<0x112, 0xf>(v);
@@ -3230,7 +2626,7 @@ __device__ void solve_big_front(const FactorArgs<T> &a, const SnMeta &m, T *work
   T *Ws = work + ((nc + 3) & ~3);   // 2 x (32 x 33): W_b staged transposed, Ws[j * 33 + c] = W_b(j, c)
   __syncthreads();
   // t = y1 - L21^T x[rows]: the R row slices of k_big_gemv_partial summed here, in slice order (what a separate
-  // k_big_gemv_finish launch used to do)
+  // separate launch used to do)
   for (int j = tid; j < nc; j += THREADS) {
     T t = Lg[(int64_t)j * M + (M - 1)];
     if (m.nr > 0)
@@ -3505,7 +2901,7 @@ __global__ void __launch_bounds__(THREADS) k_solve_mid(FactorArgs<T> a, int w32,
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int s = a.task_sn[a.task_ptr[a.task_begin + blockIdx.x]];
   // w32: the front was factored by the 32-column block kernels (inverse diagonal blocks in winv); it also sums
-  // the partial products itself.  Otherwise k_big_gemv_finish has left t in x.
+  // the partial products itself.
   if (w32) solve_big_front<T, THREADS>(a, a.sn_meta[s], reinterpret_cast<T *>(smem_raw), part, N, R);
   else solve_front<T, THREADS, false>(a, s, a.sn_meta[s], reinterpret_cast<T *>(smem_raw));
 }

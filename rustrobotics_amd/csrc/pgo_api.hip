@@ -246,25 +246,15 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   hipGraphExec_t stage_exec_[2] = {nullptr, nullptr};
   DevBuf<T> xch_own_;               // exchange buffer 0 (boundary update matrices) unless the caller binds one
   T *xch_ = nullptr, *x_ptr_ = nullptr;
-  bool left_looking_ = true;        // RR_PGO_RIGHT_LOOKING=1: the older diag / trsm / K=32 update launches
-  int small_tile_below_ = 1 << 30;  // trailing updates of fewer 128 x 128 tiles than this use 64 x 64 tiles: measured best on EVERY
-                                    // launch (finer scheduling granularity beats the operand reuse of the large tile);
-                                    // RR_PGO_SMALL_TILE=0 brings the 128 x 128 tiles back
   int solve_threads_max_ = 512;     // RR_PGO_SOLVE_THREADS=<n>: cap of the back-substitution workgroup size
   int factor_threads_max_ = 1024;   // 16-wave workgroups for steps whose fronts exceed 128 rows (RR_PGO_FACTOR_512=1: 8 waves)
-  int64_t deep_below_ = 0;          // RR_PGO_DEEP_BELOW=<n>: trailing updates of at most n 64 x 64 tiles request their whole K strip up front (measured r02: 6.02 ms per lattice step with 2048, 5.95 with 0; sphere2500 1 % slower with it: off)
   int sp_solve_min_nc_ = 256;       // back substitution: levels whose widest pivot block has at least this many columns run k_big_solve_sp (RR_PGO_SP_SOLVE_MIN)
-  bool gather_update_ = true;       // ... and only for the pivot columns: a front's first trailing update gathers its tiles from the children (RR_PGO_NO_GATHER_UPDATE=1)
-  bool fused_build_ = true;         // big fronts: k_big_build (one gather pass) instead of zero + extend-add per child (RR_PGO_SPLIT_ASSEMBLY=1)
-  bool separate_diag32_ = false;    // RR_PGO_SEPARATE_DIAG32=1: a k_big_diag32 launch for the first block of every level
-  bool panel128_ = false;           // RR_PGO_PANEL128=1: two launches per 128-column super-panel (diagonal block in LDS by one
-                                    // workgroup, then all rows at once) instead of one per 32 columns; measured 10 % slower
+  bool gather_update_ = true;       // big fronts: k_big_build builds the pivot columns only, a front's first trailing update gathers its tiles from the children (RR_PGO_NO_GATHER_UPDATE=1: whole fronts are built)
   // k_big_flow (flow.hip.h): levels of at most flow_max_nf_ big fronts run as ONE launch of ticket-ordered tile tasks
   struct FlowLevel {
     DevBuf<FlowTask> tasks;
     DevBuf<FlowFront> fronts;
     int n_tasks = 0;
-    int nt = 2;                // MFMA tiles per wave and dimension of an UPDATE task: 2 = 64 x 64 tiles, 4 = 128 x 128
     std::vector<FlowTask> host_tasks;   // diagnostic builds: the sorted list, for rr_pgo_debug_flow_trace
     DevBuf<unsigned long long> trace;   // diagnostic builds only
     int64_t ticket_word = 0;   // index of the level's ticket in flow_flags_
@@ -278,13 +268,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
                                     // (measured on the 1M-edge lattice, r03: the levels of 1 and 2 fronts -- 1.4 k and 4.8 k tasks -- gain 25 %
                                     // and 13 %, the level of 4 fronts -- 18 k tasks -- ties, the levels of 8..32 fronts lose 10-20 %)
   bool flow_exact_ = false;         // RR_PGO_FLOW_EXACT=1: bit-identical to the launch sequence (tile (0, 0) forms the next super-panel's first block)
-  int flow_tile4_min_ = 1 << 30;       // RR_PGO_FLOW_TILE4=<n>: levels with at least n tasks at 64 x 64 tiles use 128 x 128 tiles instead
   int flow_grid_ = 0;               // persistent workgroups of a flow launch (RR_PGO_FLOW_GRID; default CUs x RRPGO_FLOW_WAVES)
-  bool overlap_ = false;            // RR_PGO_OVERLAP=1: the far part of a trailing update on a second stream, beside the next panel chain (measured neutral so far)
-  int overlap_max_nf_ = 1 << 30;    // RR_PGO_OVERLAP=<n>: only on levels with at most n fronts
-  bool rest_pending_ = false;       // a rest-update is in flight on stream2_ (ev_rest_ marks its end)
-  PooledStream stream2_;
-  EventHolder ev_chain_, ev_rest_;
   // gauge transfer (single-precision factor, Gauss-Newton; kernels.hip.h "gauge transfer")
   bool gauge_ok_ = false;            // the root front is a big front with an SE2 pivot node
   bool gauge_now_ = false;           // the system being factored was linearised without the anchor prior
@@ -302,12 +286,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<unsigned long long> stamps_;  // diagnostic builds only
   // symbolic tables
   DevBuf<int32_t> task_ptr_, task_sn_, fasm_src_, fasm_dst_, fdup_src_, fdup_dst_, scat_, rel_, perm_, sn_rows_;
-  DevBuf<SnMeta> sn_meta_, task_meta_, big_all_meta_;
-  int n_big_all_ = 0, big_all_maxM_ = 0;
-  int64_t big_all_max_asm_ = 0;
-  bool big_all_dup_ = false, big_all_small_ = false;
-  bool merged_head_ = false;         // set with the table below; RR_PGO_SERIAL_ASSEMBLY=1: zero + assemble per level
-  bool head_done_ = false;           // this factorisation has already zeroed and assembled every big front
+  DevBuf<SnMeta> sn_meta_, task_meta_;
   DevBuf<ChildMeta> child_meta_;
   std::vector<int> step_solve_lds_;  // scalars of LDS the back-solve of each step needs
   PinnedBuf<double> host_pair_;      // pinned: chi2, |dx|, and (as an int in slot 2) the device error flag
@@ -460,31 +439,13 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       for (const Step &st : sym.steps) any_big = any_big || st.kind != STEP_TASKS;
       gemv_part_.alloc(any_big ? (size_t)kGemvSlices * g.dim : 4);
     }
-    left_looking_ = getenv("RR_PGO_RIGHT_LOOKING") == nullptr;
-    overlap_ = getenv("RR_PGO_OVERLAP") != nullptr;
-    if (overlap_) {   // the second stream and its events only exist for this experiment
-      stream2_.acquire();
-      ev_chain_.create(hipEventDisableTiming);
-      ev_rest_.create(hipEventDisableTiming);
-    }
-    if (overlap_ && std::atoi(getenv("RR_PGO_OVERLAP")) > 1) overlap_max_nf_ = std::atoi(getenv("RR_PGO_OVERLAP"));
-    panel128_ = getenv("RR_PGO_PANEL128") != nullptr;
-    fused_build_ = getenv("RR_PGO_SPLIT_ASSEMBLY") == nullptr && getenv("RR_PGO_SERIAL_ASSEMBLY") == nullptr;
-    separate_diag32_ = getenv("RR_PGO_SEPARATE_DIAG32") != nullptr;
     factor_threads_max_ = getenv("RR_PGO_FACTOR_512") ? 512 : 1024;
     if (const char *e = getenv("RR_PGO_SOLVE_THREADS")) solve_threads_max_ = std::atoi(e);
-    if (const char *e = getenv("RR_PGO_SMALL_TILE")) small_tile_below_ = std::atoi(e);
-    if (const char *e = getenv("RR_PGO_DEEP_BELOW")) deep_below_ = std::atoll(e);
     if (const char *e = getenv("RR_PGO_SP_SOLVE_MIN")) sp_solve_min_nc_ = std::atoi(e);
-    gather_update_ = fused_build_ && left_looking_ && !panel128_ && !overlap_ &&
-                     getenv("RR_PGO_NO_GATHER_UPDATE") == nullptr;
-    if (const char *e = getenv("RR_PGO_MANY_TASKS")) many_tasks_ = std::atoi(e);
-    if (const char *e = getenv("RR_PGO_MANY_THREADS")) many_threads_ = std::atoi(e);
+    gather_update_ = getenv("RR_PGO_NO_GATHER_UPDATE") == nullptr;
     if (const char *e = getenv("RR_PGO_FLOW")) flow_max_nf_ = std::atoi(e);
     flow_exact_ = getenv("RR_PGO_FLOW_EXACT") != nullptr;
     if (const char *e = getenv("RR_PGO_FLOW_TASKS")) flow_max_tasks_ = std::atoi(e);
-    if (const char *e = getenv("RR_PGO_FLOW_TILE4")) flow_tile4_min_ = std::atoi(e);
-    if (!(left_looking_ && fused_build_ && !panel128_ && !separate_diag32_ && !overlap_)) flow_max_nf_ = 0;
     build_flow_levels();
     n_lin_blocks_ = (int)(((int64_t)n_list_ * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
     edge_lin_ = getenv("RR_PGO_EDGE_LINEARIZE") != nullptr && !is3d_ && !sharded_ && g_.n_edges() > 0;
@@ -548,29 +509,15 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         std::vector<SnMeta> tm(sym.task_ptr.size() - 1);
         for (size_t t = 0; t + 1 < sym.task_ptr.size(); t++) tm[t] = meta[sym.task_sn[sym.task_ptr[t]]];
         task_meta_.upload(tm);
-        // all fronts beyond LDS, level after level: zeroed and assembled by ONE launch each per iteration (they
-        // only need the linearisation) instead of a pair of ~5 us launches on the chain of every level
-        std::vector<SnMeta> ba;
+        // k_big_panel32 / k_big_update / k_big_flow address a front with 32-bit BYTE offsets from its base
         for (const Step &st : sym.steps)
           if (st.kind == STEP_BIG)
             for (int t = st.task_begin; t < st.task_end; t++) {
               const int sn = sym.task_sn[sym.task_ptr[t]];
-              ba.push_back(meta[sn]);
-              big_all_maxM_ = std::max(big_all_maxM_, sym.sn_ncols[sn] + sym.sn_nrows[sn] + 1);
-              // k_big_panel32 / k_big_update address a front with 32-bit BYTE offsets from its base
-              if ((int64_t)(sym.sn_ncols[sn] + sym.sn_nrows[sn] + 1) * (sym.sn_ncols[sn] + sym.sn_nrows[sn] + 1) * (int64_t)sizeof(T) >= (1LL << 32))
+              const int64_t Mf = sym.sn_ncols[sn] + sym.sn_nrows[sn] + 1;
+              if (Mf * Mf * (int64_t)sizeof(T) >= (1LL << 32))
                 throw ApiError(RR_PGO_EUNSUPPORTED, "a front of more than 4 GiB exceeds the 32-bit addressing of the big-front kernels");
-              big_all_max_asm_ = std::max<int64_t>(big_all_max_asm_, std::max<int64_t>(sym.fasm_ptr[sn + 1] - sym.fasm_ptr[sn], sym.sn_ncols[sn]));
-              big_all_dup_ = big_all_dup_ || sym.fdup_ptr[sn + 1] > sym.fdup_ptr[sn];
             }
-        n_big_all_ = (int)ba.size();
-        if (n_big_all_ > 0) big_all_meta_.upload(ba);
-        // ... as long as all of them stay cache resident until they are used: zeroed a GB at a time (the 1M-edge
-        // lattice) the later levels come back from HBM and the step is 3-4 % slower than zeroing level by level
-        double big_bytes = 0.0;
-        for (const SnMeta &bm : ba) big_bytes += (double)(bm.nc + bm.nr + 1) * (bm.nc + bm.nr + 1) * sizeof(T);
-        big_all_small_ = n_big_all_ > 0 && big_bytes <= 192.0 * 1024 * 1024;
-        merged_head_ = !sharded_ && big_all_small_ && getenv("RR_PGO_SERIAL_ASSEMBLY") == nullptr;
       }
       if (wblk_total > 0x7fffff00LL) throw ApiError(RR_PGO_EUNSUPPORTED, "too many diagonal blocks");
       winv_.alloc((size_t)wblk_total * 256 + 4);
@@ -587,6 +534,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     sn_rows_.upload(sym.sn_rows);
     for (const Step &st : sym.steps) {
       int need = 0;
+      if (st.kind == STEP_MID) throw ApiError(RR_PGO_EUNSUPPORTED, "internal: the panel-in-LDS step class has no kernel (SymbolicOptions::panel_budget_elems must be 0)");
       if (st.kind == STEP_TASKS) {
         for (int t = st.task_begin; t < st.task_end; t++)
           for (int q = sym.task_ptr[t]; q < sym.task_ptr[t + 1]; q++) {
@@ -610,7 +558,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     configure_kernels();
     n_launches_per_iter = 2;
     for (const Step &st : sym.steps)
-      n_launches_per_iter += st.kind == STEP_BIG ? count_big_launches(st) + count_big_solve_launches(st) : st.kind == STEP_MID ? 4 : 2;
+      n_launches_per_iter += st.kind == STEP_BIG ? count_big_launches(st) + count_big_solve_launches(st) : 2;
   }
 
   ~Engine() override {
@@ -643,13 +591,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       std::vector<Item> items;
       std::vector<FlowFront> fronts(nf);
       double level_end = 0;
-      // 64 x 64 tiles first; a level that has thousands of them is generated again with 128 x 128 tiles
-      for (int TS = 64; TS <= 128; TS *= 2) {
-      if (TS == 128 && (int)items.size() < flow_tile4_min_) break;
-      lvl->nt = TS / 32;
+      constexpr int TS = 64;           // edge of a trailing-update tile (k_big_flow<T, 2>)
       words = lvl->ticket_word + 32;   // the ticket on a 128-byte line of its own
-      items.clear();
-      level_end = 0;
       for (int z = 0; z < nf; z++) {
         const int sn = sym_.task_sn[sym_.task_ptr[st.task_begin + z]];
         const int nc = sym_.sn_ncols[sn], M = nc + sym_.sn_nrows[sn] + 1;
@@ -725,7 +668,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
                 }
               }
               t = std::max(t, prev_tiles(I0, I0 + TS - 1, J0, J0 + TS - 1) + (sp > 0 ? kHop : 0.0));
-              const double fin = t + (TS == 64 ? kTile : 2.5 * kTile);
+              const double fin = t + kTile;
               tu[(size_t)sp * ustride + tri(bx, by)] = fin;
               level_end = std::max(level_end, fin);
               if (flow_exact_ && bx == 0 && by == 0 && t0 < nc) { tw[t0 / BIG_NB] = fin + kTail; level_end = std::max(level_end, fin + kTail); }
@@ -733,7 +676,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
             }
         }
       }
-      }   // tile sizes
       if ((int64_t)items.size() > flow_max_tasks_) { words = lvl->ticket_word; continue; }   // throughput-bound level: launch sequence (its flag words are given back)
       std::sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.start != y.start ? x.start < y.start : x.seq < y.seq; });
       std::vector<FlowTask> tasks(items.size());
@@ -789,8 +731,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     fa.winv = winv_.p;
     fa.err = err_.p;
     fa.trace = lvl.trace.p;
-    if (lvl.nt == 4) hipLaunchKernelGGL((k_big_flow<T, 4>), dim3((unsigned)std::min(lvl.n_tasks, flow_grid_)), dim3(256), 0, stream_, fa);
-    else hipLaunchKernelGGL((k_big_flow<T, 2>), dim3((unsigned)std::min(lvl.n_tasks, flow_grid_)), dim3(256), 0, stream_, fa);
+    hipLaunchKernelGGL((k_big_flow<T, 2>), dim3((unsigned)std::min(lvl.n_tasks, flow_grid_)), dim3(256), 0, stream_, fa);
     check_launch("k_big_flow");
   }
 
@@ -860,7 +801,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     set_lds_attr<512>();
     HIPCHK(hipFuncSetAttribute((const void *)k_factor_tasks<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
     HIPCHK(hipFuncSetAttribute((const void *)k_solve_mid<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-    HIPCHK(hipFuncSetAttribute((const void *)k_factor_panel<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
   }
 
   template <int TH> void launch_factor_tasks(int nt, size_t lds, const FactorArgs<T> &a) {
@@ -992,12 +932,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     pend(RR_PGO_K_LINEARIZE);
   }
 
-  void launch_factor() {
-    head_done_ = false;
-    launch_factor_range(0, sym_.steps.size());
-  }
+  void launch_factor() { launch_factor_range(0, sym_.steps.size()); }
   void launch_factor_range(size_t from, size_t to) {
-    if (from == 0) head_done_ = false;
     // tickets and completion flags of the flow levels (one small kernel per factorisation; flow.hip.h, k_flow_reset)
     if (any_flow(from, to)) {
       hipLaunchKernelGGL(k_flow_reset, dim3((unsigned)std::min<int64_t>(((int64_t)flow_flags_.n + 255) / 256, 1024)), dim3(256), 0, stream_,
@@ -1018,11 +954,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         else if (fth <= 512) launch_factor_tasks<512>(nt, lds, a);
         else launch_factor_tasks<1024>(nt, lds, a);
         pend(RR_PGO_K_FACTOR);
-      } else if (st.kind == STEP_MID) {
-        hipLaunchKernelGGL((k_factor_panel<T, 1024>), dim3(st.task_end - st.task_begin), dim3(1024), (size_t)st.max_lds_elems * sizeof(T), stream_,
-                           factor_args(st.task_begin));
-        check_launch("k_factor_panel");
-        pend(RR_PGO_K_MID_FACTOR);
       } else {
         launch_big_level(st, true);
         pend(RR_PGO_K_BIGFRONT);
@@ -1030,32 +961,24 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     }
   }
 
-  // Workgroup size of an LDS-front step.  The symbolic phase sizes it for the latency of ONE task (a 16-wave
-  // workgroup per front of > 128 rows).  A level with many more tasks than the chip has CUs is bound by task
-  // THROUGHPUT instead: smaller workgroups let several tasks share a CU (a 1024-thread workgroup at 128 VGPRs
-  // owns the whole CU), which hides each task's dependent chains behind the others.
-  int many_tasks_ = 1 << 30, many_threads_ = 256;   // RR_PGO_MANY_TASKS / RR_PGO_MANY_THREADS: measured SLOWER on the lattice
-                                                    // (5244 tasks: 690 us with 1024 threads, 873 with 512, 1045 with 256), off by default
-  int step_threads(const Step &st, int nt, int cap) const {
-    int th = std::min(st.threads, cap);
-    if (nt >= many_tasks_) th = std::min(th, many_threads_);
-    return th;
-  }
+  // Workgroup size of an LDS-front step: the symbolic phase sizes it for the latency of ONE task (a 16-wave workgroup per
+  // front of > 128 rows).  Smaller workgroups for levels of thousands of tasks were measured slower (r02, lattice, 5244
+  // tasks: 690 us with 1024 threads, 873 with 512, 1045 with 256).
+  int step_threads(const Step &st, int, int cap) const { return std::min(st.threads, cap); }
 
-  const Step *first_big_step() const {
-    for (const Step &st : sym_.steps)
-      if (st.kind == STEP_BIG) return &st;
-    return nullptr;
-  }
-
-  // The huge fronts of one level, batched: zero, assemble, extend-add (one launch per child rank),
-  // then per 128-column super-panel four (panel, inner update) pairs and one K=128 trailing update.
-  // do_launch == false only counts the launches.
+  // The fronts beyond LDS of one level, batched (grid y / z = front): ONE gather pass builds the pivot columns from
+  // the children (k_big_build) and adds the H entries and the right-hand side (k_big_assemble); then either the whole
+  // level as one dataflow launch (k_big_flow: levels of few fronts and few tasks), or per 128-column super-panel four
+  // left-looking k_big_panel32 launches and one K = 128 trailing update (k_big_update; the first one of a front gathers
+  // its tiles from the children, its tile (0, 0) factors and inverts the next super-panel's first diagonal block).
+  // do_launch == false only counts the launches.  (The r01 / r02 alternatives -- right-looking K = 32 steps, whole
+  // super-panels per chain step, the two-stream far update, zero + extend-add assembly, the one-workgroup panel class --
+  // were measured slower and removed in r03: profiles/EXPERIMENTS.md.)
   int launch_big_level(const Step &st, bool do_launch) {
     const FactorArgs<T> a = factor_args(st.task_begin);
     const int nf = st.task_end - st.task_begin;
-    int maxM = 0, max_nc = 0, max_kids = 0, n = 0;
-    int64_t max_asm = 0, max_ncu = 0;
+    int maxM = 0, max_nc = 0, n = 0;
+    int64_t max_asm = 0;
     bool any_dup = false;
     std::vector<int> fr(nf);
     for (int z = 0; z < nf; z++) {
@@ -1063,11 +986,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       fr[z] = s;
       maxM = std::max(maxM, sym_.sn_ncols[s] + sym_.sn_nrows[s] + 1);
       max_nc = std::max(max_nc, sym_.sn_ncols[s]);
-      max_kids = std::max(max_kids, sym_.child_ptr[s + 1] - sym_.child_ptr[s]);
       max_asm = std::max<int64_t>(max_asm, std::max<int64_t>(sym_.fasm_ptr[s + 1] - sym_.fasm_ptr[s], sym_.sn_ncols[s]));
       any_dup = any_dup || sym_.fdup_ptr[s + 1] > sym_.fdup_ptr[s];
-      for (int q = sym_.child_ptr[s]; q < sym_.child_ptr[s + 1]; q++)
-        max_ncu = std::max<int64_t>(max_ncu, sym_.sn_nrows[sym_.child_list[q]] + 1);
     }
     auto rows_max = [&](int from) {  // max over fronts still active at column `from` of (M - from)
       int r = 0;
@@ -1075,50 +995,16 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         if (sym_.sn_ncols[s] > from) r = std::max(r, sym_.sn_ncols[s] + sym_.sn_nrows[s] + 1 - from);
       return r;
     };
-    if (fused_build_) {
-      // one pass writes every entry of the level's fronts once: the sum of the children's contributions (gathered
-      // through inverse maps), zeros elsewhere; the H entries and the rhs are added on top
-      if (do_launch) {
-        hipLaunchKernelGGL(k_big_build<T>, dim3((unsigned)std::min(std::max(((gather_update_ ? std::min(maxM, ((max_nc + 127) / 128) * 128) : maxM) + 3) / 4, 1), 8192), nf), dim3(256), 0, stream_, a, gather_update_ ? 1 : 0);
-        check_launch("k_big_build");
-        hipLaunchKernelGGL(k_big_assemble<T>, dim3((unsigned)std::min<int64_t>((max_asm + 255) / 256, 2048), nf), dim3(256), 0, stream_, a, 1);
-        check_launch("k_big_assemble");
-        if (any_dup) hipLaunchKernelGGL(k_big_assemble_dup<T>, dim3(1, nf), dim3(64), 0, stream_, a);
-      }
-      n += 2 + (any_dup ? 1 : 0);
-    } else if (merged_head_) {
-      // every big front of every level in one zero and one assemble launch, at the first big level
-      const bool first_big = &st == first_big_step();
-      if (do_launch && !head_done_) {
-        FactorArgs<T> all = a;
-        all.task_meta = big_all_meta_.p;
-        all.task_begin = 0;
-        const unsigned znb = (unsigned)std::min(std::max((big_all_maxM_ + 3) / 4, 1), 8192);
-        hipLaunchKernelGGL(k_big_zero<T>, dim3(znb, n_big_all_), dim3(256), 0, stream_, all);
-        check_launch("k_big_zero");
-        hipLaunchKernelGGL(k_big_assemble<T>, dim3((unsigned)std::min<int64_t>((big_all_max_asm_ + 255) / 256, 2048), n_big_all_), dim3(256), 0, stream_, all, 0);
-        check_launch("k_big_assemble");
-        if (big_all_dup_) hipLaunchKernelGGL(k_big_assemble_dup<T>, dim3(1, n_big_all_), dim3(64), 0, stream_, all);
-        head_done_ = true;
-      }
-      if (first_big) n += 2 + (big_all_dup_ ? 1 : 0);
-    } else {
-      const unsigned znb = (unsigned)std::min(std::max((maxM + 3) / 4, 1), 8192);   // a wave per column, four per workgroup
-      if (do_launch) { hipLaunchKernelGGL(k_big_zero<T>, dim3(znb, nf), dim3(256), 0, stream_, a); check_launch("k_big_zero"); }
-      n++;
-      if (do_launch) hipLaunchKernelGGL(k_big_assemble<T>, dim3((unsigned)std::min<int64_t>((max_asm + 255) / 256, 2048), nf), dim3(256), 0, stream_, a, 0);
-      if (do_launch) check_launch("k_big_assemble");
-      n++;
-      if (any_dup) {
-        if (do_launch) hipLaunchKernelGGL(k_big_assemble_dup<T>, dim3(1, nf), dim3(64), 0, stream_, a);
-        n++;
-      }
+    // one pass writes every entry of the level's fronts once: the sum of the children's contributions (gathered
+    // through inverse maps), zeros elsewhere; the H entries and the rhs are added on top
+    if (do_launch) {
+      hipLaunchKernelGGL(k_big_build<T>, dim3((unsigned)std::min(std::max(((gather_update_ ? std::min(maxM, ((max_nc + 127) / 128) * 128) : maxM) + 3) / 4, 1), 8192), nf), dim3(256), 0, stream_, a, gather_update_ ? 1 : 0);
+      check_launch("k_big_build");
+      hipLaunchKernelGGL(k_big_assemble<T>, dim3((unsigned)std::min<int64_t>((max_asm + 255) / 256, 2048), nf), dim3(256), 0, stream_, a, 1);
+      check_launch("k_big_assemble");
+      if (any_dup) hipLaunchKernelGGL(k_big_assemble_dup<T>, dim3(1, nf), dim3(64), 0, stream_, a);
     }
-    for (int q = 0; q < (fused_build_ ? 0 : max_kids); q++) {
-      if (do_launch) hipLaunchKernelGGL(k_big_extend_add<T>, dim3((unsigned)std::min<int64_t>((max_ncu + 3) / 4, 2048), nf), dim3(256), 0, stream_, a, q);
-      if (do_launch) check_launch("k_big_extend_add");
-      n++;
-    }
+    n += 2 + (any_dup ? 1 : 0);
     if (gauge_ok_) {
       bool has_root = false;
       for (int s : fr) has_root = has_root || s == gauge_root_;
@@ -1127,7 +1013,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         n += 2;
       }
     }
-    if (do_launch) pend(RR_PGO_K_BIGFRONT);   // closes the zero / assemble / extend-add segment
+    if (do_launch) pend(RR_PGO_K_BIGFRONT);   // closes the build / assemble segment
     if (const FlowLevel *lvl = flow_of(st)) {
       // the whole panel chain and every trailing update of the level: ONE launch of ticket-ordered tasks
       if (do_launch) {
@@ -1139,112 +1025,32 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       return n + 1;
     }
     for (int K0 = 0; K0 < max_nc; K0 += BIG_SUPER) {
-      if (left_looking_ && panel128_) {
-        // the whole super-panel in two launches: its diagonal block in LDS (one workgroup per front), then
-        // all rows below for the four 32-column blocks at once
-        const int rb = rows_max(K0) - 1;
+      // left-looking inside the super-panel: ONE launch per 32 columns (update from the columns K0..kb, multiply by the
+      // inverse diagonal block, next diagonal block).  The level's first block is factored and inverted inside its own
+      // row launch (by every workgroup); the first block of a later super-panel comes out of the previous trailing update.
+      if (do_launch) pbegin();
+      const int k_end = std::min(K0 + BIG_SUPER, max_nc);
+      for (int kb = K0; kb < k_end; kb += BIG_NB) {
+        const int rb = rows_max(kb) - 1;
         if (do_launch) {
-          pbegin();
-          hipLaunchKernelGGL(k_big_diag128<T>, dim3(1, nf), dim3(512), 0, stream_, a, K0);
-          check_launch("k_big_diag128");
-          hipLaunchKernelGGL(k_big_trsm128<T>, dim3((std::max(rb, 1) + 127) / 128, nf), dim3(256), 0, stream_, a, K0);
-          check_launch("k_big_trsm128");
-          pend(RR_PGO_K_BIG_PANEL, 2);
-        }
-        n += 2;
-      } else if (left_looking_) {
-        // left-looking inside the super-panel: the first diagonal block, then ONE launch per 32 columns
-        // (update from the columns K0..kb, multiply by the inverse diagonal block, next diagonal block)
-        // the first diagonal block of a later super-panel comes out of the previous trailing update
-        if (do_launch) pbegin();
-        const bool sep_diag = K0 == 0 && separate_diag32_;
-        if (sep_diag) {
-          if (do_launch) {
-            hipLaunchKernelGGL(k_big_diag32<T>, dim3(1, nf), dim3(64), 0, stream_, a, K0);
-            check_launch("k_big_diag32");
-          }
-          n++;
-        }
-        for (int kb = K0; kb < std::min(K0 + BIG_SUPER, max_nc); kb += BIG_NB) {
-          const int rb = rows_max(kb) - 1;
-          if (do_launch) {
-            // the level's first block is factored and inverted inside its own row launch (by every workgroup)
-            hipLaunchKernelGGL(k_big_panel32<T>, dim3((std::max(rb, 1) + 31) / 32, nf), dim3(64), 0, stream_, a, kb, K0,
-                               (kb == 0 && !separate_diag32_) ? 1 : 0);
-            check_launch("k_big_panel32");
-          }
-          n++;
-        }
-        if (do_launch) pend(RR_PGO_K_BIG_PANEL, (sep_diag ? 1 : 0) + (std::min(K0 + BIG_SUPER, max_nc) - K0 + BIG_NB - 1) / BIG_NB);
-      } else
-      for (int kb = K0; kb < std::min(K0 + BIG_SUPER, max_nc); kb += BIG_NB) {
-        const int rb = rows_max(kb) - 1;   // rows below a 1..32 wide block, at least the rhs row
-        const int gp = (std::max(rb, 1) + BIG_PANEL_ROWS - 1) / BIG_PANEL_ROWS;
-        if (do_launch) {
-          pbegin();
-          hipLaunchKernelGGL(k_big_diag<T>, dim3(1, nf), dim3(256), 0, stream_, a, kb);
-          check_launch("k_big_diag");
-          hipLaunchKernelGGL(k_big_trsm<T>, dim3(gp, nf), dim3(256), 0, stream_, a, kb);
-          check_launch("k_big_trsm");
-          pend(RR_PGO_K_BIG_PANEL, 2);
-        }
-        n += 2;
-        if (kb + BIG_NB < std::min(K0 + BIG_SUPER, max_nc)) {
-          const int nti = (std::max(rb, 1) + 127) / 128;
-          if (do_launch) { pbegin(); hipLaunchKernelGGL((k_big_update<T, 4>), dim3(nti, 1, nf), dim3(256), 0, stream_, a, kb, 0, 0); check_launch("k_big_update/0"); pend(RR_PGO_K_BIG_UPDATE); }
-          n++;
-        }
-      }
-      const int diag_tail = (left_looking_ && !panel128_) ? 1 : 0;
-      const int rt = rows_max(K0);   // rows from K0 on; the trailing part starts after the super-panel
-      const int nti = (std::max(rt, 1) + 127) / 128;
-      const bool overlap = left_looking_ && overlap_ && !prof_.on && nti > 2 && nf <= overlap_max_nf_;
-      if (!overlap) {
-        if (do_launch) {
-          if (rest_pending_) { HIPCHK(hipStreamWaitEvent(stream_, ev_rest_, 0)); rest_pending_ = false; }
-          pbegin();
-          const int gu = (gather_update_ && K0 == 0) ? 1 : 0;
-          if ((int64_t)nf * nti * (nti + 1) / 2 < small_tile_below_) {
-            const int nt64 = (std::max(rt, 1) + 63) / 64;
-            // a launch of at most a few rounds of tiles is a chain of memory round trips per tile: deep prefetch
-            if ((int64_t)nf * nt64 * (nt64 + 1) / 2 <= deep_below_)
-              hipLaunchKernelGGL((k_big_update<T, 2, 8>), dim3(nt64, nt64, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail, gu, 0);
-            else   // the lower triangle of 64 x 64 tiles as a one-dimensional grid
-              hipLaunchKernelGGL((k_big_update<T, 2, RRPGO_UPD_DEPTH>), dim3(nt64 * (nt64 + 1) / 2, 1, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail, gu, 1);
-          } else {
-            hipLaunchKernelGGL((k_big_update<T, 4>), dim3(nti, nti, nf), dim3(256), 0, stream_, a, K0, 1, diag_tail, gu);
-          }
-          check_launch("k_big_update/1");
-          pend(RR_PGO_K_BIG_UPDATE);
+          hipLaunchKernelGGL(k_big_panel32<T>, dim3((std::max(rb, 1) + 31) / 32, nf), dim3(64), 0, stream_, a, kb, K0, kb == 0 ? 1 : 0);
+          check_launch("k_big_panel32");
         }
         n++;
-      } else {
-        // the columns of the NEXT super-panel on this stream (its panel chain waits for them); everything
-        // further right on the second stream, beside that chain.  The rest-updates run one after the
-        // other there; the next-columns update of a super-panel waits for the previous rest-update
-        // (same columns), and the level ends with a join.
-        if (do_launch) {
-          HIPCHK(hipEventRecord(ev_chain_, stream_));
-          HIPCHK(hipStreamWaitEvent(stream2_, ev_chain_, 0));
-          if (rest_pending_) HIPCHK(hipStreamWaitEvent(stream_, ev_rest_, 0));
-          const int nt64 = (std::max(rt, 1) + 63) / 64;
-          if ((int64_t)nf * nti * (nti + 1) / 2 < small_tile_below_)
-            hipLaunchKernelGGL((k_big_update<T, 2>), dim3(std::max(nt64 - 2, 1), std::max(nt64 - 2, 1), nf), dim3(256), 0, stream2_, a, K0, 3, 0);
-          else
-            hipLaunchKernelGGL((k_big_update<T, 4>), dim3(nti - 1, nti - 1, nf), dim3(256), 0, stream2_, a, K0, 3, 0);
-          check_launch("k_big_update/3");
-          HIPCHK(hipEventRecord(ev_rest_, stream2_));
-          rest_pending_ = true;
-          if ((int64_t)nf * nti * (nti + 1) / 2 < small_tile_below_)
-            hipLaunchKernelGGL((k_big_update<T, 2>), dim3(nt64, 2, nf), dim3(256), 0, stream_, a, K0, 2, diag_tail);
-          else
-            hipLaunchKernelGGL((k_big_update<T, 4>), dim3(nti, 1, nf), dim3(256), 0, stream_, a, K0, 2, diag_tail);
-          check_launch("k_big_update/2");
-        }
-        n += 2;
       }
+      if (do_launch) pend(RR_PGO_K_BIG_PANEL, (k_end - K0 + BIG_NB - 1) / BIG_NB);
+      // everything right of the super-panel, Schur complement included: the lower triangle of 64 x 64 tiles as a
+      // one-dimensional grid
+      if (do_launch) {
+        pbegin();
+        const int nt64 = (std::max(rows_max(K0), 1) + 63) / 64;
+        hipLaunchKernelGGL((k_big_update<T, 2, RRPGO_UPD_DEPTH>), dim3(nt64 * (nt64 + 1) / 2, 1, nf), dim3(256), 0, stream_, a, K0,
+                           (gather_update_ && K0 == 0) ? 1 : 0);
+        check_launch("k_big_update");
+        pend(RR_PGO_K_BIG_UPDATE);
+      }
+      n++;
     }
-    if (do_launch && rest_pending_) { HIPCHK(hipStreamWaitEvent(stream_, ev_rest_, 0)); rest_pending_ = false; }
     if (do_launch) pbegin();   // re-arm: the caller closes the level with pend(BIGFRONT)
     return n;
   }
@@ -1252,8 +1058,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   int count_big_solve_launches(const Step &st) const {
     int max_nc = 1;
     for (int t = st.task_begin; t < st.task_end; t++) max_nc = std::max(max_nc, sym_.sn_ncols[sym_.task_sn[sym_.task_ptr[t]]]);
-    if (left_looking_ && max_nc >= sp_solve_min_nc_) return 1 + (max_nc + BIG_SUPER - 1) / BIG_SUPER;
-    return left_looking_ ? 2 : 3;
+    if (max_nc >= sp_solve_min_nc_) return 1 + (max_nc + BIG_SUPER - 1) / BIG_SUPER;
+    return 2;
   }
 
   void launch_solve() {
@@ -1271,7 +1077,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         else launch_solve_tasks<512>(nt, lds, a);
         pend(RR_PGO_K_SOLVE);
       } else {
-        // t = y1 - L21^T x[rows] over the whole chip (two launches), then one workgroup per front for L11
+        // t = y1 - L21^T x[rows] over the whole chip, then L11: per 128-column super-panel over the chip (wide pivot blocks) or one workgroup per front
         const int nf = st.task_end - st.task_begin;
         int max_nc = 1;
         for (int z = 0; z < nf; z++) max_nc = std::max(max_nc, sym_.sn_ncols[sym_.task_sn[sym_.task_ptr[st.task_begin + z]]]);
@@ -1284,8 +1090,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         const FactorArgs<T> fa = factor_args(st.task_begin);
         hipLaunchKernelGGL(k_big_gemv_partial<T>, dim3(cb, R, nf), dim3(256), 0, stream_, fa, gemv_part_.p, (int64_t)g_.dim, R);
         check_launch("k_big_gemv_partial");
-        const int w32 = (st.kind == STEP_BIG && left_looking_) ? 1 : 0;
-        if (w32 && max_nc >= sp_solve_min_nc_) {
+        if (max_nc >= sp_solve_min_nc_) {
           // wide pivot blocks: one launch per 128-column super-panel, L11 read by the whole chip
           const int nsp = (max_nc + BIG_SUPER - 1) / BIG_SUPER;
           for (int ell = 0; ell < nsp; ell++) {
@@ -1295,12 +1100,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           pend(RR_PGO_K_BIG_SOLVE, 1 + nsp);
           continue;
         }
-        if (!w32) {
-          hipLaunchKernelGGL(k_big_gemv_finish<T>, dim3((max_nc + 255) / 256, nf), dim3(256), 0, stream_, fa, (const T *)gemv_part_.p, (int64_t)g_.dim, R);
-          check_launch("k_big_gemv_finish");
-        }
-        hipLaunchKernelGGL((k_solve_mid<T, 1024>), dim3(nf), dim3(1024), lds, stream_, fa, w32, (const T *)gemv_part_.p, (int64_t)g_.dim, R);
-        pend(RR_PGO_K_BIG_SOLVE, w32 ? 2 : 3);
+        hipLaunchKernelGGL((k_solve_mid<T, 1024>), dim3(nf), dim3(1024), lds, stream_, fa, 1, (const T *)gemv_part_.p, (int64_t)g_.dim, R);
+        pend(RR_PGO_K_BIG_SOLVE, 2);
       }
     }
   }
@@ -1789,10 +1590,7 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
     so.nd_leaf = big_leaf;
     so.pin_node = h->g.anchor_node;   // every rank needs the anchor's entries of the solution (gauge transfer)
   }
-  // experiment knob: fronts beyond LDS whose pivot panel (M x nc scalars) fits this budget get one workgroup each with
-  // the panel in LDS (k_factor_panel).  Measured on the 1M-edge lattice (fp32): 6.56 ms per step with 36000, 6.50 with
-  // 10000, against 6.44 without -- a lone CU spends 75..140 us on such a front, the batched tiled path wins.  Off.
-  if (const char *e = std::getenv("RR_PGO_PANEL_BUDGET")) so.panel_budget_elems = std::atoll(e);   // tuning knobs
+  // tuning knobs of the symbolic phase
   if (const char *e = std::getenv("RR_PGO_TASK_US")) so.task_us = std::atof(e);
   if (const char *e = std::getenv("RR_PGO_THREADS_SHIFT")) so.threads_shift = std::atoi(e);
   if (std::getenv("RR_PGO_NO_GEO")) so.geo_nd = false;

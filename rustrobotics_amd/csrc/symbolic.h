@@ -29,9 +29,9 @@ struct SymbolicOptions {
   int my_part = 0;          // with n_parts > 1: the rank whose schedule is emitted (own subtrees, then shared top)
   int pin_node = -1;        // with n_parts > 1: this node (the anchor) is made part of the top separator
   double task_us = 0.0;     // subtrees cheaper than this (model us) become one leaf task; 0 = pick by the cost model
-  int64_t panel_budget_elems = 0;  // fronts beyond LDS whose pivot PANEL (M x nc) still fits this many LDS scalars go to
-                                   // the one-workgroup panel class (STEP_MID: panel factored in LDS, Schur complement
-                                   // streamed to the in-place front); 0: none
+  int64_t panel_budget_elems = 0;  // must stay 0: fronts beyond LDS whose pivot panel fits this budget would form a step class of
+                                   // their own (STEP_MID); its kernel (r02's one-workgroup k_factor_panel) was measured slower
+                                   // than the batched tiled path and removed in r03 -- the engine rejects such steps
 };
 
 // One (block) entry of H that has to be added into a front.

@@ -25,9 +25,7 @@ int main(int argc, char **argv) {
     opt.lds_budget_elems = getenv("F64") ? 19000 : 38000;
     opt.nd_leaf = g.n_nodes() <= 6000 ? (1 << 30) : (getenv("F64") ? 32 : 48);
     opt.split_separators = g.n_nodes() > 6000;
-    opt.panel_budget_elems = getenv("F64") ? 18000 : 36000;
   }
-  if (getenv("PANEL")) opt.panel_budget_elems = atoll(getenv("PANEL"));
   Symbolic s;
   auto t0 = std::chrono::steady_clock::now();
   std::string e = analyze(g, opt, s);

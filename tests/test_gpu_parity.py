@@ -442,20 +442,15 @@ def test_levenberg_marquardt_through_the_big_front_path(api, oracle):
     assert _state_diff_se2(g.state(), o.state()) <= 1e-6
 
 
-@pytest.mark.parametrize("env", ["RR_PGO_RIGHT_LOOKING", "RR_PGO_OVERLAP", "RR_PGO_PANEL128", "RR_PGO_SEPARATE_DIAG32", "RR_PGO_SERIAL_ASSEMBLY",
-                                 "RR_PGO_SPLIT_ASSEMBLY", "RR_PGO_NO_GATHER_UPDATE", "RR_PGO_PANEL_BUDGET=18000",
+@pytest.mark.parametrize("env", ["RR_PGO_FLOW=0", "RR_PGO_FLOW_TASKS=100000000", "RR_PGO_FLOW_EXACT", "RR_PGO_NO_GATHER_UPDATE",
                                  "RR_PGO_EDGE_LINEARIZE"])
 def test_alternate_big_front_launch_sequences_agree(api, env, monkeypatch):
-    """The big-front path has switches read when a handle is created: the older right-looking launch
-    sequence (diag / trsm / K=32 update), the two-stream trailing update, whole 128-column
-    super-panels per chain step (diagonal block in LDS + one row launch), and a launch of its own for
-    the first diagonal block of a level (the default factors it inside the first row launch), and the older
-    assembly of the big fronts (zero, assemble, one read-modify-write extend-add launch per child -- level by level
-    with RR_PGO_SERIAL_ASSEMBLY, all levels' zero/assemble at once with RR_PGO_SPLIT_ASSEMBLY alone; the default is
-    k_big_build, one gather pass per level, pivot columns only -- RR_PGO_NO_GATHER_UPDATE builds whole fronts), and the
-    one-workgroup panel class (RR_PGO_PANEL_BUDGET: pivot panel factored in LDS, k_factor_panel; off by default).
-    Each must give the default path's answer on the 100 x 100 lattice (same
-    arithmetic up to the order of the block operations)."""
+    """The switches read when a handle is created that change WHICH kernels run: the launch-per-step sequence for every
+    level (RR_PGO_FLOW=0) or the dataflow launch for every level of at most 32 fronts (RR_PGO_FLOW_TASKS), its exact mode,
+    whole fronts built by k_big_build instead of gathered by the first trailing update, and the edge-parallel
+    linearisation.  Each must give the default path's answer on the 100 x 100 lattice (same arithmetic up to the order
+    of the block operations).  (The r01 / r02 alternatives of the big-front path were removed in r03 after losing every
+    measurement: profiles/EXPERIMENTS.md.)"""
     from rustrobotics_amd import synthetic_grid_arrays
     arrays = synthetic_grid_arrays(100, 100)
     ref = api[0].from_arrays(*arrays)
