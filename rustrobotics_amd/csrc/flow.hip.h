@@ -36,9 +36,9 @@ static_assert(sizeof(FlowFront) == 32, "FlowFront is one 32-byte record");
 
 struct FlowTask {        // 16 bytes, one scalar load
   int32_t kind_front;    // kind << 24 | front slot of the level
-  int32_t p0, p1, p2;    // PANEL: kb, first row block, K0;  UPDATE: K0, bx, by;  DIAG0, CHAIN: -
+  int32_t p0, p1, p2;    // PANEL: kb, first row block, K0;  UPDATE: K0, bx, by;  DIAG0: -
 };
-constexpr int FLOW_PANEL = 0, FLOW_UPDATE = 1, FLOW_DIAG0 = 2, FLOW_CHAIN = 3;
+constexpr int FLOW_PANEL = 0, FLOW_UPDATE = 1, FLOW_DIAG0 = 2;
 constexpr int FLOW_GROUP = 4;   // row blocks per PANEL task (one per wave)
 
 template <typename T> struct FlowArgs {   // everything the launch reads: a slim kernel-argument block (the ticket loop keeps all of it in SGPRs)
@@ -346,316 +346,6 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
   RRPGO_FLOW_MARK(fa, ticket, tid >> 6, 3);
 }
 
-// ---- CHAIN: one workgroup walks the whole panel chain of ONE front (fast mode) ------------------------------------
-// With every chain step drawn by another workgroup (PANEL tasks of row block 0), a step pays two global hops on top of
-// its arithmetic: X of the diagonal block's rows to the next step's left-looking part, W to the next step's multiply --
-// each a store drain, a flag, a poll and a load round trip (~2 us).  Here the rows that become diagonal blocks stay
-// in ONE workgroup and move through LDS:
-//   waves 0 / 1 (chain waves) own the diagonal blocks of even / odd index d.  The owner of block d handles its rows
-//       rho = [32 d, 32 d + 32) for two consecutive steps: as row block 1 of step d - 2 (phase A: X(rho, d - 2), kept in
-//       LDS) and as row block 0 of step d - 1 (phase B: the left-looking update whose newest term takes
-//       its own and the partner's X from LDS, then W(d - 1) from the partner's LDS image, X(rho, d - 1),
-//       the diagonal block, factor and invert: W(d) stays in its own image for the partner).  The two waves run one
-//       step apart, so everything but [W -> X -> diagonal block -> factor-and-invert] of a step runs under the
-//       partner's factor-and-invert.
-//   wave 2 (publisher) copies X and W from LDS to memory (sc1 stores), drains and sets the global flags the PANEL tasks
-//       of the other row blocks and the UPDATE tiles wait for: no store drain on the chain waves at all.
-// Sequence words in LDS order the three waves; every spin is bounded like flow_wait's.  PANEL tasks then start at row
-// block 2 (1, 0 for the last two blocks of a front).  Operands of a step's older blocks and its C tiles still come from
-// memory (they were written a step or more ago by other workgroups), requested ahead of use.
-constexpr int FLOW_CHAIN_XB = 2 * DIAG32_LDS;                  // X of the look wave, two steps: [col * 33 + row]
-constexpr int FLOW_CHAIN_XA = FLOW_CHAIN_XB + 2 * 32 * 33;    // X of phase A, two steps
-constexpr int FLOW_CHAIN_SEQ = FLOW_CHAIN_XA + 2 * 32 * 33;   // sequence words (unsigned)
-constexpr int FLOW_CHAIN_LDS = FLOW_CHAIN_SEQ + 16;           // scalars of LDS a CHAIN task uses
-enum { CH_XSEQ = 0, CH_WSEQ = 1, CH_ASEQ = 2, CH_PUBX = 3, CH_PUBW = 4 };
-
-__device__ __forceinline__ bool chain_wait(volatile unsigned *word, unsigned need, int *err) {
-  for (unsigned spins = 0;; spins++) {
-    if (*word >= need) break;
-    if ((spins & 255u) == 255u) {
-      const int e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (e != 0 || spins >= (RRPGO_FLOW_SPIN_MAX << 2)) {
-        if (e == 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicOr(err, DEVERR_FLOW_TIMEOUT);
-        return false;
-      }
-    }
-    __builtin_amdgcn_s_sleep(0);
-  }
-  asm volatile("" ::: "memory");
-  return true;
-}
-__device__ __forceinline__ void chain_post(volatile unsigned *word, unsigned value, int lane) {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes are done (they complete in order anyway)
-  if (lane == 0) *word = value;
-}
-
-#ifdef RRPGO_FLOW_TRACE
-#define RRPGO_CHAIN_MARK(fa, step, slot)                                                                                         \
-  do {                                                                                                                            \
-    if ((fa).trace && lane == 0 && chain_slot == 0 && (step) < 256) (fa).trace[(size_t)(fa).n_tasks * 16 + (size_t)(step) * 4 + (slot)] = wall_clock64(); \
-  } while (0)
-#else
-#define RRPGO_CHAIN_MARK(fa, step, slot) do { } while (0)
-#endif
-template <typename T, int TS>
-__device__ __forceinline__ void flow_chain_wave(const FlowArgs<T> &fa, const FlowFront &ff, const SnMeta &m, T *smem, int tid, int chain_slot) {
-  using MM = Mfma16<T>;
-  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int nc = m.nc, M = nc + m.nr + 1, nblk = (nc + BIG_NB - 1) / BIG_NB;
-  T *F = fa.lvals + m.loff;
-  constexpr uint32_t SZ = (uint32_t)sizeof(T);
-  const Sc1Buf<T> fbuf(F, (uint32_t)((int64_t)M * M * (int64_t)sizeof(T)));
-  T *Sh = smem + w * DIAG32_LDS, *ShP = smem + (1 - w) * DIAG32_LDS;
-  T *Xb = smem + FLOW_CHAIN_XB, *Xa = smem + FLOW_CHAIN_XA;
-  volatile unsigned *seq = reinterpret_cast<volatile unsigned *>(smem + FLOW_CHAIN_SEQ);
-  auto ldF = [&](int col, int row) { return fbuf.ld((uint32_t)(col * M + row) * SZ); };
-  auto wave_sync = [] {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  };
-  if (w == 0) {
-    // block 0: as assembled in F
-    const int nb = min(BIG_NB, nc);
-    T dv[16];
-#pragma unroll
-    for (int t = 0; t < 16; t++) {
-      const int e = t * 64 + lane, c = e >> 5, r = e & 31;
-      dv[t] = ldF(min(c, nb - 1), min(r, nb - 1));
-    }
-#pragma unroll
-    for (int t = 0; t < 16; t++) {
-      const int e = t * 64 + lane, c = e >> 5, r = e & 31;
-      Sh[c * 33 + r] = (r < nb && c < nb && r >= c) ? dv[t] : ((r == c && r >= nb) ? (T)1 : (T)0);
-    }
-    diag32_init_tables<T>(Sh);
-    wave_sync();
-    diag32_factor_invert<T, false, true>(Sh, nb, F, M, fa.winv, fa.err, false, false);
-    chain_post(seq + CH_WSEQ, 1u, lane);
-  }
-  // the update from the super-panel's blocks [b_lo, b_hi) whose operands come from memory: my rows (irow) and the rows of
-  // the diagonal block at kb, two register sets, the next block's loads in flight under this block's MFMAs
-  for (int d = 1 + ((w + 1) & 1); d < nblk; d += 2) {   // wave 0: 2, 4, ...; wave 1: 1, 3, ...
-#pragma unroll 1
-    for (int phase = (d >= 2 ? 0 : 1); phase < 2; phase++) {
-      const int j = phase == 0 ? d - 2 : d - 1;         // the step: block j is being factored's successor ... its columns are kb..kb+31
-      const int kb = BIG_NB * j, K0 = (kb / BIG_SUPER) * BIG_SUPER, q = (kb - K0) / BIG_NB, sp = K0 / BIG_SUPER;
-      const int rowblk = phase == 0 ? 1 : 0;
-      const int R0 = kb + BIG_NB + 32 * rowblk;         // = 32 d: my rows
-      const int kn = kb + BIG_NB;
-      const bool look = phase == 1;
-      const int n_mem = look ? max(q - 1, 0) : q;       // blocks of the left-looking update that come from memory
-      auto block_flag = [&](int jj, int which) -> const unsigned * {   // as in flow_panel_wave (whole blocks only here)
-        if (which == 2) return fa.flags + ff.pf + (j - jj) * ff.pstride + (jj - 1);
-        return which == 0 ? fa.flags + ff.pf + (j - jj) * ff.pstride + rowblk + jj : nullptr;
-      };
-      {
-        const unsigned *fp = nullptr;
-        if (lane < 9) {
-          const int jj = lane / 3 + (look ? 2 : 1);       // look: blocks j - 2, j - 3; phase A: j - 1, j - 2, j - 3
-          if (jj <= q) fp = block_flag(jj, lane % 3);
-        } else if (lane <= 10) {
-          const int bx = (R0 - K0) / TS + (lane - 9), bxe = (min(R0 + 31, M - 1) - K0) / TS;
-          if (sp > 0 && bx <= bxe) fp = fa.flags + ff.uf + (sp - 1) * ff.ustride + flow_tri(bx, (kb - K0) / TS);
-        } else if (lane == 11) {
-          const int dd = (kn - K0) / TS;
-          if (look && sp > 0) fp = fa.flags + ff.uf + (sp - 1) * ff.ustride + flow_tri(dd, dd);
-        }
-        flow_wait(fp, fa.err);
-      }
-      if (look) RRPGO_CHAIN_MARK(fa, j, 0);   // global dependencies met
-      int irow[2];
-      irow[0] = min(R0 + li, M - 1);
-      irow[1] = min(R0 + 16 + li, M - 1);
-      T av[1][8][2], bv[1][8][2];   // one register set: the chain waves have a step of slack for their memory blocks, registers they have not
-      const uint32_t colb = (uint32_t)((K0 + lk) * M) * SZ;
-      const uint32_t oa0 = colb + (uint32_t)(kb + li) * SZ, oa1 = colb + (uint32_t)(kb + 16 + li) * SZ;
-      const uint32_t ob0 = colb + (uint32_t)irow[0] * SZ, ob1 = colb + (uint32_t)irow[1] * SZ;
-      const uint32_t kstep = (uint32_t)(4 * M) * SZ;
-      auto fetch = [&](int b, T (*xa)[2], T (*xb)[2]) {
-        uint32_t dd = (uint32_t)(b * 8) * kstep;
-#pragma unroll
-        for (int s4 = 0; s4 < 8; s4++) {
-          xa[s4][0] = -fbuf.ld(oa0 + dd);
-          xa[s4][1] = -fbuf.ld(oa1 + dd);
-          xb[s4][0] = fbuf.ld(ob0 + dd);
-          xb[s4][1] = fbuf.ld(ob1 + dd);
-          dd += kstep;
-        }
-      };
-      typename MM::Acc acc[2][2], nxt[2][2];
-#pragma unroll
-      for (int jb = 0; jb < 2; jb++)
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-          for (int ib = 0; ib < 2; ib++) acc[ib][jb][r] = ldF(kb + 16 * jb + MM::row(lane, r), irow[ib]);
-      if (n_mem > 0) fetch(0, av[0], bv[0]);
-      if (look) {
-#pragma unroll
-        for (int jb = 0; jb < 2; jb++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int cn = min(kn + 16 * jb + MM::row(lane, r), M - 1);
-#pragma unroll
-            for (int ib = 0; ib < 2; ib++) nxt[ib][jb][r] = ldF(cn, irow[ib]);
-          }
-      }
-#pragma unroll
-      for (int b = 0; b < BIG_SUPER / BIG_NB - 1; b++) {
-        if (b < n_mem) {
-          constexpr int slot = 0;
-          if (b > 0) fetch(b, av[0], bv[0]);
-#pragma unroll
-          for (int s4 = 0; s4 < 8; s4++) {
-#pragma unroll
-            for (int ib = 0; ib < 2; ib++)
-#pragma unroll
-              for (int jb = 0; jb < 2; jb++) acc[ib][jb] = MM::mma(av[slot][s4][jb], bv[slot][s4][ib], acc[ib][jb]);
-            if (look) {
-#pragma unroll
-              for (int ib = 0; ib < 2; ib++)
-#pragma unroll
-                for (int jb = 0; jb <= ib; jb++) nxt[ib][jb] = MM::mma(-bv[slot][s4][jb], bv[slot][s4][ib], nxt[ib][jb]);
-            }
-          }
-        }
-      }
-      if (look && q >= 1) {
-        // newest block (j - 1): my rows' X from phase A's registers, the diagonal block's rows' X from the partner (LDS);
-        // a k-step = the four columns one accumulator register holds across the four lane groups
-        chain_wait(seq + CH_XSEQ, (unsigned)j, fa.err);
-        const T *xb = Xb + ((j - 1) & 1) * (32 * 33), *xm = Xa + ((j - 1) & 1) * (32 * 33);   // xm: my own phase A result (kept in LDS, not in registers)
-#pragma unroll
-        for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int col = 16 * cb + MM::row(lane, r);
-            const T a0 = -xb[col * 33 + li], a1 = -xb[col * 33 + 16 + li];
-            const T b0 = xm[col * 33 + li], b1 = xm[col * 33 + 16 + li];
-            acc[0][0] = MM::mma(a0, b0, acc[0][0]);
-            acc[0][1] = MM::mma(a1, b0, acc[0][1]);
-            acc[1][0] = MM::mma(a0, b1, acc[1][0]);
-            acc[1][1] = MM::mma(a1, b1, acc[1][1]);
-            nxt[0][0] = MM::mma(-b0, b0, nxt[0][0]);
-            nxt[1][0] = MM::mma(-b0, b1, nxt[1][0]);
-            nxt[1][1] = MM::mma(-b1, b1, nxt[1][1]);
-          }
-      }
-      // ---- the diagonal block's inverse: my own image (phase A: I factored block j myself) or the partner's
-      if (look) RRPGO_CHAIN_MARK(fa, j, 1);   // everything but W is done
-      if (look) chain_wait(seq + CH_WSEQ, (unsigned)(j + 1), fa.err);
-      if (look) RRPGO_CHAIN_MARK(fa, j, 2);   // W is here
-      const T *Wl = (look ? ShP : Sh) + 32 * 33;
-      T wv[3][4];
-#pragma unroll
-      for (int t = 0; t < 3; t++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int cb = t == 0 ? 0 : 1, jb = t == 2 ? 1 : 0;
-          wv[t][r] = Wl[(16 * jb + MM::row(lane, r)) * 33 + 16 * cb + li];
-        }
-      typename MM::Acc out[2][2];
-#pragma unroll
-      for (int ib = 0; ib < 2; ib++) {
-        out[ib][0] = typename MM::Acc{0, 0, 0, 0};
-        out[ib][1] = typename MM::Acc{0, 0, 0, 0};
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          out[ib][0] = MM::mma(wv[0][r], acc[ib][0][r], out[ib][0]);
-          out[ib][1] = MM::mma(wv[1][r], acc[ib][0][r], out[ib][1]);
-          out[ib][1] = MM::mma(wv[2][r], acc[ib][1][r], out[ib][1]);
-        }
-      }
-      // X to LDS for the partner and the publisher (the ring slot of two steps ago must have been copied out)
-      chain_wait(seq + CH_PUBX, (unsigned)max(j - 1, 0), fa.err);
-      T *xo = (look ? Xb : Xa) + (j & 1) * (32 * 33);
-#pragma unroll
-      for (int ib = 0; ib < 2; ib++)
-#pragma unroll
-        for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) xo[(16 * cb + MM::row(lane, r)) * 33 + 16 * ib + li] = out[ib][cb][r];
-      chain_post(seq + (look ? CH_XSEQ : CH_ASEQ), (unsigned)(j + 1), lane);
-      if (!look) continue;
-      // ---- next diagonal block (d): last term, image, factor and invert
-#pragma unroll
-      for (int cb = 0; cb < 2; cb++)
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-          for (int ib = 0; ib < 2; ib++)
-#pragma unroll
-            for (int jb = 0; jb <= ib; jb++) nxt[ib][jb] = MM::mma(-out[jb][cb][r], out[ib][cb][r], nxt[ib][jb]);
-      const int nbn = min(BIG_NB, nc - kn);
-      chain_wait(seq + CH_PUBW, (unsigned)max(d - 1, 0), fa.err);   // my previous W (block d - 2) has been copied out of this image
-      sh_image_from_acc<T>(Sh, nxt, nbn);
-      diag32_init_tables<T>(Sh);
-      wave_sync();
-      diag32_factor_invert<T, false, true>(Sh, nbn, F, M, fa.winv, fa.err, false, false);
-      chain_post(seq + CH_WSEQ, (unsigned)(d + 1), lane);
-      RRPGO_CHAIN_MARK(fa, j, 3);             // W of the next block posted
-    }
-  }
-}
-
-// wave 2 of a CHAIN task: LDS -> memory, then the flags the rest of the launch waits for
-template <typename T>
-__device__ __forceinline__ void flow_chain_publisher(const FlowArgs<T> &fa, const FlowFront &ff, const SnMeta &m, T *smem, int tid) {
-  const int lane = tid & 63;
-  const int nc = m.nc, M = nc + m.nr + 1, nblk = (nc + BIG_NB - 1) / BIG_NB;
-  T *F = fa.lvals + m.loff;
-  constexpr uint32_t SZ = (uint32_t)sizeof(T);
-  const Sc1Buf<T> fbuf(F, (uint32_t)((int64_t)M * M * (int64_t)sizeof(T)));
-  volatile unsigned *seq = reinterpret_cast<volatile unsigned *>(smem + FLOW_CHAIN_SEQ);
-  auto copy_w = [&](int d) {   // W(d): image of wave d & 1 -> winv slot d, in diag32_factor_invert's layout
-    const T *Wl = smem + (d & 1) * DIAG32_LDS + 32 * 33;
-    const Sc1Buf<T> wbuf(fa.winv + (int64_t)m.wblk * 256 + (int64_t)d * 1024, 1024u * SZ);
-    T wo[16];
-#pragma unroll
-    for (int t = 0; t < 16; t++) {
-      const int e = t * 64 + lane, c = e >> 5, r = e & 31;
-      wo[t] = Wl[c * 33 + r];
-    }
-#pragma unroll
-    for (int t = 0; t < 16; t++) wbuf.st((uint32_t)(t * 64 + lane) * SZ, wo[t]);
-  };
-  auto copy_x = [&](const T *xs, int kb, int R0) {   // a 32 x 32 block of X: columns kb.., rows R0.. (clipped at M)
-    T v[16];
-#pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = xs[(2 * t + (lane >> 5)) * 33 + (lane & 31)];
-#pragma unroll
-    for (int t = 0; t < 16; t++) {
-      const int col = 2 * t + (lane >> 5), row = R0 + (lane & 31);
-      if (row < M) fbuf.st((uint32_t)((kb + col) * M + row) * SZ, v[t]);
-    }
-  };
-  if (!chain_wait(seq + CH_WSEQ, 1u, fa.err)) return;
-  copy_w(0);
-  flow_drain();
-  if (lane == 0) { flow_flag_set(fa.flags + ff.wf); *(seq + CH_PUBW) = 1u; }
-  for (int s = 0; s + 1 < nblk; s++) {   // step s: look X (row block 0), phase A X (row block 1, when block s + 2 exists), then W(s + 1)
-    const int kb = BIG_NB * s;
-    if (!chain_wait(seq + CH_XSEQ, (unsigned)(s + 1), fa.err)) return;
-    copy_x(smem + FLOW_CHAIN_XB + (s & 1) * (32 * 33), kb, kb + 32);
-    const bool has_a = s + 2 < nblk;
-    if (has_a) {
-      if (!chain_wait(seq + CH_ASEQ, (unsigned)(s + 1), fa.err)) return;
-      copy_x(smem + FLOW_CHAIN_XA + (s & 1) * (32 * 33), kb, kb + 64);
-    }
-    flow_drain();
-    if (lane == 0) {
-      flow_flag_set(fa.flags + ff.pf + s * ff.pstride);
-      if (has_a) flow_flag_set(fa.flags + ff.pf + s * ff.pstride + 1);
-      *(seq + CH_PUBX) = (unsigned)(s + 1);
-    }
-    if (!chain_wait(seq + CH_WSEQ, (unsigned)(s + 2), fa.err)) return;
-    copy_w(s + 1);
-    flow_drain();
-    if (lane == 0) { flow_flag_set(fa.flags + ff.wf + s + 1); *(seq + CH_PUBW) = (unsigned)(s + 2); }
-  }
-}
-
 // Tickets and completion flags are zeroed by a KERNEL at the start of every factorisation, not by a memset node: inside
 // the captured stage graphs of a sharded handle a hipMemsetAsync node was not ordered before the kernels behind it on
 // replay (r03: the second replay of a stage found the first one's flags still set -- tasks did not wait, the ticket
@@ -681,8 +371,7 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
   using UT = UpdTile<T, NT>;
   constexpr int TS = UT::TILE;
   static_assert(UT::SMEM >= DIAG32_LDS, "one LDS region serves the tile staging and the diagonal-block images");
-  constexpr int SMEM = UT::SMEM > FLOW_CHAIN_LDS ? UT::SMEM : FLOW_CHAIN_LDS;
-  __shared__ T smem[SMEM];
+  __shared__ T smem[UT::SMEM];
   __shared__ unsigned s_ticket;
   for (;;) {
     // Everything a task derives from the thread index is derived from THIS copy: the compiler would otherwise hoist
@@ -703,14 +392,6 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
     const FlowFront ff = fa.fronts[slot];
     if (kind == FLOW_PANEL) {
       flow_panel_wave<T, TS>(fa, ff, m, tk.p0, tk.p2, tk.p1 + wave, smem, tid, t);
-      continue;
-    }
-    if (kind == FLOW_CHAIN) {
-      if (tid < 16) reinterpret_cast<unsigned *>(smem + FLOW_CHAIN_SEQ)[tid] = 0u;
-      __syncthreads();
-      if (wave < 2) flow_chain_wave<T, TS>(fa, ff, m, smem, tid, slot);
-      else if (wave == 2) flow_chain_publisher<T>(fa, ff, m, smem, tid);
-      RRPGO_FLOW_MARK(fa, t, wave, 3);
       continue;
     }
     if (kind == FLOW_DIAG0) {

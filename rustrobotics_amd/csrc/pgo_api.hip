@@ -267,7 +267,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
                                     // tile THROUGHPUT, where the batched k_big_update launches (7 workgroups per CU) beat the flow kernel's two
                                     // (measured on the 1M-edge lattice, r03: the levels of 1 and 2 fronts -- 1.4 k and 4.8 k tasks -- gain 25 %
                                     // and 13 %, the level of 4 fronts -- 18 k tasks -- ties, the levels of 8..32 fronts lose 10-20 %)
-  bool flow_chain_ = true;          // RR_PGO_FLOW_CHAIN=0: every chain step a PANEL task of its own (r03's first form) instead of one CHAIN task per front
   bool flow_exact_ = false;         // RR_PGO_FLOW_EXACT=1: bit-identical to the launch sequence (tile (0, 0) forms the next super-panel's first block)
   int flow_grid_ = 0;               // persistent workgroups of a flow launch (RR_PGO_FLOW_GRID; default CUs x RRPGO_FLOW_WAVES)
   // gauge transfer (single-precision factor, Gauss-Newton; kernels.hip.h "gauge transfer")
@@ -446,7 +445,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     gather_update_ = getenv("RR_PGO_NO_GATHER_UPDATE") == nullptr;
     if (const char *e = getenv("RR_PGO_FLOW")) flow_max_nf_ = std::atoi(e);
     flow_exact_ = getenv("RR_PGO_FLOW_EXACT") != nullptr;
-    if (const char *e = getenv("RR_PGO_FLOW_CHAIN")) flow_chain_ = std::atoi(e) != 0;
     if (const char *e = getenv("RR_PGO_FLOW_TASKS")) flow_max_tasks_ = std::atoi(e);
     build_flow_levels();
     n_lin_blocks_ = (int)(((int64_t)n_list_ * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
@@ -610,10 +608,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         // finish times of the cost model
         std::vector<double> tw(nblk + 1, 0.0), tp((size_t)nblk * pstride, 0.0), tu((size_t)nsp * ustride, 0.0);
         auto tri = [](int bx, int by) { return bx * (bx + 1) / 2 + by; };
-        // fast mode: ONE workgroup walks the front's whole chain (flow_chain_wave: row blocks 0 and 1 of every step, W and X
-        // through LDS); exact mode: the chain steps are PANEL tasks like any other row block, W(0) comes from a DIAG0 task
-        const bool chain = flow_chain_ && !flow_exact_;
-        items.push_back(Item{0.0, (int64_t)items.size(), FlowTask{((chain ? FLOW_CHAIN : FLOW_DIAG0) << 24) | z, 0, 0, 0}});
+        items.push_back(Item{0.0, (int64_t)items.size(), FlowTask{(FLOW_DIAG0 << 24) | z, 0, 0, 0}});
         tw[0] = kDiag;
         for (int sp = 0; sp < nsp; sp++) {
           const int K0 = sp * BIG_SUPER, ke = std::min(K0 + BIG_SUPER, nc);
@@ -629,16 +624,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           for (int kb = K0; kb < ke; kb += BIG_NB) {
             const int blk = kb / BIG_NB, q = (kb - K0) / BIG_NB, nb = std::min(BIG_NB, nc - kb), kn = kb + BIG_NB;
             const int nrb = (M - (kb + nb) + 31) / 32;
-            const int n_chain = chain ? (blk + 1 < nblk ? 1 : 0) + (blk + 2 < nblk ? 1 : 0) : 0;   // row blocks the CHAIN task covers
-            for (int g0 = 0; g0 < nrb; g0 = (g0 < n_chain ? n_chain : g0 + FLOW_GROUP)) {
-              const bool chain_rows = g0 < n_chain;   // pseudo-group: the chain's row blocks of this step (timed, not emitted)
-              const int gw = chain_rows ? n_chain : FLOW_GROUP;
+            for (int g0 = 0; g0 < nrb; g0 += FLOW_GROUP) {
               double start = 0;   // of the task = of its earliest wave; finish times per wave
               double wstart[FLOW_GROUP];
-              for (int w = 0; w < gw && g0 + w < nrb; w++) {
+              for (int w = 0; w < FLOW_GROUP && g0 + w < nrb; w++) {
                 const int rb = g0 + w, R0 = kb + nb + 32 * rb;
                 const bool look = rb == 0 && kn < (flow_exact_ ? ke : nc);
-                const double hopw = chain_rows ? 0.2 : kHop, pub = chain_rows ? 1.0 : 0.0;   // W through LDS; X reaches memory through the publisher
                 // the step starts with everything that needs neither W nor the newest block (blocks blk - 2, blk - 3 and
                 // the C tiles), then the newest block's term, then W (hop), then X; the look wave goes on with the next block
                 double t = 0.0, tnew = 0.0;
@@ -652,14 +643,14 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
                 t = std::max(t, prev_tiles(R0, R0 + 31, kb, kb + nb - 1) + (sp > 0 ? kHop : 0.0));
                 if (look) t = std::max(t, prev_tiles(kn, kn + 31, kn, kn + 31) + (sp > 0 ? kHop : 0.0));
                 wstart[w] = t;
-                double fin = std::max(std::max(t + (q > 1 ? kPre : 0.5), tnew) + (q > 0 ? kNewest : 0.0), tw[blk] + hopw) + (chain_rows ? 0.6 : kX);
-                tp[(size_t)blk * pstride + rb] = fin + pub;   // X is published before the look wave goes on
-                if (look) { fin += chain_rows ? 3.7 : kLook; tw[blk + 1] = fin + pub; }
+                double fin = std::max(std::max(t + (q > 1 ? kPre : 0.5), tnew) + (q > 0 ? kNewest : 0.0), tw[blk] + kHop) + kX;
+                tp[(size_t)blk * pstride + rb] = fin;   // X is published before the look wave goes on
+                if (look) { fin += kLook; tw[blk + 1] = fin; }
                 level_end = std::max(level_end, fin);
                 start = w == 0 ? t : std::min(start, t);
               }
               (void)wstart;
-              if (!chain_rows) items.push_back(Item{start, (int64_t)items.size(), FlowTask{(FLOW_PANEL << 24) | z, kb, g0, K0}});
+              items.push_back(Item{start, (int64_t)items.size(), FlowTask{(FLOW_PANEL << 24) | z, kb, g0, K0}});
             }
           }
           // trailing update of the super-panel: tiles of rows / columns >= ke
@@ -704,7 +695,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         flow_levels_[si]->fronts.upload(all_fronts[si]);
 #ifdef RRPGO_FLOW_TRACE
         flow_levels_[si]->host_tasks = all_tasks[si];
-        flow_levels_[si]->trace.alloc(all_tasks[si].size() * 16 + 1024);   // + the chain of front 0: [step][4]
+        flow_levels_[si]->trace.alloc(all_tasks[si].size() * 16);
         flow_levels_[si]->trace.zero();
 #endif
       }
@@ -1894,7 +1885,6 @@ extern "C" int64_t rr_pgo_debug_flow_trace(rr_pgo *h, int32_t level, int32_t *ta
     const int64_t m = std::min<int64_t>(n, cap_tasks);
     std::memcpy(tasks, t.data(), (size_t)m * 4 * sizeof(int32_t));
     std::memcpy(stamps, st.data(), (size_t)m * 16 * sizeof(unsigned long long));
-    if (m == n) std::memcpy(stamps + (size_t)n * 16, st.data() + (size_t)n * 16, 1024 * sizeof(unsigned long long));   // caller's buffer: n * 16 + 1024
   });
   return n;
 }

@@ -29,10 +29,8 @@ while True:
     if n < 0:
         break
     tasks = np.zeros((n, 4), np.int32)
-    raw = np.zeros(n * 16 + 1024, np.uint64)
-    L.rr_pgo_debug_flow_trace(g._h, lvl, tasks.ctypes.data, raw.ctypes.data, n, C.byref(nf), C.byref(est))
-    st = raw[:n * 16].reshape(n, 4, 4)
-    chain = raw[n * 16:].reshape(256, 4)
+    st = np.zeros((n, 4, 4), np.uint64)
+    L.rr_pgo_debug_flow_trace(g._h, lvl, tasks.ctypes.data, st.ctypes.data, n, C.byref(nf), C.byref(est))
     lvl += 1
     if only and (lvl - 1) not in only:
         continue
@@ -57,20 +55,6 @@ while True:
         d = (done[:, 1] - ready[:, 1])[upd]
         x = (t[:, 1, 2] - ready[:, 1])[upd]
         print(f'   UPDATE tiles: {upd.sum()}  ready->stored mean {x.mean():.2f} us  ready->flag mean {d.mean():.2f}  p95 {np.percentile(d, 95):.2f}')
-    if chain.any():
-        c = chain.astype(np.float64) * 0.01 - t0
-        steps = [i for i in range(256) if chain[i, 3] > 0]
-        print('   CHAIN task of front 0: step   deps-met  pre-done   W-in     W-out | pre-work  wait-W  W->W   step period')
-        prev = None
-        per = []
-        for i in steps:
-            r = c[i]
-            period = (r[3] - prev) if prev is not None else 0.0
-            per.append(period)
-            if i < 12 or i >= steps[-1] - 3:
-                print(f'      {i:4d} {r[0]:9.2f}{r[1]:9.2f}{r[2]:9.2f}{r[3]:9.2f} | {r[1]-r[0]:7.2f} {r[2]-r[1]:7.2f} {r[3]-r[2]:7.2f} {period:7.2f}')
-            prev = r[3]
-        print(f'   chain: {len(steps)} steps, last W at {c[steps[-1], 3]:.1f} us, mean period {np.mean(per[1:]):.2f} us, mean W->W {np.mean([c[i,3]-c[i,2] for i in steps]):.2f}, mean wait for W {np.mean([c[i,2]-c[i,1] for i in steps]):.2f}')
     # the chain of front 0: look waves (panel tasks with first row block 0, wave 0) and tile (0, 0)
     ch = []
     for i in range(n):
