@@ -156,14 +156,16 @@ def roofline_of(g, workload, precision, prof_iters=20):
     dom = max((k for k in per_iter_us if k != "reduce"), key=lambda k: per_iter_us[k])
     n_launch = prof[dom][1] / prof_iters
     dom_us = per_iter_us[dom]
-    if dom == "big_update":
-        # the rank updates of the huge fronts are dense contractions on the matrix cores
-        achieved = stats["big_update_flops"] / (dom_us * 1e-6) / 1e12
+    if dom in ("big_update", "big_flow"):
+        # the rank updates of the huge fronts are dense contractions on the matrix cores; k_big_flow is priced by the
+        # flops of its UPDATE tiles alone (its PANEL tasks -- the latency chain it exists for -- add none here)
+        dom_flops = stats["big_update_flops"] if dom == "big_update" else stats["big_flow_flops"]
+        achieved = dom_flops / (dom_us * 1e-6) / 1e12
         peak = MFMA_PEAK_TFLOPS[precision]
         roofline = {"bound": "mfma", "kernel": KERNEL_OF[dom], "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                     "frac": achieved / peak, "traffic": None, "launches_per_step": n_launch,
                     "avg_launch_us": dom_us / max(n_launch, 1),
-                    "algorithmic_flops_per_launch": stats["big_update_flops"] / max(n_launch, 1),
+                    "algorithmic_flops_per_launch": dom_flops / max(n_launch, 1),
                     "per_step_us_by_kernel_class": per_iter_us}
     else:
         # fronts beyond LDS share the factor/solve byte budget with the LDS fronts
@@ -186,7 +188,8 @@ def roofline_of(g, workload, precision, prof_iters=20):
         ent = pmc_entry(f"{workload}:{pkey}:{roofline['kernel']}")
     if ent and ent["kernel"] == roofline["kernel"]:
         roofline["traffic"] = ent["traffic_bytes_per_launch"]
-        roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)"
+        roofline["traffic_source"] = ("offline: profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of an "
+                                      "earlier run of the same kernels, FETCH doubled per MI355X_MICROARCH.md); NOT measured in this run")
     ent = pmc_entry(f"{workload}:{pkey}:k_big_update")
     if ent and mfma_kernel:
         # the dense trailing update against its OTHER roof: K = 128 columns per pass over the trailing matrix

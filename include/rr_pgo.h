@@ -175,7 +175,8 @@ typedef struct rr_pgo_stats {
   /* algorithmic bytes of one GN iteration by phase */
   double bytes_linearize, bytes_factor, bytes_solve, bytes_update, bytes_chi2;
   double big_update_flops;   /* flops (2 per multiply-add) of one iteration's k_big_update launches */
-  int32_t reserved[6];
+  double big_flow_flops;     /* the same count for the trailing-update tiles that run inside k_big_flow launches */
+  int32_t reserved[4];
 } rr_pgo_stats;
 int rr_pgo_get_stats(const rr_pgo *h, rr_pgo_stats *out);
 

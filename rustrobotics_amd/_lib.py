@@ -53,7 +53,7 @@ class Stats(C.Structure):
         ("analyze_ms", C.c_double), ("parse_ms", C.c_double),
         ("bytes_linearize", C.c_double), ("bytes_factor", C.c_double), ("bytes_solve", C.c_double),
         ("bytes_update", C.c_double), ("bytes_chi2", C.c_double), ("big_update_flops", C.c_double),
-        ("reserved", C.c_int32 * 6),
+        ("big_flow_flops", C.c_double), ("reserved", C.c_int32 * 4),
     ]
 
 

@@ -2187,21 +2187,34 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
 }
 
 // k_big_update: everything right of the super-panel at kb, Schur complement included (K <= 128), one 64 x 64 tile per
-// workgroup; the grid's x dimension enumerates the lower triangle of tiles, t = bx (bx + 1) / 2 + by (a square grid
-// launches as many workgroups again only to have them exit).  gather: the launch for a front's FIRST super-panel forms the
+// workgroup; tile t = bx (bx + 1) / 2 + by of a front's lower triangle of tiles.  gather: the launch for a front's FIRST super-panel forms the
 // tiles right of big_built_cols from the children instead of loading them (k_big_build was told to leave them out).
-template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_update(FactorArgs<T> a, int kb, int gather) {
+template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_update(FactorArgs<T> a, int kb, int gather, const int32_t *tile_map, int n_tiles, int xcd_remap) {
   using MM = Mfma16<T>;
   using UT = UpdTile<T, NT>;
   constexpr int TILE = UT::TILE;
   __shared__ T smem[UT::SMEM];
   RRPGO_TRACE_MARK(a, 101);
-  const int t = blockIdx.x;
+  // The launch is a one-dimensional grid over the level's REAL tiles (tile_map[v] = front slot << 16 | tile of the
+  // front's lower triangle, fronts one after the other, a front's tiles row by row).  Workgroups are dealt round-robin
+  // over the 8 XCDs in dispatch order and every XCD has an L2 of its own: with neighbouring tiles on different XCDs the
+  // two 32 KB operand strips of a tile are fetched from HBM by (almost) every tile that uses them.  xcd_remap gives
+  // XCD c the c-th CONTIGUOUS eighth of the tile list instead -- whole fronts, or runs of consecutive tile rows, share
+  // one L2, where a front's 128-column operand panel (<= 1 MB) stays resident; equal tile counts per XCD.
+  // Placement only: the arithmetic of a tile does not change (speed, never correctness: MI355X_MICROARCH.md).
+  unsigned v = blockIdx.x;
+  if (xcd_remap) {
+    const unsigned total = (unsigned)n_tiles, c = v & 7u, base = total >> 3, rem = total & 7u;
+    v = c * base + min(c, rem) + (v >> 3);
+  }
+  const int packed = tile_map[v];
+  const unsigned zq = (unsigned)packed >> 16;
+  const int t = packed & 0xffff;
   int bx = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
   while (bx * (bx + 1) / 2 > t) bx--;
   while ((bx + 1) * (bx + 2) / 2 <= t) bx++;
   const int by = t - bx * (bx + 1) / 2;
-  const SnMeta m = a.task_meta[a.task_begin + blockIdx.z];
+  const SnMeta m = a.task_meta[a.task_begin + zq];
   if (kb >= m.nc) return;
   const int M = m.nc + m.nr + 1;
   const int ke = min((kb / BIG_SUPER) * BIG_SUPER + BIG_SUPER, m.nc);
@@ -2211,7 +2224,7 @@ template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(2
   if (I0 >= M || J0 >= M) return;   // uniform over the workgroup
   T *F = a.lvals + m.loff;
   typename MM::Acc acc[NT][NT];
-  [[maybe_unused]] const bool pm = bx == 2 && by == 0 && blockIdx.z == 0;
+  [[maybe_unused]] const bool pm = bx == 2 && by == 0 && zq == 0;
   RRPGO_PHASE_MARK(a, pm, 600);
   TileGather<T> tg{nullptr, -1, nullptr, nullptr, nullptr, nullptr};
   if (gather && J0 >= big_built_cols(m.nc, M)) tg = TileGather<T>{a.child_meta + m.child_begin, m.child_count, a.scat, a.lvals, a.uvals, a.xch};

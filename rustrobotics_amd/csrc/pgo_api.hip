@@ -172,6 +172,7 @@ struct EngineBase {
   virtual void profile(int iters, double *ms, int64_t *launches) = 0;
   virtual hipStream_t stream() = 0;
   virtual void read_stamps(std::vector<unsigned long long> &out) = 0;
+  virtual void mark_flow_fronts(std::vector<char> &in_flow) = 0;   // fronts whose level runs as k_big_flow
   virtual int flow_trace(int level, std::vector<int32_t> &tasks, std::vector<unsigned long long> &stamps, int *nf, double *est_us) = 0;
   // sharded runs
   virtual void exchange_buffer(int which, void **ptr, int64_t *n, int32_t *esize) = 0;
@@ -248,6 +249,10 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   T *xch_ = nullptr, *x_ptr_ = nullptr;
   int solve_threads_max_ = 512;     // RR_PGO_SOLVE_THREADS=<n>: cap of the back-substitution workgroup size
   int factor_threads_max_ = 1024;   // 16-wave workgroups for steps whose fronts exceed 128 rows (RR_PGO_FACTOR_512=1: 8 waves)
+  struct UpdMap { int64_t offset; int n_tiles; };
+  std::vector<std::vector<UpdMap>> upd_maps_;   // [step][super-panel]: slice of upd_map_buf_ (k_big_update's tile list)
+  DevBuf<int32_t> upd_map_buf_;
+  bool xcd_remap_ = true;           // RR_PGO_XCD_REMAP=0: k_big_update's tiles in dispatch order instead of one contiguous eighth of the launch per XCD
   int sp_solve_min_nc_ = 256;       // back substitution: levels whose widest pivot block has at least this many columns run k_big_solve_sp (RR_PGO_SP_SOLVE_MIN)
   bool gather_update_ = true;       // big fronts: k_big_build builds the pivot columns only, a front's first trailing update gathers its tiles from the children (RR_PGO_NO_GATHER_UPDATE=1: whole fronts are built)
   // k_big_flow (flow.hip.h): levels of at most flow_max_nf_ big fronts run as ONE launch of ticket-ordered tile tasks
@@ -442,11 +447,13 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     factor_threads_max_ = getenv("RR_PGO_FACTOR_512") ? 512 : 1024;
     if (const char *e = getenv("RR_PGO_SOLVE_THREADS")) solve_threads_max_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_SP_SOLVE_MIN")) sp_solve_min_nc_ = std::atoi(e);
+    if (const char *e = getenv("RR_PGO_XCD_REMAP")) xcd_remap_ = std::atoi(e) != 0;
     gather_update_ = getenv("RR_PGO_NO_GATHER_UPDATE") == nullptr;
     if (const char *e = getenv("RR_PGO_FLOW")) flow_max_nf_ = std::atoi(e);
     flow_exact_ = getenv("RR_PGO_FLOW_EXACT") != nullptr;
     if (const char *e = getenv("RR_PGO_FLOW_TASKS")) flow_max_tasks_ = std::atoi(e);
     build_flow_levels();
+    build_update_maps();
     n_lin_blocks_ = (int)(((int64_t)n_list_ * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
     edge_lin_ = getenv("RR_PGO_EDGE_LINEARIZE") != nullptr && !is3d_ && !sharded_ && g_.n_edges() > 0;
     if (edge_lin_) n_lin_blocks_ = std::max(1, (g_.n_edges() + LIN_THREADS - 1) / LIN_THREADS);
@@ -705,6 +712,34 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     flow_grid_ = std::max(cus, 1) * (sizeof(T) == 4 ? RRPGO_FLOW_WAVES : 1);
     if (const char *e = getenv("RR_PGO_FLOW_GRID")) flow_grid_ = std::max(1, std::atoi(e));
   }
+  // k_big_update's grid: per level of the launch sequence and per super-panel the list of real tiles, front after front
+  void build_update_maps() {
+    upd_maps_.assign(sym_.steps.size(), {});
+    std::vector<int32_t> buf;
+    for (size_t si = 0; si < sym_.steps.size(); si++) {
+      const Step &st = sym_.steps[si];
+      if (st.kind != STEP_BIG || flow_levels_[si]) continue;
+      const int nf = st.task_end - st.task_begin;
+      if (nf > 0xffff) throw ApiError(RR_PGO_EUNSUPPORTED, "more than 65535 big fronts in one level");
+      int max_nc = 0;
+      for (int z = 0; z < nf; z++) max_nc = std::max(max_nc, sym_.sn_ncols[sym_.task_sn[sym_.task_ptr[st.task_begin + z]]]);
+      for (int K0 = 0; K0 < max_nc; K0 += BIG_SUPER) {
+        UpdMap um{(int64_t)buf.size(), 0};
+        for (int z = 0; z < nf; z++) {
+          const int sn = sym_.task_sn[sym_.task_ptr[st.task_begin + z]];
+          const int nc = sym_.sn_ncols[sn], M = nc + sym_.sn_nrows[sn] + 1;
+          if (K0 >= nc) continue;
+          const int t0 = std::min(K0 + BIG_SUPER, nc), nt = (M - t0 + 63) / 64;
+          if (nt * (nt + 1) / 2 > 0xffff) throw ApiError(RR_PGO_EUNSUPPORTED, "a front of more than 65535 update tiles");
+          for (int t = 0; t < nt * (nt + 1) / 2; t++) buf.push_back((z << 16) | t);
+        }
+        um.n_tiles = (int)((int64_t)buf.size() - um.offset);
+        upd_maps_[si].push_back(um);
+      }
+    }
+    if (!buf.empty()) upd_map_buf_.upload(buf);
+  }
+  const UpdMap &upd_map(const Step &st, int sp) const { return upd_maps_[(size_t)(&st - sym_.steps.data())][(size_t)sp]; }
   bool any_flow(size_t from, size_t to) const {
     for (size_t si = from; si < to && si < flow_levels_.size(); si++) if (flow_levels_[si]) return true;
     return false;
@@ -1039,13 +1074,13 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         n++;
       }
       if (do_launch) pend(RR_PGO_K_BIG_PANEL, (k_end - K0 + BIG_NB - 1) / BIG_NB);
-      // everything right of the super-panel, Schur complement included: the lower triangle of 64 x 64 tiles as a
-      // one-dimensional grid
+      // everything right of the super-panel, Schur complement included: the level's real 64 x 64 tiles as a
+      // one-dimensional grid (upd_maps_: front slot and tile of every grid index)
       if (do_launch) {
         pbegin();
-        const int nt64 = (std::max(rows_max(K0), 1) + 63) / 64;
-        hipLaunchKernelGGL((k_big_update<T, 2, RRPGO_UPD_DEPTH>), dim3(nt64 * (nt64 + 1) / 2, 1, nf), dim3(256), 0, stream_, a, K0,
-                           (gather_update_ && K0 == 0) ? 1 : 0);
+        const UpdMap &um = upd_map(st, K0 / BIG_SUPER);
+        hipLaunchKernelGGL((k_big_update<T, 2, RRPGO_UPD_DEPTH>), dim3((unsigned)um.n_tiles), dim3(256), 0, stream_, a, K0,
+                           (gather_update_ && K0 == 0) ? 1 : 0, (const int32_t *)upd_map_buf_.p + um.offset, um.n_tiles, xcd_remap_ ? 1 : 0);
         check_launch("k_big_update");
         pend(RR_PGO_K_BIG_UPDATE);
       }
@@ -1382,6 +1417,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     check_device_error();
   }
 
+  void mark_flow_fronts(std::vector<char> &in_flow) override {
+    for (size_t si = 0; si < flow_levels_.size(); si++)
+      if (flow_levels_[si])
+        for (int t = sym_.steps[si].task_begin; t < sym_.steps[si].task_end; t++) in_flow[sym_.task_sn[sym_.task_ptr[t]]] = 1;
+  }
   // diagnostic builds: the task list and the stamps of the `level`-th flow level (-1: no such level)
   int flow_trace(int level, std::vector<int32_t> &tasks, std::vector<unsigned long long> &stamps, int *nf, double *est_us) override {
     int k = 0;
@@ -1665,19 +1705,23 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
   s.bytes_solve = (double)y.l_elems * sz + 2.0 * dim * sz;
   s.bytes_update = 3.0 * dim * sz;
   (void)N;
-  // trailing updates of the huge fronts (k_big_update): a super-panel of w columns updates the lower
-  // triangle of the T rows to its right, w * T (T + 1) / 2 multiply-adds.  (The updates INSIDE a
-  // super-panel belong to the panel kernels and are not counted here.)
-  double buf = 0;
+  // trailing updates of the huge fronts: a super-panel of w columns updates the lower triangle of the T rows to its
+  // right, w * T (T + 1) / 2 multiply-adds -- counted for the launches of k_big_update and, separately, for the tiles
+  // that run inside k_big_flow launches.  (The updates INSIDE a super-panel belong to the panel kernels / PANEL tasks
+  // and are not counted here.)
+  double buf = 0, bflow = 0;
+  std::vector<char> in_flow(y.S, 0);
+  h->engine->mark_flow_fronts(in_flow);
   for (int f = 0; f < y.S; f++)
     if (y.sn_huge[f]) {
       const double M = y.sn_ncols[f] + y.sn_nrows[f] + 1;
       for (int k0 = 0; k0 < y.sn_ncols[f]; k0 += BIG_SUPER) {
         const double w = std::min<int>(BIG_SUPER, y.sn_ncols[f] - k0), T = M - (k0 + w);
-        buf += w * T * (T + 1);
+        (in_flow[f] ? bflow : buf) += w * T * (T + 1);
       }
     }
   s.big_update_flops = buf;
+  s.big_flow_flops = bflow;
 }
 
 }  // namespace
