@@ -1450,6 +1450,12 @@ constexpr int BIG_SUPER = RRPGO_BIG_SUPER;  // super-panel width = K of the big 
 // columns [0, big_built_cols) of a front are written by k_big_build when the first trailing update gathers the rest
 // from the children: the pivot columns, rounded up to the tile grid of that update (tiles start at column 128 when
 // nc > 128 and are 64 or 128 wide)
+// Schur origin of a front whose trailing updates are split (schur_split): rows / columns from here on are formed by ONE
+// pass of k_big_schur over all pivot columns.  A front of a single super-panel: nc (that pass is its only update);
+// else nc rounded up to the 64-grid the earlier super-panels' tiles share (their last tile column reaches to it).
+__device__ __host__ __forceinline__ int big_schur_origin(int nc) {
+  return nc <= BIG_SUPER ? nc : ((nc + 63) & ~63);
+}
 __device__ __host__ __forceinline__ int big_built_cols(int nc, int M) {
   const int r = ((nc + 127) / 128) * 128;
   return nc <= BIG_SUPER ? nc : (r < M ? r : M);
@@ -1947,7 +1953,7 @@ template <typename T> struct TileGather {
   const int32_t *scat;
   const T *lvals, *uvals, *xch;
 };
-template <typename T, int NT, int DEPTH = 1, bool SC1 = false>
+template <typename T, int NT, int DEPTH = 1, bool SC1 = false, bool LONGK = false>
 __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int jmax, int I0, int J0, T *smem,
                                                 typename Mfma16<T>::Acc (&acc)[NT][NT], unsigned long long *trace = nullptr, bool pm = false,
                                                 const TileGather<T> gather = TileGather<T>{nullptr, -1, nullptr, nullptr, nullptr, nullptr},
@@ -2156,7 +2162,40 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
       __syncthreads();
     }
   };
-  if (nk == BIG_SUPER) chunks(std::true_type{});
+  // LONGK (k_big_schur: the Schur complement of a front in ONE pass over all its pivot columns, K = nc): the same chunks
+  // in the same order as the super-panel by super-panel passes -- 128 is a multiple of the chunk -- as one running
+  // double-buffered pipeline of any length; the tile is loaded (or gathered) once and stored once.
+  auto chunks_long = [&] {
+    static_assert(!LONGK || DEPTH == 1, "the long pipeline keeps one chunk in flight");
+    stash(0, ra[0], rb[0]);
+    if (1 < nchunks) fetch(1, ra[0], rb[0]);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c++) {
+      const int buf = c & 1;
+      if (wave_active) {
+#pragma unroll
+        for (int s4 = 0; s4 < KC / 4; s4++) {
+          T av[NT], bv[NT];
+#pragma unroll
+          for (int q = 0; q < NT; q++) {
+            bv[q] = As[buf][4 * s4 + lk][wi + 16 * q + li];
+            av[q] = Bs[buf][4 * s4 + lk][wj + 16 * q + li];
+          }
+#pragma unroll
+          for (int ib = 0; ib < NT; ib++)
+#pragma unroll
+            for (int jb = 0; jb < NT; jb++) acc[ib][jb] = MM::mma(av[jb], bv[ib], acc[ib][jb]);
+        }
+      }
+      if (c + 1 < nchunks) {
+        stash(buf ^ 1, ra[0], rb[0]);
+        if (c + 2 < nchunks) fetch(c + 2, ra[0], rb[0]);
+      }
+      __syncthreads();
+    }
+  };
+  if constexpr (LONGK) chunks_long();
+  else if (nk == BIG_SUPER) chunks(std::true_type{});
   else chunks(std::false_type{});
   RRPGO_PHASE_MARK(a, pm, 602);
   if (!wave_active) return false;
@@ -2189,7 +2228,7 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
 // k_big_update: everything right of the super-panel at kb, Schur complement included (K <= 128), one 64 x 64 tile per
 // workgroup; tile t = bx (bx + 1) / 2 + by of a front's lower triangle of tiles.  gather: the launch for a front's FIRST super-panel forms the
 // tiles right of big_built_cols from the children instead of loading them (k_big_build was told to leave them out).
-template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_update(FactorArgs<T> a, int kb, int gather, const int32_t *tile_map, int n_tiles, int xcd_remap) {
+template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_update(FactorArgs<T> a, int kb, int gather, const int32_t *tile_map, int n_tiles, int xcd_remap, int schur_split) {
   using MM = Mfma16<T>;
   using UT = UpdTile<T, NT>;
   constexpr int TILE = UT::TILE;
@@ -2222,13 +2261,17 @@ template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(2
   static_assert(NT == 4 || NT == 2, "tile shapes");
   const int I0 = t0 + bx * TILE, J0 = t0 + by * TILE;
   if (I0 >= M || J0 >= M) return;   // uniform over the workgroup
+  // With the Schur complement left to k_big_schur (schur_split) a super-panel's update stops at the front's Schur
+  // origin: whole tile columns for every super-panel but the last, whose tile grid starts at nc -- it only owes the
+  // strip of columns [nc, origin) the earlier super-panels' last tile column reached into.
+  const int jmax = (schur_split && ke == m.nc) ? min(big_schur_origin(m.nc), M) : M;
   T *F = a.lvals + m.loff;
   typename MM::Acc acc[NT][NT];
   [[maybe_unused]] const bool pm = bx == 2 && by == 0 && zq == 0;
   RRPGO_PHASE_MARK(a, pm, 600);
   TileGather<T> tg{nullptr, -1, nullptr, nullptr, nullptr, nullptr};
   if (gather && J0 >= big_built_cols(m.nc, M)) tg = TileGather<T>{a.child_meta + m.child_begin, m.child_count, a.scat, a.lvals, a.uvals, a.xch};
-  if (!big_update_tile<T, NT, DEPTH>(F, M, kb, ke, M, I0, J0, smem, acc, a.trace, pm, tg)) return;
+  if (!big_update_tile<T, NT, DEPTH>(F, M, kb, ke, jmax, I0, J0, smem, acc, a.trace, pm, tg)) return;
   RRPGO_PHASE_MARK(a, pm, 603);
   // The first wave of the first tile holds the next super-panel's first diagonal block (rows = columns
   // = t0 .. t0+31) in acc[0..1][0..1]: after the tile is stored it factors and inverts that block here,
@@ -2248,6 +2291,39 @@ template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(2
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     diag32_factor_invert<T, false>(Sh, nbn, F + (int64_t)t0 * M + t0, M, a.winv + (int64_t)m.wblk * 256 + (int64_t)(t0 / BIG_NB) * 1024, a.err);
   }
+}
+
+// k_big_schur: the Schur complement of every front of a level in ONE pass, K = nc: tile (bx, by) of the front's trailing
+// square from its Schur origin on, C = [children's sum, gathered | what k_big_build left] - X[I, 0:nc] X[J, 0:nc]^T.  The
+// tile is touched once (r02: once per 128 pivot columns -- read, updated, written), the k loop is nc / 16 chunks long
+// instead of 8, and the sums are the same chunks in the same order: results are bit-identical to the pass-per-super-panel
+// form.  Same grid as k_big_update: the level's real tiles, XCD c takes the c-th contiguous eighth.
+template <typename T> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_schur(FactorArgs<T> a, int gather, const int32_t *tile_map, int n_tiles, int xcd_remap) {
+  using MM = Mfma16<T>;
+  using UT = UpdTile<T, 2>;
+  __shared__ T smem[UT::SMEM];
+  RRPGO_TRACE_MARK(a, 102);
+  unsigned v = blockIdx.x;
+  if (xcd_remap) {
+    const unsigned total = (unsigned)n_tiles, c = v & 7u, base = total >> 3, rem = total & 7u;
+    v = c * base + min(c, rem) + (v >> 3);
+  }
+  const int packed = tile_map[v];
+  const unsigned zq = (unsigned)packed >> 16;
+  const int t = packed & 0xffff;
+  int bx = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while (bx * (bx + 1) / 2 > t) bx--;
+  while ((bx + 1) * (bx + 2) / 2 <= t) bx++;
+  const int by = t - bx * (bx + 1) / 2;
+  const SnMeta m = a.task_meta[a.task_begin + zq];
+  const int M = m.nc + m.nr + 1;
+  const int o = big_schur_origin(m.nc);
+  const int I0 = o + bx * 64, J0 = o + by * 64;
+  if (I0 >= M || J0 >= M) return;
+  typename MM::Acc acc[2][2];
+  TileGather<T> tg{nullptr, -1, nullptr, nullptr, nullptr, nullptr};
+  if (gather && J0 >= big_built_cols(m.nc, M)) tg = TileGather<T>{a.child_meta + m.child_begin, m.child_count, a.scat, a.lvals, a.uvals, a.xch};
+  big_update_tile<T, 2, 1, false, true>(a.lvals + m.loff, M, 0, m.nc, M, I0, J0, smem, acc, nullptr, false, tg);
 }
 
 // Back substitution for one supernode:

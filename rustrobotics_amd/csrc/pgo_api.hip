@@ -251,6 +251,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   int factor_threads_max_ = 1024;   // 16-wave workgroups for steps whose fronts exceed 128 rows (RR_PGO_FACTOR_512=1: 8 waves)
   struct UpdMap { int64_t offset; int n_tiles; };
   std::vector<std::vector<UpdMap>> upd_maps_;   // [step][super-panel]: slice of upd_map_buf_ (k_big_update's tile list)
+  std::vector<UpdMap> schur_maps_;              // [step]: k_big_schur's tile list
+  bool schur_split_ = true;                     // RR_PGO_SCHUR_SPLIT=0: every super-panel's update reaches through the Schur complement (r02)
   DevBuf<int32_t> upd_map_buf_;
   bool xcd_remap_ = true;           // RR_PGO_XCD_REMAP=0: k_big_update's tiles in dispatch order instead of one contiguous eighth of the launch per XCD
   int sp_solve_min_nc_ = 256;       // back substitution: levels whose widest pivot block has at least this many columns run k_big_solve_sp (RR_PGO_SP_SOLVE_MIN)
@@ -448,6 +450,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (const char *e = getenv("RR_PGO_SOLVE_THREADS")) solve_threads_max_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_SP_SOLVE_MIN")) sp_solve_min_nc_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_XCD_REMAP")) xcd_remap_ = std::atoi(e) != 0;
+    if (const char *e = getenv("RR_PGO_SCHUR_SPLIT")) schur_split_ = std::atoi(e) != 0;
     gather_update_ = getenv("RR_PGO_NO_GATHER_UPDATE") == nullptr;
     if (const char *e = getenv("RR_PGO_FLOW")) flow_max_nf_ = std::atoi(e);
     flow_exact_ = getenv("RR_PGO_FLOW_EXACT") != nullptr;
@@ -712,9 +715,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     flow_grid_ = std::max(cus, 1) * (sizeof(T) == 4 ? RRPGO_FLOW_WAVES : 1);
     if (const char *e = getenv("RR_PGO_FLOW_GRID")) flow_grid_ = std::max(1, std::atoi(e));
   }
-  // k_big_update's grid: per level of the launch sequence and per super-panel the list of real tiles, front after front
+  // k_big_update's and k_big_schur's grids: per level of the launch sequence the list of real tiles, front after front
+  // -- per super-panel the tiles left of the Schur origin (schur_split_: the Schur complement is ONE pass of k_big_schur
+  // at the end of the level; else every tile right of the super-panel), and the Schur tiles themselves
   void build_update_maps() {
     upd_maps_.assign(sym_.steps.size(), {});
+    schur_maps_.assign(sym_.steps.size(), UpdMap{0, 0});
     std::vector<int32_t> buf;
     for (size_t si = 0; si < sym_.steps.size(); si++) {
       const Step &st = sym_.steps[si];
@@ -723,6 +729,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       if (nf > 0xffff) throw ApiError(RR_PGO_EUNSUPPORTED, "more than 65535 big fronts in one level");
       int max_nc = 0;
       for (int z = 0; z < nf; z++) max_nc = std::max(max_nc, sym_.sn_ncols[sym_.task_sn[sym_.task_ptr[st.task_begin + z]]]);
+      auto tri_ok = [](int nt) { if (nt * (nt + 1) / 2 > 0xffff) throw ApiError(RR_PGO_EUNSUPPORTED, "a front of more than 65535 update tiles"); };
       for (int K0 = 0; K0 < max_nc; K0 += BIG_SUPER) {
         UpdMap um{(int64_t)buf.size(), 0};
         for (int z = 0; z < nf; z++) {
@@ -730,11 +737,28 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           const int nc = sym_.sn_ncols[sn], M = nc + sym_.sn_nrows[sn] + 1;
           if (K0 >= nc) continue;
           const int t0 = std::min(K0 + BIG_SUPER, nc), nt = (M - t0 + 63) / 64;
-          if (nt * (nt + 1) / 2 > 0xffff) throw ApiError(RR_PGO_EUNSUPPORTED, "a front of more than 65535 update tiles");
-          for (int t = 0; t < nt * (nt + 1) / 2; t++) buf.push_back((z << 16) | t);
+          tri_ok(nt);
+          const int o = schur_split_ ? std::min(big_schur_origin(nc), M) : M;   // tiles whose first column is left of it
+          for (int bx = 0; bx < nt; bx++)
+            for (int by = 0; by <= bx; by++)
+              if (t0 + 64 * by < o) buf.push_back((z << 16) | (bx * (bx + 1) / 2 + by));
         }
         um.n_tiles = (int)((int64_t)buf.size() - um.offset);
         upd_maps_[si].push_back(um);
+      }
+      if (schur_split_) {
+        UpdMap um{(int64_t)buf.size(), 0};
+        for (int z = 0; z < nf; z++) {
+          const int sn = sym_.task_sn[sym_.task_ptr[st.task_begin + z]];
+          const int nc = sym_.sn_ncols[sn], M = nc + sym_.sn_nrows[sn] + 1;
+          const int o = big_schur_origin(nc);
+          if (o >= M) continue;
+          const int nt = (M - o + 63) / 64;
+          tri_ok(nt);
+          for (int t = 0; t < nt * (nt + 1) / 2; t++) buf.push_back((z << 16) | t);
+        }
+        um.n_tiles = (int)((int64_t)buf.size() - um.offset);
+        schur_maps_[si] = um;
       }
     }
     if (!buf.empty()) upd_map_buf_.upload(buf);
@@ -1076,15 +1100,31 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       if (do_launch) pend(RR_PGO_K_BIG_PANEL, (k_end - K0 + BIG_NB - 1) / BIG_NB);
       // everything right of the super-panel, Schur complement included: the level's real 64 x 64 tiles as a
       // one-dimensional grid (upd_maps_: front slot and tile of every grid index)
+      const UpdMap &um = upd_map(st, K0 / BIG_SUPER);
+      if (um.n_tiles == 0) continue;   // schur_split_: a level of single-super-panel fronts has no per-super-panel update at all
       if (do_launch) {
         pbegin();
-        const UpdMap &um = upd_map(st, K0 / BIG_SUPER);
         hipLaunchKernelGGL((k_big_update<T, 2, RRPGO_UPD_DEPTH>), dim3((unsigned)um.n_tiles), dim3(256), 0, stream_, a, K0,
-                           (gather_update_ && K0 == 0) ? 1 : 0, (const int32_t *)upd_map_buf_.p + um.offset, um.n_tiles, xcd_remap_ ? 1 : 0);
+                           (gather_update_ && K0 == 0) ? 1 : 0, (const int32_t *)upd_map_buf_.p + um.offset, um.n_tiles, xcd_remap_ ? 1 : 0,
+                           schur_split_ ? 1 : 0);
         check_launch("k_big_update");
         pend(RR_PGO_K_BIG_UPDATE);
       }
       n++;
+    }
+    {
+      // the Schur complements of the level's fronts: ONE pass over all pivot columns (K = nc), each tile written once
+      const UpdMap &um = schur_maps_[(size_t)(&st - sym_.steps.data())];
+      if (schur_split_ && um.n_tiles > 0) {
+        if (do_launch) {
+          pbegin();
+          hipLaunchKernelGGL(k_big_schur<T>, dim3((unsigned)um.n_tiles), dim3(256), 0, stream_, a, gather_update_ ? 1 : 0,
+                             (const int32_t *)upd_map_buf_.p + um.offset, um.n_tiles, xcd_remap_ ? 1 : 0);
+          check_launch("k_big_schur");
+          pend(RR_PGO_K_BIG_UPDATE);
+        }
+        n++;
+      }
     }
     if (do_launch) pbegin();   // re-arm: the caller closes the level with pend(BIGFRONT)
     return n;
