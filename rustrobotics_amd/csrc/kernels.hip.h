@@ -1452,9 +1452,9 @@ constexpr int BIG_SUPER = RRPGO_BIG_SUPER;  // super-panel width = K of the big 
 // nc > 128 and are 64 or 128 wide)
 // Schur origin of a front whose trailing updates are split (schur_split): rows / columns from here on are formed by ONE
 // pass of k_big_schur over all pivot columns.  A front of a single super-panel: nc (that pass is its only update);
-// else nc rounded up to the 64-grid the earlier super-panels' tiles share (their last tile column reaches to it).
-__device__ __host__ __forceinline__ int big_schur_origin(int nc) {
-  return nc <= BIG_SUPER ? nc : ((nc + 63) & ~63);
+// else nc rounded up to the tile grid the earlier super-panels' tiles share (their last tile columns reach to it).
+__device__ __host__ __forceinline__ int big_schur_origin(int nc, int tile) {   // tile: k_big_schur's tile edge, 64 or 128
+  return nc <= BIG_SUPER ? nc : ((nc + tile - 1) & ~(tile - 1));   // (with 128 this is big_built_cols: a tile is gathered or loaded as a whole)
 }
 __device__ __host__ __forceinline__ int big_built_cols(int nc, int M) {
   const int r = ((nc + 127) / 128) * 128;
@@ -2264,7 +2264,7 @@ template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(2
   // With the Schur complement left to k_big_schur (schur_split) a super-panel's update stops at the front's Schur
   // origin: whole tile columns for every super-panel but the last, whose tile grid starts at nc -- it only owes the
   // strip of columns [nc, origin) the earlier super-panels' last tile column reached into.
-  const int jmax = (schur_split && ke == m.nc) ? min(big_schur_origin(m.nc), M) : M;
+  const int jmax = (schur_split && ke == m.nc) ? min(big_schur_origin(m.nc, schur_split), M) : M;   // schur_split = k_big_schur's tile edge, 0 = none
   T *F = a.lvals + m.loff;
   typename MM::Acc acc[NT][NT];
   [[maybe_unused]] const bool pm = bx == 2 && by == 0 && zq == 0;
@@ -2298,9 +2298,10 @@ template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(2
 // tile is touched once (r02: once per 128 pivot columns -- read, updated, written), the k loop is nc / 16 chunks long
 // instead of 8, and the sums are the same chunks in the same order: results are bit-identical to the pass-per-super-panel
 // form.  Same grid as k_big_update: the level's real tiles, XCD c takes the c-th contiguous eighth.
-template <typename T> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_schur(FactorArgs<T> a, int gather, const int32_t *tile_map, int n_tiles, int xcd_remap) {
+template <typename T, int NT> __global__ void __launch_bounds__(256, (NT == 4 ? (sizeof(T) == 4 ? 2 : 1) : sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_schur(FactorArgs<T> a, int gather, const int32_t *tile_map, int n_tiles, int xcd_remap) {
   using MM = Mfma16<T>;
-  using UT = UpdTile<T, 2>;
+  using UT = UpdTile<T, NT>;
+  constexpr int TILE = UT::TILE;
   __shared__ T smem[UT::SMEM];
   RRPGO_TRACE_MARK(a, 102);
   unsigned v = blockIdx.x;
@@ -2317,13 +2318,14 @@ template <typename T> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? R
   const int by = t - bx * (bx + 1) / 2;
   const SnMeta m = a.task_meta[a.task_begin + zq];
   const int M = m.nc + m.nr + 1;
-  const int o = big_schur_origin(m.nc);
-  const int I0 = o + bx * 64, J0 = o + by * 64;
+  const int o = big_schur_origin(m.nc, TILE);
+  const int I0 = o + bx * TILE, J0 = o + by * TILE;
   if (I0 >= M || J0 >= M) return;
-  typename MM::Acc acc[2][2];
+  typename MM::Acc acc[NT][NT];
   TileGather<T> tg{nullptr, -1, nullptr, nullptr, nullptr, nullptr};
+  // a tile is gathered as a whole or loaded as a whole: with 128-wide tiles only those that start right of the built columns
   if (gather && J0 >= big_built_cols(m.nc, M)) tg = TileGather<T>{a.child_meta + m.child_begin, m.child_count, a.scat, a.lvals, a.uvals, a.xch};
-  big_update_tile<T, 2, 1, false, true>(a.lvals + m.loff, M, 0, m.nc, M, I0, J0, smem, acc, nullptr, false, tg);
+  big_update_tile<T, NT, 1, false, true>(a.lvals + m.loff, M, 0, m.nc, M, I0, J0, smem, acc, nullptr, false, tg);
 }
 
 // Back substitution for one supernode:

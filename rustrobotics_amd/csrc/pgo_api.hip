@@ -252,6 +252,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   struct UpdMap { int64_t offset; int n_tiles; };
   std::vector<std::vector<UpdMap>> upd_maps_;   // [step][super-panel]: slice of upd_map_buf_ (k_big_update's tile list)
   std::vector<UpdMap> schur_maps_;              // [step]: k_big_schur's tile list
+  static constexpr int schur_tile_ = 64;        // k_big_schur's tile edge (128 x 128 tiles, k_big_schur<T, 4>: measured 13 % slower, r03)
   bool schur_split_ = true;                     // RR_PGO_SCHUR_SPLIT=0: every super-panel's update reaches through the Schur complement (r02)
   DevBuf<int32_t> upd_map_buf_;
   bool xcd_remap_ = true;           // RR_PGO_XCD_REMAP=0: k_big_update's tiles in dispatch order instead of one contiguous eighth of the launch per XCD
@@ -738,7 +739,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           if (K0 >= nc) continue;
           const int t0 = std::min(K0 + BIG_SUPER, nc), nt = (M - t0 + 63) / 64;
           tri_ok(nt);
-          const int o = schur_split_ ? std::min(big_schur_origin(nc), M) : M;   // tiles whose first column is left of it
+          const int o = schur_split_ ? std::min(big_schur_origin(nc, schur_tile_), M) : M;   // tiles whose first column is left of it
           for (int bx = 0; bx < nt; bx++)
             for (int by = 0; by <= bx; by++)
               if (t0 + 64 * by < o) buf.push_back((z << 16) | (bx * (bx + 1) / 2 + by));
@@ -751,9 +752,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         for (int z = 0; z < nf; z++) {
           const int sn = sym_.task_sn[sym_.task_ptr[st.task_begin + z]];
           const int nc = sym_.sn_ncols[sn], M = nc + sym_.sn_nrows[sn] + 1;
-          const int o = big_schur_origin(nc);
+          const int o = big_schur_origin(nc, schur_tile_);
           if (o >= M) continue;
-          const int nt = (M - o + 63) / 64;
+          const int nt = (M - o + schur_tile_ - 1) / schur_tile_;
           tri_ok(nt);
           for (int t = 0; t < nt * (nt + 1) / 2; t++) buf.push_back((z << 16) | t);
         }
@@ -1106,7 +1107,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         pbegin();
         hipLaunchKernelGGL((k_big_update<T, 2, RRPGO_UPD_DEPTH>), dim3((unsigned)um.n_tiles), dim3(256), 0, stream_, a, K0,
                            (gather_update_ && K0 == 0) ? 1 : 0, (const int32_t *)upd_map_buf_.p + um.offset, um.n_tiles, xcd_remap_ ? 1 : 0,
-                           schur_split_ ? 1 : 0);
+                           schur_split_ ? schur_tile_ : 0);
         check_launch("k_big_update");
         pend(RR_PGO_K_BIG_UPDATE);
       }
@@ -1118,7 +1119,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       if (schur_split_ && um.n_tiles > 0) {
         if (do_launch) {
           pbegin();
-          hipLaunchKernelGGL(k_big_schur<T>, dim3((unsigned)um.n_tiles), dim3(256), 0, stream_, a, gather_update_ ? 1 : 0,
+          hipLaunchKernelGGL((k_big_schur<T, 2>), dim3((unsigned)um.n_tiles), dim3(256), 0, stream_, a, gather_update_ ? 1 : 0,
                              (const int32_t *)upd_map_buf_.p + um.offset, um.n_tiles, xcd_remap_ ? 1 : 0);
           check_launch("k_big_schur");
           pend(RR_PGO_K_BIG_UPDATE);
