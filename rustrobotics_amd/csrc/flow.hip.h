@@ -464,4 +464,198 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
   }
 }
 
+// ---- k_big_solve_flow: the back substitution of a level's WIDE pivot blocks as ONE launch ---------------------------
+// k_big_solve_sp is one launch per 128-column super-panel, right to left: workgroup 0 of a front solves the super-panel,
+// the others fold the solution of the super-panel to its right into the columns further left -- 12 dependent launches of
+// 7.9 us for the lattice's root, 41 per iteration in all.  Here the same steps are tasks of one launch, drawn from a
+// ticket like k_big_flow's: CHAIN(front, step) solves a super-panel and publishes its x, FOLD(front, group, step) applies
+// the x of the super-panel to the right to 64 columns further left.  Two counters per front order them: xdone
+// (super-panels solved) and fdone[g] (folds group g has applied, incl. the initialisation at step 0); a chain step
+// waits for the two groups that cover its 128 columns -- their folds used the x of the step before last, so they have
+// had a whole chain step.  The list is ordered by step (chain first, then the folds nearest to the diagonal), so every
+// task waits only for smaller tickets: no deadlock whatever the grid size or what else runs on the GPU (several handles
+// may replay such launches side by side).  Same arithmetic, same order of every sum as k_big_solve_sp: bit-identical.
+// Payload (x, 128 values per step) with sc1 accesses, counters with agent-scope atomics after a drain; bounded spins.
+struct SolveFlowFront { int32_t xdone, fdone; };   // indices into the flag words: xdone; fdone + g
+struct SolveFlowTask { int32_t front, ell, group; };   // group < 0: CHAIN
+__device__ __forceinline__ bool solve_flow_wait(const unsigned *word, unsigned need, int *err) {
+  bool ok = true;
+  for (unsigned spins = 0;; spins++) {
+    if (flow_flag_ld(word) >= need) break;
+    if ((spins & 63u) == 63u) {
+      const int e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e != 0 || spins >= RRPGO_FLOW_SPIN_MAX) {
+        if (e == 0) atomicOr(err, DEVERR_FLOW_TIMEOUT);
+        ok = false;
+        break;
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  return ok;
+}
+template <typename T> __global__ void __launch_bounds__(1024) k_big_solve_flow(FactorArgs<T> a, const T *part, int64_t N, int R, unsigned *flags,
+                                                                             const SolveFlowFront *fronts, const SolveFlowTask *tasks, int n_tasks,
+                                                                             unsigned *ticket) {
+  __shared__ T xf[BIG_SUPER];              // this super-panel: t, then x
+  __shared__ T Ws[4 * 32 * 33];            // the super-panel's four W_b, staged transposed
+  __shared__ unsigned s_ticket;
+  constexpr int NW = 16;
+  constexpr uint32_t SZ = (uint32_t)sizeof(T);
+  for (;;) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    if (tid == 0) s_ticket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int tk = __builtin_amdgcn_readfirstlane((int)s_ticket);
+    __syncthreads();
+    if (tk >= n_tasks) return;
+    const SolveFlowTask task = tasks[tk];
+    const SnMeta m = a.task_meta[a.task_begin + task.front];
+    const SolveFlowFront sf = fronts[task.front];
+    const int nc = m.nc, M = nc + m.nr + 1;
+    const int S = (nc + BIG_SUPER - 1) / BIG_SUPER;
+    const T *Lg = a.lvals + m.loff;
+    T *xg = a.x + m.col0;
+    const Sc1Buf<T> xbuf(xg, (uint32_t)nc * SZ);
+    auto t_init = [&](int j) {   // y1 - L21^T x[rows], slices subtracted in slice order
+      T t = Lg[(int64_t)j * M + (M - 1)];
+      if (m.nr > 0)
+        for (int r = 0; r < R; r++) t -= part[(int64_t)r * N + m.col0 + j];
+      return t;
+    };
+    unsigned *xdone = flags + sf.xdone;
+    const int ell = task.ell, sp = S - 1 - ell;
+    const int K0 = BIG_SUPER * sp, K1 = min(nc, K0 + BIG_SUPER), K2 = min(nc, K1 + BIG_SUPER);
+    const int nright = K2 - K1;   // rows of the super-panel to the right (ell > 0)
+    if (task.group >= 0) {
+      // ---- FOLD: 64 columns left of the current super-panel, 4 per wave
+      const int g = task.group, c_lo = 64 * g, c_hi = min(K0, c_lo + 64);
+      unsigned *fdone = flags + sf.fdone + g;
+      if (ell == 0) {
+        for (int j = c_lo + tid; j < c_hi; j += 1024) xbuf.st((uint32_t)j * SZ, t_init(j));
+      } else {
+        // the fold operands do not depend on the solution: request them before the wait
+        T la[4], lb[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int i = min(c_lo + wave + NW * q, c_hi - 1);
+          const T *col = Lg + (int64_t)i * M + K1;
+          la[q] = col[min(lane, nright - 1)];
+          lb[q] = col[min(lane + 64, nright - 1)];
+        }
+        if (wave == 0) {
+          solve_flow_wait(xdone, (unsigned)ell, a.err);   // x of the super-panel to the right
+          solve_flow_wait(fdone, (unsigned)ell, a.err);   // this group's previous fold (another workgroup may have run it): the sums go in step order
+        }
+        __syncthreads();
+        const T va = xbuf.ld((uint32_t)(K1 + min(lane, nright - 1)) * SZ), vb = xbuf.ld((uint32_t)(K1 + min(lane + 64, nright - 1)) * SZ);
+        const T xa = lane < nright ? va : (T)0, xb = lane + 64 < nright ? vb : (T)0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int i = c_lo + wave + NW * q;
+          const T sum = wave_sum63<T>(la[q] * xa + lb[q] * xb);
+          if (lane == 63 && i < c_hi) xbuf.st((uint32_t)i * SZ, xbuf.ld((uint32_t)i * SZ) - sum);
+        }
+      }
+      flow_drain();
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(fdone, (unsigned)(ell + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
+    // ---- CHAIN: this super-panel.  Every load whose address does not depend on a solution is requested up front
+    const T *Wb = a.winv + (int64_t)m.wblk * 256;
+    const bool have_right = sp + 1 < S;
+    const int w = K1 - K0;
+    const int b_hi = (K1 + 31) / 32 - 1, b_lo = K0 / 32;
+    T fa_[8], fb_[8];
+    if (have_right) {
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const T *col = Lg + (int64_t)(K0 + min(wave + NW * c, w - 1)) * M + K1;
+        fa_[c] = col[min(lane, nright - 1)];
+        fb_[c] = col[min(lane + 64, nright - 1)];
+      }
+    }
+    T wreg[4], lv[4][3];
+#pragma unroll
+    for (int bb = 0; bb < 4; bb++) {
+      const int b = max(b_hi - bb, b_lo);
+      wreg[bb] = Wb[(int64_t)b * 1024 + tid];
+      const int c0 = 32 * b, cw = min(32, nc - c0), ncols = c0 - K0;
+      const T *base = Lg + c0 + min(l32, cw - 1);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int i = 2 * (wave + NW * q) + half;
+        lv[bb][q] = base[(int64_t)(K0 + min(i, max(ncols - 1, 0))) * M];
+      }
+    }
+    // the previous super-panel's x, and the folds of the steps before last into my 128 columns (groups K0 / 64, K0 / 64 + 1)
+    if (ell > 0 && wave == 0) {
+      solve_flow_wait(xdone, (unsigned)ell, a.err);
+      solve_flow_wait(flags + sf.fdone + K0 / 64, (unsigned)ell, a.err);
+      if (K0 + 64 < K1) solve_flow_wait(flags + sf.fdone + K0 / 64 + 1, (unsigned)ell, a.err);
+    }
+    __syncthreads();
+    T xa = 0, xb = 0;
+    if (have_right) {
+      const T va = xbuf.ld((uint32_t)(K1 + min(lane, nright - 1)) * SZ), vb = xbuf.ld((uint32_t)(K1 + min(lane + 64, nright - 1)) * SZ);
+      xa = lane < nright ? va : (T)0;
+      xb = lane + 64 < nright ? vb : (T)0;
+    }
+    if (tid < w) xf[tid] = ell == 0 ? t_init(K0 + tid) : xbuf.ld((uint32_t)(K0 + tid) * SZ);
+#pragma unroll
+    for (int bb = 0; bb < 4; bb++) {
+      const int c = tid >> 5, j = tid & 31;
+      Ws[bb * (32 * 33) + j * 33 + c] = wreg[bb];
+    }
+    __syncthreads();
+    if (have_right) {
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const int i = wave + NW * c;
+        const T sum = wave_sum63<T>(fa_[c] * xa + fb_[c] * xb);
+        if (lane == 63 && i < w) xf[i] -= sum;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int bb = 0; bb < 4; bb++) {
+      const int b = b_hi - bb;
+      if (b < b_lo) break;   // uniform
+      const int c0 = 32 * b, cw = min(32, nc - c0), o = c0 - K0, ncols = c0 - K0;
+      if (tid < 64) {
+        const T *ws = Ws + bb * (32 * 33) + l32;
+        const T tv = pin(xf[o + min(l32, cw - 1)]);
+        const T v = l32 < cw ? tv : (T)0;
+        T wv[32];
+#pragma unroll
+        for (int j = 0; j < 32; j++) wv[j] = ws[j * 33];
+        T x = 0;
+#pragma unroll
+        for (int j = 0; j < 32; j++) x += wv[j] * lane_bcast(v, j);
+        if (lane < cw) xf[o + lane] = x;
+      }
+      __syncthreads();
+      if (ncols > 0) {   // uniform
+        const T xv = pin(xf[o + min(l32, cw - 1)]);
+        const T xj = l32 < cw ? xv : (T)0;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const int i = 2 * (wave + NW * q) + half;
+          const T sum = half_wave_sum<T>(lv[bb][q] * xj);
+          if (l32 == 31 && i < ncols) xf[i] -= sum;
+        }
+        __syncthreads();
+      }
+    }
+    if (tid < w) xbuf.st((uint32_t)(K0 + tid) * SZ, xf[tid]);
+    flow_drain();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(xdone, (unsigned)(ell + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 }  // namespace rrpgo

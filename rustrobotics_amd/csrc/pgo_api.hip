@@ -276,6 +276,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
                                     // (measured on the 1M-edge lattice, r03: the levels of 1 and 2 fronts -- 1.4 k and 4.8 k tasks -- gain 25 %
                                     // and 13 %, the level of 4 fronts -- 18 k tasks -- ties, the levels of 8..32 fronts lose 10-20 %)
   bool flow_exact_ = false;         // RR_PGO_FLOW_EXACT=1: bit-identical to the launch sequence (tile (0, 0) forms the next super-panel's first block)
+  struct SolveFlowLevel { DevBuf<SolveFlowFront> fronts; DevBuf<SolveFlowTask> tasks; int n_tasks = 0; int64_t ticket_word = 0; };
+  std::vector<std::unique_ptr<SolveFlowLevel>> solve_flow_;   // per step: k_big_solve_flow's tasks and counters (null: k_big_solve_sp launches)
+  bool solve_flow_on_ = true;       // RR_PGO_SOLVE_FLOW=0: one k_big_solve_sp launch per 128 columns
   int flow_grid_ = 0;               // persistent workgroups of a flow launch (RR_PGO_FLOW_GRID; default CUs x RRPGO_FLOW_WAVES)
   // gauge transfer (single-precision factor, Gauss-Newton; kernels.hip.h "gauge transfer")
   bool gauge_ok_ = false;            // the root front is a big front with an SE2 pivot node
@@ -456,6 +459,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (const char *e = getenv("RR_PGO_FLOW")) flow_max_nf_ = std::atoi(e);
     flow_exact_ = getenv("RR_PGO_FLOW_EXACT") != nullptr;
     if (const char *e = getenv("RR_PGO_FLOW_TASKS")) flow_max_tasks_ = std::atoi(e);
+    if (const char *e = getenv("RR_PGO_SOLVE_FLOW")) solve_flow_on_ = std::atoi(e) != 0;
     build_flow_levels();
     build_update_maps();
     n_lin_blocks_ = (int)(((int64_t)n_list_ * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
@@ -587,7 +591,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   // order -- all the ticket scheme needs -- and roughly the order in which tasks become ready.
   void build_flow_levels() {
     flow_levels_.resize(sym_.steps.size());
-    if (flow_max_nf_ <= 0) return;
+    solve_flow_.clear();
+    solve_flow_.resize(sym_.steps.size());
     constexpr double kDiag = 4.0, kPre = 2.5, kNewest = 1.5, kX = 1.5, kLook = 4.5, kTile = 6.0, kTail = 4.5, kHop = 0.7;
     int64_t words = 0;
     std::vector<std::vector<FlowTask>> all_tasks(sym_.steps.size());
@@ -595,7 +600,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     for (size_t si = 0; si < sym_.steps.size(); si++) {
       const Step &st = sym_.steps[si];
       const int nf = st.task_end - st.task_begin;
-      if (st.kind != STEP_BIG || nf > flow_max_nf_) continue;
+      if (st.kind != STEP_BIG || nf > flow_max_nf_ || flow_max_nf_ <= 0) continue;
       auto lvl = std::make_unique<FlowLevel>();
       lvl->ticket_word = words;
       struct Item { double start; int64_t seq; FlowTask t; };
@@ -697,9 +702,55 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       all_fronts[si] = std::move(fronts);
       flow_levels_[si] = std::move(lvl);
     }
+    int dev = 0, cus = 256;
+    HIPCHK(hipGetDevice(&dev));
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    // k_big_solve_flow (back substitution of wide pivot blocks as one launch per level): a ticket and counters per front in
+    // the same zeroed block, and the level's task list: by step, the chain tasks first, then the folds, the groups nearest
+    // to the current super-panel first (the next chain step waits for those)
+    std::vector<std::vector<SolveFlowFront>> all_sf(sym_.steps.size());
+    std::vector<std::vector<SolveFlowTask>> all_st(sym_.steps.size());
+    if (solve_flow_on_)
+      for (size_t si = 0; si < sym_.steps.size(); si++) {
+        const Step &st = sym_.steps[si];
+        if (st.kind != STEP_BIG) continue;
+        const int nf = st.task_end - st.task_begin;
+        int max_nc = 1;
+        for (int z = 0; z < nf; z++) max_nc = std::max(max_nc, sym_.sn_ncols[sym_.task_sn[sym_.task_ptr[st.task_begin + z]]]);
+        if (max_nc < sp_solve_min_nc_) continue;
+        solve_flow_[si] = std::make_unique<SolveFlowLevel>();
+        solve_flow_[si]->ticket_word = words;
+        words += 32;
+        const int max_S = (max_nc + BIG_SUPER - 1) / BIG_SUPER;
+        for (int z = 0; z < nf; z++) {
+          const int nc = sym_.sn_ncols[sym_.task_sn[sym_.task_ptr[st.task_begin + z]]];
+          all_sf[si].push_back(SolveFlowFront{(int32_t)words, (int32_t)(words + 1)});
+          words += 1 + (nc + 63) / 64;
+          words = (words + 31) & ~(int64_t)31;
+        }
+        for (int ell = 0; ell < max_S; ell++) {
+          for (int z = 0; z < nf; z++) {
+            const int nc = sym_.sn_ncols[sym_.task_sn[sym_.task_ptr[st.task_begin + z]]];
+            if (ell < (nc + BIG_SUPER - 1) / BIG_SUPER) all_st[si].push_back(SolveFlowTask{z, ell, -1});
+          }
+          for (int z = 0; z < nf; z++) {
+            const int nc = sym_.sn_ncols[sym_.task_sn[sym_.task_ptr[st.task_begin + z]]];
+            const int n_sp = (nc + BIG_SUPER - 1) / BIG_SUPER;
+            if (ell >= n_sp) continue;
+            const int K0 = BIG_SUPER * (n_sp - 1 - ell);
+            for (int g = (K0 + 63) / 64 - 1; g >= 0; g--) all_st[si].push_back(SolveFlowTask{z, ell, g});   // columns [64 g, ...) left of K0
+          }
+        }
+        solve_flow_[si]->n_tasks = (int)all_st[si].size();
+      }
     if (words == 0) return;
     flow_flags_.alloc((size_t)words);
     flow_flags_.zero();
+    for (size_t si = 0; si < sym_.steps.size(); si++)
+      if (solve_flow_[si]) {
+        solve_flow_[si]->fronts.upload(all_sf[si]);
+        solve_flow_[si]->tasks.upload(all_st[si]);
+      }
     for (size_t si = 0; si < sym_.steps.size(); si++)
       if (flow_levels_[si]) {
         flow_levels_[si]->tasks.upload(all_tasks[si]);
@@ -710,9 +761,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         flow_levels_[si]->trace.zero();
 #endif
       }
-    int dev = 0, cus = 256;
-    HIPCHK(hipGetDevice(&dev));
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     flow_grid_ = std::max(cus, 1) * (sizeof(T) == 4 ? RRPGO_FLOW_WAVES : 1);
     if (const char *e = getenv("RR_PGO_FLOW_GRID")) flow_grid_ = std::max(1, std::atoi(e));
   }
@@ -765,8 +813,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (!buf.empty()) upd_map_buf_.upload(buf);
   }
   const UpdMap &upd_map(const Step &st, int sp) const { return upd_maps_[(size_t)(&st - sym_.steps.data())][(size_t)sp]; }
-  bool any_flow(size_t from, size_t to) const {
+  bool any_flow(size_t from, size_t to) const {   // a factorisation range that must zero the flag block first
     for (size_t si = from; si < to && si < flow_levels_.size(); si++) if (flow_levels_[si]) return true;
+    for (const auto &p : solve_flow_) if (p) return true;   // the back substitution of ANY level may use its counters afterwards
     return false;
   }
   const FlowLevel *flow_of(const Step &st) const {
@@ -1134,7 +1183,10 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   int count_big_solve_launches(const Step &st) const {
     int max_nc = 1;
     for (int t = st.task_begin; t < st.task_end; t++) max_nc = std::max(max_nc, sym_.sn_ncols[sym_.task_sn[sym_.task_ptr[t]]]);
-    if (max_nc >= sp_solve_min_nc_) return 1 + (max_nc + BIG_SUPER - 1) / BIG_SUPER;
+    if (max_nc >= sp_solve_min_nc_) {
+      const size_t si = (size_t)(&st - sym_.steps.data());
+      return si < solve_flow_.size() && solve_flow_[si] ? 2 : 1 + (max_nc + BIG_SUPER - 1) / BIG_SUPER;
+    }
     return 2;
   }
 
@@ -1167,6 +1219,17 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         hipLaunchKernelGGL(k_big_gemv_partial<T>, dim3(cb, R, nf), dim3(256), 0, stream_, fa, gemv_part_.p, (int64_t)g_.dim, R);
         check_launch("k_big_gemv_partial");
         if (max_nc >= sp_solve_min_nc_) {
+          if (solve_flow_[(size_t)i]) {
+            // wide pivot blocks, the whole level's chain steps and folds as ONE launch of ticketed tasks (flow.hip.h)
+            const SolveFlowLevel &sl = *solve_flow_[(size_t)i];
+            int cus_grid = std::min(sl.n_tasks, std::max(flow_grid_ / (sizeof(T) == 4 ? RRPGO_FLOW_WAVES : 1), 1));
+            hipLaunchKernelGGL(k_big_solve_flow<T>, dim3((unsigned)cus_grid), dim3(1024), 0, stream_, fa, (const T *)gemv_part_.p, (int64_t)g_.dim, R,
+                               flow_flags_.p, (const SolveFlowFront *)sl.fronts.p, (const SolveFlowTask *)sl.tasks.p, sl.n_tasks,
+                               flow_flags_.p + sl.ticket_word);
+            check_launch("k_big_solve_flow");
+            pend(RR_PGO_K_BIG_SOLVE, 2);
+            continue;
+          }
           // wide pivot blocks: one launch per 128-column super-panel, L11 read by the whole chip
           const int nsp = (max_nc + BIG_SUPER - 1) / BIG_SUPER;
           for (int ell = 0; ell < nsp; ell++) {

@@ -443,13 +443,14 @@ def test_levenberg_marquardt_through_the_big_front_path(api, oracle):
 
 
 @pytest.mark.parametrize("env", ["RR_PGO_FLOW=0", "RR_PGO_FLOW_TASKS=100000000", "RR_PGO_FLOW_EXACT", "RR_PGO_NO_GATHER_UPDATE",
-                                 "RR_PGO_SCHUR_SPLIT=0", "RR_PGO_XCD_REMAP=0", "RR_PGO_EDGE_LINEARIZE"])
+                                 "RR_PGO_SCHUR_SPLIT=0", "RR_PGO_XCD_REMAP=0", "RR_PGO_SOLVE_FLOW=0", "RR_PGO_EDGE_LINEARIZE"])
 def test_alternate_big_front_launch_sequences_agree(api, env, monkeypatch):
     """The switches read when a handle is created that change WHICH kernels run: the launch-per-step sequence for every
     level (RR_PGO_FLOW=0) or the dataflow launch for every level of at most 32 fronts (RR_PGO_FLOW_TASKS), its exact mode,
     whole fronts built by k_big_build instead of gathered by the first trailing update, every super-panel's update
     reaching through the Schur complement instead of ONE k_big_schur pass per level, tiles in dispatch order instead of
-    one contiguous eighth per XCD, and the edge-parallel linearisation.  Each must give the default path's answer on the 100 x 100 lattice (same arithmetic up to the order
+    one contiguous eighth per XCD, one k_big_solve_sp launch per 128 columns instead of ONE k_big_solve_flow launch per
+    level in the back substitution, and the edge-parallel linearisation.  Each must give the default path's answer on the 100 x 100 lattice (same arithmetic up to the order
     of the block operations).  (The r01 / r02 alternatives of the big-front path were removed in r03 after losing every
     measurement: profiles/EXPERIMENTS.md.)"""
     from rustrobotics_amd import synthetic_grid_arrays
@@ -462,7 +463,7 @@ def test_alternate_big_front_launch_sequences_agree(api, env, monkeypatch):
     monkeypatch.delenv(env)
     ealt = alt.optimize(3)
     np.testing.assert_allclose(ealt, eref, rtol=1e-9)
-    if env in ("RR_PGO_SCHUR_SPLIT", "RR_PGO_XCD_REMAP", "RR_PGO_NO_GATHER_UPDATE"):
+    if env in ("RR_PGO_SCHUR_SPLIT", "RR_PGO_XCD_REMAP", "RR_PGO_NO_GATHER_UPDATE", "RR_PGO_SOLVE_FLOW"):
         # placement, one pass or one per super-panel, gathered or built: the same chunks in the same order -- the same bits
         assert np.array_equal(ealt, eref) and np.array_equal(np.array(alt.state()), np.array(ref.state()))
     assert _state_diff_se2(alt.state(), ref.state()) <= 1e-8
