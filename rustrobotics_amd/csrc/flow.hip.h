@@ -48,6 +48,8 @@ template <typename T> struct FlowArgs {   // everything the launch reads: a slim
   unsigned *flags;
   int n_tasks;
   int gather;   // the first trailing update of a front gathers its tiles right of big_built_cols from the children
+  int schur_tile;   // > 0: the UPDATE tiles stop at the front's Schur origin (big_schur_origin with this tile edge); the Schur
+                    // complement is formed by ONE k_big_schur launch behind this one (K = nc, high occupancy); 0: UPDATE tiles reach through it
   int exact;    // 1: the next super-panel's first diagonal block comes out of tile (0, 0) of the trailing update, exactly as
                 // in the launch sequence (bit-identical results); 0: the chain wave forms it itself, left-looking over the
                 // whole super-panel like every other diagonal block -- same sums in another order, and no tile on the chain
@@ -405,6 +407,8 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
     const int ke = min(K0 + BIG_SUPER, m.nc), sp = K0 / BIG_SUPER;
     const int t0 = ke;
     const int I0 = t0 + bx * TS, J0 = t0 + by * TS;
+    // with the Schur complement left to k_big_schur the last super-panel only owes the strip [nc, origin) (see k_big_update)
+    const int jmax = (fa.schur_tile && ke == m.nc) ? min(big_schur_origin(m.nc, fa.schur_tile), M) : M;
     if (wave == 0) {
       // X of the rows of both operand strips for every 32-column block of the super-panel: lane = block (4) x strip (2)
       // x row block (up to TS / 32 + 1 = 5 of them when the strip is not aligned with the block's row blocks)
@@ -424,7 +428,7 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
         const unsigned *fp = nullptr;
         if (lane < 4) {
           const int o = K0;
-          const int bxl = (I0 - o) / TS, bxh = (min(I0 + TS - 1, M - 1) - o) / TS, byl = (J0 - o) / TS, byh = (min(J0 + TS - 1, M - 1) - o) / TS;
+          const int bxl = (I0 - o) / TS, bxh = (min(I0 + TS - 1, M - 1) - o) / TS, byl = (J0 - o) / TS, byh = (min(J0 + TS, jmax) - 1 - o) / TS;
           const int pbx = bxl + (lane >> 1), pby = byl + (lane & 1);
           if (pbx <= bxh && pby <= byh && pby <= pbx) fp = fa.flags + ff.uf + (sp - 1) * ff.ustride + flow_tri(pbx, pby);
         }
@@ -437,7 +441,7 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
     typename MM::Acc acc[NT][NT];
     TileGather<T> tg{nullptr, -1, nullptr, nullptr, nullptr, nullptr};
     if (fa.gather && K0 == 0 && J0 >= big_built_cols(m.nc, M)) tg = TileGather<T>{fa.child_meta + m.child_begin, m.child_count, fa.scat, fa.lvals, fa.uvals, fa.xch};
-    const bool have = big_update_tile<T, NT, RRPGO_FLOW_DEPTH, true>(F, M, K0, ke, M, I0, J0, smem, acc, nullptr, false, tg, tid);
+    const bool have = big_update_tile<T, NT, RRPGO_FLOW_DEPTH, true>(F, M, K0, ke, jmax, I0, J0, smem, acc, nullptr, false, tg, tid);
     RRPGO_FLOW_MARK(fa, t, wave, 2);
     flow_drain();
     __syncthreads();   // every wave's part of the tile is in memory

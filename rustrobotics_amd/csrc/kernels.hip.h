@@ -2862,7 +2862,6 @@ __device__ void solve_big_front(const FactorArgs<T> &a, const SnMeta &m, T *work
 // the launches are ordered: plain read-modify-write, fixed summation order.
 template <typename T> __global__ void __launch_bounds__(1024) k_big_solve_sp(FactorArgs<T> a, int ell, const T *part, int64_t N, int R) {
   __shared__ T xf[BIG_SUPER];              // this super-panel: t, then x
-  __shared__ T xr[BIG_SUPER];              // x of the super-panel to the right
   __shared__ T Ws[4 * 32 * 33];            // the super-panel's four W_b, staged transposed
   const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
   const int nc = m.nc, M = nc + m.nr + 1;

@@ -6,6 +6,7 @@
 // iteration replayed from one hipGraph on the handle's own stream; the host
 // reads two scalars (chi2, |dx|) per iteration.
 #include <mutex>
+#include <queue>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -13,6 +14,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -173,6 +175,7 @@ struct EngineBase {
   virtual hipStream_t stream() = 0;
   virtual void read_stamps(std::vector<unsigned long long> &out) = 0;
   virtual void mark_flow_fronts(std::vector<char> &in_flow) = 0;   // fronts whose level runs as k_big_flow
+  virtual int schur_tile() const = 0;                              // tile edge of k_big_schur, 0 = no Schur split
   virtual int flow_trace(int level, std::vector<int32_t> &tasks, std::vector<unsigned long long> &stamps, int *nf, double *est_us) = 0;
   // sharded runs
   virtual void exchange_buffer(int which, void **ptr, int64_t *n, int32_t *esize) = 0;
@@ -263,6 +266,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     DevBuf<FlowTask> tasks;
     DevBuf<FlowFront> fronts;
     int n_tasks = 0;
+    bool schur_split = false;  // the level's Schur complements are a k_big_schur launch behind the flow launch
     std::vector<FlowTask> host_tasks;   // diagnostic builds: the sorted list, for rr_pgo_debug_flow_trace
     DevBuf<unsigned long long> trace;   // diagnostic builds only
     int64_t ticket_word = 0;   // index of the level's ticket in flow_flags_
@@ -270,15 +274,16 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   };
   std::vector<std::unique_ptr<FlowLevel>> flow_levels_;   // per step of sym_.steps (null: launch sequence)
   DevBuf<unsigned> flow_flags_;     // tickets + completion flags of every flow level, zeroed at the start of a factorisation
-  int flow_max_nf_ = 32;            // RR_PGO_FLOW=<n> (0: never)
-  int flow_max_tasks_ = 16384;      // RR_PGO_FLOW_TASKS=<n>: ... and of at most n tasks.  A level with more tile work than that is bound by
-                                    // tile THROUGHPUT, where the batched k_big_update launches (7 workgroups per CU) beat the flow kernel's two
-                                    // (measured on the 1M-edge lattice, r03: the levels of 1 and 2 fronts -- 1.4 k and 4.8 k tasks -- gain 25 %
-                                    // and 13 %, the level of 4 fronts -- 18 k tasks -- ties, the levels of 8..32 fronts lose 10-20 %)
+  int flow_max_nf_ = 64;            // RR_PGO_FLOW=<n> (0: never): levels of at most n fronts ...
+  int flow_max_tasks_ = 40000;      // RR_PGO_FLOW_TASKS=<n>: ... and of at most n tasks run as ONE k_big_flow launch.  Measured on the 1M-edge
+                                    // lattice (r03, tickets in list-schedule order, Schur complements left to k_big_schur): the level of 64
+                                    // fronts gains 64 us over its launch sequence, the level of 128 fronts ties, wider levels are bound by tile
+                                    // THROUGHPUT, where the batched k_big_update launches (7 workgroups per CU) beat the flow kernel's two
   bool flow_exact_ = false;         // RR_PGO_FLOW_EXACT=1: bit-identical to the launch sequence (tile (0, 0) forms the next super-panel's first block)
   struct SolveFlowLevel { DevBuf<SolveFlowFront> fronts; DevBuf<SolveFlowTask> tasks; int n_tasks = 0; int64_t ticket_word = 0; };
   std::vector<std::unique_ptr<SolveFlowLevel>> solve_flow_;   // per step: k_big_solve_flow's tasks and counters (null: k_big_solve_sp launches)
   bool solve_flow_on_ = true;       // RR_PGO_SOLVE_FLOW=0: one k_big_solve_sp launch per 128 columns
+  int flow_schur_min_ = 512;        // RR_PGO_FLOW_SCHUR_MIN=<n>: flow levels with at least n Schur tiles leave them to k_big_schur
   int flow_grid_ = 0;               // persistent workgroups of a flow launch (RR_PGO_FLOW_GRID; default CUs x RRPGO_FLOW_WAVES)
   // gauge transfer (single-precision factor, Gauss-Newton; kernels.hip.h "gauge transfer")
   bool gauge_ok_ = false;            // the root front is a big front with an SE2 pivot node
@@ -460,6 +465,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     flow_exact_ = getenv("RR_PGO_FLOW_EXACT") != nullptr;
     if (const char *e = getenv("RR_PGO_FLOW_TASKS")) flow_max_tasks_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_SOLVE_FLOW")) solve_flow_on_ = std::atoi(e) != 0;
+    if (const char *e = getenv("RR_PGO_FLOW_SCHUR_MIN")) flow_schur_min_ = std::atoi(e);
     build_flow_levels();
     build_update_maps();
     n_lin_blocks_ = (int)(((int64_t)n_list_ * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
@@ -593,8 +599,13 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     flow_levels_.resize(sym_.steps.size());
     solve_flow_.clear();
     solve_flow_.resize(sym_.steps.size());
-    constexpr double kDiag = 4.0, kPre = 2.5, kNewest = 1.5, kX = 1.5, kLook = 4.5, kTile = 6.0, kTail = 4.5, kHop = 0.7;
+    constexpr double kDiag = 4.0, kPre = 2.5, kNewest = 1.5, kX = 1.5, kLook = 4.5, kTile = 8.0, kTail = 4.5, kHop = 0.7;
     int64_t words = 0;
+    int dev = 0, cus = 256;
+    HIPCHK(hipGetDevice(&dev));
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    flow_grid_ = std::max(cus, 1) * (sizeof(T) == 4 ? RRPGO_FLOW_WAVES : 1);
+    if (const char *e = getenv("RR_PGO_FLOW_GRID")) flow_grid_ = std::max(1, std::atoi(e));
     std::vector<std::vector<FlowTask>> all_tasks(sym_.steps.size());
     std::vector<std::vector<FlowFront>> all_fronts(sym_.steps.size());
     for (size_t si = 0; si < sym_.steps.size(); si++) {
@@ -603,12 +614,38 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       if (st.kind != STEP_BIG || nf > flow_max_nf_ || flow_max_nf_ <= 0) continue;
       auto lvl = std::make_unique<FlowLevel>();
       lvl->ticket_word = words;
-      struct Item { double start; int64_t seq; FlowTask t; };
-      std::vector<Item> items;
+      // The Schur complements of the level's fronts: as UPDATE tiles of this launch (one per super-panel), or -- when there
+      // are enough of them to fill the chip -- left to ONE k_big_schur launch behind it (K = nc, seven workgroups per CU)
+      {
+        int64_t schur_tiles = 0;
+        for (int z = 0; z < nf; z++) {
+          const int sn = sym_.task_sn[sym_.task_ptr[st.task_begin + z]];
+          const int nc = sym_.sn_ncols[sn], M = nc + sym_.sn_nrows[sn] + 1, o = big_schur_origin(nc, schur_tile_);
+          if (o < M) { const int64_t nt = (M - o + 63) / 64; schur_tiles += nt * (nt + 1) / 2; }
+        }
+        lvl->schur_split = schur_split_ && schur_tiles >= flow_schur_min_;
+      }
+      // The level's tasks in their natural order (front by front, step by step), each with the flags it waits for and the
+      // flags it sets. The ticket order is then the START order of a list schedule of this DAG on the launch's workgroups
+      // (priority: longest remaining path), so that a workgroup drawing the next ticket finds what the schedule would
+      // have given it: the next chain step of a front ahead of the bulk of the previous super-panel's far tiles.
+      struct Gen {
+        FlowTask t;
+        int need0, need1, prod0, prod1;
+        int wflag;             // the W flag a PANEL task waits for after its pre-work, or -1
+        float pre, newest;     // PANEL: work on the older blocks / on the newest block, both before W is needed
+        float dur;             // W there (or start) -> workgroup free
+        float blevel;
+      };
+      struct Need { int flag, cls; };          // cls 0: needed at the start; 1: the newest block's X (after `pre`)
+      struct Prod { int flag; float off; };    // set `off` after W arrived (or after the start)
+      std::vector<Gen> gen;
+      std::vector<Need> need;
+      std::vector<Prod> prod;
       std::vector<FlowFront> fronts(nf);
-      double level_end = 0;
       constexpr int TS = 64;           // edge of a trailing-update tile (k_big_flow<T, 2>)
       words = lvl->ticket_word + 32;   // the ticket on a 128-byte line of its own
+      const int64_t flag0 = words;
       for (int z = 0; z < nf; z++) {
         const int sn = sym_.task_sn[sym_.task_ptr[st.task_begin + z]];
         const int nc = sym_.sn_ncols[sn], M = nc + sym_.sn_nrows[sn] + 1;
@@ -621,52 +658,54 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         ff.uf = (int32_t)words; ff.ustride = ustride; words += (int64_t)nsp * ustride;
         words = (words + 31) & ~(int64_t)31;
         if (words > 0x7fffff00LL) throw ApiError(RR_PGO_EUNSUPPORTED, "too many flow flags");
-        // finish times of the cost model
-        std::vector<double> tw(nblk + 1, 0.0), tp((size_t)nblk * pstride, 0.0), tu((size_t)nsp * ustride, 0.0);
+        const int wf = (int)(ff.wf - flag0), pf = (int)(ff.pf - flag0), uf = (int)(ff.uf - flag0);
         auto tri = [](int bx, int by) { return bx * (bx + 1) / 2 + by; };
-        items.push_back(Item{0.0, (int64_t)items.size(), FlowTask{(FLOW_DIAG0 << 24) | z, 0, 0, 0}});
-        tw[0] = kDiag;
+        auto open_task = [&](FlowTask t) {
+          gen.push_back(Gen{t, (int)need.size(), 0, (int)prod.size(), 0, -1, 0.f, 0.f, 0.f, 0.f});
+        };
+        auto close_task = [&]() { gen.back().need1 = (int)need.size(); gen.back().prod1 = (int)prod.size(); };
+        open_task(FlowTask{(FLOW_DIAG0 << 24) | z, 0, 0, 0});
+        prod.push_back(Prod{wf + 0, (float)kDiag});
+        gen.back().dur = (float)kDiag;
+        close_task();
+        const int o_schur = lvl->schur_split ? std::min(big_schur_origin(nc, schur_tile_), M) : M;   // UPDATE tiles start left of it
         for (int sp = 0; sp < nsp; sp++) {
           const int K0 = sp * BIG_SUPER, ke = std::min(K0 + BIG_SUPER, nc);
-          // finish time of the previous update's tiles under rows [r0, r1] x columns [c0, c1]
-          auto prev_tiles = [&](int r0, int r1, int c0, int c1) {
-            double t = 0;
-            if (sp == 0) return t;
+          // the previous update's tiles under rows [r0, r1] x columns [c0, c1] (tiles right of the Schur origin are not
+          // this launch's: nothing waits for them)
+          auto prev_tiles = [&](int r0, int r1, int c0, int c1, int cls) {
+            if (sp == 0) return;
             for (int bx = (r0 - K0) / TS; bx <= (std::min(r1, M - 1) - K0) / TS; bx++)
               for (int by = (c0 - K0) / TS; by <= std::min((std::min(c1, M - 1) - K0) / TS, bx); by++)
-                t = std::max(t, tu[(size_t)(sp - 1) * ustride + tri(bx, by)]);
-            return t;
+                if (K0 + TS * by < o_schur) need.push_back(Need{uf + (sp - 1) * ustride + tri(bx, by), cls});
           };
           for (int kb = K0; kb < ke; kb += BIG_NB) {
             const int blk = kb / BIG_NB, q = (kb - K0) / BIG_NB, nb = std::min(BIG_NB, nc - kb), kn = kb + BIG_NB;
             const int nrb = (M - (kb + nb) + 31) / 32;
             for (int g0 = 0; g0 < nrb; g0 += FLOW_GROUP) {
-              double start = 0;   // of the task = of its earliest wave; finish times per wave
-              double wstart[FLOW_GROUP];
+              open_task(FlowTask{(FLOW_PANEL << 24) | z, kb, g0, K0});
+              Gen &g = gen.back();
+              g.wflag = wf + blk;
+              g.pre = (float)(q > 1 ? kPre : 0.5);
+              g.newest = (float)(q > 0 ? kNewest : 0.0);
+              g.dur = (float)kX;
               for (int w = 0; w < FLOW_GROUP && g0 + w < nrb; w++) {
                 const int rb = g0 + w, R0 = kb + nb + 32 * rb;
                 const bool look = rb == 0 && kn < (flow_exact_ ? ke : nc);
-                // the step starts with everything that needs neither W nor the newest block (blocks blk - 2, blk - 3 and
-                // the C tiles), then the newest block's term, then W (hop), then X; the look wave goes on with the next block
-                double t = 0.0, tnew = 0.0;
+                // a wave starts with everything that needs neither W nor the newest block (blocks blk - 2, blk - 3 and the
+                // C tiles), then the newest block's term, then W, then X; the look wave goes on with the next block
                 for (int j = 1; j <= q; j++) {
                   const int r0p = kb - 32 * j + 32;
-                  double tj = tp[(size_t)(blk - j) * pstride + (j - 1)] + kHop;
+                  need.push_back(Need{pf + (blk - j) * pstride + (j - 1), j == 1});
                   for (int rbp = (R0 - r0p) / 32; rbp <= (std::min(R0 + 31, M - 1) - r0p) / 32; rbp++)
-                    tj = std::max(tj, tp[(size_t)(blk - j) * pstride + rbp] + kHop);
-                  if (j == 1) tnew = tj; else t = std::max(t, tj);
+                    need.push_back(Need{pf + (blk - j) * pstride + rbp, j == 1});
                 }
-                t = std::max(t, prev_tiles(R0, R0 + 31, kb, kb + nb - 1) + (sp > 0 ? kHop : 0.0));
-                if (look) t = std::max(t, prev_tiles(kn, kn + 31, kn, kn + 31) + (sp > 0 ? kHop : 0.0));
-                wstart[w] = t;
-                double fin = std::max(std::max(t + (q > 1 ? kPre : 0.5), tnew) + (q > 0 ? kNewest : 0.0), tw[blk] + kHop) + kX;
-                tp[(size_t)blk * pstride + rb] = fin;   // X is published before the look wave goes on
-                if (look) { fin += kLook; tw[blk + 1] = fin; }
-                level_end = std::max(level_end, fin);
-                start = w == 0 ? t : std::min(start, t);
+                prev_tiles(R0, R0 + 31, kb, kb + nb - 1, 0);
+                if (look) prev_tiles(kn, kn + 31, kn, kn + 31, 0);
+                prod.push_back(Prod{pf + blk * pstride + rb, (float)kX});   // X is published before the look wave goes on
+                if (look) { prod.push_back(Prod{wf + blk + 1, (float)(kX + kLook)}); g.dur = (float)(kX + kLook); }
               }
-              (void)wstart;
-              items.push_back(Item{start, (int64_t)items.size(), FlowTask{(FLOW_PANEL << 24) | z, kb, g0, K0}});
+              close_task();
             }
           }
           // trailing update of the super-panel: tiles of rows / columns >= ke
@@ -675,36 +714,116 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           for (int by = 0; by < nt; by++)       // column-major: the next super-panel's own columns first
             for (int bx = by; bx < nt; bx++) {
               const int I0 = t0 + TS * bx, J0 = t0 + TS * by;
-              double t = 0;
+              if (J0 >= o_schur) continue;       // the Schur complement: one k_big_schur launch behind the flow launch
+              open_task(FlowTask{(FLOW_UPDATE << 24) | z, K0, bx, by});
               for (int kb = K0; kb < ke; kb += BIG_NB) {
                 const int nbq = std::min(BIG_NB, nc - kb), r0 = kb + nbq;
                 for (int strip = 0; strip < 2; strip++) {
                   const int lo = strip ? J0 : I0, hi = std::min(lo + TS - 1, M - 1);
-                  for (int rb = (lo - r0) / 32; rb <= (hi - r0) / 32; rb++) t = std::max(t, tp[(size_t)(kb / BIG_NB) * pstride + rb] + kHop);
+                  for (int rb = (lo - r0) / 32; rb <= (hi - r0) / 32; rb++) need.push_back(Need{pf + (kb / BIG_NB) * pstride + rb, 0});
                 }
               }
-              t = std::max(t, prev_tiles(I0, I0 + TS - 1, J0, J0 + TS - 1) + (sp > 0 ? kHop : 0.0));
-              const double fin = t + kTile;
-              tu[(size_t)sp * ustride + tri(bx, by)] = fin;
-              level_end = std::max(level_end, fin);
-              if (flow_exact_ && bx == 0 && by == 0 && t0 < nc) { tw[t0 / BIG_NB] = fin + kTail; level_end = std::max(level_end, fin + kTail); }
-              items.push_back(Item{t, (int64_t)items.size(), FlowTask{(FLOW_UPDATE << 24) | z, K0, bx, by}});
+              prev_tiles(I0, I0 + TS - 1, J0, J0 + TS - 1, 0);
+              prod.push_back(Prod{uf + sp * ustride + tri(bx, by), (float)kTile});
+              gen.back().dur = (float)kTile;
+              if (flow_exact_ && bx == 0 && by == 0 && t0 < nc) {
+                prod.push_back(Prod{wf + t0 / BIG_NB, (float)(kTile + kTail)});
+                gen.back().dur = (float)(kTile + kTail);
+              }
+              close_task();
             }
         }
       }
-      if ((int64_t)items.size() > flow_max_tasks_) { words = lvl->ticket_word; continue; }   // throughput-bound level: launch sequence (its flag words are given back)
-      std::sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.start != y.start ? x.start < y.start : x.seq < y.seq; });
-      std::vector<FlowTask> tasks(items.size());
-      for (size_t i = 0; i < items.size(); i++) tasks[i] = items[i].t;
+      const int n_gen = (int)gen.size();
+      if (n_gen > flow_max_tasks_) { words = lvl->ticket_word; continue; }   // throughput-bound level: launch sequence (its flag words are given back)
+      const int n_flags = (int)(words - flag0);
+      // who sets a flag, who waits for it
+      std::vector<int> producer(n_flags, -1), cons_ptr(n_flags + 1, 0), cons;
+      for (int i = 0; i < n_gen; i++)
+        for (int k = gen[i].prod0; k < gen[i].prod1; k++) producer[prod[k].flag] = i;
+      auto for_each_need = [&](int i, auto &&fn) {   // (flag, lead): lead = how long after the task's start the flag is needed
+        const Gen &g = gen[i];
+        for (int k = g.need0; k < g.need1; k++) fn(need[k].flag, need[k].cls ? g.pre : 0.f);
+        if (g.wflag >= 0) fn(g.wflag, g.pre + g.newest);
+      };
+      for (int i = 0; i < n_gen; i++) for_each_need(i, [&](int f, float) { cons_ptr[f + 1]++; });
+      for (int f = 0; f < n_flags; f++) cons_ptr[f + 1] += cons_ptr[f];
+      cons.resize(cons_ptr[n_flags]);
+      {
+        std::vector<int> fill(cons_ptr.begin(), cons_ptr.end() - 1);
+        for (int i = 0; i < n_gen; i++) for_each_need(i, [&](int f, float) { cons[fill[f]++] = i; });
+      }
+      // longest remaining path of every task (its consumers come later in the natural order)
+      {
+        std::vector<float> after(n_flags, 0.f);   // per flag: the longest path that starts when it is set
+        for (int i = n_gen - 1; i >= 0; i--) {
+          Gen &g = gen[i];
+          const float lead = g.pre + g.newest;
+          float bl = lead + g.dur;
+          for (int k = g.prod0; k < g.prod1; k++) bl = std::max(bl, lead + prod[k].off + after[prod[k].flag]);
+          g.blevel = bl;
+          for_each_need(i, [&](int f, float ld) { after[f] = std::max(after[f], (float)kHop + bl - ld); });
+        }
+      }
+      // the list schedule
+      std::vector<FlowTask> tasks;
+      tasks.reserve(n_gen);
+      double level_end = 0;
+      {
+        // half the launch's workgroups: the model's tiles are cheaper than loaded ones, and a chain step drawn a little
+        // early only waits, while one drawn late stalls its front (measured: 128 ... 256 slots equal, 512 1 % slower)
+        int P = std::max(1, flow_grid_ / 2);
+        if (const char *e = getenv("RR_PGO_FLOW_SLOTS")) P = std::max(1, std::atoi(e));   // experiments: a large value = order of earliest starts
+        std::vector<float> ftime(n_flags, 0.f);
+        std::vector<int> pending(n_gen, 0);
+        for (int i = 0; i < n_gen; i++) for_each_need(i, [&](int f, float) { if (producer[f] >= 0) pending[i]++; });
+        using Fut = std::pair<float, int>;                 // (earliest useful start, task)
+        std::priority_queue<Fut, std::vector<Fut>, std::greater<Fut>> future;
+        auto less_urgent = [&](int x, int y) { return gen[x].blevel != gen[y].blevel ? gen[x].blevel < gen[y].blevel : x > y; };
+        std::priority_queue<int, std::vector<int>, decltype(less_urgent)> ready(less_urgent);
+        std::priority_queue<float, std::vector<float>, std::greater<float>> slots;
+        for (int k = 0; k < P; k++) slots.push(0.f);
+        auto becomes_known = [&](int i) {
+          float r = 0.f;
+          for_each_need(i, [&](int f, float ld) { if (producer[f] >= 0) r = std::max(r, ftime[f] + (float)kHop - ld); });
+          future.push(Fut{r, i});
+        };
+        for (int i = 0; i < n_gen; i++) if (pending[i] == 0) becomes_known(i);
+        float now = 0.f;
+        for (int done = 0; done < n_gen; done++) {
+          now = std::max(now, slots.top());
+          while (!future.empty() && future.top().first <= now) { ready.push(future.top().second); future.pop(); }
+          if (ready.empty()) {
+            if (future.empty()) throw ApiError(RR_PGO_EUNSUPPORTED, "flow task graph is not schedulable");
+            now = future.top().first;
+            while (!future.empty() && future.top().first <= now) { ready.push(future.top().second); future.pop(); }
+          }
+          const int i = ready.top();
+          ready.pop();
+          slots.pop();
+          const Gen &g = gen[i];
+          float t_new = 0.f, t_w = 0.f;
+          for (int k = g.need0; k < g.need1; k++)
+            if (need[k].cls && producer[need[k].flag] >= 0) t_new = std::max(t_new, ftime[need[k].flag] + (float)kHop);
+          if (g.wflag >= 0 && producer[g.wflag] >= 0) t_w = ftime[g.wflag] + (float)kHop;
+          const float go = std::max(std::max(now + g.pre, t_new) + g.newest, t_w);
+          slots.push(go + g.dur);
+          level_end = std::max(level_end, (double)(go + g.dur));
+          tasks.push_back(g.t);
+          for (int k = g.prod0; k < g.prod1; k++) {
+            const int f = prod[k].flag;
+            ftime[f] = go + prod[k].off;
+            for (int c = cons_ptr[f]; c < cons_ptr[f + 1]; c++)
+              if (--pending[cons[c]] == 0) becomes_known(cons[c]);
+          }
+        }
+      }
       lvl->n_tasks = (int)tasks.size();
       lvl->est_us = level_end;
       all_tasks[si] = std::move(tasks);
       all_fronts[si] = std::move(fronts);
       flow_levels_[si] = std::move(lvl);
     }
-    int dev = 0, cus = 256;
-    HIPCHK(hipGetDevice(&dev));
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     // k_big_solve_flow (back substitution of wide pivot blocks as one launch per level): a ticket and counters per front in
     // the same zeroed block, and the level's task list: by step, the chain tasks first, then the folds, the groups nearest
     // to the current super-panel first (the next chain step waits for those)
@@ -761,8 +880,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         flow_levels_[si]->trace.zero();
 #endif
       }
-    flow_grid_ = std::max(cus, 1) * (sizeof(T) == 4 ? RRPGO_FLOW_WAVES : 1);
-    if (const char *e = getenv("RR_PGO_FLOW_GRID")) flow_grid_ = std::max(1, std::atoi(e));
   }
   // k_big_update's and k_big_schur's grids: per level of the launch sequence the list of real tiles, front after front
   // -- per super-panel the tiles left of the Schur origin (schur_split_: the Schur complement is ONE pass of k_big_schur
@@ -773,13 +890,14 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     std::vector<int32_t> buf;
     for (size_t si = 0; si < sym_.steps.size(); si++) {
       const Step &st = sym_.steps[si];
-      if (st.kind != STEP_BIG || flow_levels_[si]) continue;
+      if (st.kind != STEP_BIG) continue;
+      const bool flow_level = (bool)flow_levels_[si];   // its per-super-panel tiles are UPDATE tasks; only the Schur pass is a launch
       const int nf = st.task_end - st.task_begin;
       if (nf > 0xffff) throw ApiError(RR_PGO_EUNSUPPORTED, "more than 65535 big fronts in one level");
       int max_nc = 0;
       for (int z = 0; z < nf; z++) max_nc = std::max(max_nc, sym_.sn_ncols[sym_.task_sn[sym_.task_ptr[st.task_begin + z]]]);
       auto tri_ok = [](int nt) { if (nt * (nt + 1) / 2 > 0xffff) throw ApiError(RR_PGO_EUNSUPPORTED, "a front of more than 65535 update tiles"); };
-      for (int K0 = 0; K0 < max_nc; K0 += BIG_SUPER) {
+      for (int K0 = 0; K0 < max_nc && !flow_level; K0 += BIG_SUPER) {
         UpdMap um{(int64_t)buf.size(), 0};
         for (int z = 0; z < nf; z++) {
           const int sn = sym_.task_sn[sym_.task_ptr[st.task_begin + z]];
@@ -795,7 +913,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         um.n_tiles = (int)((int64_t)buf.size() - um.offset);
         upd_maps_[si].push_back(um);
       }
-      if (schur_split_) {
+      if (flow_level ? flow_levels_[si]->schur_split : schur_split_) {
         UpdMap um{(int64_t)buf.size(), 0};
         for (int z = 0; z < nf; z++) {
           const int sn = sym_.task_sn[sym_.task_ptr[st.task_begin + z]];
@@ -831,6 +949,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     fa.n_tasks = lvl.n_tasks;
     fa.gather = gather_update_ ? 1 : 0;
     fa.exact = flow_exact_ ? 1 : 0;
+    fa.schur_tile = lvl.schur_split ? schur_tile_ : 0;
     fa.front_meta = task_meta_.p + st.task_begin;
     fa.child_meta = child_meta_.p;
     fa.scat = scat_.p;
@@ -1129,9 +1248,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         pbegin();
         launch_flow(st, *lvl);
         pend(RR_PGO_K_BIG_FLOW);
-        pbegin();   // re-arm: the caller closes the level with pend(BIGFRONT)
       }
-      return n + 1;
+      n++;
+      n += launch_schur(st, a, do_launch);
+      if (do_launch) pbegin();   // re-arm: the caller closes the level with pend(BIGFRONT)
+      return n;
     }
     for (int K0 = 0; K0 < max_nc; K0 += BIG_SUPER) {
       // left-looking inside the super-panel: ONE launch per 32 columns (update from the columns K0..kb, multiply by the
@@ -1162,22 +1283,22 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       }
       n++;
     }
-    {
-      // the Schur complements of the level's fronts: ONE pass over all pivot columns (K = nc), each tile written once
-      const UpdMap &um = schur_maps_[(size_t)(&st - sym_.steps.data())];
-      if (schur_split_ && um.n_tiles > 0) {
-        if (do_launch) {
-          pbegin();
-          hipLaunchKernelGGL((k_big_schur<T, 2>), dim3((unsigned)um.n_tiles), dim3(256), 0, stream_, a, gather_update_ ? 1 : 0,
-                             (const int32_t *)upd_map_buf_.p + um.offset, um.n_tiles, xcd_remap_ ? 1 : 0);
-          check_launch("k_big_schur");
-          pend(RR_PGO_K_BIG_UPDATE);
-        }
-        n++;
-      }
-    }
+    n += launch_schur(st, a, do_launch);
     if (do_launch) pbegin();   // re-arm: the caller closes the level with pend(BIGFRONT)
     return n;
+  }
+  // the Schur complements of the level's fronts: ONE pass over all pivot columns (K = nc), each tile written once
+  int launch_schur(const Step &st, const FactorArgs<T> &a, bool do_launch) {
+    const UpdMap &um = schur_maps_[(size_t)(&st - sym_.steps.data())];
+    if (um.n_tiles == 0) return 0;   // no map: no split on this level (or no Schur complement at all)
+    if (do_launch) {
+      pbegin();
+      hipLaunchKernelGGL((k_big_schur<T, 2>), dim3((unsigned)um.n_tiles), dim3(256), 0, stream_, a, gather_update_ ? 1 : 0,
+                         (const int32_t *)upd_map_buf_.p + um.offset, um.n_tiles, xcd_remap_ ? 1 : 0);
+      check_launch("k_big_schur");
+      pend(RR_PGO_K_BIG_UPDATE);
+    }
+    return 1;
   }
   int count_big_launches(const Step &st) { return launch_big_level(st, false); }
   int count_big_solve_launches(const Step &st) const {
@@ -1521,10 +1642,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     check_device_error();
   }
 
+  int schur_tile() const override { return schur_split_ ? schur_tile_ : 0; }
   void mark_flow_fronts(std::vector<char> &in_flow) override {
     for (size_t si = 0; si < flow_levels_.size(); si++)
       if (flow_levels_[si])
-        for (int t = sym_.steps[si].task_begin; t < sym_.steps[si].task_end; t++) in_flow[sym_.task_sn[sym_.task_ptr[t]]] = 1;
+        for (int t = sym_.steps[si].task_begin; t < sym_.steps[si].task_end; t++)
+          in_flow[sym_.task_sn[sym_.task_ptr[t]]] = flow_levels_[si]->schur_split ? 1 : 2;   // 2: its Schur tiles are UPDATE tasks too
   }
   // diagnostic builds: the task list and the stamps of the `level`-th flow level (-1: no such level)
   int flow_trace(int level, std::vector<int32_t> &tasks, std::vector<unsigned long long> &stamps, int *nf, double *est_us) override {
@@ -1816,12 +1939,18 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
   double buf = 0, bflow = 0;
   std::vector<char> in_flow(y.S, 0);
   h->engine->mark_flow_fronts(in_flow);
+  const int sch_tile = h->engine->schur_tile();   // 0: no split (flow levels that keep their Schur tiles are marked 2 in in_flow)
+  auto schur_origin_fn = [&](int nc) { return (double)big_schur_origin(nc, sch_tile); };
+  const std::function<double(int)> schur_origin_of = sch_tile ? std::function<double(int)>(schur_origin_fn) : std::function<double(int)>();
   for (int f = 0; f < y.S; f++)
     if (y.sn_huge[f]) {
       const double M = y.sn_ncols[f] + y.sn_nrows[f] + 1;
       for (int k0 = 0; k0 < y.sn_ncols[f]; k0 += BIG_SUPER) {
         const double w = std::min<int>(BIG_SUPER, y.sn_ncols[f] - k0), T = M - (k0 + w);
-        (in_flow[f] ? bflow : buf) += w * T * (T + 1);
+        // with the Schur split the tiles from the Schur origin on belong to k_big_schur (a k_big_update-class launch) on every level
+        const double Ts = (schur_origin_of && in_flow[f] != 2) ? std::max(0.0, M - std::max<double>(schur_origin_of(y.sn_ncols[f]), k0 + w)) : 0.0;
+        buf += w * Ts * (Ts + 1);
+        (in_flow[f] ? bflow : buf) += w * (T * (T + 1) - Ts * (Ts + 1));
       }
     }
   s.big_update_flops = buf;

@@ -1,7 +1,8 @@
 #!/bin/bash
-# A/B of an environment switch on the lattice (fp32) and sphere2500: usage gpu_ab_env.sh "VAR=a" "VAR=b" ...
+# A/B of an environment switch on the lattice (fp32) and sphere2500 (or the workload:precision list in $WLS):
+# usage gpu_ab_env.sh "VAR=a" "VAR=b" ...
 for E in "$@"; do
-  for W in grid:400x250:1000000:f32 sphere2500:f64; do
+  for W in ${WLS:-grid:400x250:1000000:f32 sphere2500:f64}; do
     WL=${W%:*}; PR=${W##*:}
     env $E timeout -k 10 200 python bench.py --workload $WL --precision $PR --steps 40 --warmup 5 --no-cpu-baseline --no-secondary > gpurun_out/ab.json 2>gpurun_out/ab.err || { tail -5 gpurun_out/ab.err; exit 1; }
     python3 -c "
