@@ -191,9 +191,9 @@ enum {
   RR_PGO_K_REDUCE = 4,      /* k_finalize_slot                                         */
   RR_PGO_K_BIGFRONT = 5,    /* huge fronts: k_big_build + k_big_assemble (gather pass), k_flow_reset */
   RR_PGO_K_BIG_PANEL = 6,   /* k_big_panel32 (huge fronts: 32-column chain steps)       */
-  RR_PGO_K_BIG_UPDATE = 7,  /* k_big_update (huge fronts: MFMA rank-128 trailing updates) */
+  RR_PGO_K_BIG_UPDATE = 7,  /* k_big_update + k_big_schur (huge fronts: MFMA trailing updates) */
   RR_PGO_K_MID_FACTOR = 8,  /* retired in r03 (the one-workgroup panel class was removed): always 0   */
-  RR_PGO_K_BIG_SOLVE = 9,   /* k_big_gemv_partial + k_big_solve_sp / k_solve_mid        */
+  RR_PGO_K_BIG_SOLVE = 9,   /* k_big_gemv_partial + k_big_solve_flow (k_big_solve_sp) / k_solve_mid */
   RR_PGO_K_BIG_FLOW = 10,   /* k_big_flow (huge fronts of a level of few fronts: panels + updates as one dataflow launch) */
   RR_PGO_NUM_KCLASS = 11
 };

@@ -98,6 +98,9 @@ __device__ __forceinline__ bool flow_wait(const unsigned *p, int *err) {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the payload loads below the poll
   return ok;
 }
+// the mark k_flow_reset leaves in a W block that is not there yet (see there)
+__device__ __forceinline__ bool flow_w_unset(float v) { return __float_as_uint(v) == 0xffffffffu; }
+__device__ __forceinline__ bool flow_w_unset(double v) { return (unsigned long long)__double_as_longlong(v) == ~0ull; }
 // after this wave's payload stores: drain them, then the caller sets its flags
 __device__ __forceinline__ void flow_drain() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -273,16 +276,29 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
     }
   }
   // ---- now the diagonal block: wait for its inverse
-  flow_wait(lane == 0 ? fa.flags + ff.wf + blk : nullptr, fa.err);
-  RRPGO_FLOW_MARK(fa, ticket, tid >> 6, 2);
+  // (polled in place: k_flow_reset marked the block, see there; bounded like flow_wait)
   T wv[3][4];
+  for (unsigned spins = 0;; spins++) {
+    bool unset = false;
 #pragma unroll
-  for (int t = 0; t < 3; t++)
+    for (int t = 0; t < 3; t++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int cb = t == 0 ? 0 : 1, jb = t == 2 ? 1 : 0;
-      wv[t][r] = wbuf.ld((uint32_t)((16 * jb + MM::row(lane, r)) * 32 + 16 * cb + li) * SZ);
+      for (int r = 0; r < 4; r++) {
+        const int cb = t == 0 ? 0 : 1, jb = t == 2 ? 1 : 0;
+        wv[t][r] = wbuf.ld((uint32_t)((16 * jb + MM::row(lane, r)) * 32 + 16 * cb + li) * SZ);
+        unset = unset || flow_w_unset(wv[t][r]);
+      }
+    if (!__any(unset)) break;
+    if ((spins & 63u) == 63u) {
+      const int e = __hip_atomic_load(fa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e != 0 || spins >= RRPGO_FLOW_SPIN_MAX) {
+        if (e == 0 && lane == 0) atomicOr(fa.err, DEVERR_FLOW_TIMEOUT);
+        break;
+      }
     }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  RRPGO_FLOW_MARK(fa, ticket, tid >> 6, 2);
   typename MM::Acc out[2][2];
 #pragma unroll
   for (int ib = 0; ib < 2; ib++) {
@@ -353,8 +369,21 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
 // replay (r03: the second replay of a stage found the first one's flags still set -- tasks did not wait, the ticket
 // was past the end -- while eager launches and the unsharded graph, where hundreds of microseconds of other kernels
 // sit between the two, were fine).
-__global__ void __launch_bounds__(256) k_flow_reset(unsigned *words, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) words[i] = 0u;
+// It also marks the W blocks of the range's flow fronts as NOT THERE YET (blockIdx.y - 1 = entry of `wfill`: offset and
+// count of scalars in winv): a PANEL wave polls its W block itself instead of a flag followed by the block (one
+// round trip to L2 on the chain instead of two).  The mark is the all-ones pattern, a NaN no arithmetic produces
+// (hardware NaNs are 0x7fc00000 / propagated payloads of the operands); every store of a W block writes all of its
+// 1024 entries, each entry goes from the mark to its value in one store, so a block without a mark is complete.
+template <typename T>
+__global__ void __launch_bounds__(256) k_flow_reset(unsigned *words, int64_t n, T *winv, const int64_t *wfill) {
+  if (blockIdx.y == 0) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) words[i] = 0u;
+  } else {
+    const int64_t off = wfill[2 * (blockIdx.y - 1)], cnt = wfill[2 * (blockIdx.y - 1) + 1];
+    using U = typename std::conditional<sizeof(T) == 4, unsigned, unsigned long long>::type;
+    U *w = reinterpret_cast<U *>(winv + off);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) w[i] = ~(U)0;
+  }
 }
 
 #ifndef RRPGO_FLOW_DEPTH

@@ -270,9 +270,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     std::vector<FlowTask> host_tasks;   // diagnostic builds: the sorted list, for rr_pgo_debug_flow_trace
     DevBuf<unsigned long long> trace;   // diagnostic builds only
     int64_t ticket_word = 0;   // index of the level's ticket in flow_flags_
+    int wfill_begin = 0, wfill_end = 0;   // the level's fronts in flow_wfill_
     double est_us = 0;         // critical path of the cost model that orders the tasks
   };
   std::vector<std::unique_ptr<FlowLevel>> flow_levels_;   // per step of sym_.steps (null: launch sequence)
+  DevBuf<int64_t> flow_wfill_;      // per front of a flow level: offset and count of its W blocks' scalars in winv (k_flow_reset marks them)
   DevBuf<unsigned> flow_flags_;     // tickets + completion flags of every flow level, zeroed at the start of a factorisation
   int flow_max_nf_ = 64;            // RR_PGO_FLOW=<n> (0: never): levels of at most n fronts ...
   int flow_max_tasks_ = 40000;      // RR_PGO_FLOW_TASKS=<n>: ... and of at most n tasks run as ONE k_big_flow launch.  Measured on the 1M-edge
@@ -606,6 +608,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     flow_grid_ = std::max(cus, 1) * (sizeof(T) == 4 ? RRPGO_FLOW_WAVES : 1);
     if (const char *e = getenv("RR_PGO_FLOW_GRID")) flow_grid_ = std::max(1, std::atoi(e));
+    // first W block of every supernode in winv (as the SnMeta table lays them out), for the marks k_flow_reset writes
+    std::vector<int64_t> sn_wblk(sym_.S + 1, 0);
+    for (int f = 0; f < sym_.S; f++)
+      sn_wblk[f + 1] = sn_wblk[f] + (sym_.sn_big[f] ? 4 * ((sym_.sn_ncols[f] + 31) / 32) : (sym_.sn_ncols[f] + 15) / 16);
+    std::vector<int64_t> wfill;
     std::vector<std::vector<FlowTask>> all_tasks(sym_.steps.size());
     std::vector<std::vector<FlowFront>> all_fronts(sym_.steps.size());
     for (size_t si = 0; si < sym_.steps.size(); si++) {
@@ -614,17 +621,30 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       if (st.kind != STEP_BIG || nf > flow_max_nf_ || flow_max_nf_ <= 0) continue;
       auto lvl = std::make_unique<FlowLevel>();
       lvl->ticket_word = words;
-      // The Schur complements of the level's fronts: as UPDATE tiles of this launch (one per super-panel), or -- when there
-      // are enough of them to fill the chip -- left to ONE k_big_schur launch behind it (K = nc, seven workgroups per CU)
-      {
-        int64_t schur_tiles = 0;
-        for (int z = 0; z < nf; z++) {
-          const int sn = sym_.task_sn[sym_.task_ptr[st.task_begin + z]];
-          const int nc = sym_.sn_ncols[sn], M = nc + sym_.sn_nrows[sn] + 1, o = big_schur_origin(nc, schur_tile_);
-          if (o < M) { const int64_t nt = (M - o + 63) / 64; schur_tiles += nt * (nt + 1) / 2; }
+      // The Schur complements of the level's fronts: as UPDATE tiles of this launch (one per super-panel), or left to ONE
+      // k_big_schur launch behind it (K = nc, seven workgroups per CU, 75 % of the fp32 MFMA peak on the lattice's levels
+      // of 8 ... 64 fronts).  In the launch they cost twice the workgroup time, but at the top of the tree the launch is
+      // bound by its chain and most workgroups idle: the tiles stay in when the list schedule says they fit into 60 % of
+      // that idle time (lattice: the level of 2 fronts, -60 us; the level of 4 fronts would lose 70 us)
+      int64_t schur_tiles = 0;
+      double schur_in_flow_us = 0;   // workgroup time of the Schur tiles as UPDATE tasks
+      for (int z = 0; z < nf; z++) {
+        const int sn = sym_.task_sn[sym_.task_ptr[st.task_begin + z]];
+        const int nc = sym_.sn_ncols[sn], M = nc + sym_.sn_nrows[sn] + 1, o = big_schur_origin(nc, schur_tile_);
+        if (o < M) {
+          const int64_t nt = (M - o + 63) / 64;
+          schur_tiles += nt * (nt + 1) / 2;
+          schur_in_flow_us += (double)(nt * (nt + 1) / 2) * ((nc + BIG_SUPER - 1) / BIG_SUPER) * kTile;
         }
-        lvl->schur_split = schur_split_ && schur_tiles >= flow_schur_min_;
       }
+      lvl->schur_split = schur_split_ && schur_tiles >= flow_schur_min_;
+      std::vector<FlowTask> tasks;
+      std::vector<FlowFront> fronts(nf);
+      double level_end = 0, busy_us = 0;
+      bool too_many = false;
+      auto plan = [&]() {
+      tasks.clear();
+      level_end = busy_us = 0;
       // The level's tasks in their natural order (front by front, step by step), each with the flags it waits for and the
       // flags it sets. The ticket order is then the START order of a list schedule of this DAG on the launch's workgroups
       // (priority: longest remaining path), so that a workgroup drawing the next ticket finds what the schedule would
@@ -642,7 +662,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       std::vector<Gen> gen;
       std::vector<Need> need;
       std::vector<Prod> prod;
-      std::vector<FlowFront> fronts(nf);
       constexpr int TS = 64;           // edge of a trailing-update tile (k_big_flow<T, 2>)
       words = lvl->ticket_word + 32;   // the ticket on a 128-byte line of its own
       const int64_t flag0 = words;
@@ -735,7 +754,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         }
       }
       const int n_gen = (int)gen.size();
-      if (n_gen > flow_max_tasks_) { words = lvl->ticket_word; continue; }   // throughput-bound level: launch sequence (its flag words are given back)
+      if (n_gen > flow_max_tasks_) { too_many = true; return; }
       const int n_flags = (int)(words - flag0);
       // who sets a flag, who waits for it
       std::vector<int> producer(n_flags, -1), cons_ptr(n_flags + 1, 0), cons;
@@ -766,9 +785,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         }
       }
       // the list schedule
-      std::vector<FlowTask> tasks;
       tasks.reserve(n_gen);
-      double level_end = 0;
       {
         // half the launch's workgroups: the model's tiles are cheaper than loaded ones, and a chain step drawn a little
         // early only waits, while one drawn late stalls its front (measured: 128 ... 256 slots equal, 512 1 % slower)
@@ -809,6 +826,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           const float go = std::max(std::max(now + g.pre, t_new) + g.newest, t_w);
           slots.push(go + g.dur);
           level_end = std::max(level_end, (double)(go + g.dur));
+          busy_us += g.pre + g.newest + g.dur;
           tasks.push_back(g.t);
           for (int k = g.prod0; k < g.prod1; k++) {
             const int f = prod[k].flag;
@@ -818,8 +836,23 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           }
         }
       }
+      };   // plan
+      plan();
+      if (!too_many && lvl->schur_split && busy_us + schur_in_flow_us <= 0.6 * flow_grid_ * level_end) {
+        lvl->schur_split = false;
+        plan();
+        if (too_many) { too_many = false; lvl->schur_split = true; plan(); }
+      }
+      if (too_many) { words = lvl->ticket_word; continue; }   // throughput-bound level: launch sequence (its flag words are given back)
       lvl->n_tasks = (int)tasks.size();
       lvl->est_us = level_end;
+      lvl->wfill_begin = (int)(wfill.size() / 2);
+      for (int z = 0; z < nf; z++) {
+        const int sn = sym_.task_sn[sym_.task_ptr[st.task_begin + z]];
+        wfill.push_back(sn_wblk[sn] * 256);
+        wfill.push_back((int64_t)((sym_.sn_ncols[sn] + BIG_NB - 1) / BIG_NB) * 1024);
+      }
+      lvl->wfill_end = (int)(wfill.size() / 2);
       all_tasks[si] = std::move(tasks);
       all_fronts[si] = std::move(fronts);
       flow_levels_[si] = std::move(lvl);
@@ -863,6 +896,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         solve_flow_[si]->n_tasks = (int)all_st[si].size();
       }
     if (words == 0) return;
+    wfill.resize(wfill.size() + 2, 0);   // never empty
+    flow_wfill_.upload(wfill);
     flow_flags_.alloc((size_t)words);
     flow_flags_.zero();
     for (size_t si = 0; si < sym_.steps.size(); si++)
@@ -1164,8 +1199,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   void launch_factor_range(size_t from, size_t to) {
     // tickets and completion flags of the flow levels (one small kernel per factorisation; flow.hip.h, k_flow_reset)
     if (any_flow(from, to)) {
-      hipLaunchKernelGGL(k_flow_reset, dim3((unsigned)std::min<int64_t>(((int64_t)flow_flags_.n + 255) / 256, 1024)), dim3(256), 0, stream_,
-                         flow_flags_.p, (int64_t)flow_flags_.n);
+      // ... and the "not there yet" marks of the W blocks of the range's flow fronts
+      int e0 = 0, e1 = 0;
+      for (size_t si = from; si < to && si < flow_levels_.size(); si++)
+        if (flow_levels_[si]) { if (e1 == 0) e0 = flow_levels_[si]->wfill_begin; e1 = flow_levels_[si]->wfill_end; }
+      hipLaunchKernelGGL(k_flow_reset<T>, dim3((unsigned)std::min<int64_t>(((int64_t)flow_flags_.n + 255) / 256, 64), 1 + std::max(e1 - e0, 0)), dim3(256), 0,
+                         stream_, flow_flags_.p, (int64_t)flow_flags_.n, winv_.p, flow_wfill_.p + 2 * e0);
       check_launch("k_flow_reset");
     }
     for (size_t si = from; si < to; si++) {
