@@ -26,6 +26,7 @@
 
 namespace rrpgo {
 
+constexpr int FLOW_MAX_BACK = 5;   // blocks a PANEL step looks back over at most: three of its own super-panel, or four of the previous one and one
 struct FlowFront {       // one front of a flow level: where its flags live (indices into FlowArgs::flags)
   int32_t wf;            // wf[b]: W of 32-column block b is in winv (and every row the chain read for it is in F)
   int32_t pf, pstride;   // pf[b * pstride + rb]: X of row block rb of block b is in F
@@ -148,7 +149,7 @@ __device__ __forceinline__ void flow_diag0_wave(const FlowArgs<T> &fa, const Flo
 // with the first half running under the previous step's factor-and-invert.
 template <typename T, int TS /* edge of a trailing-update tile: 64 or 128 */>
 __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const FlowFront &ff, const SnMeta &m, int kb,
-                                                int K0, int rowblk, T *Sh, int tid, int ticket) {
+                                                int K0raw, int rowblk, T *Sh, int tid, int ticket) {
   static_assert(BIG_NB == 32 && BIG_SUPER == 128, "written for 32-column blocks in 128-column super-panels");
   using MM = Mfma16<T>;
   const int nb = min(BIG_NB, m.nc - kb);
@@ -158,7 +159,13 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
   T *F = fa.lvals + m.loff;
   T *Wt = fa.winv + (int64_t)m.wblk * 256 + (kb / BIG_NB) * 1024;
   const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  const int super_end = min(K0 + BIG_SUPER, m.nc);
+  // K0 = first column of the left-looking range: the super-panel's first column, or -- fast mode, the first two blocks
+  // of a super-panel (FlowTask::p2, build_flow_levels) -- the PREVIOUS super-panel's, whose update then skips these 64
+  // columns: the step after a super-panel's end does not wait for a tile of that update (6.8 us on the chain).  The
+  // next diagonal block's range starts `skip` blocks later (the second block of such a super-panel forms the third,
+  // whose columns the previous update did cover).
+  const int skip = K0raw >> 24, K0 = K0raw & 0xffffff;
+  const int super_end = min(K0 + BIG_SUPER, m.nc);   // (exact mode only: K0 is the super-panel's first column there)
   const int kn = kb + BIG_NB;
   const int blk = kb / BIG_NB, q = (kb - K0) / BIG_NB, sp = K0 / BIG_SUPER;
   // this wave also prepares the next diagonal block (nb == 32 then); across the super-panel's end only in the fast mode
@@ -174,15 +181,15 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
   {
     // ---- first wait: the C tiles (previous super-panel's trailing update) and every block but the newest
     const unsigned *fp = nullptr;
-    if (lane < 6) {
-      const int j = lane / 3 + 2;   // blocks blk - 2, blk - 3
-      if (j <= q) fp = block_flag(j, lane % 3);
-    } else if (lane <= 7) {
-      const int bx = (R0 - K0) / TS + (lane - 6), bxe = (min(R0 + 31, M - 1) - K0) / TS;
+    if (lane < 3 * (FLOW_MAX_BACK - 1)) {
+      const int j = lane / 3 + 2;   // blocks blk - 2, blk - 3, ... (a long range: not blk - 2, see wait_second)
+      if (j <= q && (j > 2 || q <= 3)) fp = block_flag(j, lane % 3);
+    } else if (lane < 3 * (FLOW_MAX_BACK - 1) + 2) {
+      const int bx = (R0 - K0) / TS + (lane - 3 * (FLOW_MAX_BACK - 1)), bxe = (min(R0 + 31, M - 1) - K0) / TS;
       if (sp > 0 && bx <= bxe) fp = fa.flags + ff.uf + (sp - 1) * ff.ustride + flow_tri(bx, (kb - K0) / TS);
-    } else if (lane == 8) {
-      const int d = (kn - K0) / TS;
-      if (look && sp > 0) fp = fa.flags + ff.uf + (sp - 1) * ff.ustride + flow_tri(d, d);
+    } else if (lane == 3 * (FLOW_MAX_BACK - 1) + 2) {
+      const int d = (kn - K0) / TS;   // the update before the next block's range (a later range: look_tile below)
+      if (look && skip == 0 && K0 > 0) fp = fa.flags + ff.uf + (K0 / BIG_SUPER - 1) * ff.ustride + flow_tri(d, d);
     }
     flow_wait(fp, fa.err);
   }
@@ -215,6 +222,11 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
   auto wait_newest = [&] {   // X of block blk - 1: my rows and the diagonal block's rows
     flow_wait(lane < 3 ? block_flag(1, lane) : nullptr, fa.err);
   };
+  // a range of more than three blocks reaches into the previous super-panel: its blocks are there long before block
+  // blk - 2 is, and at ~2 us of loads per block the pre-work has to start on them at once to stay off the chain
+  auto wait_second = [&] {
+    if (q > 3) flow_wait(lane < 3 ? block_flag(2, lane) : nullptr, fa.err);
+  };
   typename MM::Acc acc[2][2], nxt[2][2];
 #pragma unroll
   for (int jb = 0; jb < 2; jb++)
@@ -226,7 +238,7 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
     }
   if (nblk == 1) wait_newest();
   if (nblk > 0) fetch(0, av[0], bv[0]);
-  if (look) {
+  auto load_next_diag = [&] {
 #pragma unroll
     for (int jb = 0; jb < 2; jb++)
 #pragma unroll
@@ -235,7 +247,8 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
 #pragma unroll
         for (int ib = 0; ib < 2; ib++) nxt[ib][jb][r] = ldF(cn, irow[ib]);
       }
-  }
+  };
+  if (look && skip == 0) load_next_diag();
 #pragma unroll
   for (int jb = 0; jb < 2; jb++)
 #pragma unroll
@@ -253,12 +266,20 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
 #pragma unroll
-  for (int b = 0; b < BIG_SUPER / BIG_NB - 1; b++) {
+  for (int b = 0; b < FLOW_MAX_BACK; b++) {
     if (b < nblk) {
       const int slot = b & 1;
       if (b + 1 < nblk) {   // the next block's operands are in flight under this block's MFMAs
         if (b + 2 == nblk) wait_newest();
+        if (b + 3 == nblk) wait_second();
         fetch(b + 1, av[slot ^ 1], bv[slot ^ 1]);
+      }
+      if (look && skip > 0 && b == skip) {
+        // the next diagonal block's range starts here; the tile of the update before it that holds the block is
+        // finished late (it needs the previous super-panel's last X): waited for now, not before the pre-work
+        const int Kn = K0 + BIG_NB * skip, d = (kn - Kn) / TS;
+        flow_wait(lane == 0 ? fa.flags + ff.uf + (Kn / BIG_SUPER - 1) * ff.ustride + flow_tri(d, d) : nullptr, fa.err);
+        load_next_diag();
       }
 #pragma unroll
       for (int s4 = 0; s4 < 8; s4++) {
@@ -266,7 +287,7 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
         for (int ib = 0; ib < 2; ib++)
 #pragma unroll
           for (int jb = 0; jb < 2; jb++) acc[ib][jb] = MM::mma(av[slot][s4][jb], bv[slot][s4][ib], acc[ib][jb]);
-        if (look) {
+        if (look && b >= skip) {
 #pragma unroll
           for (int ib = 0; ib < 2; ib++)
 #pragma unroll

@@ -281,6 +281,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
                                     // lattice (r03, tickets in list-schedule order, Schur complements left to k_big_schur): the level of 64
                                     // fronts gains 64 us over its launch sequence, the level of 128 fronts ties, wider levels are bound by tile
                                     // THROUGHPUT, where the batched k_big_update launches (7 workgroups per CU) beat the flow kernel's two
+  bool flow_deep_ = true;           // RR_PGO_FLOW_DEEP=0: no look-back over the previous super-panel (fast mode; see build_flow_levels)
   bool flow_exact_ = false;         // RR_PGO_FLOW_EXACT=1: bit-identical to the launch sequence (tile (0, 0) forms the next super-panel's first block)
   struct SolveFlowLevel { DevBuf<SolveFlowFront> fronts; DevBuf<SolveFlowTask> tasks; int n_tasks = 0; int64_t ticket_word = 0; };
   std::vector<std::unique_ptr<SolveFlowLevel>> solve_flow_;   // per step: k_big_solve_flow's tasks and counters (null: k_big_solve_sp launches)
@@ -465,6 +466,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     gather_update_ = getenv("RR_PGO_NO_GATHER_UPDATE") == nullptr;
     if (const char *e = getenv("RR_PGO_FLOW")) flow_max_nf_ = std::atoi(e);
     flow_exact_ = getenv("RR_PGO_FLOW_EXACT") != nullptr;
+    if (const char *e = getenv("RR_PGO_FLOW_DEEP")) flow_deep_ = std::atoi(e) != 0;
     if (const char *e = getenv("RR_PGO_FLOW_TASKS")) flow_max_tasks_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_SOLVE_FLOW")) solve_flow_on_ = std::atoi(e) != 0;
     if (const char *e = getenv("RR_PGO_FLOW_SCHUR_MIN")) flow_schur_min_ = std::atoi(e);
@@ -688,39 +690,46 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         gen.back().dur = (float)kDiag;
         close_task();
         const int o_schur = lvl->schur_split ? std::min(big_schur_origin(nc, schur_tile_), M) : M;   // UPDATE tiles start left of it
+        // fast mode: the first two blocks of a super-panel look back over the previous super-panel too, and that one's
+        // update skips these 64 columns (its tile column 0) -- the chain does not wait for a tile at a super-panel's end
+        auto deep = [&](int spx) { return flow_deep_ && !flow_exact_ && spx > 0 && spx * BIG_SUPER + 64 <= nc; };
         for (int sp = 0; sp < nsp; sp++) {
           const int K0 = sp * BIG_SUPER, ke = std::min(K0 + BIG_SUPER, nc);
-          // the previous update's tiles under rows [r0, r1] x columns [c0, c1] (tiles right of the Schur origin are not
-          // this launch's: nothing waits for them)
-          auto prev_tiles = [&](int r0, int r1, int c0, int c1, int cls) {
-            if (sp == 0) return;
-            for (int bx = (r0 - K0) / TS; bx <= (std::min(r1, M - 1) - K0) / TS; bx++)
-              for (int by = (c0 - K0) / TS; by <= std::min((std::min(c1, M - 1) - K0) / TS, bx); by++)
-                if (K0 + TS * by < o_schur) need.push_back(Need{uf + (sp - 1) * ustride + tri(bx, by), cls});
+          // the tiles under rows [r0, r1] x columns [c0, c1] of the update whose tile grid starts at column Ko (the update
+          // before a left-looking range that starts there); tiles right of the Schur origin are not this launch's
+          auto prev_tiles = [&](int Ko, int r0, int r1, int c0, int c1, int cls) {
+            if (Ko <= 0) return;
+            const int spo = Ko / BIG_SUPER - 1;
+            for (int bx = (r0 - Ko) / TS; bx <= (std::min(r1, M - 1) - Ko) / TS; bx++)
+              for (int by = (c0 - Ko) / TS; by <= std::min((std::min(c1, M - 1) - Ko) / TS, bx); by++)
+                if (Ko + TS * by < o_schur && !(by == 0 && deep(spo + 1))) need.push_back(Need{uf + spo * ustride + tri(bx, by), cls});
           };
           for (int kb = K0; kb < ke; kb += BIG_NB) {
-            const int blk = kb / BIG_NB, q = (kb - K0) / BIG_NB, nb = std::min(BIG_NB, nc - kb), kn = kb + BIG_NB;
+            const int blk = kb / BIG_NB, qb = (kb - K0) / BIG_NB, nb = std::min(BIG_NB, nc - kb), kn = kb + BIG_NB;
+            const int Ks = deep(sp) && qb < 2 ? K0 - BIG_SUPER : K0;   // first column of the step's left-looking range
+            const int q = (kb - Ks) / BIG_NB;
+            const int skip = deep(sp) && qb == 1 ? BIG_SUPER / BIG_NB : 0;   // the NEXT diagonal block's range starts that many blocks later
             const int nrb = (M - (kb + nb) + 31) / 32;
             for (int g0 = 0; g0 < nrb; g0 += FLOW_GROUP) {
-              open_task(FlowTask{(FLOW_PANEL << 24) | z, kb, g0, K0});
+              open_task(FlowTask{(FLOW_PANEL << 24) | z, kb, g0, Ks | (skip << 24)});
               Gen &g = gen.back();
               g.wflag = wf + blk;
-              g.pre = (float)(q > 1 ? kPre : 0.5);
+              g.pre = (float)(q > 1 ? kPre * (q - 1) * 0.5 : 0.5);
               g.newest = (float)(q > 0 ? kNewest : 0.0);
               g.dur = (float)kX;
               for (int w = 0; w < FLOW_GROUP && g0 + w < nrb; w++) {
                 const int rb = g0 + w, R0 = kb + nb + 32 * rb;
                 const bool look = rb == 0 && kn < (flow_exact_ ? ke : nc);
-                // a wave starts with everything that needs neither W nor the newest block (blocks blk - 2, blk - 3 and the
-                // C tiles), then the newest block's term, then W, then X; the look wave goes on with the next block
+                // a wave starts with everything that needs neither W nor the newest block (the older blocks and the C
+                // tiles), then the newest block's term, then W, then X; the look wave goes on with the next block
                 for (int j = 1; j <= q; j++) {
                   const int r0p = kb - 32 * j + 32;
                   need.push_back(Need{pf + (blk - j) * pstride + (j - 1), j == 1});
                   for (int rbp = (R0 - r0p) / 32; rbp <= (std::min(R0 + 31, M - 1) - r0p) / 32; rbp++)
                     need.push_back(Need{pf + (blk - j) * pstride + rbp, j == 1});
                 }
-                prev_tiles(R0, R0 + 31, kb, kb + nb - 1, 0);
-                if (look) prev_tiles(kn, kn + 31, kn, kn + 31, 0);
+                prev_tiles(Ks, R0, R0 + 31, kb, kb + nb - 1, 0);
+                if (look) prev_tiles(Ks + BIG_NB * skip, kn, kn + 31, kn, kn + 31, 0);
                 prod.push_back(Prod{pf + blk * pstride + rb, (float)kX});   // X is published before the look wave goes on
                 if (look) { prod.push_back(Prod{wf + blk + 1, (float)(kX + kLook)}); g.dur = (float)(kX + kLook); }
               }
@@ -730,7 +739,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           // trailing update of the super-panel: tiles of rows / columns >= ke
           const int t0 = ke;
           const int nt = (M - t0 + TS - 1) / TS;
-          for (int by = 0; by < nt; by++)       // column-major: the next super-panel's own columns first
+          for (int by = deep(sp + 1) ? 1 : 0; by < nt; by++)       // column-major: the next super-panel's own columns first
             for (int bx = by; bx < nt; bx++) {
               const int I0 = t0 + TS * bx, J0 = t0 + TS * by;
               if (J0 >= o_schur) continue;       // the Schur complement: one k_big_schur launch behind the flow launch
@@ -742,7 +751,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
                   for (int rb = (lo - r0) / 32; rb <= (hi - r0) / 32; rb++) need.push_back(Need{pf + (kb / BIG_NB) * pstride + rb, 0});
                 }
               }
-              prev_tiles(I0, I0 + TS - 1, J0, J0 + TS - 1, 0);
+              prev_tiles(K0, I0, I0 + TS - 1, J0, J0 + TS - 1, 0);
               prod.push_back(Prod{uf + sp * ustride + tri(bx, by), (float)kTile});
               gen.back().dur = (float)kTile;
               if (flow_exact_ && bx == 0 && by == 0 && t0 < nc) {
