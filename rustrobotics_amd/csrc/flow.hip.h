@@ -274,9 +274,10 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
         if (b + 3 == nblk) wait_second();
         fetch(b + 1, av[slot ^ 1], bv[slot ^ 1]);
       }
-      if (look && skip > 0 && b == skip) {
-        // the next diagonal block's range starts here; the tile of the update before it that holds the block is
-        // finished late (it needs the previous super-panel's last X): waited for now, not before the pre-work
+      if (look && skip > 0 && b + 1 == skip) {
+        // the next diagonal block's range starts with the next block; the tile of the update before it that holds the
+        // diagonal block is finished late (it needs the previous super-panel's last X): waited for now, not before the
+        // pre-work, and loaded together with the newest block's operands
         const int Kn = K0 + BIG_NB * skip, d = (kn - Kn) / TS;
         flow_wait(lane == 0 ? fa.flags + ff.uf + (Kn / BIG_SUPER - 1) * ff.ustride + flow_tri(d, d) : nullptr, fa.err);
         load_next_diag();

@@ -443,14 +443,17 @@ def test_levenberg_marquardt_through_the_big_front_path(api, oracle):
 
 
 @pytest.mark.parametrize("env", ["RR_PGO_FLOW=0", "RR_PGO_FLOW_TASKS=100000000", "RR_PGO_FLOW_EXACT", "RR_PGO_NO_GATHER_UPDATE",
-                                 "RR_PGO_SCHUR_SPLIT=0", "RR_PGO_XCD_REMAP=0", "RR_PGO_SOLVE_FLOW=0", "RR_PGO_EDGE_LINEARIZE"])
+                                 "RR_PGO_SCHUR_SPLIT=0", "RR_PGO_XCD_REMAP=0", "RR_PGO_SOLVE_FLOW=0", "RR_PGO_EDGE_LINEARIZE",
+                                 "RR_PGO_FLOW_DEEP=0", "RR_PGO_FLOW_SCHUR_MIN=100000000", "RR_PGO_FLOW_SLOTS=1000000"])
 def test_alternate_big_front_launch_sequences_agree(api, env, monkeypatch):
     """The switches read when a handle is created that change WHICH kernels run: the launch-per-step sequence for every
-    level (RR_PGO_FLOW=0) or the dataflow launch for every level of at most 32 fronts (RR_PGO_FLOW_TASKS), its exact mode,
+    level (RR_PGO_FLOW=0) or the dataflow launch for every level of at most 64 fronts (RR_PGO_FLOW_TASKS), its exact mode,
     whole fronts built by k_big_build instead of gathered by the first trailing update, every super-panel's update
     reaching through the Schur complement instead of ONE k_big_schur pass per level, tiles in dispatch order instead of
     one contiguous eighth per XCD, one k_big_solve_sp launch per 128 columns instead of ONE k_big_solve_flow launch per
-    level in the back substitution, and the edge-parallel linearisation.  Each must give the default path's answer on the 100 x 100 lattice (same arithmetic up to the order
+    level in the back substitution, the edge-parallel linearisation, and three switches of the dataflow launch (panel
+    steps that never look back over the previous super-panel, Schur complements always inside the launch, tickets in
+    the order of earliest starts instead of the list schedule's).  Each must give the default path's answer on the 100 x 100 lattice (same arithmetic up to the order
     of the block operations).  (The r01 / r02 alternatives of the big-front path were removed in r03 after losing every
     measurement: profiles/EXPERIMENTS.md.)"""
     from rustrobotics_amd import synthetic_grid_arrays
@@ -485,7 +488,7 @@ def test_flow_launch_is_bit_identical_to_the_launch_sequence(api, case, monkeypa
             return api[0].from_arrays(*synthetic_grid_arrays(w, h, 1000000 if w == 400 else 0), precision=prec)
         return api[0].new(g2o_path(name), precision=prec)
 
-    monkeypatch.setenv("RR_PGO_FLOW_TASKS", "100000000")   # every level of at most 32 big fronts, also the throughput-bound ones
+    monkeypatch.setenv("RR_PGO_FLOW_TASKS", "100000000")   # every level of at most 64 big fronts, also the throughput-bound ones
     monkeypatch.setenv("RR_PGO_FLOW_EXACT", "1")   # tile (0, 0) forms the next super-panel's first block, as the launches do
     flow = make()
     monkeypatch.delenv("RR_PGO_FLOW_EXACT")
