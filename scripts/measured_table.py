@@ -1,0 +1,26 @@
+"""The 'Measured' table of DESIGN.md from the bench lines of a round: python3 scripts/measured_table.py TAG  (profiles/<TAG>_bench_*.json)"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+rows = [("intel_f64", "intel.g2o fp64 (configs[1], the headline line)"), ("intel_mixed", "intel.g2o mixed (f64 state / gradient, f32 factor)"),
+        ("m3500_f64", "input_M3500 fp64 (configs[2])"), ("dlr_f64", "dlr.g2o fp64 (pose-landmark, 17.6 k edges)"),
+        ("grid_f32", "lattice 100 k poses / 1 M edges fp32 (configs[3])"), ("sphere2500_f64", "sphere2500 fp64 SE(3) (configs[4])")]
+print("| workload | GN it/s | ms/step | launches/step | per-step time by kernel class (µs, HIP events) | roofline of the dominant class |")
+print("|---|---|---|---|---|---|")
+for key, label in rows:
+    d = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_bench_{key}.json")))
+    r = d["roofline"]
+    cls = {k: v for k, v in r["per_step_us_by_kernel_class"].items() if v >= 0.5}
+    cls_s = ", ".join(f"{k} {v:.0f}" for k, v in sorted(cls.items(), key=lambda kv: -kv[1]))
+    roof = f"`{r['kernel']}`: {r['achieved']:.3g} {r['unit']} = {100 * r['frac']:.2g} % of the {r['bound'].upper()} peak ({r['peak']:g})"
+    mk = d.get("mfma_kernel")
+    if mk:
+        roof += f"; `{mk['kernel']}`: {mk['achieved']:.1f} TFLOP/s = {100 * mk['frac']:.1f} % of the fp32 MFMA peak over {mk['launches_per_step']:.0f} launches"
+    print(f"| {label} | **{d['value']:.0f}** | {d['ms_per_step']:.3f} | {d['launches_per_step']} | {cls_s} | {roof} |")
+dflt = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_bench_default.json")))
+cb = dflt.get("cpu_baseline") or {}
+print()
+print(f"Default line (`python bench.py`, what the driver runs): {dflt['value']:.0f} {dflt['unit']}, CPU oracle on one core of the same box "
+      f"{cb.get('value', 0):.0f} {cb.get('unit', '')} ({cb.get('kind')}; {cb.get('sample', '')[:120]}).")
+for s in dflt.get("secondary", []):
+    print(f"  secondary: {s.get('workload', '?')[:60]} {s.get('dtype')} {s.get('parallelism')}: {s.get('value', 0):.1f} it/s, {s.get('ms_per_step', 0):.3f} ms")
