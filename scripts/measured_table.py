@@ -1,7 +1,12 @@
-"""The 'Measured' table of DESIGN.md from the bench lines of a round: python3 scripts/measured_table.py TAG  (profiles/<TAG>_bench_*.json)"""
-import json, os, sys
+"""The 'Measured' block of DESIGN.md (between its measured:begin / measured:end markers) from the artefacts of a round:
+python3 scripts/measured_table.py TAG [--write]   (profiles/<TAG>_bench_*.json, profiles/<TAG>_lattice_levels.txt)"""
+import io, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
+out = io.StringIO()
+_print = print
+def print(*a):   # noqa: A001 -- collect the block
+    _print(*a, file=out)
 rows = [("intel_f64", "intel.g2o fp64 (configs[1], the headline line)"), ("intel_mixed", "intel.g2o mixed (f64 state / gradient, f32 factor)"),
         ("m3500_f64", "input_M3500 fp64 (configs[2])"), ("dlr_f64", "dlr.g2o fp64 (pose-landmark, 17.6 k edges)"),
         ("grid_f32", "lattice 100 k poses / 1 M edges fp32 (configs[3])"), ("sphere2500_f64", "sphere2500 fp64 SE(3) (configs[4])")]
@@ -23,4 +28,22 @@ print()
 print(f"Default line (`python bench.py`, what the driver runs): {dflt['value']:.0f} {dflt['unit']}, CPU oracle on one core of the same box "
       f"{cb.get('value', 0):.0f} {cb.get('unit', '')} ({cb.get('kind')}; {cb.get('sample', '')[:120]}).")
 for s in dflt.get("secondary", []):
-    print(f"  secondary: {s.get('workload', '?')[:60]} {s.get('dtype')} {s.get('parallelism')}: {s.get('value', 0):.1f} it/s, {s.get('ms_per_step', 0):.3f} ms")
+    print(f"* secondary: {s.get('workload', '?')[:60]} {s.get('dtype')} {s.get('parallelism')}: {s.get('value', 0):.1f} it/s, {s.get('ms_per_step', 0):.3f} ms")
+
+print()
+print(f"Per tree level of the lattice (rocprofv3 kernel trace of one iteration with plain launches, `profiles/{tag}_lattice_levels.txt`; "
+      "`nf` = fronts of the level, launches x count = their total time in µs):")
+print()
+print("```")
+for line in open(os.path.join(ROOT, "profiles", f"{tag}_lattice_levels.txt")):
+    if line.startswith("level"):
+        print(line.rstrip())
+print("```")
+block = out.getvalue()
+if "--write" in sys.argv:
+    path = os.path.join(ROOT, "DESIGN.md")
+    doc = open(path).read()
+    a, b = doc.index("<!-- measured:begin -->"), doc.index("<!-- measured:end -->")
+    open(path, "w").write(doc[:a] + "<!-- measured:begin -->\n" + block + doc[b:])
+else:
+    _print(block)
