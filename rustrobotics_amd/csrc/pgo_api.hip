@@ -1909,6 +1909,7 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
   if (const char *e = std::getenv("RR_PGO_TASK_US")) so.task_us = std::atof(e);
   if (const char *e = std::getenv("RR_PGO_THREADS_SHIFT")) so.threads_shift = std::atoi(e);
   if (std::getenv("RR_PGO_NO_GEO")) so.geo_nd = false;
+  if (const char *e = std::getenv("RR_PGO_LDS_PIECES")) so.max_lds_pieces = std::max(1, std::atoi(e));
   if (std::getenv("RR_PGO_JOIN_SEPARATORS")) so.split_separators = false;
   if (const char *e = std::getenv("RR_PGO_ND_LEAF")) so.nd_leaf = std::atoi(e);
   double t0 = now_ms();
@@ -2241,10 +2242,8 @@ int rr_pgo_debug_stamps(rr_pgo *h, double *out, int32_t *n_sn) {
     std::vector<int> step_of(y.S, -1), task_of(y.S, -1);
     for (size_t si = 0; si < y.steps.size(); si++) {
       const Step &sp = y.steps[si];
-      if (sp.kind == STEP_TASKS) {
-        for (int t = sp.task_begin; t < sp.task_end; t++)
-          for (int q = y.task_ptr[t]; q < y.task_ptr[t + 1]; q++) { step_of[y.task_sn[q]] = (int)si; task_of[y.task_sn[q]] = t; }
-      } else { step_of[sp.sn] = (int)si; }
+      for (int t = sp.task_begin; t < sp.task_end; t++)   // (a level of fronts beyond LDS: one front per task)
+        for (int q = y.task_ptr[t]; q < y.task_ptr[t + 1]; q++) { step_of[y.task_sn[q]] = (int)si; task_of[y.task_sn[q]] = t; }
     }
     for (int s = 0; s < y.S; s++) {
       double *o = out + (size_t)s * 16;

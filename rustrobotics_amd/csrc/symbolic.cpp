@@ -675,7 +675,8 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
   if ((int)forder.size() != N) return "internal: amalgamation lost nodes";
   // A supernode whose front does not fit the LDS budget is cut into a chain of
   // narrower supernodes when that makes every piece fit (same flops, the later
-  // pivots simply travel through the first pieces' update matrices).
+  // pivots simply travel through the first pieces' update matrices) -- into at most
+  // opt.max_lds_pieces of them: every piece moves the whole update matrix through LDS.
   {
     std::vector<int32_t> nfirst, nnpos;
     for (int f = 0; f < S; f++) {
@@ -685,7 +686,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
       for (int p = a; p < a + n; p++) tot += w[forder[p]];
       int pieces = 1;
       if (lds_elems((int)tot, (int)below) > lds_budget && n > 1) {
-        for (int np = 2; np <= n && pieces == 1; np++) {
+        for (int np = 2; np <= n && np <= opt.max_lds_pieces && pieces == 1; np++) {
           // np pieces of (almost) equal node counts; check that all fit
           bool ok = true;
           int64_t done = 0;
@@ -1148,9 +1149,21 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
         Step st{};
         st.kind = STEP_TASKS;
         st.task_begin = (int)sym.task_ptr.size() - 1;
-        double worst = 0.0, worst_solve = 0.0;
+        double worst = 0.0, worst_solve = 0.0, sum = 0.0, sum_solve = 0.0;
+        // the level's tasks, the longest first: workgroups are dispatched in index order as CUs become free, so a level
+        // of thousands of tasks packs like a longest-processing-time schedule and ends with its shortest tasks (r03, the
+        // 2067 leaf tasks of the 1M-edge lattice in the order of the tree: 80 % of the CUs busy, the last 10 % of the
+        // launch with a quarter of them)
+        std::vector<std::pair<double, size_t>> level_tasks;
         for (size_t t = 0; t < tasks.size(); t++) {
           if (task_level[t] != L || tasks[t].empty() || !wanted(tasks[t][0])) continue;
+          double tc = 0.0;
+          for (int f : tasks[t]) tc += cost[f];
+          level_tasks.emplace_back(-tc, t);
+        }
+        std::stable_sort(level_tasks.begin(), level_tasks.end());
+        for (const auto &lt : level_tasks) {
+          const size_t t = lt.second;
           double tc = 0.0, ts = 0.0;
           for (int f : tasks[t]) {
             sym.task_sn.push_back(f);
@@ -1162,6 +1175,8 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
           sym.task_ptr.push_back((int)sym.task_sn.size());
           worst = std::max(worst, tc);
           worst_solve = std::max(worst_solve, ts);
+          sum += tc;
+          sum_solve += ts;
         }
         st.task_end = (int)sym.task_ptr.size() - 1;
         {
@@ -1170,7 +1185,8 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
         }
         if (st.task_end > st.task_begin) {
           sym.steps.push_back(st);
-          crit += 1.5 + worst + 1.5 + worst_solve;
+          // one workgroup per CU: a level of many tasks takes its total work over the CUs, not its longest task
+          crit += 1.5 + std::max(worst, sum / opt.n_cus) + 1.5 + std::max(worst_solve, sum_solve / opt.n_cus);
         }
         // fronts beyond LDS at this level: optional one-workgroup class, then the tiled batch
         for (int cls = 0; cls < 2; cls++) {

@@ -23,6 +23,10 @@ struct SymbolicOptions {
   bool split_separators = false;     // do not chain a region's last separator into its parent separator's supernode
   bool geo_nd = true;                // nested dissection may cut along a coordinate axis (pose graphs are spatial)
   int threads_shift = 1;             // workgroup size classes: front size is shifted left by this before the lookup
+  int max_lds_pieces = 2;            // a supernode beyond the LDS budget is cut into at most this many LDS-sized pieces, else it stays ONE front
+                                     // beyond LDS (r03, 1M-edge lattice: 54-column supernodes just over the budget were cut into three 18-column
+                                     // fronts, each moving a 237 x 237 update matrix through LDS -- two 160 us tasks in a level of 45 us tasks)
+  int n_cus = 256;                   // compute units of the device (the schedule's estimate of a level of many tasks)
   int64_t lds_budget_elems = 19000;  // LDS scalars one workgroup may use for a front (panel + packed update)
   int nd_leaf = 40;         // nested dissection stops below this many nodes
   int n_parts = 1;          // >1: top ND levels are shared, subtrees owned by ranks (power of two)
