@@ -794,6 +794,7 @@ template <typename T> struct FactorArgs {
                              // one-front tasks of the big-front kernels
   const ChildMeta *child_meta;
   const int32_t *fasm_src, *fasm_dst, *fdup_src, *fdup_dst;
+  const int32_t *fasm_colptr;   // fronts beyond LDS: start of every permuted pivot column's entries in fasm_*
   const int32_t *scat, *rel;
   const int32_t *perm;      // permuted scalar -> reference scalar
   const int32_t *sn_rows;
@@ -1523,7 +1524,12 @@ __device__ __forceinline__ void big_build_column(const FactorArgs<T> &a, const C
 }
 
 // pivot_only: columns [0, big_built_cols) only -- the first trailing update forms the rest (k_big_update, gather).
-template <typename T> __global__ void __launch_bounds__(256) k_big_build(FactorArgs<T> a, int pivot_only) {
+// with_h: the wave that wrote a pivot column then adds the column's H entries and its right-hand-side entry itself
+// (fasm_* sorted by destination, fasm_colptr) -- what the k_big_assemble launch of every level did (r03: 11 launches,
+// 71 us per iteration of the 1M-edge lattice).  The entries go on top of what this wave's OTHER lanes have just stored:
+// the stores are drained first (write-through: they are in L2 then) and the values read back past the CU's L1, which
+// may still hold the previous iteration's line.  Same sums as k_big_assemble: bit-identical.
+template <typename T> __global__ void __launch_bounds__(256) k_big_build(FactorArgs<T> a, int pivot_only, int with_h) {
   const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
   const int M = m.nc + m.nr + 1;
   T *F = a.lvals + m.loff;
@@ -1534,6 +1540,19 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_build(FactorA
     T *col = F + (int64_t)J * M;
     if (m.child_count <= 2) big_build_column<T, 2>(a, cm, m.child_count, M, J, col, lane);
     else big_build_column<T, 4>(a, cm, m.child_count, M, J, col, lane);
+  }
+  if (!with_h) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int J = blockIdx.x * 4 + wave; J < m.nc; J += gridDim.x * 4) {
+    const int t0 = a.fasm_colptr[m.col0 + J], t1 = a.fasm_colptr[m.col0 + J + 1];
+    for (int t = t0 + lane; t < t1; t += 64) {
+      T *p = F + a.fasm_dst[t];
+      *p = mem_ld<true>(p) + a.hvals[a.fasm_src[t]];
+    }
+    if (lane == 0) {
+      T *p = F + (int64_t)J * M + (M - 1);
+      *p = mem_ld<true>(p) + a.b[a.perm[m.col0 + J]];
+    }
   }
 }
 

@@ -281,6 +281,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
                                     // lattice (r03, tickets in list-schedule order, Schur complements left to k_big_schur): the level of 64
                                     // fronts gains 64 us over its launch sequence, the level of 128 fronts ties, wider levels are bound by tile
                                     // THROUGHPUT, where the batched k_big_update launches (7 workgroups per CU) beat the flow kernel's two
+  bool fused_assembly_ = true;      // RR_PGO_SPLIT_ASSEMBLY=1: H entries and rhs of the fronts beyond LDS by a k_big_assemble launch per level
   bool flow_deep_ = true;           // RR_PGO_FLOW_DEEP=0: no look-back over the previous super-panel (fast mode; see build_flow_levels)
   bool flow_exact_ = false;         // RR_PGO_FLOW_EXACT=1: bit-identical to the launch sequence (tile (0, 0) forms the next super-panel's first block)
   struct SolveFlowLevel { DevBuf<SolveFlowFront> fronts; DevBuf<SolveFlowTask> tasks; int n_tasks = 0; int64_t ticket_word = 0; };
@@ -304,7 +305,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<int> counter_, err_, blocks_done_;
   DevBuf<unsigned long long> stamps_;  // diagnostic builds only
   // symbolic tables
-  DevBuf<int32_t> task_ptr_, task_sn_, fasm_src_, fasm_dst_, fdup_src_, fdup_dst_, scat_, rel_, perm_, sn_rows_;
+  DevBuf<int32_t> task_ptr_, task_sn_, fasm_src_, fasm_dst_, fasm_colptr_, fdup_src_, fdup_dst_, scat_, rel_, perm_, sn_rows_;
   DevBuf<SnMeta> sn_meta_, task_meta_;
   DevBuf<ChildMeta> child_meta_;
   std::vector<int> step_solve_lds_;  // scalars of LDS the back-solve of each step needs
@@ -464,6 +465,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (const char *e = getenv("RR_PGO_XCD_REMAP")) xcd_remap_ = std::atoi(e) != 0;
     if (const char *e = getenv("RR_PGO_SCHUR_SPLIT")) schur_split_ = std::atoi(e) != 0;
     gather_update_ = getenv("RR_PGO_NO_GATHER_UPDATE") == nullptr;
+    fused_assembly_ = getenv("RR_PGO_SPLIT_ASSEMBLY") == nullptr;
     if (const char *e = getenv("RR_PGO_FLOW")) flow_max_nf_ = std::atoi(e);
     flow_exact_ = getenv("RR_PGO_FLOW_EXACT") != nullptr;
     if (const char *e = getenv("RR_PGO_FLOW_DEEP")) flow_deep_ = std::atoi(e) != 0;
@@ -551,6 +553,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     }
     fasm_src_.upload(sym.fasm_src);
     fasm_dst_.upload(sym.fasm_dst);
+    fasm_colptr_.upload(sym.fasm_colptr);
     fdup_src_.upload(sym.fdup_src);
     fdup_dst_.upload(sym.fdup_dst);
     scat_.upload(sym.scat);
@@ -1119,6 +1122,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     a.child_meta = child_meta_.p;
     a.fasm_src = fasm_src_.p;
     a.fasm_dst = fasm_dst_.p;
+    a.fasm_colptr = fasm_colptr_.p;
     a.fdup_src = fdup_src_.p;
     a.fdup_dst = fdup_dst_.p;
     a.scat = scat_.p;
@@ -1272,15 +1276,22 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       return r;
     };
     // one pass writes every entry of the level's fronts once: the sum of the children's contributions (gathered
-    // through inverse maps), zeros elsewhere; the H entries and the rhs are added on top
+    // through inverse maps), zeros elsewhere; the H entries and the rhs are added on top -- by the building waves
+    // themselves when the launch is a single round of workgroups (three dependent loads per column at the end of every
+    // workgroup: cheaper than a launch there, dearer on the levels of hundreds of fronts -- lattice 4.62 against 4.68 ms
+    // with every level fused, sphere2500 +1 % fused), else by a k_big_assemble launch
+    const int build_gx = std::min(std::max(((gather_update_ ? std::min(maxM, ((max_nc + 127) / 128) * 128) : maxM) + 3) / 4, 1), 8192);
+    const bool fused = fused_assembly_ && (int64_t)build_gx * nf <= 2048;
     if (do_launch) {
-      hipLaunchKernelGGL(k_big_build<T>, dim3((unsigned)std::min(std::max(((gather_update_ ? std::min(maxM, ((max_nc + 127) / 128) * 128) : maxM) + 3) / 4, 1), 8192), nf), dim3(256), 0, stream_, a, gather_update_ ? 1 : 0);
+      hipLaunchKernelGGL(k_big_build<T>, dim3((unsigned)build_gx, nf), dim3(256), 0, stream_, a, gather_update_ ? 1 : 0, fused ? 1 : 0);
       check_launch("k_big_build");
-      hipLaunchKernelGGL(k_big_assemble<T>, dim3((unsigned)std::min<int64_t>((max_asm + 255) / 256, 2048), nf), dim3(256), 0, stream_, a, 1);
-      check_launch("k_big_assemble");
+      if (!fused) {
+        hipLaunchKernelGGL(k_big_assemble<T>, dim3((unsigned)std::min<int64_t>((max_asm + 255) / 256, 2048), nf), dim3(256), 0, stream_, a, 1);
+        check_launch("k_big_assemble");
+      }
       if (any_dup) hipLaunchKernelGGL(k_big_assemble_dup<T>, dim3(1, nf), dim3(64), 0, stream_, a);
     }
-    n += 2 + (any_dup ? 1 : 0);
+    n += (fused ? 1 : 2) + (any_dup ? 1 : 0);
     if (gauge_ok_) {
       bool has_root = false;
       for (int s : fr) has_root = has_root || s == gauge_root_;

@@ -1012,6 +1012,25 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     sym.fasm_ptr[f + 1] = (int64_t)sym.fasm_src.size();
     sym.fdup_ptr[f + 1] = (int64_t)sym.fdup_src.size();
   }
+  // fronts beyond LDS: their entries in column-major order of the destination, and where every pivot column's entries
+  // start -- the wave of k_big_build that writes a column adds the column's H entries itself (no k_big_assemble launch)
+  sym.fasm_colptr.assign((size_t)g.dim + 1, 0);
+  for (int f = 0; f < S; f++) {
+    if (!sym.sn_big[f]) continue;
+    const int64_t a = sym.fasm_ptr[f], b = sym.fasm_ptr[f + 1];
+    const int nc = sym.sn_ncols[f], M = nc + sym.sn_nrows[f] + 1, c0 = sym.sn_col0[f];
+    std::vector<std::pair<int32_t, int32_t>> e((size_t)(b - a));
+    for (int64_t t = a; t < b; t++) e[(size_t)(t - a)] = {sym.fasm_dst[t], sym.fasm_src[t]};
+    std::sort(e.begin(), e.end());
+    int64_t t = a;
+    for (int J = 0; J < nc; J++) {
+      sym.fasm_colptr[c0 + J] = (int32_t)t;
+      while (t < b && e[(size_t)(t - a)].first < (int64_t)(J + 1) * M) t++;
+    }
+    if (t != b) return "internal: assembly entry outside the pivot columns";
+    sym.fasm_colptr[c0 + nc] = (int32_t)b;   // (the next front overwrites it with the same value or its own start)
+    for (int64_t q = a; q < b; q++) { sym.fasm_dst[q] = e[(size_t)(q - a)].first; sym.fasm_src[q] = e[(size_t)(q - a)].second; }
+  }
   {
     // one destination per element of a child's packed update matrix (the LDS image of the parent): sized
     // once, filled column by column with the column's part of the index hoisted

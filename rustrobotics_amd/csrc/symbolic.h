@@ -97,6 +97,7 @@ struct Symbolic {
   // that must be ADDED serially after the plain stores
   std::vector<int64_t> fasm_ptr, fdup_ptr;        // per supernode
   std::vector<int32_t> fasm_src, fasm_dst, fdup_src, fdup_dst;
+  std::vector<int32_t> fasm_colptr;   // fronts beyond LDS: per permuted pivot column, where its entries start in fasm_* (dim + 1)
   // extend-add scatter maps: for a child with a packed update matrix and a
   // parent that lives in LDS, one destination per packed element: index into
   // the parent's [panel | packed update] LDS image, -1 = skip
