@@ -137,6 +137,22 @@ int main(int argc, char **argv) {
           P[(size_t)(it.lcol + j) * M + it.lrow + i] += hv[it.src + i * it.dcol + j];
         }
     }
+    {
+      // the flat lists the kernels read must give the same image (entries of parallel edges in the dup list); for a
+      // front beyond LDS column by column through fasm_colptr (k_big_build adds a column's entries right after writing it)
+      std::vector<double> P2((size_t)M * nc, 0.0);
+      for (int64_t t = y.fasm_ptr[s]; t < y.fasm_ptr[s + 1]; t++) P2[(size_t)y.fasm_dst[t]] += hv[y.fasm_src[t]];
+      for (int64_t t = y.fdup_ptr[s]; t < y.fdup_ptr[s + 1]; t++) P2[(size_t)y.fdup_dst[t]] += hv[y.fdup_src[t]];
+      for (size_t k = 0; k < P2.size(); k++)
+        if (P2[k] != P[k]) { printf("FAIL: flat assembly list of supernode %d differs from its items at entry %zu\n", s, k); return 1; }
+      if (y.sn_big[s]) {
+        const int c0 = y.sn_col0[s];
+        if (y.fasm_colptr[c0] != y.fasm_ptr[s] || y.fasm_colptr[c0 + nc] != y.fasm_ptr[s + 1]) { printf("FAIL: column pointers of front %d do not span its list\n", s); return 1; }
+        for (int J = 0; J < nc; J++)
+          for (int t = y.fasm_colptr[c0 + J]; t < y.fasm_colptr[c0 + J + 1]; t++)
+            if (y.fasm_dst[t] / M != J) { printf("FAIL: entry %d of front %d is not in column %d\n", t, s, J); return 1; }
+      }
+    }
     for (int j = 0; j < nc; j++) P[(size_t)j * M + M - 1] = b[y.perm[y.sn_col0[s] + j]];
     for (int q = y.child_ptr[s]; q < y.child_ptr[s + 1]; q++) {
       int c = y.child_list[q];
