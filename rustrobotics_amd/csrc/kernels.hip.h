@@ -1932,24 +1932,18 @@ template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(Factor
 }
 
 #ifndef RRPGO_UPD_WAVES
-#define RRPGO_UPD_WAVES 3   // fp32: waves per SIMD the register allocation aims at (three workgroups per CU with the 37 KB chunks); fp64 would spill
-#endif
-// Rank update  C(i,j) -= sum_{k in [ka,ke)} F(i,k) F(j,k)  over i in [t0, M), j in [t0, jmax), i >= j.
-//   mode 0: after the 32-column panel at kb: the rest of its 128-column super-panel (K = 32)
-//   mode 1: after the super-panel at kb: everything to its right, Schur complement included (K <= 128)
-//   mode 2 / 3: mode 1 split into its first 128 columns and the rest
-// One 128 x 128 tile per workgroup, 64 x 64 per wave as 4 x 4 MFMA 16x16x4 tiles (16 independent
-// accumulators per wave).  The two 128-row operand strips are staged through LDS in k-chunks of
-// 32 (f32) / 16 (f64), double buffered: the global loads of chunk c+1 are in flight while the
-// MFMAs of chunk c run; one barrier per chunk.
-// NT = MFMA tiles per wave and dimension: 4 -> 64 x 64 per wave, 128 x 128 per workgroup; 2 -> 32 x 32 per wave,
-// 64 x 64 per workgroup, for launches that would not fill the chip with the large tile (the top levels of
-// the tree: a quarter of the MFMA work per wave on the critical path of the launch).
+#define RRPGO_UPD_WAVES 5   // fp32: workgroups per CU the register allocation is told to allow.  The kernels need 80 - 84 VGPRs either way (six
+#endif                      // per CU); the bound only steers the scheduler: 3 (r02) lattice 4.63 ms, 4 / 5 / 6: 4.61 / 4.60 / 4.60, 8: 4.62 (r03)
+// Rank update  C(i,j) -= sum_{k in [ka,ke)} F(i,k) F(j,k)  over i in [t0, M), j in [t0, jmax), i >= j, for one tile of
+// (32 NT) x (32 NT) per workgroup, (16 NT) x (16 NT) per wave as NT x NT MFMA 16x16x4 tiles.  The two operand strips
+// are staged through LDS in k-chunks of KC columns, double buffered: the global loads of chunk c + 1 are in flight
+// while the MFMAs of chunk c run; one barrier per chunk.  NT = 2 (64 x 64 tiles, 20 KB of LDS in fp32) is what runs;
+// NT = 4 (128 x 128) lost every measurement since r02 (two workgroups per CU) and is only kept instantiable.
 #ifndef RRPGO_UPD_KC
-#define RRPGO_UPD_KC 16
+#define RRPGO_UPD_KC 16     // 32: lattice 4.70 against 4.65 ms (r03)
 #endif
 template <typename T, int NT> struct UpdTile {
-  static constexpr int KC = RRPGO_UPD_KC;   // k-chunk staged in LDS: 36.9 KB in fp32 (three workgroups per CU), 73.7 KB in fp64 (two)
+  static constexpr int KC = RRPGO_UPD_KC;   // k-chunk staged in LDS
   static constexpr int TILE = 32 * NT, WTILE = 16 * NT;  // workgroup tile, wave tile
   static constexpr int KSTEP = 256 / TILE;               // k-rows of a chunk loaded per pass of the 256 threads
   static constexpr int LDT = TILE + 16;                  // padded row: the four k-rows a wave reads hit disjoint banks
