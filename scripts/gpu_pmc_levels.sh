@@ -18,13 +18,13 @@ acc = collections.defaultdict(lambda: [0.0, 0])
 for r in rows:
     n = r["Kernel_Name"].split("(")[0].split("rrpgo::")[-1]
     if not n.startswith("k_big") and not n.startswith("k_factor") : continue
-    gy, gz = int(r.get("Grid_Size_Y", 1)), int(r.get("Grid_Size_Z", 1))
-    nf = gz if "update" in n else gy
+    gx, gy, wg = int(r.get("Grid_Size_X", r.get("Grid_Size", 1))), int(r.get("Grid_Size_Y", 1)), int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 256)) or 256)
+    nf = gy if gy > 1 else gx // max(wg, 1)   # fronts of the level (2-D grids) or workgroups = tiles / tasks (1-D grids: k_big_update, k_big_schur, k_big_flow)
     k = (n[:26], nf)
     acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
 print("==", sys.argv[2])
 for (n, nf), (v, c) in sorted(acc.items()):
-    print(f"  {n:26s} nf={nf:5d} dispatches {c:5d} avg {v / c:12.2f}")
+    print(f"  {n:26s} n={nf:6d} dispatches {c:5d} avg {v / c:12.2f}")
 PY
 done
 cd $R; cat $OUT
