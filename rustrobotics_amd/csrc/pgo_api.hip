@@ -627,8 +627,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       auto lvl = std::make_unique<FlowLevel>();
       lvl->ticket_word = words;
       // The Schur complements of the level's fronts: as UPDATE tiles of this launch (one per super-panel), or left to ONE
-      // k_big_schur launch behind it (K = nc, seven workgroups per CU, 75 % of the fp32 MFMA peak on the lattice's levels
-      // of 8 ... 64 fronts).  In the launch they cost twice the workgroup time, but at the top of the tree the launch is
+      // k_big_schur launch behind it (K = nc, six workgroups per CU, MfmaUtil 52 - 55 % on the lattice's levels of 4 ... 32
+      // fronts).  In the launch they cost twice the workgroup time, but at the top of the tree the launch is
       // bound by its chain and most workgroups idle: the tiles stay in when the list schedule says they fit into 60 % of
       // that idle time (lattice: the level of 2 fronts, -60 us; the level of 4 fronts would lose 70 us)
       int64_t schur_tiles = 0;
