@@ -3,24 +3,28 @@
 // The launch sequence of kernels.hip.h ("huge fronts") is level-synchronous twice over: every 32-column step of
 // the panel chain and every 128-column trailing update is a launch of its own, so a level of few fronts is a chain
 // of ~8 us launches that leave most of the chip idle (r02: the six top levels of the 1M-edge lattice took 3.4 of
-// 5.8 ms at MfmaUtil 1.8 %).  Here the same arithmetic (same device functions, same order of every sum: results
-// are bit-identical to the launch sequence) runs as a dataflow:
+// 5.8 ms at MfmaUtil 1.8 %).  Here the same arithmetic (same device functions; in the exact mode the same order of
+// every sum: bit-identical to the launch sequence) runs as a dataflow:
 //
 //   task PANEL(front, kb, row-block group)   four waves = four 32-row blocks below the 32-column block at kb:
-//        left-looking update inside the super-panel, X = A W^T; the wave that owns rows kb+32..kb+63 then forms,
-//        factors and inverts the NEXT diagonal block (the chain) -- the body of k_big_panel32
+//        left-looking update over the step's range of earlier blocks (its super-panel's; for the first two blocks of
+//        a super-panel, in the fast mode, the previous super-panel's too), X = A W^T; the wave that owns rows
+//        kb+32..kb+63 then forms, factors and inverts the NEXT diagonal block (the chain) -- the body of k_big_panel32
 //   task UPDATE(front, K0, tile)             one 64 x 64 tile of the K = 128 trailing update of super-panel K0
-//        (the first one of a front gathers its tile from the children); tile (0, 0) also factors and inverts the
-//        next super-panel's first diagonal block -- the body of k_big_update
+//        (the first one of a front gathers its tile from the children); in the exact mode tile (0, 0) also factors
+//        and inverts the next super-panel's first diagonal block -- the body of k_big_update
+//   task DIAG0(front)                        the front's first diagonal block
 //
-// Workgroups draw tasks from ONE atomic ticket; the task list is in a topological order (sorted by the earliest
-// start time of a cost model, host side), so a task only ever waits for tasks with smaller tickets, which are
-// finished or held by a running workgroup: no deadlock whatever the grid size or the dispatch order.  Completion is
-// published per unit (W of a block, X of a row block, a tile) in flag words; payload moves with sc1 (write-through /
-// L1-bypassing) accesses, flags with agent-scope relaxed atomics after the storing wave's s_waitcnt vmcnt(0)
-// (MI355X_MICROARCH.md, inter-workgroup visibility; scripts/handoff_probe.hip measured this form stale-free with
-// lines shared by two producers, 0.8 us per hop against ~1.5-2 us per kernel boundary).  Every spin is bounded:
-// a wait that runs out sets DEVERR_FLOW_TIMEOUT, after which every wait returns at once and the launch drains.
+// Workgroups draw tasks from ONE atomic ticket; the task list is in a topological order (the start order of a list
+// schedule of the task DAG, host side: Engine::build_flow_levels), so a task only ever waits for tasks with smaller
+// tickets, which are finished or held by a running workgroup: no deadlock whatever the grid size or the dispatch
+// order.  Completion is published per unit (X of a row block, a tile) in flag words; payload moves with sc1
+// (write-through / L1-bypassing) accesses, flags with agent-scope relaxed atomics after the storing wave's
+// s_waitcnt vmcnt(0) (MI355X_MICROARCH.md, inter-workgroup visibility; scripts/handoff_probe.hip measured this form
+// stale-free with lines shared by two producers, 0.8 us per hop against ~1.5-2 us per kernel boundary).  The one
+// hand-off on the chain, W of a diagonal block, is polled in place (k_flow_reset marks the blocks, see there).  Every
+// spin is bounded: a wait that runs out sets DEVERR_FLOW_TIMEOUT, after which every wait returns at once and the
+// launch drains.
 // Replaces the reference's umfpack.factorize (src/mapping/pose_graph_optimization.rs:138) for those fronts.
 #pragma once
 
