@@ -98,8 +98,20 @@ enum : int { DEVERR_NOT_SPD = 1, DEVERR_FLOW_TIMEOUT = 2 };
 
 // TC = type of the state, the measurements and all factor arithmetic; T = type H and b are stored in
 // (TC == T, or TC = double with T = float: "mixed" mode, exact gradient + single-precision factor)
+// One SE(2) edge as ONE record (64 bytes in fp32, a 128-byte line in fp64): the pull form visits every edge from both
+// endpoints, and out of five arrays a visit touched five partly used 64-byte sectors (r03, PMC: 294 MB per launch on the
+// 1M-edge lattice)
+template <typename TC> struct EdgeRec {
+  int32_t from, to;
+  int64_t slot;                        // (offset into hvals << 1) | transposed
+  typename VecT<TC>::V4 meas;          // SE2: x, y, cos, sin | SE2_XY: x, y, 0, 0
+  typename VecT<TC>::V4 info_a;        // i11 i12 i13 i22
+  typename VecT<TC>::V2 info_b;        // i23 i33
+};
+static_assert(sizeof(EdgeRec<float>) == 64 && sizeof(EdgeRec<double>) == 128, "EdgeRec is four / eight sixteen-byte loads of one line");
 template <typename T, typename TC = T> struct LinArgs {
   int n_nodes;
+  const EdgeRec<TC> *e_rec;              // per edge: what the arrays below hold, as one record (k_linearize reads this)
   const typename VecT<TC>::V4 *pose;     // x, y, cos, sin  (XY landmarks: x, y, -, -)
   const int2 *e_idx;                     // from, to
   const typename VecT<TC>::V4 *e_meas;   // SE2: x, y, cos, sin | SE2_XY: x, y, 0, 0
@@ -246,11 +258,12 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<TO, T> a) {
       if (!(ent & 12)) continue;
       const bool owns = ent & 4;
       const int k = ent >> 4, kind = (ent >> 1) & 1, role = ent & 1;
-      const int2 ft = a.e_idx[k];
+      const EdgeRec<T> rec = a.e_rec[k];
+      const int2 ft = int2{rec.from, rec.to};
       const V4 other = a.pose[role ? ft.x : ft.y];
-      const V4 z = a.e_meas[k];
-      const V4 wa = a.e_info_a[k];
-      const V2 wb = a.e_info_b[k];
+      const V4 z = rec.meas;
+      const V4 wa = rec.info_a;
+      const V2 wb = rec.info_b;
       const T W[3][3] = {{wa.x, wa.y, wa.z}, {wa.y, wa.w, wb.x}, {wa.z, wb.x, wb.y}};
       T e[3], A[3][3], B[3][3];
       edge_linearize_2d<T>(kind, role ? other : self, role ? self : other, z, e, A, B);
@@ -287,7 +300,7 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<TO, T> a) {
         if (owns) chi += (double)(e[0] * we0 + e[1] * we1 + e[2] * we2);   // every edge's term is owned by one rank
         if (a.write_system && (ent & 8)) {
           // off-diagonal block H[from rows, to cols] = A^T W B
-          const int64_t so = a.e_slot[k];
+          const int64_t so = rec.slot;
           TO *dst = a.hvals + (so >> 1);
           const bool tr = so & 1;
           const int d2 = kind ? 2 : 3;

@@ -231,6 +231,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<V4> pose_, e_meas_, e_info_a_;
   DevBuf<V2> e_info_b_;
   DevBuf<int2> e_idx_;
+  DevBuf<EdgeRec<S>> e_rec_;   // SE(2): every edge's from / to / slot / measurement / information as one record (k_linearize)
   DevBuf<int64_t> e_slot_, diag_off_;
   DevBuf<int32_t> inc_ptr_, inc_list_, node_offset_, node_pcol_;
   DevBuf<uint8_t> node_dim_;
@@ -365,6 +366,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       e_meas_.upload(emeas);
       e_info_a_.upload(einfa);
       e_info_b_.upload(einfb);
+      std::vector<EdgeRec<S>> erec(E);
+      for (int k = 0; k < E; k++) erec[k] = EdgeRec<S>{eidx[k].x, eidx[k].y, eslot[k], emeas[k], einfa[k], einfb[k]};
+      e_rec_.upload(erec);
     } else {
       // SE(3): (t, -), (q) pairs; quaternions normalised like UnitQuaternion::from_quaternion
       auto pack7 = [](const double *s, V4 &a, V4 &b) {
@@ -1092,6 +1096,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     a.n_nodes = n_list_;
     a.node_list = node_list_.p;
     a.pose = pose_.p;
+    a.e_rec = e_rec_.p;
     a.e_idx = e_idx_.p;
     a.e_meas = e_meas_.p;
     a.e_info_a = e_info_a_.p;
