@@ -283,7 +283,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
                                     // fronts gains 64 us over its launch sequence, the level of 128 fronts ties, wider levels are bound by tile
                                     // THROUGHPUT, where the batched k_big_update launches (7 workgroups per CU) beat the flow kernel's two
   bool fused_assembly_ = true;      // RR_PGO_SPLIT_ASSEMBLY=1: H entries and rhs of the fronts beyond LDS by a k_big_assemble launch per level
-  int flow_deep_nf_ = 1 << 30;      // RR_PGO_FLOW_DEEP_NF=<n>: ... only on levels of at most n fronts
   bool flow_deep_ = true;           // RR_PGO_FLOW_DEEP=0: no look-back over the previous super-panel (fast mode; see build_flow_levels)
   bool flow_exact_ = false;         // RR_PGO_FLOW_EXACT=1: bit-identical to the launch sequence (tile (0, 0) forms the next super-panel's first block)
   struct SolveFlowLevel { DevBuf<SolveFlowFront> fronts; DevBuf<SolveFlowTask> tasks; int n_tasks = 0; int64_t ticket_word = 0; };
@@ -474,7 +473,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (const char *e = getenv("RR_PGO_FLOW")) flow_max_nf_ = std::atoi(e);
     flow_exact_ = getenv("RR_PGO_FLOW_EXACT") != nullptr;
     if (const char *e = getenv("RR_PGO_FLOW_DEEP")) flow_deep_ = std::atoi(e) != 0;
-    if (const char *e = getenv("RR_PGO_FLOW_DEEP_NF")) flow_deep_nf_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_FLOW_TASKS")) flow_max_tasks_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_SOLVE_FLOW")) solve_flow_on_ = std::atoi(e) != 0;
     if (const char *e = getenv("RR_PGO_FLOW_SCHUR_MIN")) flow_schur_min_ = std::atoi(e);
@@ -701,7 +699,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         const int o_schur = lvl->schur_split ? std::min(big_schur_origin(nc, schur_tile_), M) : M;   // UPDATE tiles start left of it
         // fast mode: the first two blocks of a super-panel look back over the previous super-panel too, and that one's
         // update skips these 64 columns (its tile column 0) -- the chain does not wait for a tile at a super-panel's end
-        auto deep = [&](int spx) { return flow_deep_ && nf <= flow_deep_nf_ && !flow_exact_ && spx > 0 && spx * BIG_SUPER + 64 <= nc; };
+        auto deep = [&](int spx) { return flow_deep_ && !flow_exact_ && spx > 0 && spx * BIG_SUPER + 64 <= nc; };
         for (int sp = 0; sp < nsp; sp++) {
           const int K0 = sp * BIG_SUPER, ke = std::min(K0 + BIG_SUPER, nc);
           // the tiles under rows [r0, r1] x columns [c0, c1] of the update whose tile grid starts at column Ko (the update
