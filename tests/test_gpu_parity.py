@@ -445,7 +445,7 @@ def test_levenberg_marquardt_through_the_big_front_path(api, oracle):
 @pytest.mark.parametrize("env", ["RR_PGO_FLOW=0", "RR_PGO_FLOW_TASKS=100000000", "RR_PGO_FLOW_EXACT", "RR_PGO_NO_GATHER_UPDATE",
                                  "RR_PGO_SCHUR_SPLIT=0", "RR_PGO_XCD_REMAP=0", "RR_PGO_SOLVE_FLOW=0", "RR_PGO_EDGE_LINEARIZE",
                                  "RR_PGO_FLOW_DEEP=0", "RR_PGO_FLOW_SCHUR_MIN=100000000", "RR_PGO_FLOW_SLOTS=1000000",
-                                 "RR_PGO_SPLIT_ASSEMBLY"])
+                                 "RR_PGO_SPLIT_ASSEMBLY", "RR_PGO_FLOW_GRID=1", "RR_PGO_FLOW_GRID=7"])
 def test_alternate_big_front_launch_sequences_agree(api, env, monkeypatch):
     """The switches read when a handle is created that change WHICH kernels run: the launch-per-step sequence for every
     level (RR_PGO_FLOW=0) or the dataflow launch for every level of at most 64 fronts (RR_PGO_FLOW_TASKS), its exact mode,
@@ -455,7 +455,8 @@ def test_alternate_big_front_launch_sequences_agree(api, env, monkeypatch):
     level in the back substitution, the edge-parallel linearisation, and three switches of the dataflow launch (panel
     steps that never look back over the previous super-panel, Schur complements always inside the launch, tickets in
     the order of earliest starts instead of the list schedule's), and the H entries of the fronts beyond LDS added by a
-    k_big_assemble launch per level instead of by k_big_build's own waves.  Each must give the default path's answer on the 100 x 100 lattice (same arithmetic up to the order
+    k_big_assemble launch per level instead of by k_big_build's own waves; and the dataflow launches with ONE workgroup or
+    seven instead of two per CU -- tasks wait only for smaller tickets, so any grid must finish, with the same bits.  Each must give the default path's answer on the 100 x 100 lattice (same arithmetic up to the order
     of the block operations).  (The r01 / r02 alternatives of the big-front path were removed in r03 after losing every
     measurement: profiles/EXPERIMENTS.md.)"""
     from rustrobotics_amd import synthetic_grid_arrays
@@ -468,7 +469,7 @@ def test_alternate_big_front_launch_sequences_agree(api, env, monkeypatch):
     monkeypatch.delenv(env)
     ealt = alt.optimize(3)
     np.testing.assert_allclose(ealt, eref, rtol=1e-9)
-    if env in ("RR_PGO_SCHUR_SPLIT", "RR_PGO_XCD_REMAP", "RR_PGO_NO_GATHER_UPDATE", "RR_PGO_SOLVE_FLOW", "RR_PGO_SPLIT_ASSEMBLY"):
+    if env in ("RR_PGO_SCHUR_SPLIT", "RR_PGO_XCD_REMAP", "RR_PGO_NO_GATHER_UPDATE", "RR_PGO_SOLVE_FLOW", "RR_PGO_SPLIT_ASSEMBLY", "RR_PGO_FLOW_GRID"):
         # placement, one pass or one per super-panel, gathered or built: the same chunks in the same order -- the same bits
         assert np.array_equal(ealt, eref) and np.array_equal(np.array(alt.state()), np.array(ref.state()))
     assert _state_diff_se2(alt.state(), ref.state()) <= 1e-8
