@@ -690,6 +690,30 @@ def test_iterate_async_equals_optimize_without_break(api):
     assert np.abs(g1.state() - g2.state()).max() <= 1e-12
 
 
+def test_handles_that_run_at_the_same_time_do_not_disturb_each_other(api):
+    """Four handles with fronts beyond LDS iterate at the same time on their own streams: their dataflow launches
+    (k_big_flow, k_big_solve_flow: workgroups that wait for flags inside a launch) share the chip with each other's, and no
+    launch can count on all of its workgroups being resident.  Every handle must end where a handle that ran alone ends,
+    to the last bit (tasks wait only for smaller tickets of their own launch)."""
+    from rustrobotics_amd import synthetic_grid_arrays
+    arrays = synthetic_grid_arrays(100, 100)
+    alone = api[0].from_arrays(*arrays, precision="f32")
+    assert alone.stats()["n_big_fronts"] > 0
+    alone.iterate_async(4); alone.sync()
+    crowd = [api[0].from_arrays(*arrays, precision="f32") for _ in range(4)]
+    crowd.append(api[0].new(g2o_path("sphere2500")))   # an SE(3) graph in fp64 in the same crowd
+    for _ in range(4):
+        for g in crowd:
+            g.iterate_async(1)
+    for g in crowd:
+        g.sync()
+    for g in crowd[:4]:
+        assert np.array_equal(np.array(g.state()), np.array(alone.state()))
+    ref3 = api[0].new(g2o_path("sphere2500"))
+    ref3.iterate_async(4); ref3.sync()
+    assert np.array_equal(np.array(crowd[4].state()), np.array(ref3.state()))
+
+
 # ---- SE(3): build-defined maths (the reference's SE(3) path is todo!(), SURVEY F4) -- oracle only ----
 
 def _quat_state_diff(a, b):
