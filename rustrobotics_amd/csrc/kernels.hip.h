@@ -1146,7 +1146,7 @@ template <typename T> __device__ __forceinline__ void init_w16_identity(T *wscr,
 struct NoUAddr { __device__ float *operator()(int, int) const { return nullptr; } };
 template <typename T, int THREADS, bool FAST = false, typename UAddr = NoUAddr>
 __device__ __forceinline__ void panel_factor(T *P, int M, int nc, int *err, T *wscr /* 16 * 17 (FAST: W16_SCR) scalars of LDS */, T *wout,
-                             unsigned long long *acc = nullptr, int nu = 0, UAddr uaddr = UAddr()) {
+                             unsigned long long *acc = nullptr, int nu = 0, UAddr uaddr = UAddr(), bool defer_u = false) {
   using MM = Mfma16<T>;
   constexpr int NB = 16;
   constexpr int NW = THREADS / 64;
@@ -1162,7 +1162,7 @@ __device__ __forceinline__ void panel_factor(T *P, int M, int nc, int *err, T *w
     int total = 0;
     for (int jb = 1; jb < nj; jb++) total += max(ni - jb, 0);
     const int nt = (nu + 15) >> 4;   // tiles of the update matrix (lower triangle), after the panel's own
-    const int utotal = nt * (nt + 1) / 2;
+    const int utotal = defer_u ? 0 : nt * (nt + 1) / 2;   // deferred: the caller subtracts ALL pivot columns from the update matrix in one pass
     for (int t = wave - first_wave; t < total + utotal; t += nwaves) {
       if (t < total) {
         int jb = 1, rem = t;
@@ -1366,20 +1366,29 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
   __syncthreads();
   RRPGO_STAMP(a, s, 3);
   // ---- partial factorisation + Schur complement
+  // A wide update matrix (fp32 fronts of the large graphs: ~240 rows below ~50 pivot columns) is not updated block by block
+  // under the diagonal chain -- every 16 columns would move the whole triangle through the MFMA pipe and back into LDS
+  // (5 us per block, r03 stamps) -- but once, by ALL pivot columns, after the panel: the same FMAs in the same order
+  // (bit-identical), the triangle read and written once.  Lattice -30 us per iteration; narrow fronts keep the overlap
+  // (intel with every front deferred: -2 %), and the fp64 instantiation is compiled without the option.
+#ifndef RRPGO_DEFER_U_MIN
+#define RRPGO_DEFER_U_MIN 128
+#endif
+  const bool defer_u = sizeof(T) == 4 && nu >= RRPGO_DEFER_U_MIN && nc > 16;
   auto uaddr = [&](int i, int j) {   // 32-bit index arithmetic for the packed triangle in LDS
     return IN_PLACE ? U + ((int64_t)j * uld + i) : U + (j * nu - ((j * (j - 1)) >> 1) + (i - j));
   };
 #ifdef RRPGO_STAMPS
   if (tid == 0 && a.stamps) { a.stamps[(int64_t)s * 12 + 7] = 0; a.stamps[(int64_t)s * 12 + 8] = 0; a.stamps[(int64_t)s * 12 + 9] = 0; }
-  panel_factor<T, THREADS, !IN_PLACE>(P, M, nc, a.err, dinv, a.winv + (int64_t)m.wblk * 256, a.stamps ? a.stamps + (int64_t)s * 12 : nullptr, nu, uaddr);
+  panel_factor<T, THREADS, !IN_PLACE>(P, M, nc, a.err, dinv, a.winv + (int64_t)m.wblk * 256, a.stamps ? a.stamps + (int64_t)s * 12 : nullptr, nu, uaddr, defer_u);
 #else
-  panel_factor<T, THREADS, !IN_PLACE>(P, M, nc, a.err, dinv, a.winv + (int64_t)m.wblk * 256, nullptr, nu, uaddr);
+  panel_factor<T, THREADS, !IN_PLACE>(P, M, nc, a.err, dinv, a.winv + (int64_t)m.wblk * 256, nullptr, nu, uaddr, defer_u);
 #endif
   RRPGO_STAMP(a, s, 4);
   {
     // U(i,j) -= sum_k L21[i][k] L21[j][k]  (i >= j), 16 x 16 tiles on the matrix cores: the columns of the
     // LAST 16-column block only, the earlier blocks went in under the diagonal chain (panel_factor)
-    const int klast = ((nc - 1) >> 4) << 4;
+    const int klast = defer_u ? 0 : ((nc - 1) >> 4) << 4;
     const int nt = (nu + 15) >> 4;
     const int wave = wave_index();
     // the tiles of the lower triangle dealt round-robin: t-th tile of the column-major enumeration
