@@ -1282,7 +1282,17 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
   if (IN_PLACE) {
     for (int64_t t = tid; t < (int64_t)M * M; t += THREADS) P[t] = 0;  // whole front, ld M
   } else {
-    for (int t = tid; t < psize + usize; t += THREADS) P[t] = 0;
+    if constexpr (sizeof(T) == 4) {
+      // fp32 (the 150 KB fronts of the large graphs): 16-byte stores (P is 16-byte aligned), a quarter of the LDS
+      // instructions; the last 1 - 3 scalars one by one.  (fp64: the small graphs' fronts, measured 0.4 % slower this way.)
+      using V4z = typename VecT<T>::V4;
+      const int n4 = (psize + usize) >> 2;
+      V4z *P4 = reinterpret_cast<V4z *>(P);
+      for (int t = tid; t < n4; t += THREADS) P4[t] = V4z{0, 0, 0, 0};
+      if (tid < ((psize + usize) & 3)) P[4 * n4 + tid] = 0;
+    } else {
+      for (int t = tid; t < psize + usize; t += THREADS) P[t] = 0;
+    }
   }
   constexpr int EPRE = 4;
   int ed[EPRE];
