@@ -277,11 +277,13 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   std::vector<std::unique_ptr<FlowLevel>> flow_levels_;   // per step of sym_.steps (null: launch sequence)
   DevBuf<int64_t> flow_wfill_;      // per front of a flow level: offset and count of its W blocks' scalars in winv (k_flow_reset marks them)
   DevBuf<unsigned> flow_flags_;     // tickets + completion flags of every flow level, zeroed at the start of a factorisation
-  int flow_max_nf_ = 64;            // RR_PGO_FLOW=<n> (0: never): levels of at most n fronts ...
-  int flow_max_tasks_ = 40000;      // RR_PGO_FLOW_TASKS=<n>: ... and of at most n tasks run as ONE k_big_flow launch.  Measured on the 1M-edge
-                                    // lattice (r03, tickets in list-schedule order, Schur complements left to k_big_schur): the level of 64
-                                    // fronts gains 64 us over its launch sequence, the level of 128 fronts ties, wider levels are bound by tile
-                                    // THROUGHPUT, where the batched k_big_update launches (7 workgroups per CU) beat the flow kernel's two
+  int flow_max_nf_ = 1 << 20;       // RR_PGO_FLOW=<n> (0: never): levels of at most n fronts ...
+  int flow_max_tasks_ = 1 << 20;    // RR_PGO_FLOW_TASKS=<n>: ... and of at most n tasks run as ONE k_big_flow launch: by default every level.
+                                    // History on the 1M-edge lattice (r03): with tickets in the order of earliest starts only the levels of 1
+                                    // and 2 fronts gained; with the list schedule and the Schur complements left to k_big_schur the levels up
+                                    // to 64 fronts; with W polled in place and no tile on the chain every level does (limits 64 / 128 / 256 /
+                                    // none: 4.57 / 4.54 / 4.53 / 4.52 ms) -- the launch sequence (k_big_panel32 + k_big_update) remains as the
+                                    // parity alternative (RR_PGO_FLOW=0)
   bool fused_assembly_ = true;      // RR_PGO_SPLIT_ASSEMBLY=1: H entries and rhs of the fronts beyond LDS by a k_big_assemble launch per level
   bool flow_deep_ = true;           // RR_PGO_FLOW_DEEP=0: no look-back over the previous super-panel (fast mode; see build_flow_levels)
   bool flow_exact_ = false;         // RR_PGO_FLOW_EXACT=1: bit-identical to the launch sequence (tile (0, 0) forms the next super-panel's first block)
