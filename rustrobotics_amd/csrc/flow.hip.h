@@ -395,23 +395,24 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
 // replay (r03: the second replay of a stage found the first one's flags still set -- tasks did not wait, the ticket
 // was past the end -- while eager launches and the unsharded graph, where hundreds of microseconds of other kernels
 // sit between the two, were fine).
-// It also marks the W blocks of the range's flow fronts as NOT THERE YET (blockIdx.y - 1 = entry of `wfill`: offset and
-// count of scalars in winv): a PANEL wave polls its W block itself instead of a flag followed by the block (one
+// It also marks the W blocks of the range's flow fronts as NOT THERE YET (workgroups flag_wgs.. = entries of `wfill`: offset
+// and count of scalars in winv, four blocks each): a PANEL wave polls its W block itself instead of a flag followed by the block (one
 // round trip to L2 on the chain instead of two).  The mark is the all-ones pattern, a NaN no arithmetic produces
 // (hardware NaNs are 0x7fc00000 / propagated payloads of the operands); every store of a W block writes all of its
 // 1024 entries, each entry goes from the mark to its value in one store, so a block without a mark is complete.
 template <typename T>
-__global__ void __launch_bounds__(256) k_flow_reset(unsigned *words, int64_t n, T *winv, const int64_t *wfill) {
-  if (blockIdx.y == 0) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) words[i] = 0u;
+__global__ void __launch_bounds__(256) k_flow_reset(unsigned *words, int64_t n, int flag_wgs, T *winv, const int64_t *wfill) {
+  if ((int)blockIdx.x < flag_wgs) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)flag_wgs * 256) words[i] = 0u;
   } else {
-    const int64_t off = wfill[2 * (blockIdx.y - 1)], cnt = wfill[2 * (blockIdx.y - 1) + 1];
+    // one entry of `wfill` per workgroup: offset and count (<= 4096, a multiple of 1024) of scalars in winv
+    const int e = (int)blockIdx.x - flag_wgs;
+    const int64_t off = wfill[2 * e], cnt = wfill[2 * e + 1];
     using U = typename std::conditional<sizeof(T) == 4, unsigned, unsigned long long>::type;
     U *w = reinterpret_cast<U *>(winv + off);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * 256) w[i] = ~(U)0;
+    for (int64_t i = threadIdx.x; i < cnt; i += 256) w[i] = ~(U)0;
   }
 }
-
 #ifndef RRPGO_FLOW_DEPTH
 #define RRPGO_FLOW_DEPTH 4   // k-chunks of a trailing-update tile requested ahead of the MFMAs (the launch sequence's k_big_update uses 1 at
 #endif                       // seven workgroups per CU; here two workgroups per CU have to cover a chunk's memory round trip themselves)

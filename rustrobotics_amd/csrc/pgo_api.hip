@@ -271,11 +271,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     std::vector<FlowTask> host_tasks;   // diagnostic builds: the sorted list, for rr_pgo_debug_flow_trace
     DevBuf<unsigned long long> trace;   // diagnostic builds only
     int64_t ticket_word = 0;   // index of the level's ticket in flow_flags_
-    int wfill_begin = 0, wfill_end = 0;   // the level's fronts in flow_wfill_
+    int wfill_begin = 0, wfill_end = 0;   // the level's entries in flow_wfill_
     double est_us = 0;         // critical path of the cost model that orders the tasks
   };
   std::vector<std::unique_ptr<FlowLevel>> flow_levels_;   // per step of sym_.steps (null: launch sequence)
-  DevBuf<int64_t> flow_wfill_;      // per front of a flow level: offset and count of its W blocks' scalars in winv (k_flow_reset marks them)
+  DevBuf<int64_t> flow_wfill_;      // per four W blocks of a front of a flow level: offset and count of scalars in winv (k_flow_reset marks them)
   DevBuf<unsigned> flow_flags_;     // tickets + completion flags of every flow level, zeroed at the start of a factorisation
   int flow_max_nf_ = 1 << 20;       // RR_PGO_FLOW=<n> (0: never): levels of at most n fronts ...
   int flow_max_tasks_ = 1 << 20;    // RR_PGO_FLOW_TASKS=<n>: ... and of at most n tasks run as ONE k_big_flow launch: by default every level.
@@ -867,8 +867,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       lvl->wfill_begin = (int)(wfill.size() / 2);
       for (int z = 0; z < nf; z++) {
         const int sn = sym_.task_sn[sym_.task_ptr[st.task_begin + z]];
-        wfill.push_back(sn_wblk[sn] * 256);
-        wfill.push_back((int64_t)((sym_.sn_ncols[sn] + BIG_NB - 1) / BIG_NB) * 1024);
+        const int64_t w0 = sn_wblk[sn] * 256, wn = (int64_t)((sym_.sn_ncols[sn] + BIG_NB - 1) / BIG_NB) * 1024;
+        for (int64_t o = 0; o < wn; o += 4096) { wfill.push_back(w0 + o); wfill.push_back(std::min<int64_t>(4096, wn - o)); }   // one workgroup of k_flow_reset each
       }
       lvl->wfill_end = (int)(wfill.size() / 2);
       all_tasks[si] = std::move(tasks);
@@ -1223,8 +1223,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       int e0 = 0, e1 = 0;
       for (size_t si = from; si < to && si < flow_levels_.size(); si++)
         if (flow_levels_[si]) { if (e1 == 0) e0 = flow_levels_[si]->wfill_begin; e1 = flow_levels_[si]->wfill_end; }
-      hipLaunchKernelGGL(k_flow_reset<T>, dim3((unsigned)std::min<int64_t>(((int64_t)flow_flags_.n + 255) / 256, 64), 1 + std::max(e1 - e0, 0)), dim3(256), 0,
-                         stream_, flow_flags_.p, (int64_t)flow_flags_.n, winv_.p, flow_wfill_.p + 2 * e0);
+      const int flag_wgs = (int)std::min<int64_t>(((int64_t)flow_flags_.n + 255) / 256, 256);
+      hipLaunchKernelGGL(k_flow_reset<T>, dim3((unsigned)(flag_wgs + std::max(e1 - e0, 0))), dim3(256), 0, stream_, flow_flags_.p, (int64_t)flow_flags_.n, flag_wgs,
+                         winv_.p, flow_wfill_.p + 2 * e0);
       check_launch("k_flow_reset");
     }
     for (size_t si = from; si < to; si++) {
