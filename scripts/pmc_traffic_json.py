@@ -19,6 +19,8 @@ def table(wl, counter):
 def entry(wl, kernels, label, per_step_iters=None):
     f, w = table(wl, "FETCH_SIZE"), table(wl, "WRITE_SIZE")
     n = sum(f[k][0] for k in kernels if k in f)
+    if n == 0:
+        return None   # the kernel does not run in this configuration (k_big_panel32 since every level is a flow launch)
     fk = sum(f[k][1] for k in kernels if k in f)
     wk = sum(w[k][1] for k in kernels if k in w)
     e = {"kernel": label, "fetch_kib_per_launch": round(fk / n, 1), "write_kib_per_launch": round(wk / n, 1),
@@ -40,9 +42,11 @@ doc["grid:400x250:1000000:f32"] = entry("grid", ["k_big_flow"], "k_big_flow", gr
 doc["grid:400x250:1000000:f32:k_big_update"] = entry("grid", ["k_big_update", "k_big_schur"], "k_big_update+k_big_schur", grid_iters)
 doc["grid:400x250:1000000:f32:k_big_update"]["note"] = (
     "r02 (profiles/r02z_grid_*_SIZE.txt): k_big_update 48 launches per step x 160.6 MB = 7.7 GB per step, plus 177 k_big_panel32 launches x 14.7 MB "
-    "= 2.6 GB. r03: the per-super-panel updates of the levels of at most 64 fronts are UPDATE tasks of k_big_flow (entry above, which also "
-    "holds those levels' panel traffic), the Schur complements one k_big_schur pass per level")
-doc["grid:400x250:1000000:f32:k_big_panel32"] = entry("grid", ["k_big_panel32"], "k_big_panel32", grid_iters)
+    "= 2.6 GB. r03: the panel steps and per-super-panel updates of every level are tasks of k_big_flow (entry above), the Schur "
+    "complements one k_big_schur pass per level")
+panel = entry("grid", ["k_big_panel32"], "k_big_panel32", grid_iters)
+if panel:
+    doc["grid:400x250:1000000:f32:k_big_panel32"] = panel
 json.dump(doc, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 for k, v in doc.items():
     if k != "_comment":
