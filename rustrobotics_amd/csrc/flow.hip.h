@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(256) k_flow_reset(unsigned *words, int64_t n, 
 }
 #ifndef RRPGO_FLOW_DEPTH
 #define RRPGO_FLOW_DEPTH 4   // k-chunks of a trailing-update tile requested ahead of the MFMAs (the launch sequence's k_big_update uses 1 at
-#endif                       // seven workgroups per CU; here two workgroups per CU have to cover a chunk's memory round trip themselves)
+#endif                       // six workgroups per CU; here two workgroups per CU have to cover a chunk's memory round trip themselves)
 #ifndef RRPGO_FLOW_WAVES
 #define RRPGO_FLOW_WAVES 2   // fp32: waves per SIMD the register allocation aims at (= workgroups per CU): the panel wave keeps ~200 values in flight;
 #endif                       // fp64 (two registers per value) runs one workgroup per CU
