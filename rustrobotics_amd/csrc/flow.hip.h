@@ -46,9 +46,15 @@ struct FlowTask {        // 16 bytes, one scalar load
 constexpr int FLOW_PANEL = 0, FLOW_UPDATE = 1, FLOW_DIAG0 = 2;
 constexpr int FLOW_GROUP = 4;   // row blocks per PANEL task (one per wave)
 
+struct alignas(128) FlowRec {   // what a workgroup loads per ticket: the task and its front's records in ONE 128-byte line
+  FlowTask t;                   // (the front's records in tables of their own were a second, dependent round trip
+  FlowFront ff;                 // per task: ~0.8 us of a 6 us task on the levels that are bound by their task count)
+  SnMeta m;
+  int32_t pad[4];
+};
+static_assert(sizeof(FlowRec) == 128, "FlowRec is one 128-byte line");
 template <typename T> struct FlowArgs {   // everything the launch reads: a slim kernel-argument block (the ticket loop keeps all of it in SGPRs)
-  const FlowTask *tasks;
-  const FlowFront *fronts;
+  const FlowRec *tasks;
   unsigned *ticket;
   unsigned *flags;
   int n_tasks;
@@ -58,7 +64,6 @@ template <typename T> struct FlowArgs {   // everything the launch reads: a slim
   int exact;    // 1: the next super-panel's first diagonal block comes out of tile (0, 0) of the trailing update, exactly as
                 // in the launch sequence (bit-identical results); 0: the chain wave forms it itself, left-looking over the
                 // whole super-panel like every other diagonal block -- same sums in another order, and no tile on the chain
-  const SnMeta *front_meta;      // task_meta of the level's first front (slot 0)
   const ChildMeta *child_meta;
   const int32_t *scat;
   T *lvals, *uvals, *xch, *winv;
@@ -444,10 +449,11 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
     __syncthreads();   // everybody has read it (and is done with smem) before the next round rewrites it
     if (t >= fa.n_tasks) return;
     RRPGO_FLOW_MARK(fa, t, wave, 0);
-    const FlowTask tk = fa.tasks[t];
-    const int kind = tk.kind_front >> 24, slot = tk.kind_front & 0xffffff;
-    const SnMeta m = fa.front_meta[slot];
-    const FlowFront ff = fa.fronts[slot];
+    const FlowRec rec = fa.tasks[t];
+    const FlowTask tk = rec.t;
+    const int kind = tk.kind_front >> 24;
+    const SnMeta m = rec.m;
+    const FlowFront ff = rec.ff;
     if (kind == FLOW_PANEL) {
       flow_panel_wave<T, TS>(fa, ff, m, tk.p0, tk.p2, tk.p1 + wave, smem, tid, t);
       continue;

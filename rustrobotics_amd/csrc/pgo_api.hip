@@ -264,8 +264,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   bool gather_update_ = true;       // big fronts: k_big_build builds the pivot columns only, a front's first trailing update gathers its tiles from the children (RR_PGO_NO_GATHER_UPDATE=1: whole fronts are built)
   // k_big_flow (flow.hip.h): levels of at most flow_max_nf_ big fronts run as ONE launch of ticket-ordered tile tasks
   struct FlowLevel {
-    DevBuf<FlowTask> tasks;
-    DevBuf<FlowFront> fronts;
+    DevBuf<FlowRec> tasks;     // every task with a copy of its front's records (one 128-byte load per task)
     int n_tasks = 0;
     bool schur_split = false;  // the level's Schur complements are a k_big_schur launch behind the flow launch
     std::vector<FlowTask> host_tasks;   // diagnostic builds: the sorted list, for rr_pgo_debug_flow_trace
@@ -275,6 +274,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     double est_us = 0;         // critical path of the cost model that orders the tasks
   };
   std::vector<std::unique_ptr<FlowLevel>> flow_levels_;   // per step of sym_.steps (null: launch sequence)
+  std::vector<SnMeta> host_task_meta_;   // host copy of task_meta_ (one record per task = per front of a big level)
   DevBuf<int64_t> flow_wfill_;      // per four W blocks of a front of a flow level: offset and count of scalars in winv (k_flow_reset marks them)
   DevBuf<unsigned> flow_flags_;     // tickets + completion flags of every flow level, zeroed at the start of a factorisation
   int flow_max_nf_ = 1 << 20;       // RR_PGO_FLOW=<n> (0: never): levels of at most n fronts ...
@@ -478,8 +478,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (const char *e = getenv("RR_PGO_FLOW_TASKS")) flow_max_tasks_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_SOLVE_FLOW")) solve_flow_on_ = std::atoi(e) != 0;
     if (const char *e = getenv("RR_PGO_FLOW_SCHUR_MIN")) flow_schur_min_ = std::atoi(e);
-    build_flow_levels();
-    build_update_maps();
     n_lin_blocks_ = (int)(((int64_t)n_list_ * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
     edge_lin_ = getenv("RR_PGO_EDGE_LINEARIZE") != nullptr && !is3d_ && !sharded_ && g_.n_edges() > 0;
     if (edge_lin_) n_lin_blocks_ = std::max(1, (g_.n_edges() + LIN_THREADS - 1) / LIN_THREADS);
@@ -542,6 +540,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         std::vector<SnMeta> tm(sym.task_ptr.size() - 1);
         for (size_t t = 0; t + 1 < sym.task_ptr.size(); t++) tm[t] = meta[sym.task_sn[sym.task_ptr[t]]];
         task_meta_.upload(tm);
+        host_task_meta_ = tm;
         // k_big_panel32 / k_big_update / k_big_flow address a front with 32-bit BYTE offsets from its base
         for (const Step &st : sym.steps)
           if (st.kind == STEP_BIG)
@@ -557,6 +556,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       winv_.zero();
       child_meta_.upload(cm);
     }
+    build_flow_levels();   // (after the front records: every flow task carries a copy of its front's)
+    build_update_maps();
     fasm_src_.upload(sym.fasm_src);
     fasm_dst_.upload(sym.fasm_dst);
     fasm_colptr_.upload(sym.fasm_colptr);
@@ -925,8 +926,18 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       }
     for (size_t si = 0; si < sym_.steps.size(); si++)
       if (flow_levels_[si]) {
-        flow_levels_[si]->tasks.upload(all_tasks[si]);
-        flow_levels_[si]->fronts.upload(all_fronts[si]);
+        {
+          const Step &st = sym_.steps[si];
+          std::vector<FlowRec> recs(all_tasks[si].size());
+          for (size_t i = 0; i < recs.size(); i++) {
+            const int slot = all_tasks[si][i].kind_front & 0xffffff;
+            recs[i].t = all_tasks[si][i];
+            recs[i].ff = all_fronts[si][slot];
+            recs[i].m = host_task_meta_[st.task_begin + slot];
+            std::memset(recs[i].pad, 0, sizeof(recs[i].pad));
+          }
+          flow_levels_[si]->tasks.upload(recs);
+        }
 #ifdef RRPGO_FLOW_TRACE
         flow_levels_[si]->host_tasks = all_tasks[si];
         flow_levels_[si]->trace.alloc(all_tasks[si].size() * 16);
@@ -996,14 +1007,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   void launch_flow(const Step &st, const FlowLevel &lvl) {
     FlowArgs<T> fa;
     fa.tasks = lvl.tasks.p;
-    fa.fronts = lvl.fronts.p;
     fa.ticket = flow_flags_.p + lvl.ticket_word;
     fa.flags = flow_flags_.p;
     fa.n_tasks = lvl.n_tasks;
     fa.gather = gather_update_ ? 1 : 0;
     fa.exact = flow_exact_ ? 1 : 0;
     fa.schur_tile = lvl.schur_split ? schur_tile_ : 0;
-    fa.front_meta = task_meta_.p + st.task_begin;
     fa.child_meta = child_meta_.p;
     fa.scat = scat_.p;
     fa.lvals = lvals_.p;
