@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rustrobotics_amd import PoseGraph, synthetic_grid_arrays
 arrays = synthetic_grid_arrays(400, 250, 1000000)
 for rep in range(2):
