@@ -131,6 +131,8 @@ template <typename T, typename TC = T> struct LinArgs {
   TC lambda;                             // added to every diagonal entry when > 0 (LM, :362-366)
   int write_system;                      // 0: chi2 only
   const uint8_t *adds_diag;              // sharded runs: per node, 1 = this rank adds prior / lambda (shared nodes: rank 0)
+  unsigned *zero_words;                  // flags and tickets of the dataflow launches that follow (lds_flow.hip.h): zeroed here,
+  int n_zero_words;                      // one launch ahead of their first use (0: none)
 };
 
 // ---------------------------------------------------------------- factor maths
@@ -240,6 +242,7 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<TO, T> a) {
   using V2 = typename VecT<T>::V2;
   __shared__ double red[LIN_THREADS / 64];
   const int gid = blockIdx.x * LIN_THREADS + threadIdx.x;
+  for (int i = gid; i < a.n_zero_words; i += gridDim.x * LIN_THREADS) a.zero_words[i] = 0u;
   const int slot = gid / LIN_GROUP, sub = gid % LIN_GROUP;
   const int node = slot < a.n_nodes ? (a.node_list ? a.node_list[slot] : slot) : -1;
   double chi = 0.0;
@@ -507,6 +510,8 @@ template <typename T, typename TC = T> struct LinArgs3 {
   TC lambda;
   int write_system;
   const uint8_t *adds_diag;             // sharded runs: per node, 1 = this rank adds prior / lambda
+  unsigned *zero_words;                 // as LinArgs::zero_words
+  int n_zero_words;
 };
 
 template <typename T> __device__ __forceinline__ void q_mul(const T a[4], const T b[4], T r[4]) {
@@ -591,6 +596,7 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize_se3(LinArgs3<TO, T> a
   using V4 = typename VecT<T>::V4;
   __shared__ double red[LIN_THREADS / 64];
   const int gid = blockIdx.x * LIN_THREADS + threadIdx.x;
+  for (int i = gid; i < a.n_zero_words; i += gridDim.x * LIN_THREADS) a.zero_words[i] = 0u;
   const int slot = gid / LIN_GROUP, sub = gid % LIN_GROUP;
   const int node = slot < a.n_nodes ? (a.node_list ? a.node_list[slot] : slot) : -1;
   double chi = 0.0;
@@ -820,9 +826,49 @@ template <typename T> struct FactorArgs {
   T *winv;                  // inverse diagonal blocks, kept for the back substitution: 16 x 16 per 16 columns of an
                             // LDS front ([block][j][c] = W(j, c)), 32 x 32 per 32 columns of a big front ([block][j][c] = W(c, j))
   int *err;
-  unsigned long long *stamps;  // [S][8], diagnostic builds only (else null)
+  unsigned long long *stamps;  // [S][12], diagnostic builds only (else null)
   unsigned long long *trace;   // diagnostic trace region (else null)
+  // dataflow launches of the LDS fronts (lds_flow.hip.h; null / 0 elsewhere)
+  const int32_t *child_dep;    // per child_meta entry: index in dep_flags of the flag that says the child's update matrix is in memory,
+                               // -1 = the child was factored earlier in the same task (by this workgroup)
+  const int32_t *parent_dep;   // per front, back substitution: index of the flag that says the parent's solution is in memory, -1 = none
+                               // (a root, or the parent was solved earlier in the same task)
+  unsigned *dep_flags;         // [0, S): factor flags, [S, 2 S): solve flags; zeroed before every factorisation
+  int parent_dep_self;         // S: a front's own solve flag is dep_flags[S + s]
+  unsigned long long wait_ticks;   // bound of one wait, 100 MHz ticks
 };
+
+// ---- hand-offs between workgroups of ONE launch (lds_flow.hip.h; flow.hip.h has the same policy for the fronts beyond
+// LDS): payload with sc1 accesses (written through to memory, read past this CU's L1), the flag with agent-scope relaxed
+// atomics after the storing waves' s_waitcnt vmcnt(0) and a workgroup barrier.  A wait is bounded in TIME (100 MHz wall
+// clock): when it runs out -- or another wait already has -- DEVERR_FLOW_TIMEOUT is set and every later wait returns at
+// once, so the launch drains; addresses never depend on data, k_update does not apply a step while a flag is set.
+__device__ __forceinline__ unsigned dep_flag_ld(const unsigned *p) { return __hip_atomic_load(const_cast<unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void dep_flag_set(unsigned *p) { __hip_atomic_store(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void dep_drain() {   // after this wave's payload stores, before the barrier that precedes the flag
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ bool dep_wait(const unsigned *p, int *err, unsigned long long max_ticks) {   // wave-uniform p
+  bool ok = true;
+  if (dep_flag_ld(p) == 0u) {
+    const unsigned long long t0 = wall_clock64();
+    for (unsigned spins = 1;; spins++) {
+      __builtin_amdgcn_s_sleep(1);
+      if (dep_flag_ld(p) != 0u) break;
+      if ((spins & 31u) == 0u) {
+        const int e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e != 0 || wall_clock64() - t0 > max_ticks) {
+          if (e == 0 && (threadIdx.x & 63) == 0) atomicOr(err, DEVERR_FLOW_TIMEOUT);
+          ok = false;
+          break;
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the payload loads below the poll
+  return ok;
+}
 
 // update-matrix element (i >= j) of an n x n lower triangle: packed columns, or
 // a plain column-major square when ld > 0
@@ -1255,13 +1301,21 @@ __device__ __forceinline__ void panel_factor(T *P, int M, int nc, int *err, T *w
 // memory counter, i.e. it would wait for global loads that were requested early on purpose.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <typename T, int THREADS, bool IN_PLACE>
+// FLOW (lds_flow.hip.h: fronts of several workgroups of ONE launch): a child that another workgroup factors is waited
+// for right before ITS extend-add -- everything that does not depend on it (zeroing, H entries, rhs, the children before
+// it, its scatter map) is done by then; update matrices move with sc1 accesses; the front's flag is set as soon as its
+// update matrix is in memory, the panel is copied out after that.  The arithmetic is the same in both forms.
+template <typename T, int THREADS, bool IN_PLACE, bool FLOW = false>
 __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *P, T *U, int uld, T *dinv) {
+  static_assert(!(FLOW && IN_PLACE), "the dataflow form is for fronts in LDS");
   const int tid = threadIdx.x;
   const int nc = m.nc, nr = m.nr;
   const int M = nc + nr + 1, nu = nr + 1;
   const int psize = M * nc, usize = nu * (nu + 1) / 2;
   RRPGO_STAMP(a, s, 0);
+#ifdef RRPGO_STAMPS
+  if (FLOW && tid == 0 && a.stamps) a.stamps[(int64_t)s * 12 + 10] = 0;
+#endif
   // ---- original entries of H that live in this front's pivot columns and the rhs row: index, then
   // value -- two dependent global round trips (~1.2 us).  The first APRE entries of every thread are
   // requested BEFORE the zeroing pass and its barrier, which hides them.
@@ -1278,7 +1332,11 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
   }
   if (tid < nc) pb = a.b[a.perm[m.col0 + tid]];
   ChildMeta cnext{};
-  if (m.child_count > 0) cnext = a.child_meta[m.child_begin];
+  int dnext = -1;   // FLOW: flag of the child cnext, -1 = nothing to wait for
+  if (m.child_count > 0) {
+    cnext = a.child_meta[m.child_begin];
+    if (FLOW) dnext = a.child_dep[m.child_begin];
+  }
   if (IN_PLACE) {
     for (int64_t t = tid; t < (int64_t)M * M; t += THREADS) P[t] = 0;  // whole front, ld M
   } else {
@@ -1298,20 +1356,39 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
   int ed[EPRE];
   T ev[EPRE];
   auto child_u = [&](const ChildMeta &c) { return (c.uld > 0 ? a.lvals : c.uld < 0 ? a.xch : a.uvals) + c.uoff; };
-  auto prefetch = [&](const ChildMeta &c) {
+  // a child's update matrix: plain loads, or (FLOW) sc1 loads by 32-bit byte offset -- another workgroup of this launch wrote it
+  auto uc_ld = [&](const T *Uc, const Sc1Buf<T> &ub, int t) -> T {
+    if constexpr (FLOW) return ub.ld((uint32_t)t * (uint32_t)sizeof(T));
+    else return Uc[t];
+  };
+  auto prefetch_map = [&](const ChildMeta &c) {
 #pragma unroll
     for (int u = 0; u < EPRE; u++) { ed[u] = -1; ev[u] = 0; }
     if (IN_PLACE || c.scat_ptr < 0) return;
     const int32_t *map = a.scat + c.scat_ptr;
-    const T *Uc = child_u(c);
     const int cnt = c.ncu * (c.ncu + 1) / 2;
 #pragma unroll
     for (int u = 0; u < EPRE; u++) {
       const int t = tid + u * THREADS;
-      if (t < cnt) { ed[u] = map[t]; ev[u] = Uc[t]; }
+      if (t < cnt) ed[u] = map[t];
     }
   };
-  if (m.child_count > 0) prefetch(cnext);   // under the barrier and the assembly stores
+  auto prefetch_val = [&](const ChildMeta &c) {
+    if (IN_PLACE || c.scat_ptr < 0) return;
+    const T *Uc = child_u(c);
+    const int cnt = c.ncu * (c.ncu + 1) / 2;
+    [[maybe_unused]] const Sc1Buf<T> ub(Uc, FLOW ? (uint32_t)cnt * (uint32_t)sizeof(T) : 0u);
+#pragma unroll
+    for (int u = 0; u < EPRE; u++) {
+      const int t = tid + u * THREADS;
+      if (t < cnt) ev[u] = uc_ld(Uc, ub, t);
+    }
+  };
+  auto prefetch = [&](const ChildMeta &c, int dep) {   // the values only when the child's update matrix is known to be there
+    prefetch_map(c);
+    if (!FLOW || dep < 0) prefetch_val(c);
+  };
+  if (m.child_count > 0) prefetch(cnext, dnext);   // under the barrier and the assembly stores
   if (IN_PLACE) __syncthreads();
   else lds_barrier();
   RRPGO_STAMP(a, s, 1);
@@ -1335,21 +1412,36 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
   // are requested while child q is being added (each child is otherwise a global round trip + a barrier).
   for (int q = 0; q < m.child_count; q++) {
     const ChildMeta c = cnext;
-    if (q + 1 < m.child_count) cnext = a.child_meta[m.child_begin + q + 1];   // the next record in flight under this child
+    const int dep = dnext;
+    if (q + 1 < m.child_count) {   // the next record in flight under this child
+      cnext = a.child_meta[m.child_begin + q + 1];
+      if (FLOW) dnext = a.child_dep[m.child_begin + q + 1];
+    }
     const T *Uc = child_u(c);
+    if (FLOW && dep >= 0) {   // every wave for itself; the barrier below joins them
+#ifdef RRPGO_STAMPS
+      const unsigned long long w0_ = wall_clock64();
+#endif
+      dep_wait(a.dep_flags + dep, a.err, a.wait_ticks);
+#ifdef RRPGO_STAMPS
+      if (tid == 0 && a.stamps) a.stamps[(int64_t)s * 12 + 10] += wall_clock64() - w0_;   // time spent waiting for children
+#endif
+    }
     __syncthreads();
     if (!IN_PLACE && c.scat_ptr >= 0) {
       // packed child, LDS parent: one precomputed destination per element, coalesced
       const int32_t *map = a.scat + c.scat_ptr;
       const int cnt = c.ncu * (c.ncu + 1) / 2;
+      [[maybe_unused]] const Sc1Buf<T> ub(Uc, FLOW ? (uint32_t)cnt * (uint32_t)sizeof(T) : 0u);
+      if (FLOW && dep >= 0) prefetch_val(c);   // (its map entries were requested before the wait)
 #pragma unroll
       for (int u = 0; u < EPRE; u++)
         if (ed[u] >= 0) P[ed[u]] += ev[u];
-      if (q + 1 < m.child_count) prefetch(cnext);
+      if (q + 1 < m.child_count) prefetch(cnext, dnext);
       int t = tid + EPRE * THREADS;
       for (; t + 3 * THREADS < cnt; t += 4 * THREADS) {
         const int d0 = map[t], d1 = map[t + THREADS], d2 = map[t + 2 * THREADS], d3 = map[t + 3 * THREADS];
-        const T v0 = Uc[t], v1 = Uc[t + THREADS], v2 = Uc[t + 2 * THREADS], v3 = Uc[t + 3 * THREADS];
+        const T v0 = uc_ld(Uc, ub, t), v1 = uc_ld(Uc, ub, t + THREADS), v2 = uc_ld(Uc, ub, t + 2 * THREADS), v3 = uc_ld(Uc, ub, t + 3 * THREADS);
         if (d0 >= 0) P[d0] += v0;
         if (d1 >= 0) P[d1] += v1;
         if (d2 >= 0) P[d2] += v2;
@@ -1357,10 +1449,10 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
       }
       for (; t < cnt; t += THREADS) {
         const int d0 = map[t];
-        if (d0 >= 0) P[d0] += Uc[t];
+        if (d0 >= 0) P[d0] += uc_ld(Uc, ub, t);
       }
     } else {
-      if (q + 1 < m.child_count) prefetch(cnext);
+      if (q + 1 < m.child_count) prefetch(cnext, dnext);
       const int32_t *rel = a.rel + c.rel_ptr;
       const int ncu = c.ncu;
       for (int t = tid; t < ncu * ncu; t += THREADS) {
@@ -1416,6 +1508,16 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
     // panel -> L storage, packed update -> U storage (both offsets are multiples of 4 scalars)
     T *Lg = a.lvals + m.loff;
     T *Ug = (m.uld < 0 ? a.xch : a.uvals) + m.uoff;
+    if constexpr (FLOW) {
+      // the update matrix first, written through; the parent's workgroup may go on as soon as the flag is set -- the
+      // panel (read by the back substitution, a later launch) is copied out behind that
+      const Sc1Buf<T> ub(Ug, (uint32_t)usize * (uint32_t)sizeof(T));
+      for (int t = tid; t < usize; t += THREADS) ub.st((uint32_t)t * (uint32_t)sizeof(T), U[t]);
+      dep_drain();
+      __syncthreads();
+      if (tid == 0) dep_flag_set(a.dep_flags + s);
+      RRPGO_STAMP(a, s, 11);
+    }
     if ((psize & 1) == 0) {
       const V2 *sp = reinterpret_cast<const V2 *>(P);
       V2 *dp = reinterpret_cast<V2 *>(Lg);
@@ -1423,7 +1525,8 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
     } else {
       for (int t = tid; t < psize; t += THREADS) Lg[t] = P[t];
     }
-    for (int t = tid; t < usize; t += THREADS) Ug[t] = U[t];
+    if constexpr (!FLOW)
+      for (int t = tid; t < usize; t += THREADS) Ug[t] = U[t];
     __syncthreads();
   }
   RRPGO_STAMP(a, s, 6);
@@ -2381,7 +2484,10 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (NT == 4 ? 
 // memory with every thread streaming a slice of the panel (coalesced along the
 // rows), partial sums combined per column through LDS.
 // work: STAGE: nc*ldt + nr + nc*NSLICE ; else nr + nc scalars.
-template <typename T, int THREADS, bool STAGE>
+// FLOW (k_solve_flow, lds_flow.hip.h): the fronts of one launch's workgroups hand the solution down the tree -- a front
+// waits for its parent's flag right before it gathers x[rows] (its own loads of L21 are in flight by then), reads and
+// writes x with sc1 accesses and sets its own flag when its part of x is in memory.  Same arithmetic in both forms.
+template <typename T, int THREADS, bool STAGE, bool FLOW = false>
 __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *work) {
   const int tid = threadIdx.x;
   const int nc = m.nc, nr = m.nr;
@@ -2391,6 +2497,39 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *w
   if (STAGE) {
     T *x2 = work;                 // nr
     T *t1 = x2 + nr;              // nc
+    using MM = Mfma16<T>;
+    constexpr int NW = THREADS / 64;
+    const int wave = wave_index(), lane = tid & 63, l16 = lane & 15;
+    const int nblk = (nc + 15) >> 4;
+    int kr[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) kr[r] = MM::row(lane, r);
+    // a-operand of x = W^T u: A[m = l16][k-slot r] = W(kr[r], l16) = winv[kr[r] * 16 + l16]; three blocks in flight
+    const T *Wg = a.winv + (int64_t)m.wblk * 256 + l16;
+    T w0[4], w1[4], w2[4];
+    // a-operand of u = t_b - L(b+1, b)^T x_(b+1): -L(16 (b+1) + k, 16 b + m), m = l16; rows clamped into the front
+    T la0[4], la1[4];
+    auto lblock = [&](int b, T (&dst)[4]) {   // operand block of chain step b (uses block b + 1), b clamped
+      const int bc = max(min(b, nblk - 2), 0);
+      const T *col = Lg + (int64_t)(16 * bc + l16) * M + 16 * bc + 16;
+      const int cwn = nc - (16 * bc + 16);   // >= 1 when nblk >= 2
+#pragma unroll
+      for (int r = 0; r < 4; r++) dst[r] = col[max(min(kr[r], cwn - 1), 0)];
+    };
+    auto chain_preload = [&] {   // operands of the first chain steps (wave 0): nothing here depends on x
+      if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          w0[r] = Wg[(nblk - 1) * 256 + kr[r] * 16];
+          w1[r] = Wg[max(nblk - 2, 0) * 256 + kr[r] * 16];
+          w2[r] = Wg[max(nblk - 3, 0) * 256 + kr[r] * 16];
+        }
+        if (nblk >= 2) {
+          lblock(nblk - 2, la0);
+          lblock(nblk - 3, la1);
+        }
+      }
+    };
     __syncthreads();
     RRPGO_STAMP_SOLVE(a, s, 0);
     // The loads of the L21^T x2 product do not depend on x2: when the shape allows (nr <= 128, at most GV
@@ -2411,7 +2550,12 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *w
           gy[g] = col[nr];
         }
     }
-    for (int i = tid; i < nr; i += THREADS) x2[i] = a.x[rows[i]];
+    if constexpr (FLOW) {
+      chain_preload();
+      const int pdep = a.parent_dep[s];
+      if (pdep >= 0) dep_wait(a.dep_flags + pdep, a.err, a.wait_ticks);   // every wave for itself; the barrier below joins them
+    }
+    for (int i = tid; i < nr; i += THREADS) x2[i] = mem_ld<FLOW>(a.x + rows[i]);
     __syncthreads();
     RRPGO_STAMP_SOLVE(a, s, 1);
     // t1[j] = y1[j] - sum_i L21[i][j] x2[i]
@@ -2469,37 +2613,7 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *w
     // next two steps in flight like W, a fold thread owns one column i and requests its 16 contiguous
     // entries L(c0.., i) BEFORE the barrier that releases the block -- no address depends on x.
     {
-      using MM = Mfma16<T>;
-      constexpr int NW = THREADS / 64;
-      const int wave = wave_index(), lane = tid & 63, l16 = lane & 15;
-      const int nblk = (nc + 15) >> 4;
-      int kr[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) kr[r] = MM::row(lane, r);
-      // a-operand of x = W^T u: A[m = l16][k-slot r] = W(kr[r], l16) = winv[kr[r] * 16 + l16]; three blocks in flight
-      const T *Wg = a.winv + (int64_t)m.wblk * 256 + l16;
-      T w0[4], w1[4], w2[4];
-      // a-operand of u = t_b - L(b+1, b)^T x_(b+1): -L(16 (b+1) + k, 16 b + m), m = l16; rows clamped into the front
-      T la0[4], la1[4];
-      auto lblock = [&](int b, T (&dst)[4]) {   // operand block of chain step b (uses block b + 1), b clamped
-        const int bc = max(min(b, nblk - 2), 0);
-        const T *col = Lg + (int64_t)(16 * bc + l16) * M + 16 * bc + 16;
-        const int cwn = nc - (16 * bc + 16);   // >= 1 when nblk >= 2
-#pragma unroll
-        for (int r = 0; r < 4; r++) dst[r] = col[max(min(kr[r], cwn - 1), 0)];
-      };
-      if (wave == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          w0[r] = Wg[(nblk - 1) * 256 + kr[r] * 16];
-          w1[r] = Wg[max(nblk - 2, 0) * 256 + kr[r] * 16];
-          w2[r] = Wg[max(nblk - 3, 0) * 256 + kr[r] * 16];
-        }
-        if (nblk >= 2) {
-          lblock(nblk - 2, la0);
-          lblock(nblk - 3, la1);
-        }
-      }
+      if constexpr (!FLOW) chain_preload();
       __syncthreads();
       RRPGO_STAMP_SOLVE(a, s, 2);
       typename MM::Acc xprev = {0, 0, 0, 0};
@@ -2572,8 +2686,12 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *w
     }
     __syncthreads();
     RRPGO_STAMP_SOLVE(a, s, 3);
-    for (int j = tid; j < nc; j += THREADS) a.x[m.col0 + j] = t1[j];
+    for (int j = tid; j < nc; j += THREADS) mem_st<FLOW>(a.x + m.col0 + j, t1[j]);
+    if constexpr (FLOW) dep_drain();
     __syncthreads();
+    if constexpr (FLOW) {
+      if (tid == 0) dep_flag_set(a.dep_flags + a.parent_dep_self + s);
+    }
     RRPGO_STAMP_SOLVE(a, s, 4);
   } else {
     // Front in place in HBM (fronts beyond LDS), left-looking over 64-column chunks from the right:

@@ -1,0 +1,100 @@
+// lds_flow.hip.h -- k_factor_flow / k_solve_flow: the multifrontal factorisation and the back substitution of a graph
+// whose fronts ALL live in LDS (intel.g2o, M3500, dlr: up to a few thousand poses) as ONE launch each.
+//
+// The level schedule (k_factor_tasks / k_solve_tasks, one launch per level of the task tree) pays for every level the
+// slowest task of that level plus a kernel boundary, and a front's workgroup cannot begin before the launch of its
+// level does.  Here a front's workgroup is resident from the start of the launch:
+//
+//   tasks      every subtree cheaper than a threshold (walked in postorder by one workgroup, exactly as before) and every
+//              front above those as a task of its own (symbolic.cpp, build_flow_schedule)
+//   tickets    workgroups draw tasks from ONE atomic counter; the list is in the start order of a list schedule of the
+//              task tree, a topological order: a task only waits for tasks with smaller tickets, which are finished or
+//              held by a running workgroup -- no deadlock whatever the grid size, the dispatch order or other kernels
+//              on the device
+//   hand-off   factorisation: a front's packed update matrix is written through to memory (sc1 stores), then its flag is
+//              set; the parent waits for the flag right before THAT child's extend-add -- zeroing its LDS image, adding
+//              the H entries and the right-hand side, the earlier children and the child's scatter map are behind it by
+//              then -- and reads the update matrix with sc1 loads.  The panel (which only the back substitution reads,
+//              a later launch) is copied out after the flag.  Back substitution: the same with x handed from a parent
+//              to its children.
+//   order      children are added in a fixed order (symbolic.cpp: by the cost model's finish time), so every sum -- and
+//              the result, bit for bit -- is the same as in the level schedule (process_front / solve_front are the same
+//              code with FLOW = true).
+//
+// Every wait is bounded in time (dep_wait, kernels.hip.h).  Replaces umfpack.factorize / umfpack.solve
+// (reference src/mapping/pose_graph_optimization.rs:138-141).
+#pragma once
+
+namespace rrpgo {
+
+struct alignas(128) LdsFlowTask {   // what a workgroup loads per ticket: ONE 128-byte line
+  SnMeta m;                         // record of the task's first front (factorisation) / last front (back substitution)
+  int32_t sn;                       // that front
+  int32_t sn_begin, sn_end;         // the task's fronts: task_sn[sn_begin .. sn_end)
+  int32_t pad[13];
+};
+static_assert(sizeof(LdsFlowTask) == 128, "LdsFlowTask is one 128-byte line");
+
+// the next ticket, the same in every thread of the workgroup (one atomic, broadcast through LDS; the barriers inside the
+// task that follows separate this read from the next write)
+__device__ __forceinline__ int lds_flow_ticket(unsigned *ticket, int *slot) {
+  if (threadIdx.x == 0) *slot = (int)atomicAdd(ticket, 1u);
+  __syncthreads();
+  return __builtin_amdgcn_readfirstlane(*slot);
+}
+
+template <typename T, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_factor_flow(FactorArgs<T> a, const LdsFlowTask *tasks, int n_tasks, unsigned *ticket) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  __shared__ T dinv[W16_SCR];   // inverse of the current 16 x 16 diagonal block + an identity (diag16_factor_invert_full)
+  __shared__ int ticket_slot[2];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+  init_w16_identity<T>(dinv, threadIdx.x, THREADS);
+  if (THREADS > 256 && wave_index() == 0) __builtin_amdgcn_s_setprio(RRPGO_CHAIN_PRIO);
+  for (int round = 0;; round++) {
+    const int tk = lds_flow_ticket(ticket, &ticket_slot[round & 1]);
+    if (tk >= n_tasks) break;
+    const LdsFlowTask tr = tasks[tk];
+    int snext = tr.sn;
+    SnMeta mnext = tr.m;
+    for (int si = tr.sn_begin; si < tr.sn_end; si++) {
+      const int s = snext;
+      const SnMeta m = mnext;
+      if (si + 1 < tr.sn_end) {   // the next front's record in flight under this front
+        snext = a.task_sn[si + 1];
+        mnext = a.sn_meta[snext];
+      }
+      process_front<T, THREADS, false, true>(a, s, m, smem, smem + (m.nc + m.nr + 1) * m.nc, 0, dinv);
+    }
+  }
+}
+
+template <typename T, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_solve_flow(FactorArgs<T> a, const LdsFlowTask *tasks, int n_tasks, unsigned *ticket) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  __shared__ int ticket_slot[2];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+  for (int round = 0;; round++) {
+    const int tk = lds_flow_ticket(ticket, &ticket_slot[round & 1]);
+    if (tk >= n_tasks) break;
+    const LdsFlowTask tr = tasks[tk];
+    int snext = tr.sn;
+    SnMeta mnext = tr.m;
+    for (int si = tr.sn_end - 1; si >= tr.sn_begin; si--) {
+      const int s = snext;
+      const SnMeta m = mnext;
+      if (si > tr.sn_begin) {
+        snext = a.task_sn[si - 1];
+        mnext = a.sn_meta[snext];
+      }
+      solve_front<T, THREADS, true, true>(a, s, m, smem);
+    }
+  }
+}
+
+// (the flags and the two tickets are zeroed by the linearisation kernel of the same iteration: LinArgs::zero_words)
+__global__ void __launch_bounds__(256) k_zero_words(unsigned *w, int n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) w[i] = 0u;
+}
+
+}  // namespace rrpgo

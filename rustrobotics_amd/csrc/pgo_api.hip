@@ -24,6 +24,7 @@
 #include "host_graph.h"
 #include "kernels.hip.h"
 #include "flow.hip.h"
+#include "lds_flow.hip.h"
 #include "symbolic.h"
 
 #ifndef RRPGO_UPD_DEPTH
@@ -292,6 +293,14 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   bool solve_flow_on_ = true;       // RR_PGO_SOLVE_FLOW=0: one k_big_solve_sp launch per 128 columns
   int flow_schur_min_ = 512;        // RR_PGO_FLOW_SCHUR_MIN=<n>: flow levels with at least n Schur tiles leave them to k_big_schur
   int flow_grid_ = 0;               // persistent workgroups of a flow launch (RR_PGO_FLOW_GRID; default CUs x RRPGO_FLOW_WAVES)
+  // k_factor_flow / k_solve_flow (lds_flow.hip.h): every front in LDS, the factorisation and the back substitution ONE launch each
+  bool lds_flow_ = false;
+  DevBuf<int32_t> child_dep_, parent_dep_;
+  std::vector<int32_t> host_child_dep_;
+  DevBuf<unsigned> dep_flags_;      // [0, S) factor flags, [S, 2 S) solve flags, then the two tickets on lines of their own, then a word nobody sets
+  DevBuf<LdsFlowTask> lds_ftasks_, lds_stasks_;
+  int lds_n_tasks_ = 0, lds_flow_cus_ = 256;
+  unsigned long long wait_ticks_ = 200000000ull;   // bound of one in-launch wait: 2 s of the 100 MHz wall clock (RR_PGO_FLOW_TIMEOUT_MS)
   // gauge transfer (single-precision factor, Gauss-Newton; kernels.hip.h "gauge transfer")
   bool gauge_ok_ = false;            // the root front is a big front with an SE2 pivot node
   bool gauge_now_ = false;           // the system being factored was linearised without the anchor prior
@@ -555,6 +564,55 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       winv_.alloc((size_t)wblk_total * 256 + 4);
       winv_.zero();
       child_meta_.upload(cm);
+      if (const char *e = getenv("RR_PGO_FLOW_TIMEOUT_MS")) wait_ticks_ = (unsigned long long)std::max(1.0, std::atof(e) * 1e5);
+      if (sym.lds_flow) {
+        // dataflow launches of the LDS fronts: who waits for whom (a dependency inside one task needs no flag), and
+        // one 128-byte record per ticket
+        if (sharded_ || world_ > 1) throw ApiError(RR_PGO_EUNSUPPORTED, "internal: dataflow schedule on a sharded handle");
+        lds_flow_ = true;
+        const int nt = (int)sym.task_ptr.size() - 1;
+        std::vector<int32_t> task_of(sym.S, -1);
+        for (int t = 0; t < nt; t++)
+          for (int q = sym.task_ptr[t]; q < sym.task_ptr[t + 1]; q++) task_of[sym.task_sn[q]] = t;
+        host_child_dep_.assign(cm.size(), -1);
+        std::vector<int32_t> pdep(sym.S, -1);
+        for (int f = 0; f < sym.S; f++) {
+          for (int q = sym.child_ptr[f]; q < sym.child_ptr[f + 1]; q++) {
+            const int c = sym.child_list[q];
+            if (task_of[c] != task_of[f]) host_child_dep_[q] = c;
+            else if (c > f) throw ApiError(RR_PGO_EUNSUPPORTED, "internal: child after its parent in one task");
+          }
+          const int pf = sym.sn_parent[f];
+          if (pf >= 0 && task_of[pf] != task_of[f]) pdep[f] = sym.S + pf;
+        }
+        child_dep_.upload(host_child_dep_);
+        parent_dep_.upload(pdep);
+        dep_flags_.alloc((size_t)2 * sym.S + 128);
+        dep_flags_.zero();
+        std::vector<LdsFlowTask> ft(nt), stk(nt);
+        for (int t = 0; t < nt; t++) {
+          LdsFlowTask r{};
+          r.sn_begin = sym.task_ptr[t];
+          r.sn_end = sym.task_ptr[t + 1];
+          r.sn = sym.task_sn[r.sn_begin];
+          r.m = meta[r.sn];
+          ft[t] = r;
+        }
+        if ((int)sym.solve_order.size() != nt) throw ApiError(RR_PGO_EUNSUPPORTED, "internal: solve order of the dataflow schedule");
+        for (int k = 0; k < nt; k++) {
+          LdsFlowTask r = ft[sym.solve_order[k]];
+          r.sn = sym.task_sn[r.sn_end - 1];
+          r.m = meta[r.sn];
+          stk[k] = r;
+        }
+        lds_ftasks_.upload(ft);
+        lds_stasks_.upload(stk);
+        lds_n_tasks_ = nt;
+        int dev = 0;
+        HIPCHK(hipGetDevice(&dev));
+        (void)hipDeviceGetAttribute(&lds_flow_cus_, hipDeviceAttributeMultiprocessorCount, dev);
+        lds_flow_cus_ = std::max(lds_flow_cus_, 1);
+      }
     }
     build_flow_levels();   // (after the front records: every flow task carries a copy of its front's)
     build_update_maps();
@@ -594,6 +652,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     n_launches_per_iter = 2;
     for (const Step &st : sym.steps)
       n_launches_per_iter += st.kind == STEP_BIG ? count_big_launches(st) + count_big_solve_launches(st) : 2;
+    if (lds_flow_) n_launches_per_iter = 4;   // linearise, k_factor_flow, k_solve_flow, update
   }
 
   ~Engine() override {
@@ -1091,6 +1150,10 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     set_lds_attr<512>();
     HIPCHK(hipFuncSetAttribute((const void *)k_factor_tasks<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
     HIPCHK(hipFuncSetAttribute((const void *)k_solve_mid<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void *)k_factor_flow<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void *)k_factor_flow<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void *)k_solve_flow<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void *)k_solve_flow<T, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
   }
 
   template <int TH> void launch_factor_tasks(int nt, size_t lds, const FactorArgs<T> &a) {
@@ -1125,6 +1188,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     a.lambda = lm ? (S)lambda : (S)0;
     a.write_system = write_system;
     a.adds_diag = norm_counts_.p;
+    a.zero_words = lds_flow_ ? dep_flags_.p : nullptr;
+    a.n_zero_words = lds_flow_ ? 2 * sym_.S + 64 : 0;
     return a;
   }
 
@@ -1159,6 +1224,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
 #else
     a.trace = nullptr;
 #endif
+    a.child_dep = child_dep_.p;
+    a.parent_dep = parent_dep_.p;
+    a.dep_flags = dep_flags_.p;
+    a.parent_dep_self = sym_.S;
+    a.wait_ticks = wait_ticks_;
     return a;
   }
 
@@ -1192,6 +1262,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       // the edge-parallel form (experiment knob RR_PGO_EDGE_LINEARIZE): clear + prior, one thread per edge, mirror
       const LinArgs<T, S> la = lin_args(lambda, lm, write_system, reference_prior);
       const unsigned nb = (unsigned)((g_.n_nodes() + 255) / 256);
+      if (lds_flow_) hipLaunchKernelGGL(k_zero_words, dim3(4), dim3(256), 0, stream_, dep_flags_.p, 2 * sym_.S + 64);
       if (write_system) hipLaunchKernelGGL((k_lin_init<T, S>), dim3(nb), dim3(256), 0, stream_, la);
       hipLaunchKernelGGL((k_linearize_edges<T, S>), dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_, la, g_.n_edges());
       if (write_system) hipLaunchKernelGGL((k_lin_finish<T, S>), dim3(nb), dim3(256), 0, stream_, la);
@@ -1218,6 +1289,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       a.lambda = lm ? (S)lambda : (S)0;
       a.write_system = write_system;
       a.adds_diag = norm_counts_.p;
+      a.zero_words = lds_flow_ ? dep_flags_.p : nullptr;
+      a.n_zero_words = lds_flow_ ? 2 * sym_.S + 64 : 0;
       hipLaunchKernelGGL((k_linearize_se3<T, S>), dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_, a);
     }
     check_launch("k_linearize");
@@ -1236,6 +1309,22 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       hipLaunchKernelGGL(k_flow_reset<T>, dim3((unsigned)(flag_wgs + std::max(e1 - e0, 0))), dim3(256), 0, stream_, flow_flags_.p, (int64_t)flow_flags_.n, flag_wgs,
                          winv_.p, flow_wfill_.p + 2 * e0);
       check_launch("k_flow_reset");
+    }
+    if (lds_flow_) {
+      // every front in LDS: the whole factorisation as ONE launch of ticket-ordered tasks (lds_flow.hip.h)
+      const Step &st = sym_.steps[0];
+      pbegin();
+      const size_t lds = (size_t)st.max_lds_elems * sizeof(T);
+      const FactorArgs<T> a = factor_args(0);
+      const int grid = std::min(lds_n_tasks_, lds_flow_cus_);
+      unsigned *ticket = dep_flags_.p + 2 * sym_.S;
+      if (std::min(st.threads, factor_threads_max_) <= 256)
+        hipLaunchKernelGGL((k_factor_flow<T, 256>), dim3(grid), dim3(256), lds, stream_, a, (const LdsFlowTask *)lds_ftasks_.p, lds_n_tasks_, ticket);
+      else
+        hipLaunchKernelGGL((k_factor_flow<T, 1024>), dim3(grid), dim3(1024), lds, stream_, a, (const LdsFlowTask *)lds_ftasks_.p, lds_n_tasks_, ticket);
+      check_launch("k_factor_flow");
+      pend(RR_PGO_K_FACTOR);
+      return;
     }
     for (size_t si = from; si < to; si++) {
       const Step &st = sym_.steps[si];
@@ -1388,6 +1477,22 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   }
 
   void launch_solve() {
+    if (lds_flow_) {
+      const Step &st = sym_.steps[0];
+      pbegin();
+      const size_t lds = (size_t)step_solve_lds_[0] * sizeof(T);
+      const FactorArgs<T> a = factor_args(0);
+      const int sth = std::min(st.threads, solve_threads_max_);
+      const int grid = std::min(lds_n_tasks_, lds_flow_cus_ * (sth <= 256 ? 4 : 2));
+      unsigned *ticket = dep_flags_.p + 2 * sym_.S + 32;
+      if (sth <= 256)
+        hipLaunchKernelGGL((k_solve_flow<T, 256>), dim3(grid), dim3(256), lds, stream_, a, (const LdsFlowTask *)lds_stasks_.p, lds_n_tasks_, ticket);
+      else
+        hipLaunchKernelGGL((k_solve_flow<T, 512>), dim3(grid), dim3(512), lds, stream_, a, (const LdsFlowTask *)lds_stasks_.p, lds_n_tasks_, ticket);
+      check_launch("k_solve_flow");
+      pend(RR_PGO_K_SOLVE);
+      return;
+    }
     for (int i = (int)sym_.steps.size() - 1; i >= 0; i--) {   // shared top fronts first, then this rank's subtrees
       const Step &st = sym_.steps[i];
       const size_t lds = (size_t)step_solve_lds_[i] * sizeof(T);
@@ -1934,6 +2039,10 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
     so.pin_node = h->g.anchor_node;   // every rank needs the anchor's entries of the solution (gauge transfer)
   }
   // tuning knobs of the symbolic phase
+  // graphs whose fronts all fit LDS: ONE dataflow launch for the factorisation, one for the back substitution (lds_flow.hip.h);
+  // RR_PGO_LDS_FLOW=0 keeps one launch per level of the task tree (the parity alternative: bit-identical results)
+  so.lds_flow = opt.world_size <= 1 && !opt.sharded;
+  if (const char *e = std::getenv("RR_PGO_LDS_FLOW")) so.lds_flow = so.lds_flow && std::atoi(e) != 0;
   if (const char *e = std::getenv("RR_PGO_TASK_US")) so.task_us = std::atof(e);
   if (const char *e = std::getenv("RR_PGO_THREADS_SHIFT")) so.threads_shift = std::atoi(e);
   if (std::getenv("RR_PGO_NO_GEO")) so.geo_nd = false;

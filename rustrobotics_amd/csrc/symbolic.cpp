@@ -944,6 +944,20 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     for (int f = 0; f < S; f++)
       if (sym.sn_parent[f] >= 0) sym.child_list[fill[sym.sn_parent[f]]++] = f;
   }
+  if (sym.n_big == 0 && opt.n_parts <= 1) {
+    // Graphs whose fronts all live in LDS (the dataflow launches of lds_flow.hip.h): a front adds its children's update
+    // matrices in the order in which the cost model expects them to be FINISHED (the subtree with the longest chain
+    // last), so that a parent which waits for its children one by one waits for the last one only.  The order is a
+    // function of the tree alone -- the same whatever task partition or launch form runs it: sums, hence bits, agree.
+    std::vector<double> fin(S, 0.0);
+    for (int f = 0; f < S; f++) {
+      double latest = 0.0;
+      for (int q = sym.child_ptr[f]; q < sym.child_ptr[f + 1]; q++) latest = std::max(latest, fin[sym.child_list[q]]);
+      fin[f] = latest + front_cost_us(sym.sn_ncols[f], sym.sn_nrows[f], sym.child_ptr[f + 1] - sym.child_ptr[f]);
+      std::stable_sort(sym.child_list.begin() + sym.child_ptr[f], sym.child_list.begin() + sym.child_ptr[f + 1],
+                       [&](int32_t a, int32_t b) { return fin[a] < fin[b]; });
+    }
+  }
   {
     // blocks are sorted by column position, so a supernode's blocks are contiguous
     std::vector<int64_t> blk_begin(S + 1, 0);
@@ -1236,7 +1250,167 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     sym.est_critical_us = crit;
     return crit;
   };
-  if (opt.task_us > 0) {
+  // ---- 8b. dataflow schedule (lds_flow.hip.h): ONE launch for the factorisation, ONE for the back substitution.
+  // Tasks: every maximal subtree cheaper than the threshold (a workgroup walks it in postorder, as in the level
+  // schedule), and every front above those a task of its own -- its workgroup does the front's child-independent
+  // pre-work (zero the LDS image, H entries, rhs, scatter maps) while the children are still being factored elsewhere.
+  // Tickets are handed out in the START order of a list schedule of the task tree on n_cus workgroups (priority:
+  // longest remaining path), which is a topological order: a task only ever waits for tasks with smaller tickets.
+  auto build_flow_schedule = [&](double task_us, bool keep) {
+    std::vector<double> cost(S), scost(S), sub(S, 0.0), pre(S);
+    for (int f = 0; f < S; f++) {
+      const int nc = sym.sn_ncols[f], nr = sym.sn_nrows[f];
+      cost[f] = front_cost_us(nc, nr, sym.child_ptr[f + 1] - sym.child_ptr[f]);
+      scost[f] = 1.6 + 1.3 * (double)((nc + 15) / 16);
+      // what a front's workgroup can do before its last child is there: zeroing + assembly (the model's fixed part and
+      // most of its per-element part) and the extend-add of the earlier children
+      pre[f] = std::min(0.6 * cost[f], 1.6 + 2.4e-4 * (double)lds_elems(nc, nr) +
+                                          0.65 * std::max(0, sym.child_ptr[f + 1] - sym.child_ptr[f] - 1));
+      sub[f] += cost[f];
+      if (sym.sn_parent[f] >= 0) sub[sym.sn_parent[f]] += sub[f];
+    }
+    std::vector<char> top(S, 0);
+    for (int f = 0; f < S; f++) {
+      if (sub[f] > task_us) top[f] = 1;
+      if (top[f] && sym.sn_parent[f] >= 0) top[sym.sn_parent[f]] = 1;
+    }
+    std::vector<int32_t> task_of(S, -1);
+    std::vector<std::vector<int32_t>> tasks;
+    for (int f = 0; f < S; f++) {
+      if (top[f]) { task_of[f] = (int)tasks.size(); tasks.emplace_back(1, f); continue; }
+      const int p = sym.sn_parent[f];
+      if (p >= 0 && !top[p]) continue;   // inside a leaf subtree: its root collects it below
+      task_of[f] = (int)tasks.size();
+      tasks.emplace_back();
+    }
+    for (int f = S - 1; f >= 0; f--)
+      if (!top[f] && task_of[f] < 0) task_of[f] = task_of[sym.sn_parent[f]];
+    for (int f = 0; f < S; f++)
+      if (!top[f]) tasks[task_of[f]].push_back(f);
+    const int nt = (int)tasks.size();
+    // the task tree: parent task = task of the parent of the task's last front
+    std::vector<int> tparent(nt, -1), ndeps(nt, 0);
+    std::vector<double> tpre(nt, 0.0), tdur(nt, 0.0), tsolve(nt, 0.0);
+    for (int t = 0; t < nt; t++) {
+      const int last = tasks[t].back(), p = sym.sn_parent[last];
+      if (p >= 0) { tparent[t] = task_of[p]; ndeps[task_of[p]]++; }
+      double c = 0, sc = 0;
+      for (int f : tasks[t]) { c += cost[f]; sc += scost[f]; }
+      tpre[t] = top[tasks[t][0]] ? pre[tasks[t][0]] : 0.0;
+      tdur[t] = c - tpre[t];
+      tsolve[t] = sc;
+    }
+    constexpr double kHop = 1.5;   // flag + payload round trip between two workgroups of one launch
+    const int P = std::max(1, opt.n_cus);
+    // list schedule of a forest of tasks whose dependencies point ONE way (deps -> parent for the factorisation,
+    // parent -> children for the back substitution); returns the start order and the makespan
+    auto list_schedule = [&](const std::vector<std::vector<int>> &succ, const std::vector<int> &n_pred, const std::vector<double> &lead,
+                             const std::vector<double> &dur, std::vector<int32_t> &order) {
+      std::vector<double> blevel(nt, 0.0), ready(nt, 0.0), finish(nt, 0.0);
+      {
+        // longest remaining path: successors come later in a topological order of `succ`; compute by memoised DFS
+        std::vector<int> state(nt, 0), stack;
+        for (int r = 0; r < nt; r++) {
+          if (state[r]) continue;
+          stack.push_back(r);
+          while (!stack.empty()) {
+            const int t = stack.back();
+            if (state[t] == 0) {
+              state[t] = 1;
+              for (int s2 : succ[t]) if (!state[s2]) stack.push_back(s2);
+            } else {
+              stack.pop_back();
+              if (state[t] == 2) continue;
+              state[t] = 2;
+              double b = 0;
+              for (int s2 : succ[t]) b = std::max(b, kHop + blevel[s2] - lead[s2]);
+              blevel[t] = lead[t] + dur[t] + std::max(0.0, b);
+            }
+          }
+        }
+      }
+      std::vector<int> pending(n_pred);
+      std::vector<int> known;   // tasks whose predecessors have all been started (small: linear scans are fine)
+      for (int t = 0; t < nt; t++) if (pending[t] == 0) known.push_back(t);
+      std::priority_queue<double, std::vector<double>, std::greater<double>> slots;
+      for (int k = 0; k < P; k++) slots.push(0.0);
+      order.clear();
+      double makespan = 0.0;
+      for (int done = 0; done < nt; done++) {
+        const double now = slots.top();
+        slots.pop();
+        // among the tasks that would not wait (ready - lead <= now) the one with the longest remaining path; if every
+        // known task would wait, the one that becomes ready first
+        int best = -1;
+        for (size_t k = 0; k < known.size(); k++) {
+          const int t = known[k];
+          const bool ok_t = ready[t] - lead[t] <= now, ok_b = best >= 0 && ready[best] - lead[best] <= now;
+          if (best < 0 || (ok_t && !ok_b) || (ok_t == ok_b && (ok_t ? blevel[t] > blevel[best] : ready[t] - lead[t] < ready[best] - lead[best]))) best = t;
+        }
+        known.erase(std::find(known.begin(), known.end(), best));
+        const double go = std::max(now + lead[best], ready[best]);
+        finish[best] = go + dur[best];
+        makespan = std::max(makespan, finish[best]);
+        slots.push(finish[best]);
+        order.push_back(best);
+        for (int s2 : succ[best]) {
+          ready[s2] = std::max(ready[s2], finish[best] + kHop);
+          if (--pending[s2] == 0) known.push_back(s2);
+        }
+      }
+      return makespan;
+    };
+    std::vector<std::vector<int>> up(nt), down(nt);
+    std::vector<int> n_pred_solve(nt, 0);
+    for (int t = 0; t < nt; t++)
+      if (tparent[t] >= 0) { up[t].push_back(tparent[t]); down[tparent[t]].push_back(t); n_pred_solve[t] = 1; }
+    std::vector<int32_t> forder, sorder;
+    const double f_us = list_schedule(up, ndeps, tpre, tdur, forder);
+    const std::vector<double> zero(nt, 0.0);
+    const double s_us = list_schedule(down, n_pred_solve, zero, tsolve, sorder);
+    const double crit = 1.5 + f_us + 1.5 + s_us;
+    if (!keep) return crit;
+    sym.task_ptr.assign(1, 0);
+    sym.task_sn.clear();
+    sym.steps.clear();
+    Step st{};
+    st.kind = STEP_TASKS;
+    st.sn = -1;
+    std::vector<int32_t> new_id(nt, -1);
+    for (int k = 0; k < nt; k++) {
+      new_id[forder[k]] = k;
+      for (int f : tasks[forder[k]]) {
+        sym.task_sn.push_back(f);
+        st.max_front = std::max(st.max_front, sym.sn_ncols[f] + sym.sn_nrows[f] + 1);
+        st.max_lds_elems = std::max<int64_t>(st.max_lds_elems, lds_elems(sym.sn_ncols[f], sym.sn_nrows[f]));
+      }
+      sym.task_ptr.push_back((int)sym.task_sn.size());
+    }
+    st.task_end = nt;
+    {
+      const int mf = st.max_front << opt.threads_shift;
+      st.threads = mf <= 20 ? 64 : mf <= 48 ? 128 : mf <= 96 ? 256 : mf <= 128 ? 512 : 1024;
+    }
+    sym.steps.push_back(st);
+    sym.solve_order.resize(nt);
+    for (int k = 0; k < nt; k++) sym.solve_order[k] = new_id[sorder[k]];
+    sym.lds_flow = true;
+    sym.est_factor_us = f_us;
+    sym.est_solve_us = s_us;
+    sym.est_critical_us = crit;
+    return crit;
+  };
+  if (opt.lds_flow && sym.n_big == 0 && opt.n_parts <= 1 && S > 0) {
+    double best = 1e300, best_t = 40;
+    if (opt.task_us > 0) best_t = opt.task_us;
+    else
+      for (double t = 4.0; t < 260.0; t *= 1.12) {
+        const double c = build_flow_schedule(t, false);
+        if (c < best) { best = c; best_t = t; }
+      }
+    build_flow_schedule(best_t, true);
+    sym.task_us_used = best_t;
+  } else if (opt.task_us > 0) {
     build_schedule(opt.task_us);
   } else {
     // the score is a jagged function of the threshold (a subtree flips between "leaf task" and "top"):

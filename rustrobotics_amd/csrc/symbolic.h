@@ -33,6 +33,8 @@ struct SymbolicOptions {
   int my_part = 0;          // with n_parts > 1: the rank whose schedule is emitted (own subtrees, then shared top)
   int pin_node = -1;        // with n_parts > 1: this node (the anchor) is made part of the top separator
   double task_us = 0.0;     // subtrees cheaper than this (model us) become one leaf task; 0 = pick by the cost model
+  bool lds_flow = false;    // graphs whose fronts all fit LDS (and n_parts == 1): ONE task list in ticket order for the dataflow
+                            // launches k_factor_flow / k_solve_flow (lds_flow.hip.h) instead of one step per tree level
   int64_t panel_budget_elems = 0;  // must stay 0: fronts beyond LDS whose pivot panel fits this budget would form a step class of
                                    // their own (STEP_MID); its kernel (r02's one-workgroup k_factor_panel) was measured slower
                                    // than the batched tiled path and removed in r03 -- the engine rejects such steps
@@ -109,6 +111,13 @@ struct Symbolic {
   // ---- schedule
   std::vector<int32_t> task_ptr, task_sn;
   std::vector<Step> steps;           // factor order; the back-solve walks it backwards
+  // ---- dataflow schedule of the LDS fronts (SymbolicOptions::lds_flow; all fronts in LDS, one rank): `steps` is ONE
+  // STEP_TASKS step whose tasks are in TICKET order -- the start order of a list schedule of the task tree, so every task
+  // comes after the tasks of its fronts' children -- and the back substitution draws its tasks in solve_order (parents
+  // before children).  Leaf subtrees cheaper than the threshold are one task, every front above them a task of its own.
+  bool lds_flow = false;
+  std::vector<int32_t> solve_order;  // ticket -> task for k_solve_flow
+  double est_factor_us = 0.0, est_solve_us = 0.0;   // the cost model's makespans of the two launches
   // ---- sharding over ranks (n_parts > 1): steps [0, n_local_steps) are this rank's own subtrees,
   // the rest are the shared top fronts every rank factors after the exchange.  Boundary fronts
   // (owned, parent shared) publish their update matrix, packed, in the exchange buffer.

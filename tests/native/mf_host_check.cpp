@@ -39,6 +39,7 @@ int main(int argc, char **argv) {
   if (getenv("LEAF")) opt.nd_leaf = atoi(getenv("LEAF"));
   if (getenv("PARTS")) opt.n_parts = atoi(getenv("PARTS"));
   if (getenv("LDS")) opt.lds_budget_elems = atoll(getenv("LDS"));
+  if (getenv("FLOW")) opt.lds_flow = true;   // the dataflow schedule of lds_flow.hip.h (tasks of ONE step in ticket order)
   Symbolic y;
   std::string e = analyze(g, opt, y);
   if (!e.empty()) { printf("analyze error: %s\n", e.c_str()); return 2; }
@@ -91,7 +92,9 @@ int main(int argc, char **argv) {
           if (done_step[s] >= 0) { printf("FAIL: supernode %d scheduled twice\n", s); exit(1); }
           for (int cq = ys.child_ptr[s]; cq < ys.child_ptr[s + 1]; cq++) {
             int c = ys.child_list[cq];
-            bool ok = done_step[c] >= 0 && (done_step[c] < step_counter || (st.kind == STEP_TASKS && pos_in_task[c] == t + 1000000 * (int)(&ys != &y)));
+            // level schedule: in an earlier step, or earlier in the same task; dataflow schedule (ONE step, tasks in
+            // ticket order): earlier in the list, i.e. in a task with a smaller ticket or earlier in the same task
+            bool ok = done_step[c] >= 0 && (ys.lds_flow || done_step[c] < step_counter || (st.kind == STEP_TASKS && pos_in_task[c] == t + 1000000 * (int)(&ys != &y)));
             if (!ok) { printf("FAIL: supernode %d scheduled before its child %d\n", s, c); exit(1); }
           }
           done_step[s] = step_counter;
@@ -121,6 +124,28 @@ int main(int argc, char **argv) {
     printf("sharded over %d ranks: %d boundary fronts, exchange buffer %lld scalars\n", opt.n_parts, nb, (long long)y.xch_elems);
   }
   if (n_sched != S) { printf("FAIL: schedule covers %d of %d supernodes\n", n_sched, S); return 1; }
+  if (getenv("FLOW") && !getenv("FLOW_OPTIONAL") && !y.lds_flow) { printf("FAIL: no dataflow schedule was built\n"); return 1; }
+  if (y.lds_flow) {
+    // the back substitution's ticket order: a permutation of the tasks in which a front's parent is solved in a task
+    // with a smaller ticket, or later in the same task's (reversed) walk
+    const int nt = (int)y.task_ptr.size() - 1;
+    if (y.steps.size() != 1 || (int)y.solve_order.size() != nt) { printf("FAIL: dataflow schedule shape\n"); return 1; }
+    std::vector<int> ticket_of(nt, -1), task_of(S, -1);
+    for (int k = 0; k < nt; k++) {
+      const int t = y.solve_order[k];
+      if (t < 0 || t >= nt || ticket_of[t] >= 0) { printf("FAIL: solve order is not a permutation\n"); return 1; }
+      ticket_of[t] = k;
+    }
+    for (int t = 0; t < nt; t++)
+      for (int q = y.task_ptr[t]; q < y.task_ptr[t + 1]; q++) task_of[y.task_sn[q]] = t;
+    for (int s2 = 0; s2 < S; s2++) {
+      const int p2 = y.sn_parent[s2];
+      if (p2 < 0) continue;
+      if (task_of[p2] != task_of[s2] && ticket_of[task_of[p2]] >= ticket_of[task_of[s2]]) { printf("FAIL: front %d is solved before its parent\n", s2); return 1; }
+      if (task_of[p2] == task_of[s2] && p2 < s2) { printf("FAIL: parent before child inside a task\n"); return 1; }
+    }
+    printf("dataflow schedule: %d tasks, model %.1f + %.1f us\n", nt, y.est_factor_us, y.est_solve_us);
+  }
 
   // ---- numeric multifrontal, same data flow as the kernels
   std::vector<double> L((size_t)y.l_elems + 4, 0.0), Uv((size_t)y.u_elems + 4, 0.0), x(dim, 0.0);

@@ -21,6 +21,7 @@ int main(int argc, char **argv) {
   if (getenv("PARTS")) opt.n_parts = atoi(getenv("PARTS"));
   if (getenv("LDS")) opt.lds_budget_elems = atoll(getenv("LDS"));
   if (getenv("TASKUS")) opt.task_us = atof(getenv("TASKUS"));
+  if (getenv("FLOW")) opt.lds_flow = true;
   if (getenv("API")) {   // the options rr_pgo_create uses for a graph of this size (pgo_api.hip, build_handle), fp32 budget
     opt.lds_budget_elems = getenv("F64") ? 19000 : 38000;
     opt.nd_leaf = g.n_nodes() <= 6000 ? (1 << 30) : (getenv("F64") ? 32 : 48);
@@ -34,6 +35,7 @@ int main(int argc, char **argv) {
   printf("N=%d E=%d dim=%d | analyze %.1f ms | S=%d Lblocks=%lld l_elems=%lld u_elems=%lld flops=%.3g | maxfront=%d maxpiv=%d big=%d | steps=%zu tasks=%zu est_crit=%.1f us task_us=%.0f\n",
          s.N, g.n_edges(), s.dim, ms, s.S, (long long)s.nnz_l_blocks, (long long)s.l_elems, (long long)s.u_elems,
          (double)s.factor_flops, s.max_front, s.max_pivot_cols, s.n_big, s.steps.size(), s.task_ptr.size() - 1, s.est_critical_us, s.task_us_used);
+  if (s.lds_flow) printf("  lds_flow: %zu tasks, est factor %.1f us, solve %.1f us\n", s.task_ptr.size() - 1, s.est_factor_us, s.est_solve_us);
   if (getenv("HIST")) {
     // fronts by size class: count, flops share
     const int edges[] = {64, 128, 256, 384, 512, 768, 1024, 1536, 2048, 4096, 1 << 30};

@@ -307,6 +307,10 @@ def mfcheck(tmp_path_factory):
     ([g2o_path("dlr")], {"LEAF": "1000000"}),
     ([g2o_path("input_M3500_g2o")], {"LEAF": "64", "LDS": "38000"}),
     (["grid", "40", "25"], {"LEAF": "64"}),
+    ([g2o_path("intel")], {"LEAF": "1000000", "FLOW": "1"}),        # the dataflow schedule (lds_flow.hip.h): ticket order
+    ([g2o_path("dlr")], {"LEAF": "1000000", "FLOW": "1"}),
+    ([g2o_path("input_M3500_g2o")], {"LEAF": "1000000", "LDS": "19000", "FLOW": "1"}),
+    ([g2o_path("simulation-pose-landmark")], {"LEAF": "1000000", "FLOW": "1"}),
     (["grid", "60", "40"], {"LEAF": "64", "PARTS": "2"}),           # rank-owned subtrees + shared top
     (["grid", "60", "40"], {"LEAF": "64", "PARTS": "4"}),
     (["grid", "100", "100"], {"LEAF": "64", "PARTS": "8"}),
