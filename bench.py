@@ -188,6 +188,8 @@ def roofline_of(g, workload, precision, prof_iters=20):
         ent = pmc_entry(f"{workload}:{pkey}:{roofline['kernel']}")
     if ent and ent["kernel"] == roofline["kernel"]:
         roofline["traffic"] = ent["traffic_bytes_per_launch"]
+        if roofline["bound"] == "hbm" and roofline.get("algorithmic_bytes_per_launch"):
+            roofline["traffic_ratio"] = ent["traffic_bytes_per_launch"] / roofline["algorithmic_bytes_per_launch"]   # counter / algorithmic
         roofline["traffic_source"] = ("offline: profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of an "
                                       "earlier run of the same kernels, FETCH doubled per MI355X_MICROARCH.md); NOT measured in this run")
     ent = pmc_entry(f"{workload}:{pkey}:k_big_update")
@@ -378,11 +380,11 @@ def secondary_entry(ctx, workload, precision, steps, warmup, sharded):
         stats = g.stats()
         g.set_state(state0)
         roofline, mfma_kernel, class_bytes = roofline_of(g, workload, precision, prof_iters=10)
-        rec.update({"launches_per_step": stats["n_launches_per_iter"], "factor_flops": 2 * stats["factor_flops"],
+        rec.update({"launches_per_step": stats["n_launches_per_iter"], "factor_flops": stats["factor_flops"],
                     "algorithmic_bytes_per_step": sum(class_bytes.values()), "analyze_ms": stats["analyze_ms"],
                     "roofline": roofline, "mfma_kernel": mfma_kernel})
         if mfma_kernel:
-            rec["step_tflops"] = 2 * stats["factor_flops"] / (dt / steps) / 1e12
+            rec["step_tflops"] = stats["factor_flops"] / (dt / steps) / 1e12   # (factor_flops counts 2 per multiply-add)
     rec["wall_s"] = time.perf_counter() - t_wall
     return rec if ctx.rank == 0 else None
 
@@ -496,7 +498,8 @@ def main():
                 "optimize10_ms": opt_ms, "new_plus_optimize10_ms": closure_ms, "errors": [float(e) for e in errors],
                 "analyze_ms": stats["analyze_ms"], "parse_ms": stats["parse_ms"],
                 "launches_per_step": stats["n_launches_per_iter"], "supernodes": stats["n_supernodes"],
-                "factor_flops": 2 * stats["factor_flops"], "algorithmic_bytes_per_step": sum(class_bytes.values()),
+                "factor_flops": stats["factor_flops"], "algorithmic_bytes_per_step": sum(class_bytes.values()),
+                "stored_factor_bytes": stats["stored_factor_bytes"],
                 "big_fronts": stats["n_big_fronts"], "max_front": stats["max_front"],
                 "roofline": roofline, "mfma_kernel": mfma_kernel,
             }

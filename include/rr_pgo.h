@@ -27,6 +27,8 @@
 extern "C" {
 #endif
 
+#define RR_PGO_ABI_VERSION 4  /* see rr_pgo_abi_version() */
+
 typedef struct rr_pgo rr_pgo; /* opaque: replaces `struct PoseGraph`, pose_graph_optimization.rs:155-163 */
 
 enum {
@@ -44,7 +46,11 @@ enum {
                          * Like the reference (Err at :271 comes before update_nodes) the handle's state is the one
                          * before the failed iteration: the step is not applied, the caller may retry, e.g. with LM. */
   RR_PGO_ENOMEM = -6,
-  RR_PGO_EUNSUPPORTED = -7
+  RR_PGO_EUNSUPPORTED = -7,
+  RR_PGO_ETIMEOUT = -8  /* a wait between workgroups of one launch (the dataflow launches k_factor_flow / k_solve_flow /
+                         * k_big_flow / k_big_solve_flow hand fronts, tiles and solutions to each other) ran out of time:
+                         * the launch drained without applying the step -- the handle's state is the one before the call, the
+                         * handle stays usable.  No counterpart in the reference (its solver is one thread). */
 };
 
 /* enum PoseGraphSolver, pose_graph_optimization.rs:28-32 */
@@ -176,13 +182,26 @@ typedef struct rr_pgo_stats {
   double bytes_linearize, bytes_factor, bytes_solve, bytes_update, bytes_chi2;
   double big_update_flops;   /* flops (2 per multiply-add) of one iteration's k_big_update launches */
   double big_flow_flops;     /* the same count for the trailing-update tiles that run inside k_big_flow launches */
-  int32_t reserved[4];
+  double stored_factor_bytes;/* bytes of the factor AS STORED (supernodal panels with their padding; fronts beyond LDS: the whole
+                              * in-place M x M front) -- NOT what bytes_factor / bytes_solve are computed from: those follow
+                              * SURVEY 8(d), nnzblk(L) * d^2 * s, every datum moved once */
+  int32_t abi_version;       /* RR_PGO_ABI_VERSION of the library that filled the struct */
+  int32_t reserved;
 } rr_pgo_stats;
 int rr_pgo_get_stats(const rr_pgo *h, rr_pgo_stats *out);
 
+/* Host-only: parse + symbolic analysis of a g2o file, the rr_pgo_stats a handle on it would report (fields that depend
+ * on the device -- n_launches_per_iter, big_update_flops, big_flow_flops -- are 0).  Needs no HIP device. */
+int rr_pgo_analyze_g2o(const char *path, const rr_pgo_options *opt, rr_pgo_stats *out);
+
+/* ABI version: bumped whenever a struct layout, an enum that sizes a caller's array (RR_PGO_NUM_KCLASS) or the meaning
+ * of an argument changes.  r03 -> 3 (RR_PGO_NUM_KCLASS 10 -> 11), r04 -> 4 (rr_pgo_stats: stored_factor_bytes,
+ * abi_version; RR_PGO_ETIMEOUT; rr_pgo_profile takes the length of the caller's arrays). */
+int32_t rr_pgo_abi_version(void);
+
 /* Per-kernel timing measured with HIP events on the handle's own stream.
  * Runs `iters` eager (non-graph) GN iterations with an event pair around every
- * launch and accumulates per kernel class.  Arrays have RR_PGO_NUM_KCLASS slots. */
+ * launch and accumulates per kernel class.  The caller passes the length of its arrays (RR_PGO_NUM_KCLASS). */
 enum {
   RR_PGO_K_LINEARIZE = 0,   /* k_linearize                                             */
   RR_PGO_K_FACTOR = 1,      /* k_factor_tasks (fronts in LDS)                          */
@@ -197,8 +216,9 @@ enum {
   RR_PGO_K_BIG_FLOW = 10,   /* k_big_flow (huge fronts of a level of few fronts: panels + updates as one dataflow launch) */
   RR_PGO_NUM_KCLASS = 11
 };
-int rr_pgo_profile(rr_pgo *h, int32_t iters, double *ms_total /*[NUM_KCLASS]*/,
-                   int64_t *launches /*[NUM_KCLASS]*/);
+int rr_pgo_profile(rr_pgo *h, int32_t iters, double *ms_total /*[n_classes]*/,
+                   int64_t *launches /*[n_classes]*/, int32_t n_classes /* length of the two arrays: at most that many
+                   classes are written (a caller built against an older RR_PGO_NUM_KCLASS is not overrun) */);
 
 /* ---- synthetic workload (BASELINE config 4) -------------------- */
 

@@ -12,7 +12,8 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librr_pgo.so")
 
-OK, EINVAL, EIO, EPARSE, ENODEVICE, ENOTSPD, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7
+OK, EINVAL, EIO, EPARSE, ENODEVICE, ENOTSPD, ENOMEM, EUNSUPPORTED, ETIMEOUT = 0, -1, -2, -3, -4, -5, -6, -7, -8
+ABI_VERSION = 4   # RR_PGO_ABI_VERSION this mirror was written against (load() checks the library's)
 F64, F32, MIXED = 0, 1, 2
 PRECISIONS = {"f64": F64, "f32": F32, "mixed": MIXED}
 NUM_KCLASS = 11
@@ -25,7 +26,7 @@ EXPORTS = (
     "rr_pgo_num_nodes", "rr_pgo_num_edges", "rr_pgo_dim", "rr_pgo_state_len", "rr_pgo_anchor_node",
     "rr_pgo_get_graph", "rr_pgo_chi2", "rr_pgo_linearize_solve", "rr_pgo_update", "rr_pgo_optimize",
     "rr_pgo_get_state", "rr_pgo_set_state", "rr_pgo_assemble", "rr_pgo_iterate_async", "rr_pgo_sync",
-    "rr_pgo_get_stats", "rr_pgo_profile", "rr_pgo_synth_grid", "rr_pgo_synth_free",
+    "rr_pgo_get_stats", "rr_pgo_analyze_g2o", "rr_pgo_abi_version", "rr_pgo_profile", "rr_pgo_synth_grid", "rr_pgo_synth_free",
     "rr_pgo_exchange_buffer", "rr_pgo_set_exchange_buffer", "rr_pgo_stage", "rr_pgo_stage_scalars", "rr_pgo_stream",
     "rr_pgo_node_owner",
 )
@@ -53,7 +54,7 @@ class Stats(C.Structure):
         ("analyze_ms", C.c_double), ("parse_ms", C.c_double),
         ("bytes_linearize", C.c_double), ("bytes_factor", C.c_double), ("bytes_solve", C.c_double),
         ("bytes_update", C.c_double), ("bytes_chi2", C.c_double), ("big_update_flops", C.c_double),
-        ("big_flow_flops", C.c_double), ("reserved", C.c_int32 * 4),
+        ("big_flow_flops", C.c_double), ("stored_factor_bytes", C.c_double), ("abi_version", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -105,7 +106,7 @@ def load():
     L.rr_pgo_iterate_async.argtypes = [vp, C.c_int32]
     L.rr_pgo_sync.argtypes = [vp]
     L.rr_pgo_get_stats.argtypes = [vp, C.POINTER(Stats)]
-    L.rr_pgo_profile.argtypes = [vp, C.c_int32, dp, C.POINTER(C.c_int64)]
+    L.rr_pgo_profile.argtypes = [vp, C.c_int32, dp, C.POINTER(C.c_int64), C.c_int32]
     L.rr_pgo_synth_grid.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64, C.POINTER(vp),
                                     C.POINTER(GraphDesc)]
     L.rr_pgo_synth_free.argtypes = [vp]
@@ -117,5 +118,9 @@ def load():
     L.rr_pgo_stream.argtypes = [vp]
     L.rr_pgo_stream.restype = vp
     L.rr_pgo_node_owner.argtypes = [vp, ip]
+    L.rr_pgo_analyze_g2o.argtypes = [C.c_char_p, C.POINTER(Options), C.POINTER(Stats)]
+    L.rr_pgo_abi_version.restype = C.c_int32
+    if L.rr_pgo_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} speaks ABI version {L.rr_pgo_abi_version()}, this mirror {ABI_VERSION}: rebuild the library")
     _lib = L
     return L

@@ -474,7 +474,10 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       for (const Step &st : sym.steps) any_big = any_big || st.kind != STEP_TASKS;
       gemv_part_.alloc(any_big ? (size_t)kGemvSlices * g.dim : 4);
     }
+    // LDS fronts: 16-wave workgroups for fronts of more than 128 rows (RR_PGO_FACTOR_512=1 / RR_PGO_FACTOR_256=1: 8 / 4 waves;
+    // intel.g2o r04: 4318 / 4134 it/s with 16 / 8 waves)
     factor_threads_max_ = getenv("RR_PGO_FACTOR_512") ? 512 : 1024;
+    if (getenv("RR_PGO_FACTOR_256")) factor_threads_max_ = 256;
     if (const char *e = getenv("RR_PGO_SOLVE_THREADS")) solve_threads_max_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_SP_SOLVE_MIN")) sp_solve_min_nc_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_XCD_REMAP")) xcd_remap_ = std::atoi(e) != 0;
@@ -612,6 +615,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         HIPCHK(hipGetDevice(&dev));
         (void)hipDeviceGetAttribute(&lds_flow_cus_, hipDeviceAttributeMultiprocessorCount, dev);
         lds_flow_cus_ = std::max(lds_flow_cus_, 1);
+        if (const char *e = getenv("RR_PGO_LDS_FLOW_GRID")) lds_flow_cus_ = std::max(1, std::atoi(e));   // workgroups of the two dataflow launches (experiments)
       }
     }
     build_flow_levels();   // (after the front records: every flow task carries a copy of its front's)
@@ -645,7 +649,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       step_solve_lds_.push_back(need);
     }
 #ifdef RRPGO_STAMPS
-    stamps_.alloc((size_t)sym.S * 12 + 400000);
+    stamps_.alloc((size_t)sym.S * 12 + 400000 + (size_t)sym.S * 1280);   // per-front phase stamps | launch trace | panel_flow chain stamps
     stamps_.zero();
 #endif
     configure_kernels();
@@ -1136,7 +1140,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     check_launch("k_big_gauge");
   }
 
-  static constexpr int kMaxLds = 160 * 1024 - 4608;  // the kernels also hold static __shared__ scratch (inverse diagonal block + identity: W16_SCR scalars)
+#if defined(RRPGO_STAMPS) && defined(RRPGO_WAVE_TRACE)
+  static constexpr int kMaxLds = 160 * 1024 - 9216 - 8192;   // (diagnostic build: the per-wave trace of panel_flow lives in LDS)
+#else
+  static constexpr int kMaxLds = 160 * 1024 - 9216;
+#endif  // the kernels also hold static __shared__ scratch (panel_flow: two W slots + identity + counters, PANEL_SCR scalars)
 
   template <int TH> void set_lds_attr() {
     HIPCHK(hipFuncSetAttribute((const void *)k_factor_tasks<T, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
@@ -1151,6 +1159,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     HIPCHK(hipFuncSetAttribute((const void *)k_factor_tasks<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
     HIPCHK(hipFuncSetAttribute((const void *)k_solve_mid<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
     HIPCHK(hipFuncSetAttribute((const void *)k_factor_flow<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+    HIPCHK(hipFuncSetAttribute((const void *)k_factor_flow<T, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
     HIPCHK(hipFuncSetAttribute((const void *)k_factor_flow<T, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
     HIPCHK(hipFuncSetAttribute((const void *)k_solve_flow<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
     HIPCHK(hipFuncSetAttribute((const void *)k_solve_flow<T, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
@@ -1223,6 +1232,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     a.trace = stamps_.p ? stamps_.p + (size_t)sym_.S * 12 : nullptr;
 #else
     a.trace = nullptr;
+#endif
+#ifdef RRPGO_STAMPS
+    a.ptrace = stamps_.p ? stamps_.p + (size_t)sym_.S * 12 + 400000 : nullptr;
+#else
+    a.ptrace = nullptr;
 #endif
     a.child_dep = child_dep_.p;
     a.parent_dep = parent_dep_.p;
@@ -1320,6 +1334,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       unsigned *ticket = dep_flags_.p + 2 * sym_.S;
       if (std::min(st.threads, factor_threads_max_) <= 256)
         hipLaunchKernelGGL((k_factor_flow<T, 256>), dim3(grid), dim3(256), lds, stream_, a, (const LdsFlowTask *)lds_ftasks_.p, lds_n_tasks_, ticket);
+      else if (std::min(st.threads, factor_threads_max_) <= 512)
+        hipLaunchKernelGGL((k_factor_flow<T, 512>), dim3(grid), dim3(512), lds, stream_, a, (const LdsFlowTask *)lds_ftasks_.p, lds_n_tasks_, ticket);
       else
         hipLaunchKernelGGL((k_factor_flow<T, 1024>), dim3(grid), dim3(1024), lds, stream_, a, (const LdsFlowTask *)lds_ftasks_.p, lds_n_tasks_, ticket);
       check_launch("k_factor_flow");
@@ -1643,6 +1659,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   void throw_on_flag(int e) {
     if (!e) return;
     HIPCHK(hipMemsetAsync(err_.p, 0, sizeof(int), stream_));
+    // (a launch that drains after a timed-out hand-off computes on tiles that are not there: whatever else it flags is noise)
+    if (e & DEVERR_FLOW_TIMEOUT)
+      throw ApiError(RR_PGO_ETIMEOUT, "a hand-off between workgroups of one launch timed out; the step was not applied");
     if (e & DEVERR_NOT_SPD) throw ApiError(RR_PGO_ENOTSPD, "normal matrix is not positive definite (non-positive pivot)");
     throw ApiError(RR_PGO_ENODEVICE, "device-side error flag " + std::to_string(e));
   }
@@ -2012,7 +2031,8 @@ void fill_desc(const HostGraph &g, rr_pgo_graph_desc *d) {
   d->edge_info = g.edge_info.data();
 }
 
-void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, double parse_ms) {
+// host part of PoseGraph::new: options, symbolic analysis, the statistics that need no device
+void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, double parse_ms) {
   rr_pgo_options opt;
   if (opt_in) opt = *opt_in; else rr_pgo_default_options(&opt);
   h->opt = opt;
@@ -2074,6 +2094,43 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
   }
   if (!err.empty()) throw ApiError(RR_PGO_EINVAL, err);
   double t1 = now_ms();
+  rr_pgo_stats &s = h->stats;
+  std::memset(&s, 0, sizeof s);
+  const Symbolic &y = h->sym;
+  const double sz = opt.precision == RR_PGO_F64 ? 8.0 : 4.0;
+  int64_t diag_elems = 0, off_elems = 0;
+  for (int i = 0; i < y.N; i++) { int d = node_dim(h->g.node_kind[i]); diag_elems += d * d; }
+  off_elems = y.n_hvals - diag_elems;
+  s.nnz_h_blocks = y.N + y.n_offblocks;
+  s.nnz_l_scalars = y.l_elems;
+  s.factor_flops = y.factor_flops;
+  s.n_supernodes = y.S;
+  s.n_levels = (int)y.steps.size();
+  s.max_front = y.max_front;
+  s.max_pivot_cols = y.max_pivot_cols;
+  s.n_big_fronts = y.n_big;
+  s.analyze_ms = t1 - t0;
+  s.parse_ms = parse_ms;
+  s.abi_version = RR_PGO_ABI_VERSION;
+  // algorithmic bytes per GN iteration, SURVEY.md 8(d): every datum moved once.  The factor is priced at its NONZEROS,
+  // nnzblk(L) * d^2 scalars (Symbolic::nnz_l_entries) -- written once by the factorisation, read by the forward and by
+  // the backward substitution -- not at what is stored: the supernodal panels carry padding and a front beyond LDS keeps
+  // its whole M x M square in place (stored_factor_bytes; 2.2 x the nonzeros on the 1M-edge lattice)
+  const double dim = y.dim;
+  double edge_stream = 0;
+  for (int k = 0; k < h->g.n_edges(); k++)
+    edge_stream += 8.0 + sz * (edge_meas_len(h->g.edge_kind[k]) + edge_info_len(h->g.edge_kind[k]));
+  s.bytes_linearize = edge_stream + dim * sz /*poses*/ + (diag_elems + off_elems) * sz + dim * sz;
+  s.bytes_chi2 = 0;  // fused into the linearisation pass
+  s.bytes_factor = (diag_elems + off_elems) * sz + (double)y.nnz_l_entries * sz;
+  s.bytes_solve = 2.0 * (double)y.nnz_l_entries * sz + 4.0 * dim * sz;
+  s.bytes_update = 3.0 * dim * sz;
+  s.stored_factor_bytes = (double)y.l_elems * sz;
+}
+
+void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, double parse_ms) {
+  analyze_handle(h, opt_in, parse_ms);
+  const rr_pgo_options opt = h->opt;
   // device
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -2089,35 +2146,8 @@ void build_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, doub
   else h->engine = std::make_unique<Engine<float, double>>(h->g, h->sym, wr, ww, shd);
   // stats
   rr_pgo_stats &s = h->stats;
-  std::memset(&s, 0, sizeof s);
   const Symbolic &y = h->sym;
-  const double sz = opt.precision == RR_PGO_F64 ? 8.0 : 4.0;
-  int64_t diag_elems = 0, off_elems = 0;
-  for (int i = 0; i < y.N; i++) { int d = node_dim(h->g.node_kind[i]); diag_elems += d * d; }
-  off_elems = y.n_hvals - diag_elems;
-  s.nnz_h_blocks = y.N + y.n_offblocks;
-  s.nnz_l_scalars = y.l_elems;
-  s.factor_flops = y.factor_flops;
-  s.n_supernodes = y.S;
-  s.n_levels = (int)y.steps.size();
   s.n_launches_per_iter = h->engine->n_launches_per_iter;
-  s.max_front = y.max_front;
-  s.max_pivot_cols = y.max_pivot_cols;
-  s.n_big_fronts = y.n_big;
-  s.analyze_ms = t1 - t0;
-  s.parse_ms = parse_ms;
-  // algorithmic bytes per GN iteration, SURVEY.md 8(d): every datum moved once
-  const double E = h->g.n_edges(), N = y.N, dim = y.dim;
-  double edge_stream = 0;
-  for (int k = 0; k < h->g.n_edges(); k++)
-    edge_stream += 8.0 + sz * (edge_meas_len(h->g.edge_kind[k]) + edge_info_len(h->g.edge_kind[k]));
-  (void)E;
-  s.bytes_linearize = edge_stream + dim * sz /*poses*/ + (diag_elems + off_elems) * sz + dim * sz;
-  s.bytes_chi2 = 0;  // fused into the linearisation pass
-  s.bytes_factor = (diag_elems + off_elems) * sz + (double)y.l_elems * sz;
-  s.bytes_solve = (double)y.l_elems * sz + 2.0 * dim * sz;
-  s.bytes_update = 3.0 * dim * sz;
-  (void)N;
   // trailing updates of the huge fronts: a super-panel of w columns updates the lower triangle of the T rows to its
   // right, w * T (T + 1) / 2 multiply-adds -- counted for the launches of k_big_update and, separately, for the tiles
   // that run inside k_big_flow launches.  (The updates INSIDE a super-panel belong to the panel kernels / PANEL tasks
@@ -2295,15 +2325,35 @@ int rr_pgo_sync(rr_pgo *h) {
   return guarded([&] { h->engine->sync(); });
 }
 
+int32_t rr_pgo_abi_version(void) { return RR_PGO_ABI_VERSION; }
+
+int rr_pgo_analyze_g2o(const char *path, const rr_pgo_options *opt, rr_pgo_stats *out) {
+  if (!path || !out) { g_last_error = "null argument"; return RR_PGO_EINVAL; }
+  return guarded([&] {
+    auto h = std::make_unique<rr_pgo>();
+    const double t0 = now_ms();
+    bool io_error = false;
+    const std::string err = load_g2o(path, h->g, io_error);
+    if (!err.empty()) throw ApiError(io_error ? RR_PGO_EIO : RR_PGO_EPARSE, err);
+    analyze_handle(h, opt, now_ms() - t0);
+    *out = h->stats;
+  });
+}
+
 int rr_pgo_get_stats(const rr_pgo *h, rr_pgo_stats *out) {
   if (!h || !out) { g_last_error = "null argument"; return RR_PGO_EINVAL; }
   *out = h->stats;
   return RR_PGO_OK;
 }
 
-int rr_pgo_profile(rr_pgo *h, int32_t iters, double *ms_total, int64_t *launches) {
-  if (!h || !ms_total || !launches || iters < 0) { g_last_error = "bad argument"; return RR_PGO_EINVAL; }
-  return guarded([&] { h->engine->profile(iters, ms_total, launches); });
+int rr_pgo_profile(rr_pgo *h, int32_t iters, double *ms_total, int64_t *launches, int32_t n_classes) {
+  if (!h || !ms_total || !launches || iters < 0 || n_classes < 0) { g_last_error = "bad argument"; return RR_PGO_EINVAL; }
+  return guarded([&] {
+    double ms[RR_PGO_NUM_KCLASS];
+    int64_t n[RR_PGO_NUM_KCLASS];
+    h->engine->profile(iters, ms, n);
+    for (int k = 0; k < std::min<int>(n_classes, RR_PGO_NUM_KCLASS); k++) { ms_total[k] = ms[k]; launches[k] = n[k]; }
+  });
 }
 
 int rr_pgo_synth_grid(int32_t width, int32_t height, int64_t n_edges_target, uint64_t seed_meas,
@@ -2388,6 +2438,37 @@ int rr_pgo_debug_stamps(rr_pgo *h, double *out, int32_t *n_sn) {
       o[4] = y.child_ptr[s + 1] - y.child_ptr[s];
       for (int q = 0; q < 10; q++) o[5 + q] = (double)st[(size_t)s * 12 + q];
       o[15] = y.sn_parent[s];
+    }
+  });
+}
+// Diagnostic build only: chain stamps of panel_flow, [S][16][8] shader clocks, then per wave and step [S][16][8][8] (1280 per front)
+int rr_pgo_debug_ptrace(rr_pgo *h, double *out) {
+  if (!h || !out) return RR_PGO_EINVAL;
+  return guarded([&] {
+    std::vector<unsigned long long> st;
+    h->engine->read_stamps(st);
+    const size_t off = (size_t)h->sym.S * 12 + 400000;
+    for (size_t i = 0; i < (size_t)h->sym.S * 1280; i++) out[i] = (double)st[off + i];
+  });
+}
+// Diagnostic build only: the raw stamps ([S][12], 100 MHz ticks) + per front: parent, task (= ticket of the dataflow
+// schedule), pivot columns, rows below, children.  out: [S][20] doubles.
+int rr_pgo_debug_stamps12(rr_pgo *h, double *out, int32_t *n_sn) {
+  if (!h) return RR_PGO_EINVAL;
+  return guarded([&] {
+    const Symbolic &y = h->sym;
+    *n_sn = y.S;
+    if (!out) return;
+    std::vector<unsigned long long> st;
+    h->engine->read_stamps(st);
+    std::vector<int> task_of(y.S, -1);
+    for (size_t t = 0; t + 1 < y.task_ptr.size(); t++)
+      for (int q = y.task_ptr[t]; q < y.task_ptr[t + 1]; q++) task_of[y.task_sn[q]] = (int)t;
+    for (int s = 0; s < y.S; s++) {
+      double *o = out + (size_t)s * 20;
+      for (int q = 0; q < 12; q++) o[q] = (double)st[(size_t)s * 12 + q];
+      o[12] = y.sn_parent[s]; o[13] = task_of[s]; o[14] = y.sn_ncols[s]; o[15] = y.sn_nrows[s];
+      o[16] = y.child_ptr[s + 1] - y.child_ptr[s]; o[17] = y.lds_flow ? 1 : 0; o[18] = o[19] = 0;
     }
   });
 }

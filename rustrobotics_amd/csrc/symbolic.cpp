@@ -559,6 +559,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
       for (int x : s) sum += w[order[x]];
       cc[j] = sum;
       nblk += (int64_t)s.size() + 1;
+      sym.nnz_l_entries += (int64_t)w[v] * (w[v] + sum);   // the column's d x d diagonal block and the blocks below it, no padding
       if (!s.empty()) {
         int pj = s[0];
         if (parent[j] != pj) return "internal: etree mismatch";

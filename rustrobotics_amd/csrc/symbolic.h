@@ -130,6 +130,7 @@ struct Symbolic {
   std::vector<int8_t> col_owner;     // per permuted scalar column: owner rank, -1 = shared
   // ---- stats
   int64_t nnz_l_blocks = 0;          // node-level nonzero blocks of L (no padding)
+  int64_t nnz_l_entries = 0;         // their scalars: sum over the blocks of d_row * d_col (nnzblk(L) * d^2)
   int64_t factor_flops = 0;
   int32_t max_front = 0, max_pivot_cols = 0, n_big = 0;
   double est_critical_us = 0.0;

@@ -249,10 +249,20 @@ class PoseGraph:
         _check(_lib.load().rr_pgo_get_stats(self._h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in _lib.Stats._fields_ if k != "reserved"}
 
+    @staticmethod
+    def analyze(file_path, precision="f64"):
+        """Host-only: parse + symbolic analysis, the statistics a handle on the file would report (no device needed)."""
+        opt = _lib.Options()
+        _lib.load().rr_pgo_default_options(C.byref(opt))
+        opt.precision = _lib.PRECISIONS[precision]
+        s = _lib.Stats()
+        _check(_lib.load().rr_pgo_analyze_g2o(str(file_path).encode(), C.byref(opt), C.byref(s)))
+        return {k: getattr(s, k) for k, _ in _lib.Stats._fields_ if k != "reserved"}
+
     def profile(self, iters):
         ms = np.zeros(_lib.NUM_KCLASS)
         n = np.zeros(_lib.NUM_KCLASS, np.int64)
-        _check(_lib.load().rr_pgo_profile(self._h, iters, _dp(ms), n.ctypes.data_as(C.POINTER(C.c_int64))))
+        _check(_lib.load().rr_pgo_profile(self._h, iters, _dp(ms), n.ctypes.data_as(C.POINTER(C.c_int64)), _lib.NUM_KCLASS))
         return {name: (float(ms[i]), int(n[i])) for i, name in enumerate(_lib.KCLASS_NAMES)}
 
 

@@ -60,6 +60,7 @@ def test_struct_layouts_match_the_c_compiler(abi_client):
             d = getattr(cls, fname)
             assert seen.pop((cname, fname)) == (d.offset, d.size), (cname, fname)
     assert seen.pop(("enum", "RR_PGO_NUM_KCLASS"))[0] == _lib.NUM_KCLASS == len(_lib.KCLASS_NAMES)
+    assert seen.pop(("enum", "RR_PGO_ABI_VERSION"))[0] == _lib.ABI_VERSION == _lib.load().rr_pgo_abi_version()
     assert not seen, f"fields the ctypes mirror does not know: {seen}"
 
 
@@ -318,3 +319,23 @@ def mfcheck(tmp_path_factory):
 def test_symbolic_tables_drive_a_correct_factorization(mfcheck, args, env):
     out = subprocess.run([mfcheck, *args], env={**os.environ, **env}, capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
+
+
+def test_algorithmic_bytes_follow_survey_8d(lib):
+    """SURVEY.md 8(d), worked totals for intel.g2o in fp64: linearise 0.90 MB, solve 0.43 + 3 x 1.24 + 0.17 = 4.3 MB with
+    nnzblk(L) = 17 193 [probe], update 0.12 MB -- 5.4 MB per iteration with chi2 fused into the linearisation.  The
+    statistics bench.py's roofline divides by must be THAT figure (every datum moved once, the factor at its nonzeros), not
+    the padded storage of the supernodal panels (r03 reported 7.17 MB)."""
+    from rustrobotics_amd import PoseGraph
+    s = PoseGraph.analyze(g2o_path("intel"))
+    assert s["abi_version"] == 4
+    assert s["n_supernodes"] > 0 and s["n_big_fronts"] == 0 and s["n_launches_per_iter"] == 0   # (no device: no engine)
+    total = s["bytes_linearize"] + s["bytes_chi2"] + s["bytes_factor"] + s["bytes_solve"] + s["bytes_update"]
+    assert abs(total - 5.4e6) <= 0.05 * 5.4e6, total
+    assert abs(s["bytes_linearize"] - 0.90e6) <= 0.06 * 0.90e6
+    assert abs(s["bytes_factor"] + s["bytes_solve"] - 4.3e6) <= 0.05 * 4.3e6
+    assert abs(s["bytes_update"] - 0.12e6) <= 0.05 * 0.12e6
+    assert s["stored_factor_bytes"] > s["bytes_factor"] - 0.45e6   # padding only ever adds
+    # fp32 halves every scalar but not the 8 index bytes per edge
+    s32 = PoseGraph.analyze(g2o_path("intel"), precision="f32")
+    assert 0.5 * total < s32["bytes_linearize"] + s32["bytes_factor"] + s32["bytes_solve"] + s32["bytes_update"] < 0.52 * total
