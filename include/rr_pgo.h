@@ -220,6 +220,15 @@ int rr_pgo_profile(rr_pgo *h, int32_t iters, double *ms_total /*[n_classes]*/,
                    int64_t *launches /*[n_classes]*/, int32_t n_classes /* length of the two arrays: at most that many
                    classes are written (a caller built against an older RR_PGO_NUM_KCLASS is not overrun) */);
 
+/* ---- testing ------------------------------------------------------------- */
+
+/* Failure injection for the dataflow launches (tests only; no counterpart in the reference): make ONE hand-off between
+ * workgroups never arrive, so that the waits behind it run into their time bound (environment RR_PGO_FLOW_TIMEOUT_MS,
+ * read when the handle is created; default 2000) and the next iteration returns RR_PGO_ETIMEOUT with the state untouched.
+ * mode 1: a child front of the factorisation of the LDS fronts (k_factor_flow); 2: a parent front of their back
+ * substitution (k_solve_flow); 3: one panel step of the fronts beyond LDS (k_big_flow); 0: put everything back. */
+int rr_pgo_debug_withhold(rr_pgo *h, int32_t mode);
+
 /* ---- synthetic workload (BASELINE config 4) -------------------- */
 
 /* Deterministic SE(2) lattice graph: W x H poses in boustrophedon order, the

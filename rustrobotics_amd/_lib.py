@@ -26,7 +26,7 @@ EXPORTS = (
     "rr_pgo_num_nodes", "rr_pgo_num_edges", "rr_pgo_dim", "rr_pgo_state_len", "rr_pgo_anchor_node",
     "rr_pgo_get_graph", "rr_pgo_chi2", "rr_pgo_linearize_solve", "rr_pgo_update", "rr_pgo_optimize",
     "rr_pgo_get_state", "rr_pgo_set_state", "rr_pgo_assemble", "rr_pgo_iterate_async", "rr_pgo_sync",
-    "rr_pgo_get_stats", "rr_pgo_analyze_g2o", "rr_pgo_abi_version", "rr_pgo_profile", "rr_pgo_synth_grid", "rr_pgo_synth_free",
+    "rr_pgo_get_stats", "rr_pgo_analyze_g2o", "rr_pgo_abi_version", "rr_pgo_debug_withhold", "rr_pgo_profile", "rr_pgo_synth_grid", "rr_pgo_synth_free",
     "rr_pgo_exchange_buffer", "rr_pgo_set_exchange_buffer", "rr_pgo_stage", "rr_pgo_stage_scalars", "rr_pgo_stream",
     "rr_pgo_node_owner",
 )
@@ -120,6 +120,7 @@ def load():
     L.rr_pgo_node_owner.argtypes = [vp, ip]
     L.rr_pgo_analyze_g2o.argtypes = [C.c_char_p, C.POINTER(Options), C.POINTER(Stats)]
     L.rr_pgo_abi_version.restype = C.c_int32
+    L.rr_pgo_debug_withhold.argtypes = [vp, C.c_int32]
     if L.rr_pgo_abi_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH} speaks ABI version {L.rr_pgo_abi_version()}, this mirror {ABI_VERSION}: rebuild the library")
     _lib = L

@@ -68,6 +68,7 @@ template <typename T> struct FlowArgs {   // everything the launch reads: a slim
   const int32_t *scat;
   T *lvals, *uvals, *xch, *winv;
   int *err;
+  unsigned long long wait_ticks;   // bound of one wait, 100 MHz wall-clock ticks (RR_PGO_FLOW_TIMEOUT_MS; default 2 s)
   unsigned long long *trace;   // diagnostic build (-DRRPGO_FLOW_TRACE): [ticket][wave][4] wall-clock stamps, else null
 };
 
@@ -81,23 +82,22 @@ template <typename T> struct FlowArgs {   // everything the launch reads: a slim
 #define RRPGO_FLOW_MARK(fa, t, wv, slot) do { } while (0)
 #endif
 
-#ifndef RRPGO_FLOW_SPIN_MAX
-#define RRPGO_FLOW_SPIN_MAX (1u << 22)   // polls of one wait before it gives up (seconds: a poll is a memory round trip)
-#endif
 
 __device__ __forceinline__ unsigned flow_flag_ld(const unsigned *p) { return __hip_atomic_load(const_cast<unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void flow_flag_set(unsigned *p) { __hip_atomic_store(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // One wave waits until every flag its lanes name (nullptr = none) is set.  Bounded; false = gave up or the launch
 // is draining after an error (the caller goes on: addresses never depend on data, the results are reported invalid).
-__device__ __forceinline__ bool flow_wait(const unsigned *p, int *err) {
+__device__ __forceinline__ bool flow_wait(const unsigned *p, int *err, unsigned long long max_ticks) {
   bool ok = true;
+  unsigned long long t0 = 0;
   for (unsigned spins = 0;; spins++) {
     const unsigned v = p ? flow_flag_ld(p) : 1u;
     if (__all(v != 0u)) break;
     if ((spins & 63u) == 63u) {
+      if (t0 == 0) t0 = wall_clock64();   // (the bound is wall-clock time, not a poll count: a poll's cost varies with clocks, contention and profilers)
       const int e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (e != 0 || spins >= RRPGO_FLOW_SPIN_MAX) {
+      if (e != 0 || wall_clock64() - t0 > max_ticks) {
         if (e == 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicOr(err, DEVERR_FLOW_TIMEOUT);
         ok = false;
         break;
@@ -200,7 +200,7 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
       const int d = (kn - K0) / TS;   // the update before the next block's range (a later range: look_tile below)
       if (look && skip == 0 && K0 > 0) fp = fa.flags + ff.uf + (K0 / BIG_SUPER - 1) * ff.ustride + flow_tri(d, d);
     }
-    flow_wait(fp, fa.err);
+    flow_wait(fp, fa.err, fa.wait_ticks);
   }
   RRPGO_FLOW_MARK(fa, ticket, tid >> 6, 1);
   constexpr uint32_t SZ = (uint32_t)sizeof(T);
@@ -229,12 +229,12 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
     }
   };
   auto wait_newest = [&] {   // X of block blk - 1: my rows and the diagonal block's rows
-    flow_wait(lane < 3 ? block_flag(1, lane) : nullptr, fa.err);
+    flow_wait(lane < 3 ? block_flag(1, lane) : nullptr, fa.err, fa.wait_ticks);
   };
   // a range of more than three blocks reaches into the previous super-panel: its blocks are there long before block
   // blk - 2 is, and at ~2 us of loads per block the pre-work has to start on them at once to stay off the chain
   auto wait_second = [&] {
-    if (q > 3) flow_wait(lane < 3 ? block_flag(2, lane) : nullptr, fa.err);
+    if (q > 3) flow_wait(lane < 3 ? block_flag(2, lane) : nullptr, fa.err, fa.wait_ticks);
   };
   typename MM::Acc acc[2][2], nxt[2][2];
 #pragma unroll
@@ -288,7 +288,7 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
         // diagonal block is finished late (it needs the previous super-panel's last X): waited for now, not before the
         // pre-work, and loaded together with the newest block's operands
         const int Kn = K0 + BIG_NB * skip, d = (kn - Kn) / TS;
-        flow_wait(lane == 0 ? fa.flags + ff.uf + (Kn / BIG_SUPER - 1) * ff.ustride + flow_tri(d, d) : nullptr, fa.err);
+        flow_wait(lane == 0 ? fa.flags + ff.uf + (Kn / BIG_SUPER - 1) * ff.ustride + flow_tri(d, d) : nullptr, fa.err, fa.wait_ticks);
         load_next_diag();
       }
 #pragma unroll
@@ -309,6 +309,7 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
   // ---- now the diagonal block: wait for its inverse
   // (polled in place: k_flow_reset marked the block, see there; bounded like flow_wait)
   T wv[3][4];
+  unsigned long long wt0 = 0;
   for (unsigned spins = 0;; spins++) {
     bool unset = false;
 #pragma unroll
@@ -321,8 +322,9 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
       }
     if (!__any(unset)) break;
     if ((spins & 63u) == 63u) {
+      if (wt0 == 0) wt0 = wall_clock64();
       const int e = __hip_atomic_load(fa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (e != 0 || spins >= RRPGO_FLOW_SPIN_MAX) {
+      if (e != 0 || wall_clock64() - wt0 > fa.wait_ticks) {
         if (e == 0 && lane == 0) atomicOr(fa.err, DEVERR_FLOW_TIMEOUT);
         break;
       }
@@ -484,7 +486,7 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
           const int rb = (lo - r0) / 32 + k;
           if (rb <= (hi - r0) / 32) fp = fa.flags + ff.pf + (kb / BIG_NB) * ff.pstride + rb;
         }
-        flow_wait(fp, fa.err);
+        flow_wait(fp, fa.err, fa.wait_ticks);
       }
       if (sp > 0) {   // the tiles of the previous super-panel's update under this one (its grid starts at K0)
         const unsigned *fp = nullptr;
@@ -494,7 +496,7 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
           const int pbx = bxl + (lane >> 1), pby = byl + (lane & 1);
           if (pbx <= bxh && pby <= byh && pby <= pbx) fp = fa.flags + ff.uf + (sp - 1) * ff.ustride + flow_tri(pbx, pby);
         }
-        flow_wait(fp, fa.err);
+        flow_wait(fp, fa.err, fa.wait_ticks);
       }
     }
     __syncthreads();
@@ -544,13 +546,15 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
 // Payload (x, 128 values per step) with sc1 accesses, counters with agent-scope atomics after a drain; bounded spins.
 struct SolveFlowFront { int32_t xdone, fdone; };   // indices into the flag words: xdone; fdone + g
 struct SolveFlowTask { int32_t front, ell, group; };   // group < 0: CHAIN
-__device__ __forceinline__ bool solve_flow_wait(const unsigned *word, unsigned need, int *err) {
+__device__ __forceinline__ bool solve_flow_wait(const unsigned *word, unsigned need, int *err, unsigned long long max_ticks) {
   bool ok = true;
+  unsigned long long t0 = 0;
   for (unsigned spins = 0;; spins++) {
     if (flow_flag_ld(word) >= need) break;
     if ((spins & 63u) == 63u) {
+      if (t0 == 0) t0 = wall_clock64();
       const int e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (e != 0 || spins >= RRPGO_FLOW_SPIN_MAX) {
+      if (e != 0 || wall_clock64() - t0 > max_ticks) {
         if (e == 0) atomicOr(err, DEVERR_FLOW_TIMEOUT);
         ok = false;
         break;
@@ -613,8 +617,8 @@ template <typename T> __global__ void __launch_bounds__(1024) k_big_solve_flow(F
           lb[q] = col[min(lane + 64, nright - 1)];
         }
         if (wave == 0) {
-          solve_flow_wait(xdone, (unsigned)ell, a.err);   // x of the super-panel to the right
-          solve_flow_wait(fdone, (unsigned)ell, a.err);   // this group's previous fold (another workgroup may have run it): the sums go in step order
+          solve_flow_wait(xdone, (unsigned)ell, a.err, a.wait_ticks);   // x of the super-panel to the right
+          solve_flow_wait(fdone, (unsigned)ell, a.err, a.wait_ticks);   // this group's previous fold (another workgroup may have run it): the sums go in step order
         }
         __syncthreads();
         const T va = xbuf.ld((uint32_t)(K1 + min(lane, nright - 1)) * SZ), vb = xbuf.ld((uint32_t)(K1 + min(lane + 64, nright - 1)) * SZ);
@@ -660,9 +664,9 @@ template <typename T> __global__ void __launch_bounds__(1024) k_big_solve_flow(F
     }
     // the previous super-panel's x, and the folds of the steps before last into my 128 columns (groups K0 / 64, K0 / 64 + 1)
     if (ell > 0 && wave == 0) {
-      solve_flow_wait(xdone, (unsigned)ell, a.err);
-      solve_flow_wait(flags + sf.fdone + K0 / 64, (unsigned)ell, a.err);
-      if (K0 + 64 < K1) solve_flow_wait(flags + sf.fdone + K0 / 64 + 1, (unsigned)ell, a.err);
+      solve_flow_wait(xdone, (unsigned)ell, a.err, a.wait_ticks);
+      solve_flow_wait(flags + sf.fdone + K0 / 64, (unsigned)ell, a.err, a.wait_ticks);
+      if (K0 + 64 < K1) solve_flow_wait(flags + sf.fdone + K0 / 64 + 1, (unsigned)ell, a.err, a.wait_ticks);
     }
     __syncthreads();
     T xa = 0, xb = 0;

@@ -8,9 +8,10 @@
 //   k_big_* / k_solve_mid / k_big_flow (flow.hip.h)  fronts beyond LDS (see "huge fronts" below)
 //   k_linearize_se3 / k_update_se3, k_pack_boundary / k_pack_shared / k_sum_shared   SE(3), sharding over ranks
 //
-// Wavefront = 64 lanes.  All cross-workgroup dependencies are kernel boundaries
-// on one stream; inside a launch a workgroup only reads what it wrote itself
-// or what an earlier launch wrote.
+// Wavefront = 64 lanes.  Cross-workgroup dependencies are kernel boundaries on one stream -- except inside the dataflow
+// launches (k_factor_flow / k_solve_flow, lds_flow.hip.h; k_big_flow / k_big_solve_flow, flow.hip.h), whose workgroups hand
+// update matrices, tiles and solutions to each other behind flags: sc1 payload, agent-scope flag, bounded waits (dep_wait
+// below, flow_wait there).  Everywhere else a workgroup only reads what it wrote itself or what an earlier launch wrote.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -3752,14 +3753,19 @@ template <typename T> __global__ void __launch_bounds__(256) k_pack_shared(const
 // A rank whose own subtrees hit a non-positive pivot in stage 0 publishes that in the last scalar of its chunk
 // (k_pack_err); after the all-gather every rank folds the P flags into its own device flag (k_merge_err) BEFORE
 // stage 1's k_update tests it: either every rank applies the step or none does, and every rank reports ENOTSPD.
+// The scalar carries the flag BITS (small integers, exact in fp32 too): a rank whose stage 0 timed out in a dataflow
+// launch makes the group report a timeout, not a matrix that is not positive definite.
 template <typename T> __global__ void k_pack_err(const int *err, T *dst) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = (T)(*err != 0 ? 1 : 0);
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = (T)(*err & 0xff);
 }
 template <typename T> __global__ void k_merge_err(int *err, const T *xch, int64_t chunk, int64_t off, int P) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  bool any = false;
-  for (int r = 0; r < P; r++) any = any || xch[(int64_t)r * chunk + off] != (T)0;
-  if (any) atomicOr(err, DEVERR_NOT_SPD);
+  int bits = 0;
+  for (int r = 0; r < P; r++) {
+    const T v = xch[(int64_t)r * chunk + off];
+    bits |= (v >= (T)0 && v < (T)256) ? (int)v : DEVERR_NOT_SPD;   // (anything else -- a NaN from a rank in trouble -- counts as a failure)
+  }
+  if (bits) atomicOr(err, bits);
 }
 template <typename T> __global__ void __launch_bounds__(256) k_sum_shared(const int64_t *src_off, int n, T *hvals, T *b, const T *xch, int64_t chunk, int64_t off, int P) {
   const int i = blockIdx.x * 256 + threadIdx.x;

@@ -183,6 +183,7 @@ struct EngineBase {
   virtual void set_exchange_buffer(int which, void *ptr, int64_t n) = 0;
   virtual void stage(int stage, double lambda, int lm) = 0;
   virtual void read_last_scalars(double *chi, double *norm) = 0;
+  virtual void debug_withhold(int mode) = 0;   // failure injection for the dataflow launches (rr_pgo_debug_withhold)
   int n_launches_per_iter = 0;
 };
 
@@ -301,6 +302,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<LdsFlowTask> lds_ftasks_, lds_stasks_;
   int lds_n_tasks_ = 0, lds_flow_cus_ = 256;
   unsigned long long wait_ticks_ = 200000000ull;   // bound of one in-launch wait: 2 s of the 100 MHz wall clock (RR_PGO_FLOW_TIMEOUT_MS)
+  // failure injection (rr_pgo_debug_withhold): what was changed, to put it back
+  int withheld_child_ = -1, withheld_parent_ = -1, withheld_level_ = -1, withheld_task_ = -1;
+  int32_t withheld_parent_val_ = -1;
+  FlowRec withheld_rec_{};
+  static constexpr int kDeadFlagWords = 4096;   // flag words behind the live ones that no consumer ever looks at
   // gauge transfer (single-precision factor, Gauss-Newton; kernels.hip.h "gauge transfer")
   bool gauge_ok_ = false;            // the root front is a big front with an SE2 pivot node
   bool gauge_now_ = false;           // the system being factored was linearised without the anchor prior
@@ -485,7 +491,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     gather_update_ = getenv("RR_PGO_NO_GATHER_UPDATE") == nullptr;
     fused_assembly_ = getenv("RR_PGO_SPLIT_ASSEMBLY") == nullptr;
     if (const char *e = getenv("RR_PGO_FLOW")) flow_max_nf_ = std::atoi(e);
-    flow_exact_ = getenv("RR_PGO_FLOW_EXACT") != nullptr;
+    if (const char *e = getenv("RR_PGO_FLOW_EXACT")) flow_exact_ = std::atoi(e) != 0;
     if (const char *e = getenv("RR_PGO_FLOW_DEEP")) flow_deep_ = std::atoi(e) != 0;
     if (const char *e = getenv("RR_PGO_FLOW_TASKS")) flow_max_tasks_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_SOLVE_FLOW")) solve_flow_on_ = std::atoi(e) != 0;
@@ -980,7 +986,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (words == 0) return;
     wfill.resize(wfill.size() + 2, 0);   // never empty
     flow_wfill_.upload(wfill);
-    flow_flags_.alloc((size_t)words);
+    flow_flags_.alloc((size_t)words + kDeadFlagWords);
     flow_flags_.zero();
     for (size_t si = 0; si < sym_.steps.size(); si++)
       if (solve_flow_[si]) {
@@ -1083,6 +1089,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     fa.xch = xch_;
     fa.winv = winv_.p;
     fa.err = err_.p;
+    fa.wait_ticks = wait_ticks_;
     fa.trace = lvl.trace.p;
     hipLaunchKernelGGL((k_big_flow<T, 2>), dim3((unsigned)std::min(lvl.n_tasks, flow_grid_)), dim3(256), 0, stream_, fa);
     check_launch("k_big_flow");
@@ -1961,6 +1968,74 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     throw_on_flag(*eflag);
   }
 
+  // Test-only failure injection: make ONE hand-off of a dataflow launch never arrive, so that the waits behind it run
+  // into their time bound (RR_PGO_FLOW_TIMEOUT_MS).  mode 1: k_factor_flow -- the root front's last foreign child's flag
+  // is looked for in a word nobody sets; 2: k_solve_flow -- the same for the parent flag of one front; 3: k_big_flow --
+  // the first PANEL task of the first flow level publishes its X blocks in the dead words behind the live flags;
+  // 0: everything back.  The captured graphs hold pointers, not contents: no re-capture.
+  void debug_withhold(int mode) override {
+    HIPCHK(hipStreamSynchronize(stream_));
+    if (mode == 0) {
+      if (withheld_child_ >= 0) {
+        HIPCHK(hipMemcpy(child_dep_.p + withheld_child_, &host_child_dep_[withheld_child_], sizeof(int32_t), hipMemcpyHostToDevice));
+        withheld_child_ = -1;
+      }
+      if (withheld_parent_ >= 0) {
+        HIPCHK(hipMemcpy(parent_dep_.p + withheld_parent_, &withheld_parent_val_, sizeof(int32_t), hipMemcpyHostToDevice));
+        withheld_parent_ = -1;
+      }
+      if (withheld_level_ >= 0) {
+        HIPCHK(hipMemcpy(flow_levels_[withheld_level_]->tasks.p + withheld_task_, &withheld_rec_, sizeof(FlowRec), hipMemcpyHostToDevice));
+        withheld_level_ = -1;
+      }
+      return;
+    }
+    if (mode == 1 || mode == 2) {
+      if (!lds_flow_) throw ApiError(RR_PGO_EUNSUPPORTED, "this handle does not run the dataflow launches of the LDS fronts");
+      const int32_t dead = 2 * sym_.S + 96;   // inside dep_flags_, behind the words the linearisation zeroes, never set
+      if (mode == 1) {
+        for (int q = (int)host_child_dep_.size() - 1; q >= 0; q--)
+          if (host_child_dep_[q] >= 0) {
+            HIPCHK(hipMemcpy(child_dep_.p + q, &dead, sizeof(int32_t), hipMemcpyHostToDevice));
+            withheld_child_ = q;
+            return;
+          }
+        throw ApiError(RR_PGO_EUNSUPPORTED, "no front waits for a child of another task");
+      }
+      std::vector<int32_t> pd(sym_.S);
+      HIPCHK(hipMemcpy(pd.data(), parent_dep_.p, pd.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+      for (int f = 0; f < sym_.S; f++)
+        if (pd[f] >= 0) {
+          withheld_parent_ = f;
+          withheld_parent_val_ = pd[f];
+          HIPCHK(hipMemcpy(parent_dep_.p + f, &dead, sizeof(int32_t), hipMemcpyHostToDevice));
+          return;
+        }
+      throw ApiError(RR_PGO_EUNSUPPORTED, "no front waits for a parent of another task");
+    }
+    if (mode == 3) {
+      for (size_t si = 0; si < flow_levels_.size(); si++) {
+        if (!flow_levels_[si]) continue;
+        FlowLevel &l = *flow_levels_[si];
+        std::vector<FlowRec> recs((size_t)l.n_tasks);
+        HIPCHK(hipMemcpy(recs.data(), l.tasks.p, recs.size() * sizeof(FlowRec), hipMemcpyDeviceToHost));
+        for (int t = 0; t < l.n_tasks; t++)
+          if ((recs[t].t.kind_front >> 24) == FLOW_PANEL) {
+            withheld_level_ = (int)si;
+            withheld_task_ = t;
+            withheld_rec_ = recs[t];
+            FlowRec bad = recs[t];
+            bad.ff.pf = (int32_t)((int64_t)flow_flags_.n - kDeadFlagWords);   // its X flags land in the dead words
+            bad.ff.pstride = 1;
+            HIPCHK(hipMemcpy(l.tasks.p + t, &bad, sizeof(FlowRec), hipMemcpyHostToDevice));
+            return;
+          }
+      }
+      throw ApiError(RR_PGO_EUNSUPPORTED, "this handle has no dataflow level of fronts beyond LDS");
+    }
+    throw ApiError(RR_PGO_EINVAL, "mode must be 0 .. 3");
+  }
+
   void profile(int iters, double *ms, int64_t *launches) override {
     HIPCHK(hipEventCreate(&prof_.e0));
     HIPCHK(hipEventCreate(&prof_.e1));
@@ -2326,6 +2401,11 @@ int rr_pgo_sync(rr_pgo *h) {
 }
 
 int32_t rr_pgo_abi_version(void) { return RR_PGO_ABI_VERSION; }
+
+int rr_pgo_debug_withhold(rr_pgo *h, int32_t mode) {
+  if (!h) { g_last_error = "null argument"; return RR_PGO_EINVAL; }
+  return guarded([&] { h->engine->debug_withhold(mode); });
+}
 
 int rr_pgo_analyze_g2o(const char *path, const rr_pgo_options *opt, rr_pgo_stats *out) {
   if (!path || !out) { g_last_error = "null argument"; return RR_PGO_EINVAL; }

@@ -95,6 +95,29 @@ def test_assembled_system_matches_oracle(api, oracle, name, lm):
     """H (incl. the 1e7 prior, :330-336, and + lambda I, :362-366) and b = -J^T W e (:361), every stored block of
     every SE(2) dataset (intel: 102 492 scalars of H) against the oracle's summed COO."""
     g, o = api[0].new(g2o_path(name)), oracle.load(g2o_path(name))
+    _assert_system_matches_oracle(g, o, name, lm, 1e-12, 1e-11)
+
+
+@pytest.mark.parametrize("name", SE2_FILES)
+def test_edge_parallel_linearisation_matches_the_oracle(api, oracle, name, monkeypatch):
+    """The kernel form north_star words (RR_PGO_EDGE_LINEARIZE=1: k_lin_init + k_linearize_edges + k_lin_finish, one thread
+    per edge, wave-reduced scatter-add with floating-point atomics) against the ORACLE, not against the pull form: chi2
+    (pose_graph_optimization.rs:537-574) at 1e-12, every block of H and b (:434-486, :165-192, :305-369) at 1e-11 -- the
+    order of the atomic sums moves the last bits, nothing more."""
+    monkeypatch.setenv("RR_PGO_EDGE_LINEARIZE", "1")
+    g = api[0].new(g2o_path(name))
+    monkeypatch.delenv("RR_PGO_EDGE_LINEARIZE")
+    o = oracle.load(g2o_path(name))
+    assert abs(g.global_error() - o.global_error()) <= 1e-12 * o.global_error()
+    for lm in (False, True):
+        _assert_system_matches_oracle(g, o, name, lm, 1e-11, 1e-11)
+    # and a whole step through the edge-parallel system: the first Gauss-Newton step of the oracle
+    dx = g.linearize_and_solve()
+    odx = o.linearize_and_solve()
+    assert np.abs(dx - odx).max() <= 1e-8 * max(1.0, np.abs(odx).max())
+
+
+def _assert_system_matches_oracle(g, o, name, lm, tol_h, tol_b):
     kinds, offs = o.node_kinds(), o.node_offsets()
     dims = np.where(kinds == 0, 3, 2)
     br, bc, bo, vals, b = g.assemble(0.37 if lm else 0.0, lm)
@@ -112,8 +135,8 @@ def test_assembled_system_matches_oracle(api, oracle, name, lm):
     L = sp.csc_matrix((ovals, rowidx, colptr), shape=(n, n))
     Ho = (L + sp.tril(L, -1).T).tocsc()
     scale = np.abs(Ho).max()
-    assert abs(H - Ho).max() <= 1e-12 * scale
-    assert np.abs(b - ob).max() <= 1e-11 * np.abs(ob).max()
+    assert abs(H - Ho).max() <= tol_h * scale
+    assert np.abs(b - ob).max() <= tol_b * np.abs(ob).max()
     assert H.diagonal().max() > 1e7  # the prior is there
     if name == "intel" and not lm:
         assert (H != 0).sum() <= 102492 and len(vals) == 9 * (1728 + 4830)   # nnz(H) = 9 (N + 2E) with both triangles
@@ -549,6 +572,65 @@ def test_edge_parallel_linearisation_agrees_with_the_pull_form(api, name, monkey
     # amplifies the last bits of the first step to ~1e-8 of chi2 by the fourth
     np.testing.assert_allclose(alt.optimize(4), ref.optimize(4), rtol=1e-6)
     assert _state_diff_se2(alt.state(), ref.state()) <= 1e-5
+
+
+@pytest.mark.parametrize("mode,what", [(1, "intel"), (2, "intel"), (3, "lattice")])
+def test_a_hand_off_that_never_arrives_times_out_and_leaves_the_state_untouched(api, mode, what, monkeypatch):
+    """Failure injection for the dataflow launches (k_factor_flow, k_solve_flow, k_big_flow): ONE flag is withheld
+    (rr_pgo_debug_withhold), the wait behind it runs into its time bound (RR_PGO_FLOW_TIMEOUT_MS, here 20 ms), every later
+    wait gives up at once, the launch drains, k_update does not apply the step.  The call returns RR_PGO_ETIMEOUT -- not
+    ENODEVICE, not ENOTSPD -- in bounded time, the state is the one before the call bit for bit, and with the hand-off
+    restored the same handle reaches the answer of a fresh one."""
+    import ctypes as C
+    import time
+    from rustrobotics_amd import _lib, synthetic_grid_arrays
+    PoseGraph, _, PoseGraphError = api
+    make = (lambda: PoseGraph.new(g2o_path("intel"))) if what == "intel" else (lambda: PoseGraph.from_arrays(*synthetic_grid_arrays(100, 100)))
+    ref = make()
+    eref = ref.optimize(3)
+    monkeypatch.setenv("RR_PGO_FLOW_TIMEOUT_MS", "20")
+    g = make()
+    monkeypatch.delenv("RR_PGO_FLOW_TIMEOUT_MS")
+    s0 = np.array(g.state())
+    L = _lib.load()
+    assert L.rr_pgo_debug_withhold(g._h, mode) == 0, L.rr_pgo_last_error()
+    t0 = time.perf_counter()
+    with pytest.raises(PoseGraphError) as ei:
+        g.optimize(3)
+    assert time.perf_counter() - t0 < 10.0                       # bounded: one 20 ms wait, then the launch drains
+    assert ei.value.code == _lib.ETIMEOUT, str(ei.value)
+    assert np.array_equal(np.array(g.state()), s0)               # the step was not applied
+    with pytest.raises(PoseGraphError) as ei:                    # and again: the flag is sticky only until it is reported
+        g.linearize_and_solve()
+    assert ei.value.code == _lib.ETIMEOUT
+    assert L.rr_pgo_debug_withhold(g._h, 0) == 0
+    assert np.array_equal(np.array(g.optimize(3)), np.array(eref))
+    assert np.array_equal(np.array(g.state()), np.array(ref.state()))
+
+
+@pytest.mark.parametrize("name", ["intel", "input_M3500_g2o", "dlr", "simulation-pose-landmark"])
+def test_lds_dataflow_launches_are_bit_identical_to_the_level_schedule(api, name, monkeypatch):
+    """k_factor_flow / k_solve_flow (ONE launch each, ticket-ordered tasks, flags between workgroups) against the level
+    schedule (RR_PGO_LDS_FLOW=0: one launch per level of the task tree): the same fronts, the same child order, the same
+    code per front -- chi2 trajectory and state must agree bit for bit; so must a launch with ONE workgroup drawing every
+    ticket in turn (tasks only ever wait for smaller tickets: any grid finishes) and another task granularity.
+    (The dissection depth is pinned: for graphs of 2400 .. 6000 poses the library picks it by the schedule's estimated
+    critical path, which is not the same function for the two schedules -- another tree is another summation order.)"""
+    monkeypatch.setenv("RR_PGO_ND_LEAF", "1000000")
+    ref = api[0].new(g2o_path(name))
+    eref, sref = np.array(ref.optimize(4)), np.array(ref.state())
+    for env, val in (("RR_PGO_LDS_FLOW", "0"), ("RR_PGO_LDS_FLOW_GRID", "1"), ("RR_PGO_LDS_FLOW_GRID", "7"), ("RR_PGO_TASK_US", "60")):
+        monkeypatch.setenv(env, val)
+        alt = api[0].new(g2o_path(name))
+        monkeypatch.delenv(env)
+        assert np.array_equal(np.array(alt.optimize(4)), eref), (env, val)
+        assert np.array_equal(np.array(alt.state()), sref), (env, val)
+    # Levenberg-Marquardt drives the same launches outside the captured graph
+    lm = api[0].new(g2o_path(name), api[1].LevenbergMarquardt)
+    monkeypatch.setenv("RR_PGO_LDS_FLOW", "0")
+    lm0 = api[0].new(g2o_path(name), api[1].LevenbergMarquardt)
+    monkeypatch.delenv("RR_PGO_LDS_FLOW")
+    assert np.array_equal(np.array(lm.optimize(5)), np.array(lm0.optimize(5)))
 
 
 def test_fronts_beyond_lds_f32_reaches_the_f64_minimum(api):
