@@ -12,12 +12,14 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rr_pgo.h"
@@ -339,10 +341,20 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       explicit ArenaScope(DeviceArena *a) { t_arena = a; }
       ~ArenaScope() { t_arena = nullptr; }
     } scope(&arena_);
+    const bool ctimes = getenv("RR_PGO_ANALYZE_TIMES") != nullptr;   // wall time of the phases of this constructor on stderr
+    double ct0 = now_ms();
+    auto cmark = [&](const char *what) {
+      if (!ctimes) return;
+      const double t = now_ms();
+      std::fprintf(stderr, "engine:  %-12s %8.3f ms\n", what, t - ct0);
+      ct0 = t;
+    };
     // the factor storage dominates: one chunk sized for it and the value arrays, tables follow in 8 MB chunks
     arena_.reserve((size_t)(sym.l_elems + sym.u_elems + sym.n_hvals + 8 * (int64_t)g.dim + sym.xch_elems) * sizeof(T) + (4u << 20));
     stream_.acquire();
+    cmark("stream");
     host_pair_.alloc(3);
+    cmark("pinned");
     const int N = g.n_nodes(), E = g.n_edges();
     // ---- graph arrays
     is3d_ = g.has_se3;
@@ -423,6 +435,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     node_offset_.upload(g.node_offset);
     node_pcol_.upload(sym.node_pcol);
     diag_off_.upload(sym.diag_off);
+    cmark("graph arrays");
     // ---- numeric buffers
     hvals_.alloc((size_t)sym.n_hvals);
     hvals_.zero();
@@ -510,6 +523,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     err_.zero();
     blocks_done_.alloc(1);
     blocks_done_.zero();
+    cmark("numeric");
     // ---- symbolic tables
     task_ptr_.upload(sym.task_ptr);
     task_sn_.upload(sym.task_sn);
@@ -624,8 +638,10 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         if (const char *e = getenv("RR_PGO_LDS_FLOW_GRID")) lds_flow_cus_ = std::max(1, std::atoi(e));   // workgroups of the two dataflow launches (experiments)
       }
     }
+    cmark("front tables");
     build_flow_levels();   // (after the front records: every flow task carries a copy of its front's)
     build_update_maps();
+    cmark("flow levels");
     fasm_src_.upload(sym.fasm_src);
     fasm_dst_.upload(sym.fasm_dst);
     fasm_colptr_.upload(sym.fasm_colptr);
@@ -658,7 +674,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     stamps_.alloc((size_t)sym.S * 12 + 400000 + (size_t)sym.S * 1280);   // per-front phase stamps | launch trace | panel_flow chain stamps
     stamps_.zero();
 #endif
+    cmark("index tables");
     configure_kernels();
+    cmark("kernel attrs");
     n_launches_per_iter = 2;
     for (const Step &st : sym.steps)
       n_launches_per_iter += st.kind == STEP_BIG ? count_big_launches(st) + count_big_solve_launches(st) : 2;
@@ -1736,11 +1754,16 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       // chi2 of the state BEFORE an update comes out of that iteration's own
       // linearisation pass, so errors[i] is known once iteration i has run and
       // one chi2-only pass after the loop supplies the last entry.
-      ensure_gn_graph();
+      // an iteration of a handful of launches (the dataflow form of the small graphs: four) is enqueued as it is; capturing
+      // and instantiating a hipGraph costs more than ten such iterations save (the closure the reference's bench times,
+      // benches/graph_slam.rs:9-10, is ONE new() + optimize(10)).  Graphs of dozens of launches replay a captured graph.
+      const bool eager = n_launches_per_iter <= 8 && !gn_exec_;
+      if (!eager) ensure_gn_graph();
       reset_counter();
       int done = 0;
       for (int i = 0; i < iters; i++) {
-        HIPCHK(hipGraphLaunch(gn_exec_, stream_));
+        if (eager) enqueue_gn_iteration();
+        else HIPCHK(hipGraphLaunch(gn_exec_, stream_));
         double chi, nrm;
         read_slot(i, &chi, &nrm);
         errors[ne++] = chi;
@@ -2152,16 +2175,36 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
     // sphere2500: +20..26 % measured) and lengthen it on intel.  The front cost model ranks the candidates
     // the way the measurements do, so the estimated critical path picks the leaf size.  Below 2400 nodes
     // no cut ever won and the extra analyses would only lengthen set-up (one-shot callers time it).
+    // The candidates are independent host computations: one thread each (r04: the six analyses in sequence were 35 ms
+    // of M3500's and 55 ms of dlr's constructor on the GPU box, against 2 - 3 ms of optimize(10)).
     static const int kLeaf[] = {1 << 30, 3000, 2000, 1400, 1000, 700};
+    std::vector<int> leaves;
+    for (int leaf : kLeaf)
+      if (leaf == (1 << 30) || leaf < h->g.n_nodes()) leaves.push_back(leaf);   // (a leaf size >= the graph is no cut at all)
+    std::vector<Symbolic> cands(leaves.size());
+    std::vector<std::string> errs(leaves.size());
+    {
+      std::vector<std::thread> pool;
+      for (size_t c = 1; c < leaves.size(); c++)
+        pool.emplace_back([&, c] {
+          SymbolicOptions o = so;
+          o.nd_leaf = leaves[c];
+          try { errs[c] = analyze(h->g, o, cands[c]); } catch (const std::exception &e) { errs[c] = e.what(); }
+        });
+      {
+        SymbolicOptions o = so;
+        o.nd_leaf = leaves[0];
+        errs[0] = analyze(h->g, o, cands[0]);
+      }
+      for (std::thread &t : pool) t.join();
+    }
     Symbolic best;
     double best_crit = -1.0;
-    for (int leaf : kLeaf) {
-      if (leaf != (1 << 30) && leaf >= h->g.n_nodes()) continue;   // same as no cut at all
-      so.nd_leaf = leaf;
-      Symbolic cand;
-      err = analyze(h->g, so, cand);
-      if (!err.empty()) break;
-      if (best_crit < 0 || cand.est_critical_us < best_crit) { best_crit = cand.est_critical_us; best = std::move(cand); }
+    for (size_t c = 0; c < leaves.size(); c++) {
+      if (!errs[c].empty()) { err = errs[c]; break; }
+      if (std::getenv("RR_PGO_ANALYZE_TIMES"))
+        std::fprintf(stderr, "analyze: nd_leaf %d -> estimated critical path %.1f us (%d big fronts, %d supernodes)\n", leaves[c], cands[c].est_critical_us, cands[c].n_big, cands[c].S);
+      if (best_crit < 0 || cands[c].est_critical_us < best_crit) { best_crit = cands[c].est_critical_us; best = std::move(cands[c]); }
     }
     if (err.empty()) h->sym = std::move(best);
   } else {

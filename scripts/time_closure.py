@@ -1,0 +1,14 @@
+"""The closure the reference's criterion bench times (benches/graph_slam.rs:9-10): PoseGraph::new(file) + optimize(10), phase by phase.
+usage: RR_PGO_ANALYZE_TIMES=1 python scripts/time_closure.py [name]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rustrobotics_amd import PoseGraph
+name = sys.argv[1] if len(sys.argv) > 1 else 'intel'
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests/golden/g2o', name + '.g2o')
+g = PoseGraph.new(path); g.optimize(10); del g      # warm: module load, first-use initialisation of the runtime
+for rep in range(3):
+    sys.stderr.write('--- rep %d\n' % rep)
+    t0 = time.perf_counter(); g = PoseGraph.new(path); t1 = time.perf_counter(); e = g.optimize(10); t2 = time.perf_counter()
+    s = g.stats()
+    print(f'{name}: new {1e3 * (t1 - t0):.2f} ms (parse {s["parse_ms"]:.2f}, analyze {s["analyze_ms"]:.2f}), optimize(10) {1e3 * (t2 - t1):.2f} ms ({len(e) - 1} iterations), total {1e3 * (t2 - t0):.2f} ms')
+    t3 = time.perf_counter(); del g; print(f'   drop {1e3 * (time.perf_counter() - t3):.2f} ms')
