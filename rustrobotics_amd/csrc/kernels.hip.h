@@ -2337,7 +2337,13 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
 #pragma unroll
     for (int c = 0; c < 16; c++) x[c] = src[c * sstride];
   }
+#if RRPGO_DPP_SWEEP == 2
+  bad = chol16_dpp2<T>(x);   // (leaves garbage above the diagonal of L: zeroed on the way out, the images below rely on it)
+#pragma unroll
+  for (int c = 0; c < 16; c++) x[c] = (rowlane && c > q) ? (T)0 : x[c];
+#else
   bad = chol16_invert<T>(x, ll);
+#endif
 #pragma unroll
   for (int c = 0; c < 16; c++) Sh[rowlane ? c * 33 + q : WOFF + q * 33 + c] = x[c];   // L11(q, c) | W11(c, q)
   sync();
@@ -2373,7 +2379,13 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
 #pragma unroll
     for (int c = 0; c < 16; c++) x[c] = src[c * sstride];
   }
+#if RRPGO_DPP_SWEEP == 2
+  bad = chol16_dpp2<T>(x) || bad;
+#pragma unroll
+  for (int c = 0; c < 16; c++) x[c] = (rowlane && c > q) ? (T)0 : x[c];
+#else
   bad = chol16_invert<T>(x, ll) || bad;
+#endif
   if (bad && lane == 0) atomicOr(err, DEVERR_NOT_SPD);
 #pragma unroll
   for (int c = 0; c < 16; c++) Sh[rowlane ? (16 + c) * 33 + 16 + q : WOFF + (16 + q) * 33 + 16 + c] = x[c];
