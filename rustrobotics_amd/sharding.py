@@ -7,6 +7,8 @@ pose_graph_optimization.rs:230); the loop control mirrors `optimize` (:247-303).
 
   gauss_newton(shards, iters, coll)      the loop, over whatever collectives `coll` provides
   EmulatedCollectives                    P ranks emulated in one process on one GPU (tests, projections)
+  HostStagedCollectives                  one rank of a torch.distributed group, collectives staged through host memory (gloo):
+                                         several PROCESSES that share one GPU
   TorchShardDriver                       one rank of a torch.distributed (RCCL) group: collectives are issued on
                                          the handle's own HIP stream, an iteration has no host synchronisation
 """
@@ -106,6 +108,47 @@ class EmulatedCollectives:
         tot = self.torch.stack(self.scal).sum(0)
         for s in self.scal:
             s.copy_(tot)
+        self.torch.cuda.synchronize()
+
+
+class HostStagedCollectives:
+    """One rank of a torch.distributed group whose collectives go through HOST memory: the rank's chunk of exchange buffer
+    0 and the two scalars of buffer 1 are copied to CPU tensors, all-gathered / all-reduced there (gloo) and copied
+    back.  For ranks that cannot use RCCL between them -- several processes that share ONE GPU (the closest thing to
+    N > 1 a one-GPU box allows: tests/test_gpu_parity.py) -- the protocol, the buffers and every kernel are the ones
+    TorchShardDriver drives over RCCL."""
+
+    def __init__(self, torch, dist, shard):
+        self.torch, self.dist, self.g = torch, dist, shard
+        self.rank, self.P = dist.get_rank(), dist.get_world_size()
+        _, n, es = shard.exchange_info(0)
+        self.xch = torch.zeros(n, dtype=torch.float64 if es == 8 else torch.float32, device="cuda")
+        shard.bind_exchange(0, self.xch.data_ptr(), self.xch.numel())
+        self.scal = torch.zeros(2, dtype=torch.float64, device="cuda")
+        shard.bind_exchange(1, self.scal.data_ptr(), 2)
+        self.chunk = n // self.P
+        self.bytes_moved = 0
+
+    def _sync(self):
+        self.torch.cuda.synchronize()   # (not PoseGraph.sync(): that would report -- and clear -- the rank's error flag early)
+
+    def all_gather_boundary(self):
+        self._sync()
+        c, r = self.chunk, self.rank
+        mine = self.xch[r * c:(r + 1) * c].cpu()
+        parts = [self.torch.empty_like(mine) for _ in range(self.P)]
+        self.dist.all_gather(parts, mine)
+        for q, t in enumerate(parts):
+            if q != r:
+                self.xch[q * c:(q + 1) * c].copy_(t)
+        self.torch.cuda.synchronize()
+        self.bytes_moved += (self.P - 1) * c * self.xch.element_size()
+
+    def all_reduce_scalars(self):
+        self._sync()
+        t = self.scal.cpu()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        self.scal.copy_(t)
         self.torch.cuda.synchronize()
 
 

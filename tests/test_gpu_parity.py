@@ -361,6 +361,61 @@ def test_failed_factorisation_is_agreed_on_by_every_rank(api):
         assert np.array_equal(np.array(g.state()), s)
 
 
+def _run_two_shard_processes(tmp_path, mode):
+    """two fresh child processes (never exec from this one: it has touched the GPU), both on device 0"""
+    import json
+    import subprocess
+    import sys
+    port = str(29700 + (os.getpid() % 2000) + (0 if mode == "lattice" else 1))
+    outs = [str(tmp_path / f"{mode}{r}.json") for r in range(2)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"), str(r), "2", port, mode, outs[r]],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            log, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(log)
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    return [json.load(open(o)) for o in outs]
+
+
+def test_two_processes_drive_a_sharded_graph_on_one_gpu(api, oracle, tmp_path):
+    """The closest thing to N > 1 this pool allows: TWO PROCESSES, each with a real world_size = 2 handle on GPU 0, driven
+    through the stage protocol with the two collectives staged through gloo on host memory (HostStagedCollectives; over
+    RCCL the same buffers go through TorchShardDriver).  The 60 x 40 lattice against the ORACLE at 1e-9: chi2 trajectory,
+    iteration count and every pose taken from the rank that owns it."""
+    from rustrobotics_amd import synthetic_grid_arrays
+    res = sorted(_run_two_shard_processes(tmp_path, "lattice"), key=lambda r: r["rank"])
+    arrays = synthetic_grid_arrays(60, 40)
+    o = oracle.from_arrays(*arrays)
+    eo = o.optimize(10)
+    for r in res:
+        assert len(r["errors"]) == len(eo)
+        np.testing.assert_allclose(r["errors"], eo, rtol=1e-9)
+        assert r["gathered_bytes"] > 0
+    assert res[0]["errors"] == res[1]["errors"] and res[0]["norms"] == res[1]["norms"]   # the all-reduced scalars are the same bits
+    owner = np.array(res[0]["owner"])
+    assert set(owner.tolist()) == {-1, 0, 1}
+    st = np.array(res[0]["state"]).reshape(-1, 3)
+    st1 = np.array(res[1]["state"]).reshape(-1, 3)
+    st[owner == 1] = st1[owner == 1]
+    assert np.array_equal(st[owner == -1], st1[owner == -1])     # the shared top separator: identical on both ranks
+    assert _state_diff_se2(st.ravel(), o.state()) <= 1e-8
+
+
+def test_two_processes_agree_on_a_failed_factorisation(api, tmp_path):
+    """... and a non-positive pivot inside ONE process's own subtree: its flag travels with its chunk of the all-gather, so
+    BOTH processes skip the update and BOTH report RR_PGO_ENOTSPD, their states untouched."""
+    res = _run_two_shard_processes(tmp_path, "notspd")
+    assert [r["code"] for r in res] == [-5, -5]
+    assert all(r["state_unchanged"] for r in res)
+
+
 def test_rank_partial_calls_are_refused_on_a_sharded_rank(api):
     """chi2 / update / assemble on ONE rank of a sharded graph would silently return that rank's share:
     RR_PGO_EUNSUPPORTED instead; stage 2 + the all-reduce is the sharded chi2."""
