@@ -593,10 +593,15 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         // one 128-byte record per ticket
         if (sharded_ || world_ > 1) throw ApiError(RR_PGO_EUNSUPPORTED, "internal: dataflow schedule on a sharded handle");
         lds_flow_ = true;
-        const int nt = (int)sym.task_ptr.size() - 1;
+        // (the dataflow step is step 0: every LDS front; fronts beyond LDS follow level by level as STEP_BIG steps)
+        if (sym.steps.empty() || sym.steps[0].kind != STEP_TASKS || sym.steps[0].task_begin != 0)
+          throw ApiError(RR_PGO_EUNSUPPORTED, "internal: the dataflow step must come first");
+        for (size_t si = 1; si < sym.steps.size(); si++)
+          if (sym.steps[si].kind != STEP_BIG) throw ApiError(RR_PGO_EUNSUPPORTED, "internal: a second LDS step behind the dataflow step");
+        const int nt = sym.steps[0].task_end;
         std::vector<int32_t> task_of(sym.S, -1);
-        for (int t = 0; t < nt; t++)
-          for (int q = sym.task_ptr[t]; q < sym.task_ptr[t + 1]; q++) task_of[sym.task_sn[q]] = t;
+        for (size_t t = 0; t + 1 < sym.task_ptr.size(); t++)
+          for (int q = sym.task_ptr[t]; q < sym.task_ptr[t + 1]; q++) task_of[sym.task_sn[q]] = (int)t;
         host_child_dep_.assign(cm.size(), -1);
         std::vector<int32_t> pdep(sym.S, -1);
         for (int f = 0; f < sym.S; f++) {
@@ -606,7 +611,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
             else if (c > f) throw ApiError(RR_PGO_EUNSUPPORTED, "internal: child after its parent in one task");
           }
           const int pf = sym.sn_parent[f];
-          if (pf >= 0 && task_of[pf] != task_of[f]) pdep[f] = sym.S + pf;
+          if (pf >= 0 && !sym.sn_big[pf] && task_of[pf] != task_of[f]) pdep[f] = sym.S + pf;   // (a parent beyond LDS was solved by an earlier launch)
         }
         child_dep_.upload(host_child_dep_);
         parent_dep_.upload(pdep);
@@ -680,7 +685,10 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     n_launches_per_iter = 2;
     for (const Step &st : sym.steps)
       n_launches_per_iter += st.kind == STEP_BIG ? count_big_launches(st) + count_big_solve_launches(st) : 2;
-    if (lds_flow_) n_launches_per_iter = 4;   // linearise, k_factor_flow, k_solve_flow, update
+    if (lds_flow_) {   // linearise, k_factor_flow, the levels of fronts beyond LDS, k_solve_flow, update
+      n_launches_per_iter = 4;
+      for (size_t si = 1; si < sym.steps.size(); si++) n_launches_per_iter += count_big_launches(sym.steps[si]) + count_big_solve_launches(sym.steps[si]);
+    }
   }
 
   ~Engine() override {
@@ -1349,8 +1357,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
                          winv_.p, flow_wfill_.p + 2 * e0);
       check_launch("k_flow_reset");
     }
-    if (lds_flow_) {
-      // every front in LDS: the whole factorisation as ONE launch of ticket-ordered tasks (lds_flow.hip.h)
+    if (lds_flow_ && from == 0 && to > 0) {
+      // every front in LDS: their whole factorisation as ONE launch of ticket-ordered tasks (lds_flow.hip.h)
       const Step &st = sym_.steps[0];
       pbegin();
       const size_t lds = (size_t)st.max_lds_elems * sizeof(T);
@@ -1365,7 +1373,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         hipLaunchKernelGGL((k_factor_flow<T, 1024>), dim3(grid), dim3(1024), lds, stream_, a, (const LdsFlowTask *)lds_ftasks_.p, lds_n_tasks_, ticket);
       check_launch("k_factor_flow");
       pend(RR_PGO_K_FACTOR);
-      return;
+      from = 1;
     }
     for (size_t si = from; si < to; si++) {
       const Step &st = sym_.steps[si];
@@ -1518,6 +1526,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   }
 
   void launch_solve() {
+    launch_solve_steps(lds_flow_ ? 1 : 0);   // the fronts beyond LDS (and, in the level schedule, everything), top down
     if (lds_flow_) {
       const Step &st = sym_.steps[0];
       pbegin();
@@ -1532,9 +1541,10 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         hipLaunchKernelGGL((k_solve_flow<T, 512>), dim3(grid), dim3(512), lds, stream_, a, (const LdsFlowTask *)lds_stasks_.p, lds_n_tasks_, ticket);
       check_launch("k_solve_flow");
       pend(RR_PGO_K_SOLVE);
-      return;
     }
-    for (int i = (int)sym_.steps.size() - 1; i >= 0; i--) {   // shared top fronts first, then this rank's subtrees
+  }
+  void launch_solve_steps(int first_step) {
+    for (int i = (int)sym_.steps.size() - 1; i >= first_step; i--) {   // shared top fronts first, then this rank's subtrees
       const Step &st = sym_.steps[i];
       const size_t lds = (size_t)step_solve_lds_[i] * sizeof(T);
       pbegin();

@@ -1297,6 +1297,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
   // Tickets are handed out in the START order of a list schedule of the task tree on n_cus workgroups (priority:
   // longest remaining path), which is a topological order: a task only ever waits for tasks with smaller tickets.
   std::vector<double> fcost, fscost, fsub, fpre;   // per front, the same for every threshold
+  std::vector<int32_t> big_level(S, -1);           // fronts beyond LDS: their level (step) in the level schedule
   auto build_flow_schedule = [&](double task_us, bool keep) {
     if (fcost.empty()) {
       fcost.resize(S); fscost.resize(S); fsub.assign(S, 0.0); fpre.resize(S);
@@ -1313,14 +1314,17 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
       }
     }
     const std::vector<double> &cost = fcost, &scost = fscost, &sub = fsub, &pre = fpre;
+    // fronts beyond LDS are not part of the launch: they sit above every LDS front (a front's parent is at least as
+    // large), run level by level behind it, and their LDS children are the roots of the launch's forest
     std::vector<char> top(S, 0);
     for (int f = 0; f < S; f++) {
-      if (sub[f] > task_us) top[f] = 1;
+      if (sym.sn_big[f] || sub[f] > task_us) top[f] = 1;
       if (top[f] && sym.sn_parent[f] >= 0) top[sym.sn_parent[f]] = 1;
     }
     std::vector<int32_t> task_of(S, -1);
     std::vector<std::vector<int32_t>> tasks;
     for (int f = 0; f < S; f++) {
+      if (sym.sn_big[f]) continue;
       if (top[f]) { task_of[f] = (int)tasks.size(); tasks.emplace_back(1, f); continue; }
       const int p = sym.sn_parent[f];
       if (p >= 0 && !top[p]) continue;   // inside a leaf subtree: its root collects it below
@@ -1332,12 +1336,12 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     for (int f = 0; f < S; f++)
       if (!top[f]) tasks[task_of[f]].push_back(f);
     const int nt = (int)tasks.size();
-    // the task tree: parent task = task of the parent of the task's last front
+    // the task forest: parent task = task of the parent of the task's last front (none: a root, or a front beyond LDS)
     std::vector<int> tparent(nt, -1), ndeps(nt, 0);
     std::vector<double> tpre(nt, 0.0), tdur(nt, 0.0), tsolve(nt, 0.0);
     for (int t = 0; t < nt; t++) {
       const int last = tasks[t].back(), p = sym.sn_parent[last];
-      if (p >= 0) { tparent[t] = task_of[p]; ndeps[task_of[p]]++; }
+      if (p >= 0 && !sym.sn_big[p]) { tparent[t] = task_of[p]; ndeps[task_of[p]]++; }
       double c = 0, sc = 0;
       for (int f : tasks[t]) { c += cost[f]; sc += scost[f]; }
       tpre[t] = top[tasks[t][0]] ? pre[tasks[t][0]] : 0.0;
@@ -1373,9 +1377,14 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
           }
         }
       }
+      // tasks whose predecessors have all been started: `later` by the time from which they would not wait, `now_ok` (those
+      // that would not wait at the current time) by the longest remaining path
       std::vector<int> pending(n_pred);
-      std::vector<int> known;   // tasks whose predecessors have all been started (small: linear scans are fine)
-      for (int t = 0; t < nt; t++) if (pending[t] == 0) known.push_back(t);
+      using Fut = std::pair<double, int>;
+      std::priority_queue<Fut, std::vector<Fut>, std::greater<Fut>> later;
+      auto less_urgent = [&](int x, int y) { return blevel[x] != blevel[y] ? blevel[x] < blevel[y] : x > y; };
+      std::priority_queue<int, std::vector<int>, decltype(less_urgent)> now_ok(less_urgent);
+      for (int t = 0; t < nt; t++) if (pending[t] == 0) later.push(Fut{ready[t] - lead[t], t});
       std::priority_queue<double, std::vector<double>, std::greater<double>> slots;
       for (int k = 0; k < P; k++) slots.push(0.0);
       order.clear();
@@ -1383,15 +1392,10 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
       for (int done = 0; done < nt; done++) {
         const double now = slots.top();
         slots.pop();
-        // among the tasks that would not wait (ready - lead <= now) the one with the longest remaining path; if every
-        // known task would wait, the one that becomes ready first
-        int best = -1;
-        for (size_t k = 0; k < known.size(); k++) {
-          const int t = known[k];
-          const bool ok_t = ready[t] - lead[t] <= now, ok_b = best >= 0 && ready[best] - lead[best] <= now;
-          if (best < 0 || (ok_t && !ok_b) || (ok_t == ok_b && (ok_t ? blevel[t] > blevel[best] : ready[t] - lead[t] < ready[best] - lead[best]))) best = t;
-        }
-        known.erase(std::find(known.begin(), known.end(), best));
+        while (!later.empty() && later.top().first <= now) { now_ok.push(later.top().second); later.pop(); }
+        int best;
+        if (!now_ok.empty()) { best = now_ok.top(); now_ok.pop(); }
+        else { best = later.top().second; later.pop(); }   // every known task would wait: the one that becomes ready first
         const double go = std::max(now + lead[best], ready[best]);
         finish[best] = go + dur[best];
         makespan = std::max(makespan, finish[best]);
@@ -1399,7 +1403,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
         order.push_back(best);
         for (int s2 : succ[best]) {
           ready[s2] = std::max(ready[s2], finish[best] + kHop);
-          if (--pending[s2] == 0) known.push_back(s2);
+          if (--pending[s2] == 0) later.push(Fut{ready[s2] - lead[s2], s2});
         }
       }
       return makespan;
@@ -1409,42 +1413,96 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     for (int t = 0; t < nt; t++)
       if (tparent[t] >= 0) { up[t].push_back(tparent[t]); down[tparent[t]].push_back(t); n_pred_solve[t] = 1; }
     std::vector<int32_t> forder, sorder;
-    const double f_us = list_schedule(up, ndeps, tpre, tdur, forder);
+    const double f_us = nt ? list_schedule(up, ndeps, tpre, tdur, forder) : 0.0;
     const std::vector<double> zero(nt, 0.0);
-    const double s_us = list_schedule(down, n_pred_solve, zero, tsolve, sorder);
-    const double crit = 1.5 + f_us + 1.5 + s_us;
+    const double s_us = nt ? list_schedule(down, n_pred_solve, zero, tsolve, sorder) : 0.0;
+    // the fronts beyond LDS, level by level behind the launch, grouped as the level schedule groups them (big_level:
+    // measured on sphere2500, fewer and wider levels -- a level = the big fronts whose big children are all in earlier
+    // ones -- cost the big-front launches 4 %); priced like the level schedule does
+    const std::vector<int32_t> &blvl = big_level;
+    int maxb = -1;
+    for (int f = 0; f < S; f++) maxb = std::max(maxb, (int)blvl[f]);
+    double crit = 1.5 + f_us + 1.5 + s_us;
+    for (int L = 0; L <= maxb; L++) {
+      double w2 = 0.0;
+      for (int f = 0; f < S; f++) if (blvl[f] == L) w2 = std::max(w2, cost[f]);
+      crit += 1.5 + w2;
+    }
     if (!keep) return crit;
     sym.task_ptr.assign(1, 0);
     sym.task_sn.clear();
     sym.steps.clear();
-    Step st{};
-    st.kind = STEP_TASKS;
-    st.sn = -1;
     std::vector<int32_t> new_id(nt, -1);
-    for (int k = 0; k < nt; k++) {
-      new_id[forder[k]] = k;
-      for (int f : tasks[forder[k]]) {
-        sym.task_sn.push_back(f);
-        st.max_front = std::max(st.max_front, sym.sn_ncols[f] + sym.sn_nrows[f] + 1);
-        st.max_lds_elems = std::max<int64_t>(st.max_lds_elems, lds_elems(sym.sn_ncols[f], sym.sn_nrows[f]));
+    if (nt > 0) {
+      Step st{};
+      st.kind = STEP_TASKS;
+      st.sn = -1;
+      for (int k = 0; k < nt; k++) {
+        new_id[forder[k]] = k;
+        for (int f : tasks[forder[k]]) {
+          sym.task_sn.push_back(f);
+          st.max_front = std::max(st.max_front, sym.sn_ncols[f] + sym.sn_nrows[f] + 1);
+          st.max_lds_elems = std::max<int64_t>(st.max_lds_elems, lds_elems(sym.sn_ncols[f], sym.sn_nrows[f]));
+        }
+        sym.task_ptr.push_back((int)sym.task_sn.size());
       }
-      sym.task_ptr.push_back((int)sym.task_sn.size());
+      st.task_end = nt;
+      {
+        const int mf = st.max_front << opt.threads_shift;
+        st.threads = mf <= 20 ? 64 : mf <= 48 ? 128 : mf <= 96 ? 256 : mf <= 128 ? 512 : 1024;
+      }
+      sym.steps.push_back(st);
     }
-    st.task_end = nt;
-    {
-      const int mf = st.max_front << opt.threads_shift;
-      st.threads = mf <= 20 ? 64 : mf <= 48 ? 128 : mf <= 96 ? 256 : mf <= 128 ? 512 : 1024;
+    for (int L = 0; L <= maxb; L++) {
+      Step b{};
+      b.kind = STEP_BIG;
+      b.sn = -1;
+      b.task_begin = (int)sym.task_ptr.size() - 1;
+      for (int f = 0; f < S; f++)
+        if (blvl[f] == L) {
+          if (!sym.sn_huge[f]) return -1.0;   // (the one-workgroup class of fronts beyond LDS has no kernel: cannot happen with panel_budget_elems == 0)
+          sym.task_sn.push_back(f);
+          sym.task_ptr.push_back((int)sym.task_sn.size());
+          b.max_front = std::max(b.max_front, sym.sn_ncols[f] + sym.sn_nrows[f] + 1);
+        }
+      b.task_end = (int)sym.task_ptr.size() - 1;
+      b.threads = 1024;
+      if (b.task_end > b.task_begin) sym.steps.push_back(b);
     }
-    sym.steps.push_back(st);
     sym.solve_order.resize(nt);
     for (int k = 0; k < nt; k++) sym.solve_order[k] = new_id[sorder[k]];
-    sym.lds_flow = true;
+    sym.lds_flow = nt > 0;
     sym.est_factor_us = f_us;
     sym.est_solve_us = s_us;
     sym.est_critical_us = crit;
     return crit;
   };
-  if (opt.lds_flow && sym.n_big == 0 && opt.n_parts <= 1 && S > 0) {
+  // (the dataflow step holds EVERY front that lives in LDS and runs before the first level of fronts beyond LDS: that needs
+  // the big fronts to sit above all LDS fronts.  A front's parent is not always the larger of the two -- a child with a
+  // wide pivot block can be beyond LDS under an LDS parent; such a tree keeps the level schedule.)
+  bool big_below_lds = false;
+  for (int f = 0; f < S && !big_below_lds; f++)
+    if (sym.sn_big[f] && sym.sn_parent[f] >= 0 && !sym.sn_big[sym.sn_parent[f]]) big_below_lds = true;
+  // ... and it pays where the LDS fronts are bound by latency, not where thousands of tasks keep every CU busy anyway (the
+  // 1M-edge lattice: 9 255 LDS fronts, 2 634 tasks in two levels -- as ONE launch of waiting workgroups 555 + 143 us against
+  // 521 + 122 us of level launches; sphere2500, 545 LDS fronts: 91 + 38 against 126 + 56 us)
+  int n_lds_fronts = 0;
+  for (int f = 0; f < S; f++) n_lds_fronts += !sym.sn_big[f];
+  if (opt.lds_flow && opt.n_parts <= 1 && S > 0 && !big_below_lds && n_lds_fronts <= 8 * opt.n_cus) {
+    if (sym.n_big > 0) {   // the levels of the fronts beyond LDS: from the level schedule
+      double best = 1e300, best_t = 90;
+      for (double t = 10.0; t < 260.0; t *= 1.12) {
+        const double c = build_schedule(t);
+        if (c < best) { best = c; best_t = t; }
+      }
+      build_schedule(best_t);
+      int L = 0;
+      for (const Step &st : sym.steps)
+        if (st.kind == STEP_BIG) {
+          for (int t = st.task_begin; t < st.task_end; t++) big_level[sym.task_sn[sym.task_ptr[t]]] = L;
+          L++;
+        }
+    }
     double best = 1e300, best_t = 40;
     if (opt.task_us > 0) best_t = opt.task_us;
     else

@@ -128,8 +128,12 @@ int main(int argc, char **argv) {
   if (y.lds_flow) {
     // the back substitution's ticket order: a permutation of the tasks in which a front's parent is solved in a task
     // with a smaller ticket, or later in the same task's (reversed) walk
-    const int nt = (int)y.task_ptr.size() - 1;
-    if (y.steps.size() != 1 || (int)y.solve_order.size() != nt) { printf("FAIL: dataflow schedule shape\n"); return 1; }
+    // step 0 = the dataflow step (every LDS front), then the levels of fronts beyond LDS
+    if (y.steps.empty() || y.steps[0].kind != STEP_TASKS || y.steps[0].task_begin != 0) { printf("FAIL: dataflow schedule shape\n"); return 1; }
+    for (size_t si = 1; si < y.steps.size(); si++)
+      if (y.steps[si].kind != STEP_BIG) { printf("FAIL: an LDS step behind the dataflow step\n"); return 1; }
+    const int nt = y.steps[0].task_end;
+    if ((int)y.solve_order.size() != nt) { printf("FAIL: dataflow schedule shape\n"); return 1; }
     std::vector<int> ticket_of(nt, -1), task_of(S, -1);
     for (int k = 0; k < nt; k++) {
       const int t = y.solve_order[k];
@@ -137,10 +141,13 @@ int main(int argc, char **argv) {
       ticket_of[t] = k;
     }
     for (int t = 0; t < nt; t++)
-      for (int q = y.task_ptr[t]; q < y.task_ptr[t + 1]; q++) task_of[y.task_sn[q]] = t;
+      for (int q = y.task_ptr[t]; q < y.task_ptr[t + 1]; q++) {
+        if (y.sn_big[y.task_sn[q]]) { printf("FAIL: a front beyond LDS in the dataflow step\n"); return 1; }
+        task_of[y.task_sn[q]] = t;
+      }
     for (int s2 = 0; s2 < S; s2++) {
       const int p2 = y.sn_parent[s2];
-      if (p2 < 0) continue;
+      if (p2 < 0 || y.sn_big[s2] || y.sn_big[p2]) continue;   // (fronts beyond LDS are solved by earlier launches)
       if (task_of[p2] != task_of[s2] && ticket_of[task_of[p2]] >= ticket_of[task_of[s2]]) { printf("FAIL: front %d is solved before its parent\n", s2); return 1; }
       if (task_of[p2] == task_of[s2] && p2 < s2) { printf("FAIL: parent before child inside a task\n"); return 1; }
     }

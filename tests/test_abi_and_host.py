@@ -312,6 +312,9 @@ def mfcheck(tmp_path_factory):
     ([g2o_path("dlr")], {"LEAF": "1000000", "FLOW": "1"}),
     ([g2o_path("input_M3500_g2o")], {"LEAF": "1000000", "LDS": "19000", "FLOW": "1"}),
     ([g2o_path("simulation-pose-landmark")], {"LEAF": "1000000", "FLOW": "1"}),
+    (["grid", "100", "100"], {"LEAF": "48", "LDS": "38000", "FLOW": "1"}),            # dataflow step + levels of fronts beyond LDS
+    ([g2o_path("sphere2500")], {"LEAF": "1000", "LDS": "19000", "FLOW": "1"}),
+    ([g2o_path("intel")], {"LEAF": "40", "FLOW": "1", "FLOW_OPTIONAL": "1"}),         # a front beyond LDS under an LDS parent: level schedule
     (["grid", "60", "40"], {"LEAF": "64", "PARTS": "2"}),           # rank-owned subtrees + shared top
     (["grid", "60", "40"], {"LEAF": "64", "PARTS": "4"}),
     (["grid", "100", "100"], {"LEAF": "64", "PARTS": "8"}),
