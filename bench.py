@@ -158,6 +158,9 @@ def roofline_of(g, workload, precision, prof_iters=20):
     per_iter_us = {k: 1e3 * v[0] / prof_iters for k, v in prof.items()}
     class_bytes = {"linearize": stats["bytes_linearize"], "factor": stats["bytes_factor"],
                    "solve": stats["bytes_solve"], "update": stats["bytes_update"]}
+    kernel_of = dict(KERNEL_OF)
+    if stats.get("lds_dataflow"):   # the LDS fronts as ONE dataflow launch each (lds_flow.hip.h)
+        kernel_of.update(factor="k_factor_flow", solve="k_solve_flow")
     dom = max((k for k in per_iter_us if k != "reduce"), key=lambda k: per_iter_us[k])
     n_launch = prof[dom][1] / prof_iters
     dom_us = per_iter_us[dom]
@@ -167,7 +170,7 @@ def roofline_of(g, workload, precision, prof_iters=20):
         dom_flops = stats["big_update_flops"] if dom == "big_update" else stats["big_flow_flops"]
         achieved = dom_flops / (dom_us * 1e-6) / 1e12
         peak = MFMA_PEAK_TFLOPS[precision]
-        roofline = {"bound": "mfma", "kernel": KERNEL_OF[dom], "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+        roofline = {"bound": "mfma", "kernel": kernel_of[dom], "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                     "frac": achieved / peak, "traffic": None, "launches_per_step": n_launch,
                     "avg_launch_us": dom_us / max(n_launch, 1),
                     "algorithmic_flops_per_launch": dom_flops / max(n_launch, 1),
@@ -176,7 +179,7 @@ def roofline_of(g, workload, precision, prof_iters=20):
         # fronts beyond LDS share the factor/solve byte budget with the LDS fronts
         nbytes = class_bytes.get(dom, stats["bytes_solve"] if dom == "big_solve" else stats["bytes_factor"])
         achieved = nbytes / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
-        roofline = {"bound": "hbm", "kernel": KERNEL_OF[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        roofline = {"bound": "hbm", "kernel": kernel_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "launches_per_step": n_launch,
                     "avg_launch_us": dom_us / max(n_launch, 1),
                     "algorithmic_bytes_per_launch": nbytes / max(n_launch, 1),

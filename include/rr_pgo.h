@@ -186,7 +186,8 @@ typedef struct rr_pgo_stats {
                               * in-place M x M front) -- NOT what bytes_factor / bytes_solve are computed from: those follow
                               * SURVEY 8(d), nnzblk(L) * d^2 * s, every datum moved once */
   int32_t abi_version;       /* RR_PGO_ABI_VERSION of the library that filled the struct */
-  int32_t reserved;
+  int32_t lds_dataflow;      /* 1: the fronts that live in LDS are factored and solved by the two dataflow launches
+                              * (k_factor_flow / k_solve_flow), 0: by one launch per level of the task tree */
 } rr_pgo_stats;
 int rr_pgo_get_stats(const rr_pgo *h, rr_pgo_stats *out);
 

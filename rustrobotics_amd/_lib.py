@@ -54,7 +54,7 @@ class Stats(C.Structure):
         ("analyze_ms", C.c_double), ("parse_ms", C.c_double),
         ("bytes_linearize", C.c_double), ("bytes_factor", C.c_double), ("bytes_solve", C.c_double),
         ("bytes_update", C.c_double), ("bytes_chi2", C.c_double), ("big_update_flops", C.c_double),
-        ("big_flow_flops", C.c_double), ("stored_factor_bytes", C.c_double), ("abi_version", C.c_int32), ("reserved", C.c_int32),
+        ("big_flow_flops", C.c_double), ("stored_factor_bytes", C.c_double), ("abi_version", C.c_int32), ("lds_dataflow", C.c_int32),
     ]
 
 

@@ -2240,6 +2240,7 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
   s.analyze_ms = t1 - t0;
   s.parse_ms = parse_ms;
   s.abi_version = RR_PGO_ABI_VERSION;
+  s.lds_dataflow = y.lds_flow ? 1 : 0;
   // algorithmic bytes per GN iteration, SURVEY.md 8(d): every datum moved once.  The factor is priced at its NONZEROS,
   // nnzblk(L) * d^2 scalars (Symbolic::nnz_l_entries) -- written once by the factorisation, read by the forward and by
   // the backward substitution -- not at what is stored: the supernodal panels carry padding and a front beyond LDS keeps

@@ -68,6 +68,7 @@ if hasattr(L, 'rr_pgo_debug_ptrace'):
     raw = np.zeros((S, 1280))
     L.rr_pgo_debug_ptrace(g._h, raw.ctypes.data_as(C.POINTER(C.c_double)))
     pt = raw[:, :128].reshape(S, 16, 8)
+    if not pt.any(): sys.exit(0)   # (a build without panel_flow: no chain stamps)
     wt = raw[:, 128:1152].reshape(S, 16, 8, 8)
     names = ['W seen', 'X formed', 'X publ', 'D done', 'slot free', 'rows in', 'sweep', 'W publ']
     print('panel_flow chain, per pivot block (ns since the previous block\'s W was published; block 0: since its own D):')

@@ -37,7 +37,7 @@ doc = {"_comment": f"HBM-side traffic per launch of the dominant kernel class, f
                    "coalesced reads by exactly 2x on gfx950 -> doubled; our loads are 4-8 B/lane, a width the guide calls uncalibrated, so "
                    "treat the read half as an upper-side estimate. bench.py copies the entry of the matching workload + kernel into "
                    "roofline.traffic and marks it as offline."}
-doc["intel:f64"] = entry("intel", ["k_factor_tasks"], "k_factor_tasks")
+doc["intel:f64"] = entry("intel", ["k_factor_flow"], "k_factor_flow") or entry("intel", ["k_factor_tasks"], "k_factor_tasks")
 doc["grid:400x250:1000000:f32"] = entry("grid", ["k_big_flow"], "k_big_flow", grid_iters)
 doc["grid:400x250:1000000:f32:k_big_update"] = entry("grid", ["k_big_update", "k_big_schur"], "k_big_update+k_big_schur", grid_iters)
 doc["grid:400x250:1000000:f32:k_big_update"]["note"] = (

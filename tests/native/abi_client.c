@@ -30,7 +30,7 @@ _Static_assert(offsetof(rr_pgo_graph_desc, node_kind) == 8 && offsetof(rr_pgo_gr
 _Static_assert(sizeof(rr_pgo_stats) == 3 * 8 + 6 * 4 + 10 * 8 + 2 * 4, "rr_pgo_stats");
 _Static_assert(offsetof(rr_pgo_stats, analyze_ms) == 48 && offsetof(rr_pgo_stats, big_update_flops) == 104 &&
                    offsetof(rr_pgo_stats, big_flow_flops) == 112 && offsetof(rr_pgo_stats, stored_factor_bytes) == 120 &&
-                   offsetof(rr_pgo_stats, abi_version) == 128 && offsetof(rr_pgo_stats, reserved) == 132,
+                   offsetof(rr_pgo_stats, abi_version) == 128 && offsetof(rr_pgo_stats, lds_dataflow) == 132,
                "rr_pgo_stats field offsets");
 
 #define FIELD(S, f) printf(#S " " #f " %zu %zu\n", offsetof(S, f), sizeof(((S *)0)->f))
@@ -52,7 +52,7 @@ static int print_layout(void) {
   FIELD(rr_pgo_stats, analyze_ms); FIELD(rr_pgo_stats, parse_ms); FIELD(rr_pgo_stats, bytes_linearize);
   FIELD(rr_pgo_stats, bytes_factor); FIELD(rr_pgo_stats, bytes_solve); FIELD(rr_pgo_stats, bytes_update);
   FIELD(rr_pgo_stats, bytes_chi2); FIELD(rr_pgo_stats, big_update_flops); FIELD(rr_pgo_stats, big_flow_flops);
-  FIELD(rr_pgo_stats, stored_factor_bytes); FIELD(rr_pgo_stats, abi_version); FIELD(rr_pgo_stats, reserved);
+  FIELD(rr_pgo_stats, stored_factor_bytes); FIELD(rr_pgo_stats, abi_version); FIELD(rr_pgo_stats, lds_dataflow);
   printf("enum RR_PGO_NUM_KCLASS %d 0\n", (int)RR_PGO_NUM_KCLASS);
   printf("enum RR_PGO_ABI_VERSION %d 0\n", (int)RR_PGO_ABI_VERSION);
   return 0;
