@@ -1214,26 +1214,87 @@ template <typename T, int K, int J> struct Chol16Upd2 {
 template <typename T, int K> struct Chol16Upd2<T, K, 16> {
   static __device__ __forceinline__ void run(T (&)[16], T, T) {}
 };
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// 1/sqrt(d) in five stages (the operations of chain_rsqrt, one dependent step each), so that the sweep can put a few of a
+// column's multiply-adds between two stages: a wave issues in order, and the inline-assembly multiply-adds are scheduling
+// barriers to the compiler -- what is not interleaved in the source is not interleaved at all.
+template <typename T> struct RsqStages;
+template <> struct RsqStages<double> {
+  double d, y, hy, e, t, u;
+  __device__ __forceinline__ void s0(double dd) { d = dd; y = __builtin_amdgcn_rsq(d); }
+  __device__ __forceinline__ void s1() { hy = d * y; }
+  __device__ __forceinline__ void s2() { e = __builtin_fma(-hy, y, 1.0); }
+  __device__ __forceinline__ void s3() { t = __builtin_fma(0.375, e, 0.5); u = y * e; }
+  __device__ __forceinline__ double s4() { return __builtin_fma(u, t, y); }
+};
+template <> struct RsqStages<float> {
+  float d, y, hy, e;
+  __device__ __forceinline__ void s0(float dd) { d = dd; y = __builtin_amdgcn_rsqf(d); }
+  __device__ __forceinline__ void s1() { hy = 0.5f * d * y; }
+  __device__ __forceinline__ void s2() { e = __builtin_fmaf(-hy, y, 1.5f); }
+  __device__ __forceinline__ void s3() {}
+  __device__ __forceinline__ float s4() { return y * e; }
+};
+template <typename T, int K, int J, int JE> struct Chol16UpdR {   // the multiply-adds of column K for the entries J .. JE - 1
+  static __device__ __forceinline__ void run(T (&x)[16], T nb, T l) {
+    if constexpr (J < JE && J < 16) {
+      if constexpr (J > K) fmac_bcast<J>(x[J], nb, l);
+      Chol16UpdR<T, K, J + 1, JE>::run(x, nb, l);
+    }
+  }
+};
 template <typename T, int K> struct Chol16Col2 {
-  static __device__ __forceinline__ void run(T (&x)[16], bool &bad) {
-    const T d = lane_bcast(x[K], K);
-    bad = bad || !(d > (T)0);
-    const T l = x[K] * chain_rsqrt(d);   // block rows: L(q, K) (garbage above the diagonal, see chol16_dpp); identity rows: their multiplier
+  // inv = 1 / sqrt(pivot K), already formed while column K - 1 was being applied
+  static __device__ __forceinline__ void run(T (&x)[16], T inv, int ncols, bool &bad) {
+    if (K >= ncols) return;   // (columns past a partial block are identity columns: sweeping them changes nothing)
+    const T l = x[K] * inv;   // block rows: L(q, K) (garbage above the diagonal, see chol16_dpp); identity rows: their multiplier
     x[K] = l;
     T nb = even_rows_to_odd<true>(l);    // -L(., K) in both rows of every pair
     asm volatile("s_nop 1" : "+v"(nb));  // VALU write -> DPP read of the same register
-    Chol16Upd2<T, K, K + 1>::run(x, nb, l);
-    Chol16Col2<T, K + 1>::run(x, bad);
+    T invn = (T)1;
+    if constexpr (K + 1 < 16) {
+      // The NEXT pivot ahead of this column's update: d' = x[K+1](K+1) - L(K+1, K)^2 from two broadcast values, rounded
+      // exactly as the multiply-add below rounds that entry; its 1/sqrt is formed in stages BETWEEN the column's
+      // multiply-adds, so the chain of a column is multiply -> FMA -> rsqrt stages and the fifteen multiply-adds, the row
+      // copy and the wait states fill its latencies instead of following it.
+      const T la = lane_bcast(l, K + 1), b = lane_bcast(x[K + 1], K + 1);
+      const T dn = fma_t(-la, la, b);
+      bad = bad || !(dn > (T)0);
+      RsqStages<T> r;
+      __builtin_amdgcn_sched_barrier(0);
+      r.s0(dn);
+      __builtin_amdgcn_sched_barrier(0);
+      Chol16UpdR<T, K, K + 1, K + 4>::run(x, nb, l);
+      __builtin_amdgcn_sched_barrier(0);
+      r.s1();
+      __builtin_amdgcn_sched_barrier(0);
+      Chol16UpdR<T, K, K + 4, K + 7>::run(x, nb, l);
+      __builtin_amdgcn_sched_barrier(0);
+      r.s2();
+      __builtin_amdgcn_sched_barrier(0);
+      Chol16UpdR<T, K, K + 7, K + 10>::run(x, nb, l);
+      __builtin_amdgcn_sched_barrier(0);
+      r.s3();
+      __builtin_amdgcn_sched_barrier(0);
+      Chol16UpdR<T, K, K + 10, K + 13>::run(x, nb, l);
+      __builtin_amdgcn_sched_barrier(0);
+      invn = r.s4();
+      __builtin_amdgcn_sched_barrier(0);
+      Chol16UpdR<T, K, K + 13, 16>::run(x, nb, l);
+    }
+    Chol16Col2<T, K + 1>::run(x, invn, ncols, bad);
   }
 };
 template <typename T> struct Chol16Col2<T, 16> {
-  static __device__ __forceinline__ void run(T (&)[16], bool &) {}
+  static __device__ __forceinline__ void run(T (&)[16], T, int, bool &) {}
 };
 // lanes (mod 32) 0..15: row q of the block in, row q of L out (GARBAGE above the diagonal); lanes 16..31: row q of an
-// identity in, x[c] = W(c, q) out
-template <typename T> __device__ __forceinline__ bool chol16_dpp2(T (&x)[16]) {
-  bool bad = false;
-  Chol16Col2<T, 0>::run(x, bad);
+// identity in, x[c] = W(c, q) out.  ncols < 16: the block is padded with an identity from column ncols on.
+template <typename T> __device__ __forceinline__ bool chol16_dpp2(T (&x)[16], int ncols = 16) {
+  const T d0 = lane_bcast(x[0], 0);
+  bool bad = !(d0 > (T)0);
+  Chol16Col2<T, 0>::run(x, chain_rsqrt(d0), ncols, bad);
   return bad;
 }
 
@@ -1351,7 +1412,7 @@ __device__ __forceinline__ void diag16_factor_invert_part(T *P, int M, int k0, i
     x[c] = *pc;
   }
 #if RRPGO_DPP_SWEEP == 2
-  const bool bad = chol16_dpp2<T>(x);
+  const bool bad = chol16_dpp2<T>(x, nb);
 #else
   const bool bad = chol16_invert<T>(x, ll);
 #endif
@@ -2338,7 +2399,7 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
     for (int c = 0; c < 16; c++) x[c] = src[c * sstride];
   }
 #if RRPGO_DPP_SWEEP == 2
-  bad = chol16_dpp2<T>(x);   // (leaves garbage above the diagonal of L: zeroed on the way out, the images below rely on it)
+  bad = chol16_dpp2<T>(x, min(nb, 16));   // (leaves garbage above the diagonal of L: zeroed on the way out, the images below rely on it)
 #pragma unroll
   for (int c = 0; c < 16; c++) x[c] = (rowlane && c > q) ? (T)0 : x[c];
 #else
@@ -2380,7 +2441,7 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
     for (int c = 0; c < 16; c++) x[c] = src[c * sstride];
   }
 #if RRPGO_DPP_SWEEP == 2
-  bad = chol16_dpp2<T>(x) || bad;
+  bad = chol16_dpp2<T>(x, max(nb - 16, 0)) || bad;
 #pragma unroll
   for (int c = 0; c < 16; c++) x[c] = (rowlane && c > q) ? (T)0 : x[c];
 #else
