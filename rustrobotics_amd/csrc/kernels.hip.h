@@ -844,6 +844,7 @@ template <typename T> struct FactorArgs {
   unsigned *dep_flags;         // [0, S): factor flags, [S, 2 S): solve flags; zeroed before every factorisation
   int parent_dep_self;         // S: a front's own solve flag is dep_flags[S + s]
   unsigned long long wait_ticks;   // bound of one wait, 100 MHz ticks
+  int solve_lds;                   // k_solve_flow: scalars of dynamic LDS (decides, front by front, whether its L11 image fits)
 };
 
 // ---- hand-offs between workgroups of ONE launch (lds_flow.hip.h; flow.hip.h has the same policy for the fronts beyond
@@ -3115,6 +3116,18 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (NT == 4 ? 
   big_update_tile<T, NT, 1, false, true>(a.lvals + m.loff, M, 0, m.nc, M, I0, J0, smem, acc, nullptr, false, tg);
 }
 
+// a0 / a1 += v[lane k of the 16-lane row] * op[k] over the even / odd k = K .. 15: a 16 x 16 matrix-vector product with the
+// vector spread over the lanes of a row and lane m holding column m of the matrix, sixteen DPP multiply-adds in two chains
+template <typename T, int K> struct BcastDot16 {
+  static __device__ __forceinline__ void run(T &a0, T &a1, T v, const T (&op)[16]) {
+    fmac_bcast<K>((K & 1) ? a1 : a0, v, op[K]);
+    BcastDot16<T, K + 1>::run(a0, a1, v, op);
+  }
+};
+template <typename T> struct BcastDot16<T, 16> {
+  static __device__ __forceinline__ void run(T &, T &, T, const T (&)[16]) {}
+};
+
 // Back substitution for one supernode:
 //   x1 = L11^-T ( y1 - L21^T x[rows] ),  y1 = the rhs row of the factored panel.
 // STAGE (fronts of the LDS path): L11 is staged into LDS TRANSPOSED with an odd
@@ -3134,43 +3147,57 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *w
   const T *Lg = a.lvals + m.loff;
   const int32_t *rows = a.sn_rows + m.rows_ptr;
   if (STAGE) {
-    T *x2 = work;                 // nr
-    T *t1 = x2 + nr;              // nc
-    using MM = Mfma16<T>;
     constexpr int NW = THREADS / 64;
     const int wave = wave_index(), lane = tid & 63, l16 = lane & 15;
-    const int nblk = (nc + 15) >> 4;
-    int kr[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) kr[r] = MM::row(lane, r);
-    // a-operand of x = W^T u: A[m = l16][k-slot r] = W(kr[r], l16) = winv[kr[r] * 16 + l16]; three blocks in flight
-    const T *Wg = a.winv + (int64_t)m.wblk * 256 + l16;
-    T w0[4], w1[4], w2[4];
-    // a-operand of u = t_b - L(b+1, b)^T x_(b+1): -L(16 (b+1) + k, 16 b + m), m = l16; rows clamped into the front
-    T la0[4], la1[4];
-    auto lblock = [&](int b, T (&dst)[4]) {   // operand block of chain step b (uses block b + 1), b clamped
-      const int bc = max(min(b, nblk - 2), 0);
-      const T *col = Lg + (int64_t)(16 * bc + l16) * M + 16 * bc + 16;
-      const int cwn = nc - (16 * bc + 16);   // >= 1 when nblk >= 2
-#pragma unroll
-      for (int r = 0; r < 4; r++) dst[r] = col[max(min(kr[r], cwn - 1), 0)];
-    };
-    auto chain_preload = [&] {   // operands of the first chain steps (wave 0): nothing here depends on x
-      if (wave == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          w0[r] = Wg[(nblk - 1) * 256 + kr[r] * 16];
-          w1[r] = Wg[max(nblk - 2, 0) * 256 + kr[r] * 16];
-          w2[r] = Wg[max(nblk - 3, 0) * 256 + kr[r] * 16];
-        }
-        if (nblk >= 2) {
-          lblock(nblk - 2, la0);
-          lblock(nblk - 3, la1);
-        }
-      }
-    };
+    const int nblk = (nc + 15) >> 4, ncp = 16 * nblk;
+    T *x2 = work;                      // nr
+    T *t1 = x2 + ((nr + 3) & ~3);      // 16 nblk (t, then x; zero past nc: a partial last block needs no masks), 16-byte aligned
+    // The chain and the fold read L11 and the W blocks from an LDS image when the launch has the room for the front's
+    // (a.solve_lds; column j at Ll + j ldl, ldl odd, rows padded with zeros to whole blocks; W_b TRANSPOSED in the place
+    // of the diagonal block b, which nobody reads).  In k_solve_flow it is staged while the front waits for its parent;
+    // a chain step then makes no trip to memory.
+    T *Ll = t1 + ncp;
+    const int ldl = ncp + 1;
+    const bool img = ((nr + 3) & ~3) + ncp + ncp * ldl + 2 <= a.solve_lds;
     __syncthreads();
     RRPGO_STAMP_SOLVE(a, s, 0);
+    if (tid < ncp - nc) t1[nc + tid] = (T)0;
+    if (img) {
+      constexpr int SB = 8;   // columns a wave has in flight
+      const bool two = ncp > 64;
+      for (int j0 = wave; j0 < nc; j0 += NW * SB) {
+        T v[SB][2];
+#pragma unroll
+        for (int u = 0; u < SB; u++) {
+          const T *col = Lg + (int64_t)min(j0 + NW * u, nc - 1) * M;
+          v[u][0] = col[min(lane, nc - 1)];
+          if (two) v[u][1] = col[min(lane + 64, nc - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < SB; u++) {
+          const int j = j0 + NW * u;
+          if (j < nc) {
+            if (lane < ncp && (lane >> 4) > (j >> 4)) Ll[j * ldl + lane] = lane < nc ? v[u][0] : (T)0;
+            if (two && lane + 64 < ncp && ((lane + 64) >> 4) > (j >> 4)) Ll[j * ldl + lane + 64] = lane + 64 < nc ? v[u][1] : (T)0;
+          }
+        }
+      }
+      for (int j = wave; j < nc; j += NW)   // fronts wider than 128 columns
+        for (int i = lane + 128; i < ncp; i += 64)
+          if ((i >> 4) > (j >> 4)) Ll[j * ldl + i] = i < nc ? Lg[(int64_t)j * M + i] : (T)0;
+      const T *Wsrc = a.winv + (int64_t)m.wblk * 256;
+      for (int i0 = tid; i0 < nblk * 256; i0 += 4 * THREADS) {
+        T v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = Wsrc[min(i0 + u * THREADS, nblk * 256 - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + u * THREADS;
+          const int cb = 16 * (i >> 8), wk = (i >> 4) & 15, wm = i & 15;   // W_b(k, m) -> image (row 16 b + k, column 16 b + m)
+          if (i < nblk * 256) Ll[(cb + wm) * ldl + cb + wk] = v[u];
+        }
+      }
+    }
     // The loads of the L21^T x2 product do not depend on x2: when the shape allows (nr <= 128, at most GV
     // columns per wave) a wave requests all of them before anything else, so that one memory round trip
     // is hidden under the gather of x2 instead of one per group of four columns after it.
@@ -3190,7 +3217,6 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *w
         }
     }
     if constexpr (FLOW) {
-      chain_preload();
       const int pdep = a.parent_dep[s];
       if (pdep >= 0) dep_wait(a.dep_flags + pdep, a.err, a.wait_ticks);   // every wave for itself; the barrier below joins them
     }
@@ -3241,88 +3267,123 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *w
     }
     // L11^T x = t, backward, by 16-column blocks with the inverse diagonal blocks W_b = L_bb^-1:
     //   x_b = W_b^T ( t_b - sum_{b' > b} L(b', b)^T x_b' ).
-    // The first wave runs the chain on the matrix cores with every vector in BROADCAST FORM: register s of
-    // lane (lk, li) holds entry MM::row(lane, s) of the vector, the same in all 16 columns li.  That is at
-    // once the accumulator layout of a 16 x 16 result with equal columns and the b-operand layout of the next
-    // product (k-slot = MM::row), so  u = t_b - L(b+1, b)^T x_(b+1)  and  x_b = W_b^T u  are eight dependent
-    // MFMAs with no lane broadcast in between (the v_readlane version spent ~100 instructions per block).
-    // The other waves fold the finished block into everything two or more blocks to its left, one barrier
-    // behind; so there is one barrier per 16 columns and nobody writes an entry somebody else is reading.
-    // L11 is read straight from global memory (no LDS image): the chain wave keeps the operand blocks of the
-    // next two steps in flight like W, a fold thread owns one column i and requests its 16 contiguous
-    // entries L(c0.., i) BEFORE the barrier that releases the block -- no address depends on x.
-    {
-      if constexpr (!FLOW) chain_preload();
+    // The first wave runs the chain: a vector lives spread over the 16 lanes of a row (the four rows of the wave
+    // compute the same), lane m holds column m of the operand block, and a 16 x 16 product is sixteen DPP
+    // multiply-adds (v_fmac row_newbcast, two chains of eight):
+    //   u = t_b - L(b+1, b)^T x_(b+1),   la[k] = L(16 (b+1) + k, 16 b + m)
+    //   x_b = W_b^T u,                   wv[k] = W_b(k, m)
+    // (the matrix cores need eight DEPENDENT v_mfma per step, ~100 clocks each in fp64).  The other waves fold the
+    // finished block into everything two or more blocks to its left, one barrier behind: a fold thread owns one
+    // column i, requests its 16 contiguous entries L(c0.., i) BEFORE the barrier that releases the block -- no
+    // address depends on x -- and reads x_b with vector loads; four partial sums keep its dependent chain short.
+    // So there is one barrier per 16 columns and nobody writes an entry somebody else is reading.
+    auto chain = [&](auto img_c) {
+      constexpr bool IMG = decltype(img_c)::value;
+      const T *Wg = a.winv + (int64_t)m.wblk * 256 + l16;
+      T la[16], wv[16];
+      auto lblock = [&](int b, T (&dst)[16]) {   // operand block of chain step b (uses block b + 1), b clamped
+        const int bc = max(min(b, nblk - 2), 0);
+        if constexpr (IMG) {
+          const T *col = Ll + (16 * bc + l16) * ldl + 16 * bc + 16;
+#pragma unroll
+          for (int k = 0; k < 16; k++) dst[k] = col[k];
+        } else {
+          const T *col = Lg + (int64_t)(16 * bc + l16) * M + 16 * bc + 16;
+          const int cwn = nc - (16 * bc + 16);   // >= 1 when nblk >= 2; rows clamped into the front: they meet x = 0
+#pragma unroll
+          for (int k = 0; k < 16; k++) dst[k] = col[max(min(k, cwn - 1), 0)];
+        }
+      };
+      auto wblock = [&](int b, T (&dst)[16]) {   // W operand of chain step b, b clamped
+        const int bc = max(b, 0);
+        if constexpr (IMG) {
+          const T *col = Ll + (16 * bc + l16) * ldl + 16 * bc;
+#pragma unroll
+          for (int k = 0; k < 16; k++) dst[k] = col[k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 16; k++) dst[k] = Wg[bc * 256 + k * 16];
+        }
+      };
+      const bool chainer = wave == 0 && lane < 16;   // one 16-lane row carries the chain
+      auto chain_preload = [&] {   // operands of the first chain step: nothing here depends on x
+        if (chainer) {
+          wblock(nblk - 1, wv);
+          if (nblk >= 2) lblock(nblk - 2, la);
+        }
+      };
+      if constexpr (!IMG) chain_preload();   // from memory: in flight across the barrier
       __syncthreads();
+      if constexpr (IMG) {
+        chain_preload();
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the loop below starts with nothing of its own in flight
+      }
       RRPGO_STAMP_SOLVE(a, s, 2);
-      typename MM::Acc xprev = {0, 0, 0, 0};
+      T xprev = 0;
       const int fi = NW == 1 ? tid : tid - 64;            // the fold thread's column
       constexpr int FSTRIDE = NW == 1 ? THREADS : THREADS - 64;
+      using XV = T __attribute__((ext_vector_type(16 / sizeof(T))));
+      constexpr int XE = 16 / sizeof(T);
       for (int b = nblk - 1; b >= 0; b--) {
         const int c0 = 16 * b, cw = min(16, nc - c0);
         const int lim = c0 - 16;
         T fl[16];
         const bool folder = (NW == 1 || wave > 0) && fi >= 0 && fi < lim;
-        if (NW > 1 && folder) {   // requested before the barrier
-          const T *lcol = Lg + (int64_t)fi * M + c0;
+        auto fold_operands = [&] {
+          if constexpr (IMG) {
+            const T *lcol = Ll + fi * ldl + c0;
 #pragma unroll
-          for (int j = 0; j < 16; j++) fl[j] = lcol[min(j, cw - 1)];
-        }
-        if (wave == 0) {
-          typename MM::Acc v;
+            for (int j = 0; j < 16; j++) fl[j] = lcol[j];
+          } else {
+            const T *lcol = Lg + (int64_t)fi * M + c0;
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const T tv = pin(t1[c0 + min(kr[r], cw - 1)]);
-            v[r] = kr[r] < cw ? tv : (T)0;
+            for (int j = 0; j < 16; j++) fl[j] = lcol[min(j, cw - 1)];   // past the block's width: meets x = 0
           }
+        };
+        if (NW > 1 && folder) fold_operands();   // requested before the barrier
+        if (chainer) {
+          T u = t1[c0 + l16];
           if (b + 1 < nblk) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) v = MM::mma(-la0[r], xprev[r], v);   // xprev is zero past the block's width
-#pragma unroll
-            for (int r = 0; r < 4; r++) la0[r] = la1[r];
-            lblock(b - 2, la1);
+            T a0 = 0, a1 = 0;
+            asm volatile("s_nop 1" : "+v"(xprev));   // VALU write -> DPP read of the same register
+            BcastDot16<T, 0>::run(a0, a1, xprev, la);   // xprev is zero past the block's width
+            u -= a0 + a1;
+            lblock(b - 1, la);
           }
-          typename MM::Acc x = {0, 0, 0, 0};
-#pragma unroll
-          for (int r = 0; r < 4; r++) x = MM::mma(w0[r], v[r], x);
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            x[r] = kr[r] < cw ? x[r] : (T)0;
-            if (l16 == 0 && kr[r] < cw) t1[c0 + kr[r]] = x[r];
-          }
+          T x0 = 0, x1 = 0;
+          asm volatile("s_nop 1" : "+v"(u));
+          BcastDot16<T, 0>::run(x0, x1, u, wv);
+          T x = x0 + x1;
+          x = l16 < cw ? x : (T)0;
+          t1[c0 + lane] = x;
           xprev = x;
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            w0[r] = w1[r];
-            w1[r] = w2[r];
-            w2[r] = Wg[max(b - 3, 0) * 256 + kr[r] * 16];
-          }
+          wblock(b - 1, wv);
         }
         __syncthreads();
         if (NW == 1 || wave > 0) {
-          if (NW == 1 && folder) {
-            const T *lcol = Lg + (int64_t)fi * M + c0;
-#pragma unroll
-            for (int j = 0; j < 16; j++) fl[j] = lcol[min(j, cw - 1)];
-          }
+          if (NW == 1 && folder) fold_operands();
           if (folder) {
-            T tv = t1[fi];
+            const XV *xp = reinterpret_cast<const XV *>(t1 + c0);
+            T p[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-              const T xj = t1[c0 + min(j, cw - 1)];
-              tv -= fl[j] * (j < cw ? xj : (T)0);
+            for (int q = 0; q < 16 / XE; q++) {
+              const XV xv = xp[q];
+#pragma unroll
+              for (int e = 0; e < XE; e++) p[(q * XE + e) & 3] += fl[q * XE + e] * xv[e];
             }
-            t1[fi] = tv;
+            t1[fi] -= (p[0] + p[1]) + (p[2] + p[3]);
           }
           for (int i = fi + FSTRIDE; i < lim; i += FSTRIDE) {   // fronts wider than the workgroup (not on the LDS path today)
-            const T *lcol = Lg + (int64_t)i * M + c0;
+            const T *lcol = IMG ? Ll + i * ldl + c0 : Lg + (int64_t)i * M + c0;
             T tv = t1[i];
             for (int j = 0; j < cw; j++) tv -= lcol[j] * t1[c0 + j];
             t1[i] = tv;
           }
         }
       }
-    }
+    };
+    if (img) chain(std::true_type{});
+    else chain(std::false_type{});
     __syncthreads();
     RRPGO_STAMP_SOLVE(a, s, 3);
     for (int j = tid; j < nc; j += THREADS) mem_st<FLOW>(a.x + m.col0 + j, t1[j]);

@@ -303,6 +303,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<unsigned> dep_flags_;      // [0, S) factor flags, [S, 2 S) solve flags, then the two tickets on lines of their own, then a word nobody sets
   DevBuf<LdsFlowTask> lds_ftasks_, lds_stasks_;
   int lds_n_tasks_ = 0, lds_flow_cus_ = 256;
+  bool solve_image_ = false;   // level schedule: L11 images in LDS for the back substitution too (RR_PGO_SOLVE_IMAGE)
   unsigned long long wait_ticks_ = 200000000ull;   // bound of one in-launch wait: 2 s of the 100 MHz wall clock (RR_PGO_FLOW_TIMEOUT_MS)
   // failure injection (rr_pgo_debug_withhold): what was changed, to put it back
   int withheld_child_ = -1, withheld_parent_ = -1, withheld_level_ = -1, withheld_task_ = -1;
@@ -587,6 +588,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       winv_.alloc((size_t)wblk_total * 256 + 4);
       winv_.zero();
       child_meta_.upload(cm);
+      if (const char *e = getenv("RR_PGO_SOLVE_IMAGE")) solve_image_ = atoi(e) != 0;
       if (const char *e = getenv("RR_PGO_FLOW_TIMEOUT_MS")) wait_ticks_ = (unsigned long long)std::max(1.0, std::atof(e) * 1e5);
       if (sym.lds_flow) {
         // dataflow launches of the LDS fronts: who waits for whom (a dependency inside one task needs no flag), and
@@ -664,7 +666,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           for (int q = sym.task_ptr[t]; q < sym.task_ptr[t + 1]; q++) {
             int s = sym.task_sn[q], nc = sym.sn_ncols[s], nr = sym.sn_nrows[s];
             if (nc > 256) throw ApiError(RR_PGO_EUNSUPPORTED, "internal: LDS-path supernode wider than 256 columns");
-            need = std::max(need, nc * (nc | 1) + nr + nc + 2);
+            // x[rows] and t, padded as solve_front lays them out; k_solve_flow adds an LDS image of L11 where it fits
+            const int ncp = (nc + 15) / 16 * 16, base = ((nr + 3) & ~3) + ncp + 2;
+            const int cap = (int)((size_t)kMaxLds / sizeof(T));
+            const bool image = (sym.lds_flow && &st == &sym.steps[0]) || solve_image_;
+            need = std::max(need, image && base + ncp * (ncp + 1) <= cap ? base + ncp * (ncp + 1) : base);
           }
       } else {
         for (int t = st.task_begin; t < st.task_end; t++) {
@@ -1276,6 +1282,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     a.dep_flags = dep_flags_.p;
     a.parent_dep_self = sym_.S;
     a.wait_ticks = wait_ticks_;
+    a.solve_lds = 0;
     return a;
   }
 
@@ -1531,7 +1538,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       const Step &st = sym_.steps[0];
       pbegin();
       const size_t lds = (size_t)step_solve_lds_[0] * sizeof(T);
-      const FactorArgs<T> a = factor_args(0);
+      FactorArgs<T> a = factor_args(0);
+      a.solve_lds = step_solve_lds_[0];
       const int sth = std::min(st.threads, solve_threads_max_);
       const int grid = std::min(lds_n_tasks_, lds_flow_cus_ * (sth <= 256 ? 4 : 2));
       unsigned *ticket = dep_flags_.p + 2 * sym_.S + 32;
@@ -1551,6 +1559,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       if (st.kind == STEP_TASKS) {
         const int nt = st.task_end - st.task_begin;
         FactorArgs<T> a = factor_args(st.task_begin);
+        a.solve_lds = step_solve_lds_[i];
         const int sth = step_threads(st, nt, solve_threads_max_);
         if (sth <= 64) launch_solve_tasks<64>(nt, lds, a);
         else if (sth <= 128) launch_solve_tasks<128>(nt, lds, a);
