@@ -30,6 +30,8 @@
 
 namespace rrpgo {
 
+constexpr unsigned X_PENDING_WORD = 0x7ff8deadu;   // see x_wait
+
 template <typename T> struct VecT;
 template <> struct VecT<float> { using V4 = float4; using V2 = float2; };
 template <> struct VecT<double> { using V4 = double4; using V2 = double2; };
@@ -140,6 +142,8 @@ template <typename T, typename TC = T> struct LinArgs {
   const uint8_t *adds_diag;              // sharded runs: per node, 1 = this rank adds prior / lambda (shared nodes: rank 0)
   unsigned *zero_words;                  // flags and tickets of the dataflow launches that follow (lds_flow.hip.h): zeroed here,
   int n_zero_words;                      // one launch ahead of their first use (0: none)
+  unsigned *fill_words;                  // the solution vector of k_solve_flow: every word set to X_PENDING_WORD here (a front
+  int n_fill_words;                      // of that launch waits for its ancestors' entries themselves, x_wait) (0: none)
 };
 
 // ---------------------------------------------------------------- factor maths
@@ -250,6 +254,7 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<TO, T> a) {
   __shared__ double red[LIN_THREADS / 64];
   const int gid = blockIdx.x * LIN_THREADS + threadIdx.x;
   for (int i = gid; i < a.n_zero_words; i += gridDim.x * LIN_THREADS) a.zero_words[i] = 0u;
+  for (int i = gid; i < a.n_fill_words; i += gridDim.x * LIN_THREADS) a.fill_words[i] = X_PENDING_WORD;
   const int slot = gid / LIN_GROUP, sub = gid % LIN_GROUP;
   const int node = slot < a.n_nodes ? (a.node_list ? a.node_list[slot] : slot) : -1;
   double chi = 0.0;
@@ -519,6 +524,8 @@ template <typename T, typename TC = T> struct LinArgs3 {
   const uint8_t *adds_diag;             // sharded runs: per node, 1 = this rank adds prior / lambda
   unsigned *zero_words;                 // as LinArgs::zero_words
   int n_zero_words;
+  unsigned *fill_words;                 // as LinArgs::fill_words
+  int n_fill_words;
 };
 
 template <typename T> __device__ __forceinline__ void q_mul(const T a[4], const T b[4], T r[4]) {
@@ -604,6 +611,7 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize_se3(LinArgs3<TO, T> a
   __shared__ double red[LIN_THREADS / 64];
   const int gid = blockIdx.x * LIN_THREADS + threadIdx.x;
   for (int i = gid; i < a.n_zero_words; i += gridDim.x * LIN_THREADS) a.zero_words[i] = 0u;
+  for (int i = gid; i < a.n_fill_words; i += gridDim.x * LIN_THREADS) a.fill_words[i] = X_PENDING_WORD;
   const int slot = gid / LIN_GROUP, sub = gid % LIN_GROUP;
   const int node = slot < a.n_nodes ? (a.node_list ? a.node_list[slot] : slot) : -1;
   double chi = 0.0;
@@ -994,6 +1002,34 @@ template <bool SC1, typename T> __device__ __forceinline__ T mem_ld(const T *p) 
 template <bool SC1, typename T> __device__ __forceinline__ void mem_st(T *p, T v) {
   if constexpr (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else *p = v;
+}
+
+// An entry of the solution vector that k_solve_flow has not produced yet holds X_PENDING_WORD in each of its 32-bit words
+// (the linearisation kernel of the iteration puts it there): a NaN with a payload no arithmetic produces, in fp32 and fp64
+// alike.  x_wait returns the entry once it is there -- the payload is its own flag: no separate flag round trip, and the
+// producer neither drains its stores nor meets at a barrier before the consumers may go on.  Bounded in time like dep_wait.
+__device__ __forceinline__ bool x_pending(float v) { return __builtin_bit_cast(unsigned, v) == X_PENDING_WORD; }
+__device__ __forceinline__ bool x_pending(double v) {
+  return (unsigned)__double2hiint(v) == X_PENDING_WORD && (unsigned)__double2loint(v) == X_PENDING_WORD;
+}
+template <typename T> __device__ __forceinline__ T x_wait(const T *p, int *err, unsigned long long max_ticks) {
+  T v = mem_ld<true>(p);
+  if (x_pending(v)) {
+    const unsigned long long t0 = wall_clock64();
+    for (unsigned spins = 1;; spins++) {
+      __builtin_amdgcn_s_sleep(1);
+      v = mem_ld<true>(p);
+      if (!x_pending(v)) break;
+      if ((spins & 31u) == 0u) {
+        const int e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e != 0 || wall_clock64() - t0 > max_ticks) {
+          if (e == 0) atomicOr(err, DEVERR_FLOW_TIMEOUT);
+          break;
+        }
+      }
+    }
+  }
+  return v;
 }
 
 // The same policy through a buffer resource (a front, a W slot): sc1 accesses by 32-bit byte offset from a uniform
@@ -3128,6 +3164,25 @@ template <typename T> struct BcastDot16<T, 16> {
   static __device__ __forceinline__ void run(T &, T &, T, const T (&)[16]) {}
 };
 
+// the sum of v over the 16 lanes of the calling lane's row by rotations within the row (8, 4, 2, 1): every lane ends with
+// the sum of all 16 -- associated in an order that depends on the lane, so ONE lane's result is used (lane 0 of the row:
+// ((v0 + v8) + (v4 + v12)) + ((v2 + v10) + (v6 + v14)) + the same of the odd lanes)
+template <int ROR> __device__ __forceinline__ float row_ror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + ROR, 0xf, 0xf, false));
+}
+template <int ROR> __device__ __forceinline__ double row_ror(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + ROR, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + ROR, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <typename T> __device__ __forceinline__ T row_sum16(T v) {
+  v += row_ror<8>(v);
+  v += row_ror<4>(v);
+  v += row_ror<2>(v);
+  v += row_ror<1>(v);
+  return v;
+}
+
 // Back substitution for one supernode:
 //   x1 = L11^-T ( y1 - L21^T x[rows] ),  y1 = the rhs row of the factored panel.
 // STAGE (fronts of the LDS path): L11 is staged into LDS TRANSPOSED with an odd
@@ -3150,20 +3205,56 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *w
     constexpr int NW = THREADS / 64;
     const int wave = wave_index(), lane = tid & 63, l16 = lane & 15;
     const int nblk = (nc + 15) >> 4, ncp = 16 * nblk;
-    T *x2 = work;                      // nr
-    T *t1 = x2 + ((nr + 3) & ~3);      // 16 nblk (t, then x; zero past nc: a partial last block needs no masks), 16-byte aligned
-    // The chain and the fold read L11 and the W blocks from an LDS image when the launch has the room for the front's
-    // (a.solve_lds; column j at Ll + j ldl, ldl odd, rows padded with zeros to whole blocks; W_b TRANSPOSED in the place
-    // of the diagonal block b, which nobody reads).  In k_solve_flow it is staged while the front waits for its parent;
-    // a chain step then makes no trip to memory.
+    const int nrp = (nr + 15) & ~15;
+    T *x2 = work;         // nr, padded with zeros to whole 16s
+    T *t1 = x2 + nrp;     // 16 nblk (t, then x; zero past nc: a partial last block needs no masks), 16-byte aligned
+    // The chain reads its operands from LDS, staged in the same round trip as the loads below:
+    //   full image (k_solve_flow, when the launch has the room: a.solve_lds)   L11 and the W blocks: column j at Ll + j ldl,
+    //     ldl odd, rows padded with zeros to whole blocks; W_b TRANSPOSED in the place of the diagonal block b, which
+    //     nobody reads.  It is staged while the front waits for its parent, and the fold reads it too: a step of the chain
+    //     makes no trip to memory.
+    //   chain image (otherwise)   per block b, 2 x 16 rows of 17: W_b transposed, then L(b+1, b) transposed, zero past the
+    //     front.  The fold's operands come from memory, requested one barrier ahead.
     T *Ll = t1 + ncp;
     const int ldl = ncp + 1;
-    const bool img = ((nr + 3) & ~3) + ncp + ncp * ldl + 2 <= a.solve_lds;
+    constexpr int CBLK = 2 * 16 * 17;
+    const bool img = FLOW && nrp + ncp + ncp * ldl + 2 <= a.solve_lds;
     __syncthreads();
     RRPGO_STAMP_SOLVE(a, s, 0);
+    // t = y1 - L21^T x[rows]: the 16 lanes of a row take one column, lane q the rows q, q + 16, ... (a row of lanes reads
+    // 128 contiguous bytes of the column), the 16 partial sums are added with DPP broadcasts (row_sum16).  A workgroup
+    // covers THREADS / 16 columns per pass; the sum of a column does not depend on the workgroup's size.  Nothing of L21
+    // depends on x: when the shape allows (PM passes of RM rows per lane) the loads are requested before the front waits
+    // for its parent, so that after the wait there are R reads of x from LDS and P (R + 17) multiply-adds per lane.
+    constexpr int CPP = THREADS / 16, PM = 3, RM = 8;
+    const int q16 = tid & 15, jl = tid >> 4;
+    const int R = (nr + 15) >> 4, P = (nc + CPP - 1) / CPP;
+    const bool hoist = nr > 0 && P <= PM && R <= RM;
+    T lv[PM][RM], gy[PM];
+    if (hoist) {
+#pragma unroll
+      for (int p = 0; p < PM; p++)
+        if (p < P) {
+          const T *col = Lg + (int64_t)min(jl + p * CPP, nc - 1) * M + nc;
+#pragma unroll
+          for (int r = 0; r < RM; r++)
+            if (r < R) lv[p][r] = col[min(q16 + 16 * r, nr)];   // past the rows: the rhs entry, times the zero padding of x2
+          gy[p] = col[nr];
+        }
+    }
+    const int row0 = nr > 0 ? rows[min(tid, nr - 1)] : 0;   // where this thread's x comes from: known before the wait
     if (tid < ncp - nc) t1[nc + tid] = (T)0;
+    const T *Wsrc = a.winv + (int64_t)m.wblk * 256;
     if (img) {
-      constexpr int SB = 8;   // columns a wave has in flight
+      // the W blocks are requested first and stored last: one round trip for a front of up to 10 columns per wave
+      auto wstore = [&](int i, T v) {   // W_b(k, m) -> image (row 16 b + k, column 16 b + m)
+        const int cb = 16 * (i >> 8), wk = (i >> 4) & 15, wm = i & 15;
+        if (i < nblk * 256) Ll[(cb + wm) * ldl + cb + wk] = v;
+      };
+      T w4[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) w4[u] = Wsrc[min(tid + u * THREADS, nblk * 256 - 1)];
+      constexpr int SB = 10;   // columns a wave has in flight
       const bool two = ncp > 64;
       for (int j0 = wave; j0 < nc; j0 += NW * SB) {
         T v[SB][2];
@@ -3185,84 +3276,75 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *w
       for (int j = wave; j < nc; j += NW)   // fronts wider than 128 columns
         for (int i = lane + 128; i < ncp; i += 64)
           if ((i >> 4) > (j >> 4)) Ll[j * ldl + i] = i < nc ? Lg[(int64_t)j * M + i] : (T)0;
-      const T *Wsrc = a.winv + (int64_t)m.wblk * 256;
-      for (int i0 = tid; i0 < nblk * 256; i0 += 4 * THREADS) {
-        T v[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = Wsrc[min(i0 + u * THREADS, nblk * 256 - 1)];
+      for (int u = 0; u < 4; u++) wstore(tid + u * THREADS, w4[u]);
+      for (int i = tid + 4 * THREADS; i < nblk * 256; i += THREADS) wstore(i, Wsrc[i]);
+    } else {
+      // entry e of the chain image: block b = e >> 9, then the 256 entries of W_b and the 256 of L(b+1, b), both in memory
+      // order; lane m of the chain finds its 16 operands k = 0 .. 15 at m * 17 + k
+      constexpr int SC = 8;
+      const int ne = (2 * nblk - 1) * 256;
+      for (int e0 = tid; e0 < ne; e0 += SC * THREADS) {
+        T v[SC];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int i = i0 + u * THREADS;
-          const int cb = 16 * (i >> 8), wk = (i >> 4) & 15, wm = i & 15;   // W_b(k, m) -> image (row 16 b + k, column 16 b + m)
-          if (i < nblk * 256) Ll[(cb + wm) * ldl + cb + wk] = v[u];
+        for (int u = 0; u < SC; u++) {
+          const int e = min(e0 + u * THREADS, ne - 1);
+          const int b = e >> 9, hi = (e >> 4) & 15, lo = e & 15;   // L: (m, k); W: (k, m) -- both contiguous in memory
+          const T *src = (e & 256) ? Lg + (int64_t)(16 * b + hi) * M + min(16 * b + 16 + lo, nc - 1) : Wsrc + b * 256 + (e & 255);
+          v[u] = *src;
+        }
+#pragma unroll
+        for (int u = 0; u < SC; u++) {
+          const int e = e0 + u * THREADS;
+          const int b = e >> 9, hi = (e >> 4) & 15, lo = e & 15;
+          if (e < ne) {
+            if (e & 256) Ll[b * CBLK + 272 + hi * 17 + lo] = 16 * b + 16 + lo >= nc ? (T)0 : v[u];
+            else Ll[b * CBLK + lo * 17 + hi] = v[u];
+          }
         }
       }
     }
-    // The loads of the L21^T x2 product do not depend on x2: when the shape allows (nr <= 128, at most GV
-    // columns per wave) a wave requests all of them before anything else, so that one memory round trip
-    // is hidden under the gather of x2 instead of one per group of four columns after it.
-    constexpr int GV = 12;
-    const int gw = wave_index(), gl = tid & 63;
-    const int gcpw = (nc + THREADS / 64 - 1) / (THREADS / 64);   // columns per wave: j = gw + NW g
-    const bool gfast = nr > 0 && nr <= 128 && gcpw <= GV;
-    T glv[GV][2], gy[GV];
-    if (gfast) {
-#pragma unroll
-      for (int g = 0; g < GV; g++)
-        if (g < gcpw) {
-          const T *col = Lg + (int64_t)min(gw + (THREADS / 64) * g, nc - 1) * M + nc;
-          glv[g][0] = col[min(gl, nr - 1)];
-          glv[g][1] = col[min(gl + 64, nr - 1)];
-          gy[g] = col[nr];
-        }
-    }
     if constexpr (FLOW) {
+      // every thread waits for its own entry of x (the parent's columns arrive last; the older ancestors' are there)
       const int pdep = a.parent_dep[s];
-      if (pdep >= 0) dep_wait(a.dep_flags + pdep, a.err, a.wait_ticks);   // every wave for itself; the barrier below joins them
+      if (pdep >= 2 * a.parent_dep_self) dep_wait(a.dep_flags + pdep, a.err, a.wait_ticks);   // failure injection only (rr_pgo_debug_withhold): a word nobody sets
+      if (tid < nr) x2[tid] = x_wait(a.x + row0, a.err, a.wait_ticks);
+      for (int i = tid + THREADS; i < nr; i += THREADS) x2[i] = x_wait(a.x + rows[i], a.err, a.wait_ticks);
+    } else {
+      if (tid < nr) x2[tid] = a.x[row0];
+      for (int i = tid + THREADS; i < nr; i += THREADS) x2[i] = a.x[rows[i]];
     }
-    for (int i = tid; i < nr; i += THREADS) x2[i] = mem_ld<FLOW>(a.x + rows[i]);
+    if (tid < nrp - nr) x2[nr + tid] = (T)0;
     __syncthreads();
     RRPGO_STAMP_SOLVE(a, s, 1);
-    // t1[j] = y1[j] - sum_i L21[i][j] x2[i]
-    if (gfast) {
-      const T xa = x2[min(gl, nr - 1)], xb = x2[min(gl + 64, nr - 1)];
-      const T x0 = gl < nr ? xa : (T)0, x1 = gl + 64 < nr ? xb : (T)0;
-#pragma unroll
-      for (int g = 0; g < GV; g++)
-        if (g < gcpw) {
-          const int j = gw + (THREADS / 64) * g;
-          const T sacc = wave_sum63<T>(glv[g][0] * x0 + glv[g][1] * x1);
-          if (gl == 63 && j < nc) t1[j] = gy[g] - sacc;
-        }
-    } else if (nr == 0) {
+    if (nr == 0) {
       // a root front has no rows below its pivot block: t1 is its rhs row
       for (int j = tid; j < nc; j += THREADS) t1[j] = Lg[(int64_t)j * M + nc];
+    } else if (hoist) {
+      T xr[RM];
+#pragma unroll
+      for (int r = 0; r < RM; r++) xr[r] = x2[min(q16 + 16 * r, nrp - 1)];   // all RM reads at once; those past R are not used
+#pragma unroll
+      for (int p = 0; p < PM; p++) {
+        if (p >= P) break;
+        T acc = lv[p][0] * xr[0];
+#pragma unroll
+        for (int r = 1; r < RM; r++) {
+          if (r >= R) break;   // wave-uniform: a branch, not a select per multiply-add
+          acc += lv[p][r] * xr[r];
+        }
+        const T tot = row_sum16(acc);
+        const int j = jl + p * CPP;
+        if (q16 == 0 && j < nc) t1[j] = gy[p] - tot;
+      }
     } else {
-      // general shape: a wave takes four columns at a time (four independent global load streams in
-      // flight), lanes over rows (coalesced)
-      const int wave = wave_index(), lane = tid & 63;
-      constexpr int NW = THREADS / 64;
-      for (int j = wave; j < nc; j += 4 * NW) {
-        const int j1 = j + NW, j2 = j + 2 * NW, j3 = j + 3 * NW;
-        const T *c0 = Lg + (int64_t)j * M + nc;
-        const T *c1 = Lg + (int64_t)(j1 < nc ? j1 : j) * M + nc;
-        const T *c2 = Lg + (int64_t)(j2 < nc ? j2 : j) * M + nc;
-        const T *c3 = Lg + (int64_t)(j3 < nc ? j3 : j) * M + nc;
-        T s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        for (int i = lane; i < nr; i += 64) {
-          const T xv = x2[i];
-          s0 += c0[i] * xv; s1 += c1[i] * xv; s2 += c2[i] * xv; s3 += c3[i] * xv;
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-          s0 += __shfl_down(s0, o); s1 += __shfl_down(s1, o);
-          s2 += __shfl_down(s2, o); s3 += __shfl_down(s3, o);
-        }
-        if (lane == 0) {
-          t1[j] = c0[nr] - s0;
-          if (j1 < nc) t1[j1] = c1[nr] - s1;
-          if (j2 < nc) t1[j2] = c2[nr] - s2;
-          if (j3 < nc) t1[j3] = c3[nr] - s3;
-        }
+      for (int j0 = 0; j0 < nc; j0 += CPP) {   // same sums, the loads behind the wait
+        const int j = j0 + jl;
+        const T *col = Lg + (int64_t)min(j, nc - 1) * M + nc;
+        T acc = 0;
+        for (int r = 0; r < R; r++) acc += col[min(q16 + 16 * r, nr)] * x2[q16 + 16 * r];
+        const T tot = row_sum16(acc);
+        if (q16 == 0 && j < nc) t1[j] = col[nr] - tot;
       }
     }
     // L11^T x = t, backward, by 16-column blocks with the inverse diagonal blocks W_b = L_bb^-1:
@@ -3279,7 +3361,6 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *w
     // So there is one barrier per 16 columns and nobody writes an entry somebody else is reading.
     auto chain = [&](auto img_c) {
       constexpr bool IMG = decltype(img_c)::value;
-      const T *Wg = a.winv + (int64_t)m.wblk * 256 + l16;
       T la[16], wv[16];
       auto lblock = [&](int b, T (&dst)[16]) {   // operand block of chain step b (uses block b + 1), b clamped
         const int bc = max(min(b, nblk - 2), 0);
@@ -3288,10 +3369,9 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *w
 #pragma unroll
           for (int k = 0; k < 16; k++) dst[k] = col[k];
         } else {
-          const T *col = Lg + (int64_t)(16 * bc + l16) * M + 16 * bc + 16;
-          const int cwn = nc - (16 * bc + 16);   // >= 1 when nblk >= 2; rows clamped into the front: they meet x = 0
+          const T *col = Ll + bc * CBLK + 272 + l16 * 17;
 #pragma unroll
-          for (int k = 0; k < 16; k++) dst[k] = col[max(min(k, cwn - 1), 0)];
+          for (int k = 0; k < 16; k++) dst[k] = col[k];
         }
       };
       auto wblock = [&](int b, T (&dst)[16]) {   // W operand of chain step b, b clamped
@@ -3301,8 +3381,9 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *w
 #pragma unroll
           for (int k = 0; k < 16; k++) dst[k] = col[k];
         } else {
+          const T *col = Ll + bc * CBLK + l16 * 17;
 #pragma unroll
-          for (int k = 0; k < 16; k++) dst[k] = Wg[bc * 256 + k * 16];
+          for (int k = 0; k < 16; k++) dst[k] = col[k];
         }
       };
       const bool chainer = wave == 0 && lane < 16;   // one 16-lane row carries the chain
@@ -3312,12 +3393,9 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *w
           if (nblk >= 2) lblock(nblk - 2, la);
         }
       };
-      if constexpr (!IMG) chain_preload();   // from memory: in flight across the barrier
       __syncthreads();
-      if constexpr (IMG) {
-        chain_preload();
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the loop below starts with nothing of its own in flight
-      }
+      chain_preload();
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the loop below starts with nothing of its own in flight
       RRPGO_STAMP_SOLVE(a, s, 2);
       T xprev = 0;
       const int fi = NW == 1 ? tid : tid - 64;            // the fold thread's column
@@ -3386,12 +3464,8 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *w
     else chain(std::false_type{});
     __syncthreads();
     RRPGO_STAMP_SOLVE(a, s, 3);
-    for (int j = tid; j < nc; j += THREADS) mem_st<FLOW>(a.x + m.col0 + j, t1[j]);
-    if constexpr (FLOW) dep_drain();
+    for (int j = tid; j < nc; j += THREADS) mem_st<FLOW>(a.x + m.col0 + j, t1[j]);   // FLOW: the entries are their own flags (x_wait)
     __syncthreads();
-    if constexpr (FLOW) {
-      if (tid == 0) dep_flag_set(a.dep_flags + a.parent_dep_self + s);
-    }
     RRPGO_STAMP_SOLVE(a, s, 4);
   } else {
     // Front in place in HBM (fronts beyond LDS), left-looking over 64-column chunks from the right:

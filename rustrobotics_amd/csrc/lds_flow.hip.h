@@ -100,9 +100,10 @@ __global__ void __launch_bounds__(THREADS) k_solve_flow(FactorArgs<T> a, const L
   }
 }
 
-// (the flags and the two tickets are zeroed by the linearisation kernel of the same iteration: LinArgs::zero_words)
-__global__ void __launch_bounds__(256) k_zero_words(unsigned *w, int n) {
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) w[i] = 0u;
+// (the flags and the two tickets are zeroed and the solution vector marked pending by the linearisation kernel of the same
+// iteration: LinArgs::zero_words, fill_words; the edge-parallel linearisation launches this instead)
+__global__ void __launch_bounds__(256) k_fill_words(unsigned *w, int n, unsigned v) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) w[i] = v;
 }
 
 }  // namespace rrpgo

@@ -303,7 +303,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<unsigned> dep_flags_;      // [0, S) factor flags, [S, 2 S) solve flags, then the two tickets on lines of their own, then a word nobody sets
   DevBuf<LdsFlowTask> lds_ftasks_, lds_stasks_;
   int lds_n_tasks_ = 0, lds_flow_cus_ = 256;
-  bool solve_image_ = false;   // level schedule: L11 images in LDS for the back substitution too (RR_PGO_SOLVE_IMAGE)
   unsigned long long wait_ticks_ = 200000000ull;   // bound of one in-launch wait: 2 s of the 100 MHz wall clock (RR_PGO_FLOW_TIMEOUT_MS)
   // failure injection (rr_pgo_debug_withhold): what was changed, to put it back
   int withheld_child_ = -1, withheld_parent_ = -1, withheld_level_ = -1, withheld_task_ = -1;
@@ -588,7 +587,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       winv_.alloc((size_t)wblk_total * 256 + 4);
       winv_.zero();
       child_meta_.upload(cm);
-      if (const char *e = getenv("RR_PGO_SOLVE_IMAGE")) solve_image_ = atoi(e) != 0;
       if (const char *e = getenv("RR_PGO_FLOW_TIMEOUT_MS")) wait_ticks_ = (unsigned long long)std::max(1.0, std::atof(e) * 1e5);
       if (sym.lds_flow) {
         // dataflow launches of the LDS fronts: who waits for whom (a dependency inside one task needs no flag), and
@@ -667,10 +665,10 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
             int s = sym.task_sn[q], nc = sym.sn_ncols[s], nr = sym.sn_nrows[s];
             if (nc > 256) throw ApiError(RR_PGO_EUNSUPPORTED, "internal: LDS-path supernode wider than 256 columns");
             // x[rows] and t, padded as solve_front lays them out; k_solve_flow adds an LDS image of L11 where it fits
-            const int ncp = (nc + 15) / 16 * 16, base = ((nr + 3) & ~3) + ncp + 2;
+            const int ncp = (nc + 15) / 16 * 16, base = ((nr + 15) & ~15) + ncp + 2;
             const int cap = (int)((size_t)kMaxLds / sizeof(T));
-            const bool image = (sym.lds_flow && &st == &sym.steps[0]) || solve_image_;
-            need = std::max(need, image && base + ncp * (ncp + 1) <= cap ? base + ncp * (ncp + 1) : base);
+            const bool image = sym.lds_flow && &st == &sym.steps[0];
+            need = std::max(need, image && base + ncp * (ncp + 1) <= cap ? base + ncp * (ncp + 1) : base + ncp / 16 * (2 * 16 * 17));
           }
       } else {
         for (int t = st.task_begin; t < st.task_end; t++) {
@@ -1238,6 +1236,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     a.adds_diag = norm_counts_.p;
     a.zero_words = lds_flow_ ? dep_flags_.p : nullptr;
     a.n_zero_words = lds_flow_ ? 2 * sym_.S + 64 : 0;
+    a.fill_words = lds_flow_ ? reinterpret_cast<unsigned *>(x_ptr_) : nullptr;
+    a.n_fill_words = lds_flow_ ? (int)((size_t)g_.dim * sizeof(T) / 4) : 0;
     return a;
   }
 
@@ -1316,7 +1316,10 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       // the edge-parallel form (experiment knob RR_PGO_EDGE_LINEARIZE): clear + prior, one thread per edge, mirror
       const LinArgs<T, S> la = lin_args(lambda, lm, write_system, reference_prior);
       const unsigned nb = (unsigned)((g_.n_nodes() + 255) / 256);
-      if (lds_flow_) hipLaunchKernelGGL(k_zero_words, dim3(4), dim3(256), 0, stream_, dep_flags_.p, 2 * sym_.S + 64);
+      if (lds_flow_) {
+        hipLaunchKernelGGL(k_fill_words, dim3(4), dim3(256), 0, stream_, dep_flags_.p, 2 * sym_.S + 64, 0u);
+        hipLaunchKernelGGL(k_fill_words, dim3(16), dim3(256), 0, stream_, reinterpret_cast<unsigned *>(x_ptr_), (int)((size_t)g_.dim * sizeof(T) / 4), X_PENDING_WORD);
+      }
       if (write_system) hipLaunchKernelGGL((k_lin_init<T, S>), dim3(nb), dim3(256), 0, stream_, la);
       hipLaunchKernelGGL((k_linearize_edges<T, S>), dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_, la, g_.n_edges());
       if (write_system) hipLaunchKernelGGL((k_lin_finish<T, S>), dim3(nb), dim3(256), 0, stream_, la);
@@ -1345,6 +1348,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       a.adds_diag = norm_counts_.p;
       a.zero_words = lds_flow_ ? dep_flags_.p : nullptr;
       a.n_zero_words = lds_flow_ ? 2 * sym_.S + 64 : 0;
+      a.fill_words = lds_flow_ ? reinterpret_cast<unsigned *>(x_ptr_) : nullptr;
+      a.n_fill_words = lds_flow_ ? (int)((size_t)g_.dim * sizeof(T) / 4) : 0;
       hipLaunchKernelGGL((k_linearize_se3<T, S>), dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_, a);
     }
     check_launch("k_linearize");
@@ -2186,6 +2191,8 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
   if (const char *e = std::getenv("RR_PGO_LDS_PIECES")) so.max_lds_pieces = std::max(1, std::atoi(e));
   if (std::getenv("RR_PGO_JOIN_SEPARATORS")) so.split_separators = false;
   if (const char *e = std::getenv("RR_PGO_ND_LEAF")) so.nd_leaf = std::atoi(e);
+  if (const char *e = std::getenv("RR_PGO_AMALG_NP")) so.amalg_np = std::atoi(e);
+  if (const char *e = std::getenv("RR_PGO_AMALG_FRAC")) so.amalg_frac = std::atof(e);
   double t0 = now_ms();
   std::string err;
   if (h->g.n_nodes() >= 2400 && h->g.n_nodes() <= 6000 && opt.world_size <= 1 && !opt.sharded && !std::getenv("RR_PGO_ND_LEAF")) {

@@ -665,7 +665,7 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
       // fronts merge eagerly; large ones only when it is (nearly) free.
       const int64_t m2 = np2 + nrow[p];
       bool ok = z == 0 || np2 <= 16 || (m2 <= 64 && frac <= 0.70) || (m2 <= 96 && np2 <= 64 && frac <= 0.50) ||
-                (np2 <= 72 && frac <= 0.15) || frac <= 0.03;
+                (np2 <= opt.amalg_np && frac <= opt.amalg_frac) || frac <= 0.03;
       if (!ok) continue;
       merged_into[c] = p;
       npiv[p] = np2;

@@ -29,6 +29,8 @@ struct SymbolicOptions {
   int n_cus = 256;                   // compute units of the device (the schedule's estimate of a level of many tasks)
   int64_t lds_budget_elems = 19000;  // LDS scalars one workgroup may use for a front (panel + packed update)
   int nd_leaf = 40;         // nested dissection stops below this many nodes
+  int amalg_np = 72;        // relaxed amalgamation of fronts beyond the small ones: merged pivot columns <= amalg_np and
+  double amalg_frac = 0.15; //   explicit zeros <= amalg_frac of the merged front's entries (else only when nearly free)
   int n_parts = 1;          // >1: top ND levels are shared, subtrees owned by ranks (power of two)
   int my_part = 0;          // with n_parts > 1: the rank whose schedule is emitted (own subtrees, then shared top)
   int pin_node = -1;        // with n_parts > 1: this node (the anchor) is made part of the top separator
