@@ -3338,13 +3338,30 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *w
         if (q16 == 0 && j < nc) t1[j] = gy[p] - tot;
       }
     } else {
-      for (int j0 = 0; j0 < nc; j0 += CPP) {   // same sums, the loads behind the wait
-        const int j = j0 + jl;
-        const T *col = Lg + (int64_t)min(j, nc - 1) * M + nc;
-        T acc = 0;
-        for (int r = 0; r < R; r++) acc += col[min(q16 + 16 * r, nr)] * x2[q16 + 16 * r];
-        const T tot = row_sum16(acc);
-        if (q16 == 0 && j < nc) t1[j] = col[nr] - tot;
+      // the same sums with the loads behind the wait: two columns per lane row and eight rows at a time in flight
+      for (int j0 = 0; j0 < nc; j0 += 2 * CPP) {
+        const int jA = j0 + jl, jB = jA + CPP;
+        const T *colA = Lg + (int64_t)min(jA, nc - 1) * M + nc, *colB = Lg + (int64_t)min(jB, nc - 1) * M + nc;
+        T accA = 0, accB = 0;
+        for (int r0 = 0; r0 < R; r0 += 8) {
+          T la8[8], lb8[8], x8[8];
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            const int i = min(q16 + 16 * (r0 + r), nr);   // past the rows: the rhs entry, times zero
+            la8[r] = colA[i];
+            lb8[r] = colB[i];
+            x8[r] = r0 + r < R ? x2[q16 + 16 * (r0 + r)] : (T)0;
+          }
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            if (r0 + r >= R) break;
+            accA += la8[r] * x8[r];
+            accB += lb8[r] * x8[r];
+          }
+        }
+        const T totA = row_sum16(accA), totB = row_sum16(accB);
+        if (q16 == 0 && jA < nc) t1[jA] = colA[nr] - totA;
+        if (q16 == 0 && jB < nc) t1[jB] = colB[nr] - totB;
       }
     }
     // L11^T x = t, backward, by 16-column blocks with the inverse diagonal blocks W_b = L_bb^-1:
