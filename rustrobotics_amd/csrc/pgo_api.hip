@@ -1883,7 +1883,10 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     // RR_PGO_NO_GRAPH=1: plain launches (rocprofv3 --kernel-trace crashes on replays of graphs
     // with thousands of nodes; profiling runs of the large workloads use this switch)
     static const bool no_graph = std::getenv("RR_PGO_NO_GRAPH") != nullptr;
-    if (no_graph) {
+    // a handful of launches per iteration (the dataflow launches of the small graphs): plain launches queue back to back,
+    // while consecutive graph launches leave the GPU idle for ~8 us each (rocprofv3 --kernel-trace, scripts/kernel_gaps.py)
+    static const bool force_graph = std::getenv("RR_PGO_FORCE_GRAPH") != nullptr;
+    if (no_graph || (n_launches_per_iter <= 8 && !force_graph)) {
       for (int i = 0; i < iters; i++) enqueue_gn_iteration();
       return;
     }
