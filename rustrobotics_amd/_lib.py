@@ -5,6 +5,7 @@ compute entry point of the library itself fails with RR_PGO_ENODEVICE when no
 HIP device is present.
 """
 import ctypes as C
+import glob
 import importlib.util
 import os
 import sys
@@ -77,9 +78,13 @@ def load():
     if "torch" not in sys.modules and not os.environ.get("RR_PGO_NO_TORCH_PRELOAD"):
         try:
             spec = importlib.util.find_spec("torch")
-            hip = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec and spec.origin else None
-            if hip and os.path.exists(hip):
-                C.CDLL(hip, mode=C.RTLD_GLOBAL)
+            libdir = os.path.join(os.path.dirname(spec.origin), "lib") if spec and spec.origin else None
+            # the wheel may ship the runtime under its versioned name only (libamdhip64.so.6, ...)
+            hips = sorted(glob.glob(os.path.join(libdir, "libamdhip64.so*"))) if libdir else []
+            if hips:
+                C.CDLL(hips[0], mode=C.RTLD_GLOBAL)
+            elif libdir and os.path.isdir(libdir):
+                import torch  # noqa: F401  -- a torch without a HIP runtime of that name: let torch map whatever it uses first
         except (ImportError, OSError, ValueError):
             pass
     L = C.CDLL(LIB_PATH)

@@ -22,6 +22,7 @@ for N in intel input_M3500_g2o dlr; do
   timeout -k 10 120 python scripts/gpu_flow_path.py $N > gpurun_out/critical_path_${N}_$TAG.txt 2>&1
   RR_PGO_LDS_FLOW=0 timeout -k 10 120 python scripts/gpu_flow_path.py $N > gpurun_out/critical_path_${N}_levels_$TAG.txt 2>&1
 done
+for N in intel input_M3500_g2o dlr; do timeout -k 10 120 python scripts/gpu_solve_path.py $N > gpurun_out/solve_path_${N}_$TAG.txt 2>&1; done
 for N in intel input_M3500_g2o dlr sphere2500; do RR_PGO_ANALYZE_TIMES=1 timeout -k 10 120 python scripts/time_closure.py $N > gpurun_out/closure_${N}_$TAG.txt 2>&1; done
 timeout -k 10 300 python bench.py --workload grid:400x250:1000000 --precision f32 --steps 50 --warmup 5 --no-secondary > gpurun_out/bench_grid_f32_$TAG.json 2> gpurun_out/bench_grid_$TAG.err
 rm -rf /tmp/prof_grid

@@ -1,11 +1,11 @@
-"""Diagnostic (stamps build with -DRRPGO_STAMPS_SOLVE): the critical path of the dataflow back substitution (k_solve_flow), front by
-front: root -> the leaf that finishes last.  usage: gpu_solve_path.py [intel|input_M3500_g2o|dlr]"""
+"""Diagnostic (make -C rustrobotics_amd/csrc ../librr_pgo_stamps_solve.so): the critical path of the dataflow back substitution
+(k_solve_flow), front by front: root -> the leaf that finishes last.  usage: gpu_solve_path.py [intel|input_M3500_g2o|dlr]"""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from rustrobotics_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, 'rustrobotics_amd', 'librr_pgo_stamps.so')
+_lib.LIB_PATH = os.path.join(ROOT, 'rustrobotics_amd', 'librr_pgo_stamps_solve.so')
 from rustrobotics_amd import PoseGraph
 name = sys.argv[1] if len(sys.argv) > 1 else 'intel'
 g = PoseGraph.new(os.path.join(ROOT, 'tests/golden/g2o', name + '.g2o'))
@@ -40,8 +40,3 @@ while True:
     if not ks: break
     s = max(ks, key=lambda c: fin[c])
 print('path sums (us): wait+gather %.1f, L21^T x %.1f, chain %.1f, store+flag %.1f' % tuple(tot))
-if os.environ.get('XST'):
-    raw = out[:, 5:12]
-    for q in (198, 197, 196):
-        print(q, 'cycles: t1 read %d, L mfma %d, W mfma %d, to barrier %d | folder: after barrier %+d vs chain, fold %d' % (
-            raw[q,1]-raw[q,0], raw[q,2]-raw[q,1], raw[q,3]-raw[q,2], raw[q,4]-raw[q,3], raw[q,5]-raw[q,4], raw[q,6]-raw[q,5]))
