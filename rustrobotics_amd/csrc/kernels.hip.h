@@ -966,12 +966,16 @@ __device__ __forceinline__ void tile_rank_update(const T *X, int ldx, int i0, in
   const int rem = (kb - ka) & 15;
   if (rem > 0) {   // the last 1..15 columns: clamped column index, zero on one operand
 #pragma unroll
+    for (int q = 0; q < 4; q++) {   // the eight loads together, then pinned (a pin per load made each wait for its own round trip)
+      const int off = (min(4 * q + lk, rem - 1) - lk) * ldx;
+      bv[q] = xi[off];
+      av[q] = xj[off];
+    }
+#pragma unroll
     for (int q = 0; q < 4; q++) {
-      const int kk = 4 * q + lk;
-      const int off = (min(kk, rem - 1) - lk) * ldx;
-      const T vb = pin(xi[off]), va = pin(xj[off]);
-      bv[q] = vb;
-      av[q] = kk < rem ? va : (T)0;
+      bv[q] = pin(bv[q]);
+      const T va = pin(av[q]);
+      av[q] = 4 * q + lk < rem ? va : (T)0;
     }
 #pragma unroll
     for (int q = 0; q < 4; q++)
@@ -1565,11 +1569,15 @@ __device__ __forceinline__ void panel_factor(T *P, int M, int nc, int *err, T *w
         const int i = r0 + 16 * ib + li;
         const T *arow = P + min(i, M - 1);
         typename MM::Acc x = {0, 0, 0, 0};
+        T av[4];   // the four operands requested together (a pin per load, as it was, made each wait for its own round trip)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) av[s4] = arow[(k0 + min(4 * s4 + lk, nb - 1)) * M];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) av[s4] = pin(av[s4]);
 #pragma unroll
         for (int s4 = 0; s4 < 4; s4++) {
           const int j = 4 * s4 + lk;
-          const T v = pin(arow[(k0 + min(j, nb - 1)) * M]);
-          x = MM::mma(wa[s4], j < nb ? v : (T)0, x);
+          x = MM::mma(wa[s4], j < nb ? av[s4] : (T)0, x);
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
