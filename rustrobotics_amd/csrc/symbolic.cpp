@@ -757,29 +757,15 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
   sym.S = S;
   order.swap(forder);
   for (int p = 0; p < N; p++) pos_of[order[p]] = p;
-  sym.order = order;
-  sym.pos_of = pos_of;
 
-  // permuted scalar numbering
-  sym.node_pcol.assign(N, 0);
-  sym.perm.resize(g.dim);
-  {
-    int c = 0;
-    for (int p = 0; p < N; p++) {
-      int v = order[p];
-      sym.node_pcol[v] = c;
-      for (int d = 0; d < w[v]; d++) sym.perm[c++] = g.node_offset[v] + d;
-    }
-  }
-
-  ptimer.mark("supernodes");
   // ---- 5. supernodal symbolic factorisation on the final partition ----------
   std::vector<int32_t> sn_at_pos(N);
-  for (int f = 0; f < S; f++)
-    for (int p = sym.sn_first_pos[f]; p < sym.sn_first_pos[f] + sym.sn_npos[f]; p++) sn_at_pos[p] = f;
   std::vector<std::vector<int32_t>> rows(S);  // node positions
-  sym.sn_parent.assign(S, -1);
-  {
+  auto symbolic_rows = [&] {
+    for (int f = 0; f < S; f++)
+      for (int p = sym.sn_first_pos[f]; p < sym.sn_first_pos[f] + sym.sn_npos[f]; p++) sn_at_pos[p] = f;
+    for (auto &r : rows) r.clear();
+    sym.sn_parent.assign(S, -1);
     std::vector<int32_t> mark(N, -1), head(S, -1), next(S, -1);
     for (int f = 0; f < S; f++) {
       const int a = sym.sn_first_pos[f], b = a + sym.sn_npos[f];
@@ -802,7 +788,87 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
         head[pf] = f;
       }
     }
+  };
+  symbolic_rows();
+  // The kernels walk a front's pivot columns in blocks of 16, and a block costs the same whether it holds 16 columns or one
+  // (~3 us in the factorisation, 0.4 us in the back substitution, on the critical path).  A front whose width is a few
+  // columns over a multiple of 16 hands its LAST nodes to its parent (they become the parent's first pivots: the same
+  // elimination tree, the same fill -- a front's rows are a subset of its parent's front -- so only the cut between two
+  // supernodes of a chain moves); the parent may pass a remainder on in turn, like a carry.  Fronts in LDS only.
+  if (opt.balance_blocks && opt.n_parts <= 1) {
+    std::vector<int64_t> ncs(S, 0), nrs(S, 0);
+    for (int f = 0; f < S; f++) {
+      for (int p = sym.sn_first_pos[f]; p < sym.sn_first_pos[f] + sym.sn_npos[f]; p++) ncs[f] += w[order[p]];
+      for (int x : rows[f]) nrs[f] += w[order[x]];
+    }
+    // only a parent's child on the longest chain of blocks hands nodes up: what the other children would add to the parent
+    // would lengthen that chain, and their own partial blocks are off it
+    std::vector<int64_t> chain(S, 0);
+    std::vector<int32_t> crit(S, -1);
+    for (int f = 0; f < S; f++) {
+      chain[f] += (ncs[f] + 15) / 16;
+      const int pf = sym.sn_parent[f];
+      if (pf >= 0 && (crit[pf] < 0 || chain[f] > chain[crit[pf]])) crit[pf] = f;
+      if (pf >= 0) chain[pf] = std::max(chain[pf], chain[f]);   // (pf's own blocks are added when its turn comes)
+    }
+    std::vector<int32_t> out_nodes(S, 0);   // trailing nodes a front hands to its parent
+    bool any = false;
+    for (int f = 0; f < S; f++) {
+      const int pf = sym.sn_parent[f];
+      if (pf < 0 || crit[pf] != f) continue;
+      const int64_t r = ncs[f] % 16;
+      if (r == 0 || r > opt.balance_max_rem || ncs[f] <= 16) continue;
+      if (lds_elems((int)ncs[f], (int)nrs[f]) > lds_budget || lds_elems((int)ncs[pf], (int)nrs[pf]) > lds_budget) continue;
+      int k = 0;
+      int64_t m = 0;
+      for (int p = sym.sn_first_pos[f] + sym.sn_npos[f] - 1; p > sym.sn_first_pos[f] && m < r; p--) { m += w[order[p]]; k++; }
+      if (m < r) continue;
+      if (lds_elems((int)(ncs[f] - m), (int)(nrs[f] + m)) > lds_budget || lds_elems((int)(ncs[pf] + m), (int)nrs[pf]) > lds_budget) continue;
+      const bool parent_grows = (ncs[pf] + m + 15) / 16 > (ncs[pf] + 15) / 16;
+      if (parent_grows && sym.sn_parent[pf] < 0) continue;   // a root has nobody to pass the remainder on to
+      out_nodes[f] = k;
+      ncs[f] -= m; nrs[f] += m; ncs[pf] += m;
+      any = true;
+    }
+    if (any) {
+      std::vector<std::vector<int32_t>> incoming(S);
+      for (int f = 0; f < S; f++)
+        if (out_nodes[f] > 0) {
+          const int b = sym.sn_first_pos[f] + sym.sn_npos[f];
+          for (int p = b - out_nodes[f]; p < b; p++) incoming[sym.sn_parent[f]].push_back(order[p]);
+        }
+      std::vector<int32_t> norder, nfirst(S), nnpos(S);
+      norder.reserve(N);
+      for (int f = 0; f < S; f++) {
+        nfirst[f] = (int)norder.size();
+        for (int v : incoming[f]) norder.push_back(v);
+        for (int p = sym.sn_first_pos[f]; p < sym.sn_first_pos[f] + sym.sn_npos[f] - out_nodes[f]; p++) norder.push_back(order[p]);
+        nnpos[f] = (int)norder.size() - nfirst[f];
+      }
+      if ((int)norder.size() != N) return "internal: block balancing lost nodes";
+      order.swap(norder);
+      sym.sn_first_pos.swap(nfirst);
+      sym.sn_npos.swap(nnpos);
+      for (int p = 0; p < N; p++) pos_of[order[p]] = p;
+      symbolic_rows();
+    }
   }
+  sym.order = order;
+  sym.pos_of = pos_of;
+
+  // permuted scalar numbering
+  sym.node_pcol.assign(N, 0);
+  sym.perm.resize(g.dim);
+  {
+    int c = 0;
+    for (int p = 0; p < N; p++) {
+      int v = order[p];
+      sym.node_pcol[v] = c;
+      for (int d = 0; d < w[v]; d++) sym.perm[c++] = g.node_offset[v] + d;
+    }
+  }
+
+  ptimer.mark("supernodes");
   sym.sn_ncols.resize(S);
   sym.sn_nrows.resize(S);
   sym.sn_col0.resize(S);

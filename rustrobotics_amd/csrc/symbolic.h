@@ -29,6 +29,8 @@ struct SymbolicOptions {
   int n_cus = 256;                   // compute units of the device (the schedule's estimate of a level of many tasks)
   int64_t lds_budget_elems = 19000;  // LDS scalars one workgroup may use for a front (panel + packed update)
   int nd_leaf = 40;         // nested dissection stops below this many nodes
+  bool balance_blocks = true;  // fronts a few columns over a multiple of 16 hand their last nodes to their parent (symbolic.cpp, step 5)
+  int balance_max_rem = 8;     //   "a few": at most this many columns over
   int amalg_np = 72;        // relaxed amalgamation of fronts beyond the small ones: merged pivot columns <= amalg_np and
   double amalg_frac = 0.15; //   explicit zeros <= amalg_frac of the merged front's entries (else only when nearly free)
   int n_parts = 1;          // >1: top ND levels are shared, subtrees owned by ranks (power of two)
