@@ -2195,6 +2195,7 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
   if (std::getenv("RR_PGO_JOIN_SEPARATORS")) so.split_separators = false;
   if (const char *e = std::getenv("RR_PGO_ND_LEAF")) so.nd_leaf = std::atoi(e);
   if (const char *e = std::getenv("RR_PGO_BALANCE_BLOCKS")) { so.balance_blocks = std::atoi(e) != 0; if (std::atoi(e) > 1) so.balance_max_rem = std::atoi(e); }
+  if (const char *e = std::getenv("RR_PGO_MERGE_CHAIN")) { so.merge_chain_nc = std::atoi(e); if (const char *c = std::strchr(e, ',')) so.merge_chain_gain_us = std::atof(c + 1); }
   if (const char *e = std::getenv("RR_PGO_AMALG_NP")) so.amalg_np = std::atoi(e);
   if (const char *e = std::getenv("RR_PGO_AMALG_FRAC")) so.amalg_frac = std::atof(e);
   double t0 = now_ms();

@@ -795,62 +795,126 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
   // columns over a multiple of 16 hands its LAST nodes to its parent (they become the parent's first pivots: the same
   // elimination tree, the same fill -- a front's rows are a subset of its parent's front -- so only the cut between two
   // supernodes of a chain moves); the parent may pass a remainder on in turn, like a carry.  Fronts in LDS only.
-  if (opt.balance_blocks && opt.n_parts <= 1) {
-    std::vector<int64_t> ncs(S, 0), nrs(S, 0);
-    for (int f = 0; f < S; f++) {
-      for (int p = sym.sn_first_pos[f]; p < sym.sn_first_pos[f] + sym.sn_npos[f]; p++) ncs[f] += w[order[p]];
-      for (int x : rows[f]) nrs[f] += w[order[x]];
-    }
-    // only a parent's child on the longest chain of blocks hands nodes up: what the other children would add to the parent
-    // would lengthen that chain, and their own partial blocks are off it
-    std::vector<int64_t> chain(S, 0);
-    std::vector<int32_t> crit(S, -1);
-    for (int f = 0; f < S; f++) {
-      chain[f] += (ncs[f] + 15) / 16;
-      const int pf = sym.sn_parent[f];
-      if (pf >= 0 && (crit[pf] < 0 || chain[f] > chain[crit[pf]])) crit[pf] = f;
-      if (pf >= 0) chain[pf] = std::max(chain[pf], chain[f]);   // (pf's own blocks are added when its turn comes)
-    }
-    std::vector<int32_t> out_nodes(S, 0);   // trailing nodes a front hands to its parent
-    bool any = false;
-    for (int f = 0; f < S; f++) {
-      const int pf = sym.sn_parent[f];
-      if (pf < 0 || crit[pf] != f) continue;
-      const int64_t r = ncs[f] % 16;
-      if (r == 0 || r > opt.balance_max_rem || ncs[f] <= 16) continue;
-      if (lds_elems((int)ncs[f], (int)nrs[f]) > lds_budget || lds_elems((int)ncs[pf], (int)nrs[pf]) > lds_budget) continue;
-      int k = 0;
-      int64_t m = 0;
-      for (int p = sym.sn_first_pos[f] + sym.sn_npos[f] - 1; p > sym.sn_first_pos[f] && m < r; p--) { m += w[order[p]]; k++; }
-      if (m < r) continue;
-      if (lds_elems((int)(ncs[f] - m), (int)(nrs[f] + m)) > lds_budget || lds_elems((int)(ncs[pf] + m), (int)nrs[pf]) > lds_budget) continue;
-      const bool parent_grows = (ncs[pf] + m + 15) / 16 > (ncs[pf] + 15) / 16;
-      if (parent_grows && sym.sn_parent[pf] < 0) continue;   // a root has nobody to pass the remainder on to
-      out_nodes[f] = k;
-      ncs[f] -= m; nrs[f] += m; ncs[pf] += m;
-      any = true;
-    }
-    if (any) {
+  if ((opt.balance_blocks || opt.merge_chain_nc > 0) && opt.n_parts <= 1) {
+    std::vector<int64_t> ncs, nrs;
+    std::vector<int32_t> crit;
+    auto measure = [&] {
+      ncs.assign(S, 0); nrs.assign(S, 0);
+      for (int f = 0; f < S; f++) {
+        for (int p = sym.sn_first_pos[f]; p < sym.sn_first_pos[f] + sym.sn_npos[f]; p++) ncs[f] += w[order[p]];
+        for (int x : rows[f]) nrs[f] += w[order[x]];
+      }
+      // a parent's child on the longest chain of blocks: only that one hands nodes up (what the other children would add to
+      // the parent would lengthen the chain, and their own partial blocks are off it)
+      std::vector<int64_t> chain(S, 0);
+      crit.assign(S, -1);
+      for (int f = 0; f < S; f++) {
+        chain[f] += (ncs[f] + 15) / 16;
+        const int pf = sym.sn_parent[f];
+        if (pf >= 0 && (crit[pf] < 0 || chain[f] > chain[crit[pf]])) crit[pf] = f;
+        if (pf >= 0) chain[pf] = std::max(chain[pf], chain[f]);   // (pf's own blocks are added when its turn comes)
+      }
+    };
+    // out_nodes[f] trailing nodes of front f become the first nodes of its parent; a front left empty disappears
+    auto apply_moves = [&](const std::vector<int32_t> &out_nodes) -> bool {
       std::vector<std::vector<int32_t>> incoming(S);
       for (int f = 0; f < S; f++)
         if (out_nodes[f] > 0) {
           const int b = sym.sn_first_pos[f] + sym.sn_npos[f];
           for (int p = b - out_nodes[f]; p < b; p++) incoming[sym.sn_parent[f]].push_back(order[p]);
         }
-      std::vector<int32_t> norder, nfirst(S), nnpos(S);
+      std::vector<int32_t> norder, nfirst, nnpos;
       norder.reserve(N);
       for (int f = 0; f < S; f++) {
-        nfirst[f] = (int)norder.size();
+        const int a = (int)norder.size();
         for (int v : incoming[f]) norder.push_back(v);
         for (int p = sym.sn_first_pos[f]; p < sym.sn_first_pos[f] + sym.sn_npos[f] - out_nodes[f]; p++) norder.push_back(order[p]);
-        nnpos[f] = (int)norder.size() - nfirst[f];
+        if ((int)norder.size() > a) { nfirst.push_back(a); nnpos.push_back((int)norder.size() - a); }
       }
-      if ((int)norder.size() != N) return "internal: block balancing lost nodes";
+      if ((int)norder.size() != N) return false;
       order.swap(norder);
       sym.sn_first_pos.swap(nfirst);
       sym.sn_npos.swap(nnpos);
+      S = (int)sym.sn_first_pos.size();
+      sym.S = S;
+      rows.assign(S, {});
       for (int p = 0; p < N; p++) pos_of[order[p]] = p;
       symbolic_rows();
+      return true;
+    };
+    const auto is_lds = [&](int64_t nc, int64_t nr) { return lds_elems((int)nc, (int)nr) <= lds_budget; };
+    if (opt.merge_chain_nc > 0) {
+      // A narrow front on the chain joins its parent outright when the cost model says the parent finishes earlier that way:
+      // a front on the critical path costs ~4 us of hand-off, Schur complement and copy-out in the factorisation (and ~1.2 us
+      // in the back substitution) whatever its width -- but its panel then has to wait for the parent's OTHER children.  With
+      // fin = the model's finish time of a front's subtree, f = the parent's child that finishes last, c2 = the finish of the
+      // runner-up:   before  fin(f) + cost(p)      merged  max(fin(f) - cost(f), c2) + cost(f + p).
+      // (The relaxed amalgamation above weighs zeros against a front's fixed cost everywhere; here only the one child whose
+      // chain the parent waits for.)  A front takes one child per pass; a few passes.
+      for (int pass = 0; pass < 3; pass++) {
+        measure();
+        std::vector<int32_t> kids(S, 0), out_nodes(S, 0);
+        for (int f = 0; f < S; f++)
+          if (sym.sn_parent[f] >= 0) kids[sym.sn_parent[f]]++;
+        std::vector<double> fin(S, 0.0), c1(S, 0.0), c2(S, 0.0);
+        std::vector<int32_t> last(S, -1);
+        std::vector<char> grown(S, 0);
+        bool any = false;
+        for (int p = 0; p < S; p++) {   // children before parents: c1 / c2 / last of p are complete here
+          double cost_p = front_cost_us((int)ncs[p], (int)nrs[p], kids[p]);
+          double start = c1[p];
+          const int f = last[p];
+          if (f >= 0 && !grown[f] && ncs[f] <= opt.merge_chain_nc && is_lds(ncs[f], nrs[f]) && is_lds(ncs[p], nrs[p]) &&
+              is_lds(ncs[f] + ncs[p], nrs[p])) {
+            const int64_t np2 = ncs[f] + ncs[p];
+            const double z = (double)ncs[f] * (double)std::max<int64_t>(ncs[p] + nrs[p] - nrs[f], 0);
+            const double T = 0.5 * (double)np2 * (double)(np2 + 1) + (double)np2 * (double)nrs[p];
+            const double cost_f = front_cost_us((int)ncs[f], (int)nrs[f], kids[f]);
+            const double cost_m = front_cost_us((int)np2, (int)nrs[p], kids[p] - 1 + kids[f]);
+            const double merged_fin = std::max(fin[f] - cost_f, c2[p]) + cost_m;
+            if (z / T <= opt.merge_chain_frac && fin[f] + cost_p - merged_fin > opt.merge_chain_gain_us) {
+              out_nodes[f] = sym.sn_npos[f];
+              ncs[p] = np2;
+              kids[p] += kids[f] - 1;
+              grown[p] = 1;
+              any = true;
+              start = std::max(fin[f] - cost_f, c2[p]);
+              cost_p = cost_m;
+            }
+          }
+          fin[p] = start + cost_p;
+          const int pp = sym.sn_parent[p];
+          if (pp >= 0) {
+            if (fin[p] > c1[pp]) { c2[pp] = c1[pp]; c1[pp] = fin[p]; last[pp] = p; }
+            else if (fin[p] > c2[pp]) c2[pp] = fin[p];
+          }
+        }
+        if (!any) break;
+        if (!apply_moves(out_nodes)) return "internal: chain merging lost nodes";
+      }
+    }
+    if (opt.balance_blocks) {
+      measure();
+      std::vector<int32_t> out_nodes(S, 0);   // trailing nodes a front hands to its parent
+      bool any = false;
+      for (int f = 0; f < S; f++) {
+        const int pf = sym.sn_parent[f];
+        if (pf < 0 || crit[pf] != f) continue;
+        const int64_t r = ncs[f] % 16;
+        if (r == 0 || r > opt.balance_max_rem || ncs[f] <= 16) continue;
+        if (!is_lds(ncs[f], nrs[f]) || !is_lds(ncs[pf], nrs[pf])) continue;
+        int k = 0;
+        int64_t m = 0;
+        for (int p = sym.sn_first_pos[f] + sym.sn_npos[f] - 1; p > sym.sn_first_pos[f] && m < r; p--) { m += w[order[p]]; k++; }
+        if (m < r) continue;
+        if (!is_lds(ncs[f] - m, nrs[f] + m) || !is_lds(ncs[pf] + m, nrs[pf])) continue;
+        const bool parent_grows = (ncs[pf] + m + 15) / 16 > (ncs[pf] + 15) / 16;
+        if (parent_grows && sym.sn_parent[pf] < 0) continue;   // a root has nobody to pass the remainder on to
+        out_nodes[f] = k;
+        ncs[f] -= m; nrs[f] += m; ncs[pf] += m;
+        any = true;
+      }
+      if (any && !apply_moves(out_nodes)) return "internal: block balancing lost nodes";
     }
   }
   sym.order = order;

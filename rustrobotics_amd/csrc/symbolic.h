@@ -31,6 +31,9 @@ struct SymbolicOptions {
   int nd_leaf = 40;         // nested dissection stops below this many nodes
   bool balance_blocks = true;  // fronts a few columns over a multiple of 16 hand their last nodes to their parent (symbolic.cpp, step 5)
   int balance_max_rem = 8;     //   "a few": at most this many columns over
+  int merge_chain_nc = 48;     // > 0: a front of at most this many pivot columns joins its parent when it is the parent's child on the longest
+  double merge_chain_frac = 0.5;   //   chain, both fit LDS together, the explicit zeros stay below this fraction of the merged front and the cost
+  double merge_chain_gain_us = 0.0; //  model's finish time of the parent improves by more than this
   int amalg_np = 72;        // relaxed amalgamation of fronts beyond the small ones: merged pivot columns <= amalg_np and
   double amalg_frac = 0.15; //   explicit zeros <= amalg_frac of the merged front's entries (else only when nearly free)
   int n_parts = 1;          // >1: top ND levels are shared, subtrees owned by ranks (power of two)
