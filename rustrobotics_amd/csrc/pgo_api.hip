@@ -2200,46 +2200,61 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
   if (const char *e = std::getenv("RR_PGO_AMALG_FRAC")) so.amalg_frac = std::atof(e);
   double t0 = now_ms();
   std::string err;
-  if (h->g.n_nodes() >= 2400 && h->g.n_nodes() <= 6000 && opt.world_size <= 1 && !opt.sharded && !std::getenv("RR_PGO_ND_LEAF")) {
+  if (h->g.n_nodes() <= 6000 && opt.world_size <= 1 && !opt.sharded && !(std::getenv("RR_PGO_ND_LEAF") && std::getenv("RR_PGO_AMALG_NP"))) {
     // Small graphs are bound by the critical path through the supernode tree, not by flops: a few
     // nested-dissection cuts above minimum-degree leaves shorten that path on the larger ones (M3500, dlr,
-    // sphere2500: +20..26 % measured) and lengthen it on intel.  The front cost model ranks the candidates
-    // the way the measurements do, so the estimated critical path picks the leaf size.  Below 2400 nodes
-    // no cut ever won and the extra analyses would only lengthen set-up (one-shot callers time it).
+    // sphere2500: +20..26 % measured) and lengthen it on intel; merging mid-sized fronts (relaxed amalgamation up to 72
+    // pivot columns) pays on sphere2500 and costs 2 - 4 % on intel, M3500 and dlr now that the fronts on the chain are merged
+    // by their own rule (symbolic.cpp, step 5).  The front cost model ranks the candidates the way the measurements do, so
+    // the estimated critical path picks the leaf size and the amalgamation width.  Below 2400 nodes no cut ever won.
     // The candidates are independent host computations: one thread each (r04: the six analyses in sequence were 35 ms
     // of M3500's and 55 ms of dlr's constructor on the GPU box, against 2 - 3 ms of optimize(10)).
     static const int kLeaf[] = {1 << 30, 3000, 2000, 1400, 1000, 700};
-    std::vector<int> leaves;
-    for (int leaf : kLeaf)
-      if (leaf == (1 << 30) || leaf < h->g.n_nodes()) leaves.push_back(leaf);   // (a leaf size >= the graph is no cut at all)
-    std::vector<Symbolic> cands(leaves.size());
-    std::vector<std::string> errs(leaves.size());
+    static const int kAmalg[] = {72, 16};
+    struct Cand { int leaf, np; };
+    std::vector<Cand> cl;
+    for (int leaf : kLeaf) {
+      if (std::getenv("RR_PGO_ND_LEAF")) { if (leaf != (1 << 30)) continue; leaf = so.nd_leaf; }
+      else if (leaf != (1 << 30) && (h->g.n_nodes() < 2400 || leaf >= h->g.n_nodes())) continue;   // (a leaf size >= the graph is no cut at all)
+      for (int np : kAmalg) {
+        if (std::getenv("RR_PGO_AMALG_NP")) { if (np != kAmalg[0]) continue; np = so.amalg_np; }
+        else if (h->g.n_nodes() < 2400 && np != 16) continue;   // no front beyond LDS down there: the narrow rule, ONE analysis (one-shot callers time it)
+        cl.push_back({leaf, np});
+      }
+    }
+    std::vector<Symbolic> cands(cl.size());
+    std::vector<std::string> errs(cl.size());
     {
       std::vector<std::thread> pool;
-      for (size_t c = 1; c < leaves.size(); c++)
+      for (size_t c = 1; c < cl.size(); c++)
         pool.emplace_back([&, c] {
           SymbolicOptions o = so;
-          o.nd_leaf = leaves[c];
+          o.nd_leaf = cl[c].leaf;
+          o.amalg_np = cl[c].np;
           try { errs[c] = analyze(h->g, o, cands[c]); } catch (const std::exception &e) { errs[c] = e.what(); }
         });
       {
         SymbolicOptions o = so;
-        o.nd_leaf = leaves[0];
+        o.nd_leaf = cl[0].leaf;
+        o.amalg_np = cl[0].np;
         errs[0] = analyze(h->g, o, cands[0]);
       }
       for (std::thread &t : pool) t.join();
     }
     Symbolic best;
     double best_crit = -1.0;
-    for (size_t c = 0; c < leaves.size(); c++) {
+    for (size_t c = 0; c < cl.size(); c++) {
       if (!errs[c].empty()) { err = errs[c]; break; }
       if (std::getenv("RR_PGO_ANALYZE_TIMES"))
-        std::fprintf(stderr, "analyze: nd_leaf %d -> estimated critical path %.1f us (%d big fronts, %d supernodes)\n", leaves[c], cands[c].est_critical_us, cands[c].n_big, cands[c].S);
+        std::fprintf(stderr, "analyze: nd_leaf %d, amalgamation up to %d columns -> estimated critical path %.1f us (%d big fronts, %d supernodes)\n", cl[c].leaf, cl[c].np,
+                     cands[c].est_critical_us, cands[c].n_big, cands[c].S);
       if (best_crit < 0 || cands[c].est_critical_us < best_crit) { best_crit = cands[c].est_critical_us; best = std::move(cands[c]); }
     }
     if (err.empty()) h->sym = std::move(best);
   } else {
     err = analyze(h->g, so, h->sym);
+    if (err.empty() && std::getenv("RR_PGO_ANALYZE_TIMES"))
+      std::fprintf(stderr, "analyze: estimated critical path %.1f us (%d big fronts, %d supernodes)\n", h->sym.est_critical_us, h->sym.n_big, h->sym.S);
   }
   if (!err.empty()) throw ApiError(RR_PGO_EINVAL, err);
   double t1 = now_ms();

@@ -669,9 +669,11 @@ def test_lds_dataflow_launches_are_bit_identical_to_the_level_schedule(api, name
     schedule (RR_PGO_LDS_FLOW=0: one launch per level of the task tree): the same fronts, the same child order, the same
     code per front -- chi2 trajectory and state must agree bit for bit; so must a launch with ONE workgroup drawing every
     ticket in turn (tasks only ever wait for smaller tickets: any grid finishes) and another task granularity.
-    (The dissection depth is pinned: for graphs of 2400 .. 6000 poses the library picks it by the schedule's estimated
-    critical path, which is not the same function for the two schedules -- another tree is another summation order.)"""
+    (The dissection depth and the amalgamation width are pinned: for graphs of 2400 .. 6000 poses the library picks them by
+    the schedule's estimated critical path, which is not the same function for the two schedules -- another tree is another
+    summation order.)"""
     monkeypatch.setenv("RR_PGO_ND_LEAF", "1000000")
+    monkeypatch.setenv("RR_PGO_AMALG_NP", "16")
     ref = api[0].new(g2o_path(name))
     eref, sref = np.array(ref.optimize(4)), np.array(ref.state())
     for env, val in (("RR_PGO_LDS_FLOW", "0"), ("RR_PGO_LDS_FLOW_GRID", "1"), ("RR_PGO_LDS_FLOW_GRID", "7"), ("RR_PGO_TASK_US", "60")):
