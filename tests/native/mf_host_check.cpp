@@ -40,6 +40,11 @@ int main(int argc, char **argv) {
   if (getenv("PARTS")) opt.n_parts = atoi(getenv("PARTS"));
   if (getenv("LDS")) opt.lds_budget_elems = atoll(getenv("LDS"));
   if (getenv("FLOW")) opt.lds_flow = true;   // the dataflow schedule of lds_flow.hip.h (tasks of ONE step in ticket order)
+  // the chain passes of step 5 (symbolic.cpp): fronts joining their parent / handing it their last nodes
+  if (getenv("MERGE_NC")) opt.merge_chain_nc = atoi(getenv("MERGE_NC"));
+  if (getenv("MERGE_GAIN")) opt.merge_chain_gain_us = atof(getenv("MERGE_GAIN"));
+  if (getenv("BALANCE")) { opt.balance_blocks = atoi(getenv("BALANCE")) != 0; if (atoi(getenv("BALANCE")) > 1) opt.balance_max_rem = atoi(getenv("BALANCE")); }
+  if (getenv("AMALG_NP")) opt.amalg_np = atoi(getenv("AMALG_NP"));
   Symbolic y;
   std::string e = analyze(g, opt, y);
   if (!e.empty()) { printf("analyze error: %s\n", e.c_str()); return 2; }

@@ -315,6 +315,10 @@ def mfcheck(tmp_path_factory):
     (["grid", "100", "100"], {"LEAF": "48", "LDS": "38000", "FLOW": "1"}),            # dataflow step + levels of fronts beyond LDS
     ([g2o_path("sphere2500")], {"LEAF": "1000", "LDS": "19000", "FLOW": "1"}),
     ([g2o_path("intel")], {"LEAF": "40", "FLOW": "1", "FLOW_OPTIONAL": "1"}),         # a front beyond LDS under an LDS parent: level schedule
+    ([g2o_path("intel")], {"LEAF": "1000000", "FLOW": "1", "MERGE_NC": "0", "BALANCE": "0"}),      # neither chain pass (the r03 trees)
+    ([g2o_path("input_M3500_g2o")], {"LEAF": "3000", "FLOW": "1", "MERGE_NC": "200", "MERGE_GAIN": "-50", "BALANCE": "15", "AMALG_NP": "16"}),   # both, far beyond their defaults
+    ([g2o_path("dlr")], {"LEAF": "1000000", "FLOW": "1", "MERGE_NC": "96", "MERGE_GAIN": "-5", "BALANCE": "12"}),   # 2- and 3-dim nodes moving between fronts
+    (["grid", "60", "40"], {"LEAF": "64", "MERGE_NC": "64", "MERGE_GAIN": "-5", "BALANCE": "15"}),                  # ... under fronts beyond LDS
     (["grid", "60", "40"], {"LEAF": "64", "PARTS": "2"}),           # rank-owned subtrees + shared top
     (["grid", "60", "40"], {"LEAF": "64", "PARTS": "4"}),
     (["grid", "100", "100"], {"LEAF": "64", "PARTS": "8"}),

@@ -690,6 +690,25 @@ def test_lds_dataflow_launches_are_bit_identical_to_the_level_schedule(api, name
     assert np.array_equal(np.array(lm.optimize(5)), np.array(lm0.optimize(5)))
 
 
+@pytest.mark.parametrize("name", ["intel", "input_M3500_g2o", "dlr"])
+def test_chain_passes_of_the_analysis_change_the_tree_not_the_answer(api, name, monkeypatch):
+    """symbolic.cpp, step 5: a narrow front on the critical chain joins its parent, a front a few columns over a multiple of 16
+    hands its last nodes to its parent -- other supernode partitions of the same elimination tree.  The optimisation must
+    follow the same trajectory (to rounding: another partition is another summation order) without them and with both far
+    beyond their defaults."""
+    ref = api[0].new(g2o_path(name))
+    eref, sref = np.array(ref.optimize(5)), np.array(ref.state())
+    for env in ({"RR_PGO_MERGE_CHAIN": "0", "RR_PGO_BALANCE_BLOCKS": "0"}, {"RR_PGO_MERGE_CHAIN": "200,-50", "RR_PGO_BALANCE_BLOCKS": "15"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        alt = api[0].new(g2o_path(name))
+        for k in env:
+            monkeypatch.delenv(k)
+        # (dlr's chi2 is 3.7e8 on entry and moves by factors per iteration: 8e-9 relative between two partitions, measured)
+        np.testing.assert_allclose(np.array(alt.optimize(5)), eref, rtol=1e-7)
+        np.testing.assert_allclose(np.array(alt.state()), sref, rtol=0, atol=1e-6)
+
+
 def test_fronts_beyond_lds_f32_reaches_the_f64_minimum(api):
     """Same lattice in fp32 (BASELINE config 4's precision): chi2 is reduced in f64, the solve is
     fp32 with a 1e7 prior in the matrix -> same minimum to 1e-5 relative.  The pose
