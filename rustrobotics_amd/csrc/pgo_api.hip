@@ -2210,46 +2210,53 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
     // The candidates are independent host computations: one thread each (r04: the six analyses in sequence were 35 ms
     // of M3500's and 55 ms of dlr's constructor on the GPU box, against 2 - 3 ms of optimize(10)).
     static const int kLeaf[] = {1 << 30, 3000, 2000, 1400, 1000, 700};
-    static const int kAmalg[] = {72, 16};
     struct Cand { int leaf, np; };
+    const bool np_fixed = std::getenv("RR_PGO_AMALG_NP") != nullptr;
     std::vector<Cand> cl;
     for (int leaf : kLeaf) {
       if (std::getenv("RR_PGO_ND_LEAF")) { if (leaf != (1 << 30)) continue; leaf = so.nd_leaf; }
       else if (leaf != (1 << 30) && (h->g.n_nodes() < 2400 || leaf >= h->g.n_nodes())) continue;   // (a leaf size >= the graph is no cut at all)
-      for (int np : kAmalg) {
-        if (std::getenv("RR_PGO_AMALG_NP")) { if (np != kAmalg[0]) continue; np = so.amalg_np; }
-        else if (h->g.n_nodes() < 2400 && np != 16) continue;   // no front beyond LDS down there: the narrow rule, ONE analysis (one-shot callers time it)
-        cl.push_back({leaf, np});
-      }
-    }
-    std::vector<Symbolic> cands(cl.size());
-    std::vector<std::string> errs(cl.size());
-    {
-      std::vector<std::thread> pool;
-      for (size_t c = 1; c < cl.size(); c++)
-        pool.emplace_back([&, c] {
-          SymbolicOptions o = so;
-          o.nd_leaf = cl[c].leaf;
-          o.amalg_np = cl[c].np;
-          try { errs[c] = analyze(h->g, o, cands[c]); } catch (const std::exception &e) { errs[c] = e.what(); }
-        });
-      {
-        SymbolicOptions o = so;
-        o.nd_leaf = cl[0].leaf;
-        o.amalg_np = cl[0].np;
-        errs[0] = analyze(h->g, o, cands[0]);
-      }
-      for (std::thread &t : pool) t.join();
+      cl.push_back({leaf, np_fixed ? so.amalg_np : 16});   // the narrow rule first: it wins wherever every front lives in LDS
     }
     Symbolic best;
     double best_crit = -1.0;
-    for (size_t c = 0; c < cl.size(); c++) {
-      if (!errs[c].empty()) { err = errs[c]; break; }
-      if (std::getenv("RR_PGO_ANALYZE_TIMES"))
-        std::fprintf(stderr, "analyze: nd_leaf %d, amalgamation up to %d columns -> estimated critical path %.1f us (%d big fronts, %d supernodes)\n", cl[c].leaf, cl[c].np,
-                     cands[c].est_critical_us, cands[c].n_big, cands[c].S);
-      if (best_crit < 0 || cands[c].est_critical_us < best_crit) { best_crit = cands[c].est_critical_us; best = std::move(cands[c]); }
+    int best_leaf = 0;
+    auto run = [&](const std::vector<Cand> &list) {
+      std::vector<Symbolic> cands(list.size());
+      std::vector<std::string> errs(list.size());
+      {
+        std::vector<std::thread> pool;
+        for (size_t c = 1; c < list.size(); c++)
+          pool.emplace_back([&, c] {
+            SymbolicOptions o = so;
+            o.nd_leaf = list[c].leaf;
+            o.amalg_np = list[c].np;
+            try { errs[c] = analyze(h->g, o, cands[c]); } catch (const std::exception &e) { errs[c] = e.what(); }
+          });
+        {
+          SymbolicOptions o = so;
+          o.nd_leaf = list[0].leaf;
+          o.amalg_np = list[0].np;
+          errs[0] = analyze(h->g, o, cands[0]);
+        }
+        for (std::thread &t : pool) t.join();
+      }
+      for (size_t c = 0; c < list.size(); c++) {
+        if (!errs[c].empty()) { err = errs[c]; return; }
+        if (std::getenv("RR_PGO_ANALYZE_TIMES"))
+          std::fprintf(stderr, "analyze: nd_leaf %d, amalgamation up to %d columns -> estimated critical path %.1f us (%d big fronts, %d supernodes)\n", list[c].leaf,
+                       list[c].np, cands[c].est_critical_us, cands[c].n_big, cands[c].S);
+        if (best_crit < 0 || cands[c].est_critical_us < best_crit) { best_crit = cands[c].est_critical_us; best_leaf = list[c].leaf; best = std::move(cands[c]); }
+      }
+    };
+    run(cl);
+    // fronts beyond LDS (sphere2500, torus3D: 6 x 6 blocks): there the r01 rule -- mid-sized fronts merge up to 72 columns --
+    // still pays, and with another depth than the narrow rule's (torus3D): a second round of the same depths decides
+    if (err.empty() && !np_fixed && best.n_big > 0) {
+      for (Cand &c : cl) c.np = 72;
+      run(cl);
     }
+    (void)best_leaf;
     if (err.empty()) h->sym = std::move(best);
   } else {
     err = analyze(h->g, so, h->sym);
