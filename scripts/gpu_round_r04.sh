@@ -5,7 +5,7 @@
 TAG=${1:-r04z}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout -k 10 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee gpurun_out/pytest_gpu_$TAG.log
+timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_full_$TAG.log 2>&1; tail -3 gpurun_out/pytest_gpu_full_$TAG.log | tee gpurun_out/pytest_gpu_$TAG.log   # (the full log stays: a failure keeps its message)
 python __graft_entry__.py smoke 2>&1 | tail -1 | tee gpurun_out/smoke_$TAG.log
 echo "== default bench line"; date
 timeout -k 10 900 python bench.py > gpurun_out/bench_default_$TAG.json 2> gpurun_out/bench_default_$TAG.err || echo "default bench FAILED"
