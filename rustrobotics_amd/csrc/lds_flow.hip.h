@@ -15,8 +15,10 @@
 //              set; the parent waits for the flag right before THAT child's extend-add -- zeroing its LDS image, adding
 //              the H entries and the right-hand side, the earlier children and the child's scatter map are behind it by
 //              then -- and reads the update matrix with sc1 loads.  The panel (which only the back substitution reads,
-//              a later launch) is copied out after the flag.  Back substitution: the same with x handed from a parent
-//              to its children.
+//              a later launch) is copied out after the flag.  Back substitution: no flags -- an entry of x is its own
+//              flag (the linearisation kernel fills x with a NaN payload, X_PENDING_WORD; a front spins on the entries it
+//              gathers: x_wait, kernels.hip.h), and everything that does not depend on x -- L21, the row indices, an LDS
+//              image of L11 and the inverse diagonal blocks -- is requested before that wait.
 //   order      children are added in a fixed order (symbolic.cpp: by the cost model's finish time), so every sum -- and
 //              the result, bit for bit -- is the same as in the level schedule (process_front / solve_front are the same
 //              code with FLOW = true).
