@@ -3193,15 +3193,14 @@ template <typename T> __device__ __forceinline__ T row_sum16(T v) {
 
 // Back substitution for one supernode:
 //   x1 = L11^-T ( y1 - L21^T x[rows] ),  y1 = the rhs row of the factored panel.
-// STAGE (fronts of the LDS path): L11 is staged into LDS TRANSPOSED with an odd
-// leading dimension, so the row sweeps of the backward substitution are
-// conflict-free column reads; L21^T x is accumulated straight from global
-// memory with every thread streaming a slice of the panel (coalesced along the
-// rows), partial sums combined per column through LDS.
-// work: STAGE: nc*ldt + nr + nc*NSLICE ; else nr + nc scalars.
-// FLOW (k_solve_flow, lds_flow.hip.h): the fronts of one launch's workgroups hand the solution down the tree -- a front
-// waits for its parent's flag right before it gathers x[rows] (its own loads of L21 are in flight by then), reads and
-// writes x with sc1 accesses and sets its own flag when its part of x is in memory.  Same arithmetic in both forms.
+// STAGE (fronts of the LDS path): x[rows] and t (then x1) live in LDS, padded with zeros to whole 16s; L21^T x comes
+// straight from global memory, one column per 16-lane row; the chain over 16-column blocks reads its operands (the kept
+// inverse diagonal blocks W_b and the sub-diagonal blocks of L11) from an LDS image -- all of L11 in k_solve_flow, just
+// those blocks in the level schedule -- staged in the same round trip as the L21 loads; details at the code below.
+// work: STAGE: (nr -> 16s) + (nc -> 16s) + 2 + the image (pgo_api.hip, step_solve_lds_); else nr + nc + a 64 x 65 chunk.
+// FLOW (k_solve_flow, lds_flow.hip.h): a front waits for its ancestors' entries of x themselves (x_wait: an entry that has
+// not been produced holds a NaN payload), reads and writes x with sc1 accesses and sets no flag.  Same arithmetic in both
+// forms.
 template <typename T, int THREADS, bool STAGE, bool FLOW = false>
 __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *work) {
   const int tid = threadIdx.x;
