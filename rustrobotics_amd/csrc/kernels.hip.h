@@ -920,9 +920,10 @@ template <> struct Mfma16<float> {
 // of one row i: consecutive lanes touch consecutive i (contiguous in memory).
 // Operands of four k-steps are fetched before the four dependent MFMAs issue.
 template <typename T> __device__ __forceinline__ T pin(T v);
-template <typename T, typename CAddr>
+struct StoreInPlace { template <typename T> __device__ __forceinline__ void operator()(T *p, T v) const { *p = v; } };
+template <typename T, typename CAddr, typename Store = StoreInPlace>
 __device__ __forceinline__ void tile_rank_update(const T *X, int ldx, int i0, int j0, int imax, int jmax,
-                                                 int ka, int kb, CAddr caddr) {
+                                                 int ka, int kb, CAddr caddr, Store store = Store()) {
   using MM = Mfma16<T>;
   const int lane = threadIdx.x & 63;
   const int li = lane & 15, lk = lane >> 4;
@@ -983,7 +984,7 @@ __device__ __forceinline__ void tile_rank_update(const T *X, int ldx, int i0, in
   }
 #pragma unroll
   for (int r = 0; r < 4; r++)
-    if (valid[r]) *pc[r] = -acc[r];
+    if (valid[r]) store(pc[r], -acc[r]);
 }
 
 // Keeps an unconditional load unconditional: without it the compiler sinks a load whose value is only
@@ -2160,13 +2161,20 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
     const int nt = (nu + 15) >> 4;
     const int wave = wave_index();
     // the tiles of the lower triangle dealt round-robin: t-th tile of the column-major enumeration
+    // FLOW: this pass leaves every entry of the update matrix final, and nothing reads it from LDS again: the results go
+    // straight to its place in memory (written through), not back into LDS for a copy-out pass of their own
+    [[maybe_unused]] T *Ug0 = (m.uld < 0 ? a.xch : a.uvals) + m.uoff;
+    [[maybe_unused]] const Sc1Buf<T> ub0(Ug0, (FLOW && !IN_PLACE) ? (uint32_t)usize * (uint32_t)sizeof(T) : 0u);
+    auto to_memory = [&](T *p, T v) { ub0.st((uint32_t)(p - U) * (uint32_t)sizeof(T), v); };
     for (int t = wave; t < nt * (nt + 1) / 2; t += THREADS / 64) {
       int jb = 0, rem = t;
       while (rem >= nt - jb) { rem -= nt - jb; jb++; }
       const int ib = jb + rem;
-      tile_rank_update<T>(P + nc, M, 16 * ib, 16 * jb, nu, nu, klast, nc, uaddr);
+      if constexpr (FLOW && !IN_PLACE) tile_rank_update<T>(P + nc, M, 16 * ib, 16 * jb, nu, nu, klast, nc, uaddr, to_memory);
+      else tile_rank_update<T>(P + nc, M, 16 * ib, 16 * jb, nu, nu, klast, nc, uaddr);
     }
   }
+  if constexpr (FLOW && !IN_PLACE) dep_drain();
   __syncthreads();
   RRPGO_STAMP(a, s, 5);
   if (!IN_PLACE) {
@@ -2175,12 +2183,9 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
     T *Lg = a.lvals + m.loff;
     T *Ug = (m.uld < 0 ? a.xch : a.uvals) + m.uoff;
     if constexpr (FLOW) {
-      // the update matrix first, written through; the parent's workgroup may go on as soon as the flag is set -- the
-      // panel (read by the back substitution, a later launch) is copied out behind that
-      const Sc1Buf<T> ub(Ug, (uint32_t)usize * (uint32_t)sizeof(T));
-      for (int t = tid; t < usize; t += THREADS) ub.st((uint32_t)t * (uint32_t)sizeof(T), U[t]);
-      dep_drain();
-      __syncthreads();
+      // the update matrix is in memory (the pass above, drained ahead of the barrier): the parent's workgroup may go on --
+      // the panel (read by the back substitution, a later launch) is copied out behind the flag
+      (void)Ug;
       if (tid == 0) dep_flag_set(a.dep_flags + s);
       RRPGO_STAMP(a, s, 11);
     }
