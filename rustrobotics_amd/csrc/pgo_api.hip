@@ -1781,7 +1781,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       // an iteration of a handful of launches (the dataflow form of the small graphs: four) is enqueued as it is; capturing
       // and instantiating a hipGraph costs more than ten such iterations save (the closure the reference's bench times,
       // benches/graph_slam.rs:9-10, is ONE new() + optimize(10)).  Graphs of dozens of launches replay a captured graph.
-      const bool eager = n_launches_per_iter <= 8 && !gn_exec_;
+      // (optimize() reads two scalars back after every iteration, so the enqueueing is not hidden behind the device as it is
+      // in iterate_async: dozens of launches stay one graph launch here.)  RR_PGO_FORCE_GRAPH=1: always the graph.
+      const bool eager = n_launches_per_iter <= 8 && !gn_exec_ && !std::getenv("RR_PGO_FORCE_GRAPH");
       if (!eager) ensure_gn_graph();
       reset_counter();
       int done = 0;
@@ -1883,10 +1885,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     // RR_PGO_NO_GRAPH=1: plain launches (rocprofv3 --kernel-trace crashes on replays of graphs
     // with thousands of nodes; profiling runs of the large workloads use this switch)
     static const bool no_graph = std::getenv("RR_PGO_NO_GRAPH") != nullptr;
-    // a handful of launches per iteration (the dataflow launches of the small graphs): plain launches queue back to back,
-    // while consecutive graph launches leave the GPU idle for ~8 us each (rocprofv3 --kernel-trace, scripts/kernel_gaps.py)
+    // plain launches queue back to back while consecutive graph launches leave the GPU idle for ~8 us each (rocprofv3
+    // --kernel-trace, scripts/kernel_gaps.py), and the host stays far ahead of the device even at 67 launches per iteration
+    // (the 1M-edge lattice: ~0.2 ms of enqueueing against 4.4 ms of kernels).  Measured: intel + 2 %, sphere2500 + 0.8 %,
+    // lattice + 0.7 %.  RR_PGO_FORCE_GRAPH=1: replays of the captured hipGraph (r01 - r03's form).
     static const bool force_graph = std::getenv("RR_PGO_FORCE_GRAPH") != nullptr;
-    if (no_graph || (n_launches_per_iter <= 8 && !force_graph)) {
+    if (no_graph || !force_graph) {
       for (int i = 0; i < iters; i++) enqueue_gn_iteration();
       return;
     }

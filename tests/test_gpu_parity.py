@@ -676,7 +676,8 @@ def test_lds_dataflow_launches_are_bit_identical_to_the_level_schedule(api, name
     monkeypatch.setenv("RR_PGO_AMALG_NP", "16")
     ref = api[0].new(g2o_path(name))
     eref, sref = np.array(ref.optimize(4)), np.array(ref.state())
-    for env, val in (("RR_PGO_LDS_FLOW", "0"), ("RR_PGO_LDS_FLOW_GRID", "1"), ("RR_PGO_LDS_FLOW_GRID", "7"), ("RR_PGO_TASK_US", "60")):
+    # (RR_PGO_FORCE_GRAPH: the iterations as replays of the captured hipGraph instead of plain launches)
+    for env, val in (("RR_PGO_LDS_FLOW", "0"), ("RR_PGO_LDS_FLOW_GRID", "1"), ("RR_PGO_LDS_FLOW_GRID", "7"), ("RR_PGO_TASK_US", "60"), ("RR_PGO_FORCE_GRAPH", "1")):
         monkeypatch.setenv(env, val)
         alt = api[0].new(g2o_path(name))
         monkeypatch.delenv(env)
