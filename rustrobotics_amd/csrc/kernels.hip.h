@@ -18,12 +18,6 @@
 #include <cstdint>
 #include <type_traits>
 
-#ifndef RRPGO_PANEL_FLOW
-#define RRPGO_PANEL_FLOW 0   // LDS fronts: 1 = the pivot panel as a dataflow between the waves (panel_flow, r04 experiment); 0: the barrier form (panel_factor)
-#endif
-#ifndef RRPGO_DPP_SWEEP
-#define RRPGO_DPP_SWEEP 2    // panel_factor: the 16 x 16 diagonal blocks by chol16_dpp2 (1: chol16_dpp, identity rows in registers; 0: chol16_invert, the r01 - r03 sweep)
-#endif
 #ifndef RRPGO_CHAIN_PRIO
 #define RRPGO_CHAIN_PRIO 3   // s_setprio of the wave that carries a workgroup's dependent chain
 #endif
@@ -843,7 +837,6 @@ template <typename T> struct FactorArgs {
   int *err;
   unsigned long long *stamps;  // [S][12], diagnostic builds only (else null)
   unsigned long long *trace;   // diagnostic trace region (else null)
-  unsigned long long *ptrace;  // diagnostic builds: [S][16][8] chain stamps of panel_flow (else null)
   // dataflow launches of the LDS fronts (lds_flow.hip.h; null / 0 elsewhere)
   const int32_t *child_dep;    // per child_meta entry: index in dep_flags of the flag that says the child's update matrix is in memory,
                                // -1 = the child was factored earlier in the same task (by this workgroup)
@@ -1014,9 +1007,14 @@ template <bool SC1, typename T> __device__ __forceinline__ void mem_st(T *p, T v
 // alike.  x_wait returns the entry once it is there -- the payload is its own flag: no separate flag round trip, and the
 // producer neither drains its stores nor meets at a barrier before the consumers may go on.  Bounded in time like dep_wait.
 __device__ __forceinline__ bool x_pending(float v) { return __builtin_bit_cast(unsigned, v) == X_PENDING_WORD; }
-__device__ __forceinline__ bool x_pending(double v) {
-  return (unsigned)__double2hiint(v) == X_PENDING_WORD && (unsigned)__double2loint(v) == X_PENDING_WORD;
-}
+// fp64: the HIGH word alone decides (0x7ff8dead........ is a NaN whatever the low word is, so no value is mistaken for the
+// mark).  An aligned 8-byte sc1 store was never seen torn on this chip (scripts/handoff_probe.hip, 8-byte payload-as-flag
+// form: 0 of 1e9 hand-offs, profiles/r05_handoff_probe.txt), but x_wait does not rest on that: an entry whose high word is
+// there while its low word still reads as the mark -- a torn store, or one value in 2^32 -- is read again until two
+// consecutive reads agree (x_half).
+__device__ __forceinline__ bool x_pending(double v) { return (unsigned)__double2hiint(v) == X_PENDING_WORD; }
+__device__ __forceinline__ bool x_half(float) { return false; }
+__device__ __forceinline__ bool x_half(double v) { return (unsigned)__double2loint(v) == X_PENDING_WORD; }
 template <typename T> __device__ __forceinline__ T x_wait(const T *p, int *err, unsigned long long max_ticks) {
   T v = mem_ld<true>(p);
   if (x_pending(v)) {
@@ -1032,6 +1030,15 @@ template <typename T> __device__ __forceinline__ T x_wait(const T *p, int *err, 
           break;
         }
       }
+    }
+  }
+  if (x_half(v)) {   // (never taken in fp32; in fp64 only for a torn store or a value whose low word equals the mark)
+    for (int k = 0; k < 64; k++) {
+      __builtin_amdgcn_s_sleep(1);
+      const T w = mem_ld<true>(p);
+      const bool same = __builtin_bit_cast(unsigned long long, (double)w) == __builtin_bit_cast(unsigned long long, (double)v);
+      v = w;
+      if (same) break;
     }
   }
   return v;
@@ -1116,69 +1123,6 @@ __device__ __forceinline__ double chain_rsqrt(double d) {
 }
 __device__ __forceinline__ float chain_rsqrt(float d) { return fast_rsqrt(d); }
 
-// 16 x 16 Cholesky AND inverse in the registers of one wave: lanes 0..15 hold the rows of the block,
-// lanes 16..31 the rows of an identity, so the column sweep that turns the block into L turns the
-// identity into L^-T (v_readlane broadcasts, rsqrt + Newton, no LDS and no barrier on the chain).
-// `lane` is the lane index modulo 32 (lanes 32..63 mirror 0..31).
-template <typename T> __device__ __forceinline__ bool chol16_invert(T (&x)[16], int lane) {
-  bool bad = false;
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    T d = lane_bcast(x[k], k);
-    if (!(d > (T)0)) { bad = true; d = (T)1; }
-    const T inv = chain_rsqrt(d);
-    const T lik = lane >= k ? x[k] * inv : (T)0;
-    x[k] = lik;
-#pragma unroll
-    for (int j = k + 1; j < 16; j++) x[j] -= lik * lane_bcast(lik, j);
-  }
-  return bad;
-}
-
-// 16 x 16 Cholesky AND inverse on the matrix cores, the block in ACCUMULATOR layout: register r of lane l holds
-// element (MM::row(l, r), l & 15) of a 16 x 16 matrix -- what a trailing-update tile leaves behind, so the diagonal
-// block goes from the update into the factorisation without an LDS round trip.
-//   D   in: the SYMMETRIC block (both triangles)             destroyed
-//   Lt  out: L^T  (element (k, i) = L(i, k), zero for i < k)
-//   W   out: L^-1 (element (k, i) = W(k, i), zero for i > k)
-// Column k: row k of D lives in ONE register of the 16 lanes of one lane group -- by symmetry it is column k, i.e. in the
-// a / b operand position of an MFMA for k-slot (lane >> 4): the rank-1 update D -= l l^T is ONE v_mfma (the other three
-// k-slots multiply zeros), and so is the forward substitution that carries the inverse along, F -= l w_k^T (F starts as
-// the identity; w_k = row k of F over L_kk is row k of L^-1).  On the chain of a column: v_readlane of the pivot, rsqrt,
-// one multiply, one MFMA -- the 15 - k (v_readlane, v_readlane, FMA) triples per column of the register sweep
-// (chol16_invert) are gone.  Columns nb.. (a partial last block) are skipped: Lt and W are zero there.
-template <typename T>
-__device__ __forceinline__ bool chol16_mfma(typename Mfma16<T>::Acc &D, typename Mfma16<T>::Acc &Lt, typename Mfma16<T>::Acc &W, int nb) {
-  using MM = Mfma16<T>;
-  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-  typename MM::Acc F;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    F[r] = MM::row(lane, r) == li ? (T)1 : (T)0;
-    Lt[r] = 0;
-    W[r] = 0;
-  }
-  bool bad = false;
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    constexpr bool f64 = sizeof(T) == 8;
-    const int gk = f64 ? (k & 3) : (k >> 2), rk = f64 ? (k >> 2) : (k & 3);   // lane group and register of row k
-    if (k < nb) {
-      T d = lane_bcast(D[rk], 16 * gk + k);
-      if (!(d > (T)0)) { bad = true; d = (T)1; }
-      const T vk = (lk == gk && li >= k) ? D[rk] : (T)0;   // row k = column k, from the diagonal down (off the chain: D is there before 1/sqrt)
-      const T fk = lk == gk ? F[rk] : (T)0;
-      const T inv = chain_rsqrt(d);
-      const T l = vk * inv, w = fk * inv;
-      D = MM::mma(l, -l, D);
-      F = MM::mma(l, -w, F);
-      Lt[rk] += l;
-      W[rk] += w;
-    }
-  }
-  return bad;
-}
-
 // acc += bcast * b, where bcast is the value of `a` in lane J of the calling lane's 16-lane row: ONE instruction (DPP
 // row_newbcast on the multiply-add itself; gfx90a+ allows it on the 64-bit FMA too) instead of v_readlane (x 2 in fp64)
 // + FMA.  The caller keeps two wait states between the VALU write of `a` and the first use (s_nop 1).
@@ -1188,47 +1132,6 @@ template <int J> __device__ __forceinline__ void fmac_bcast(double &acc, double 
 template <int J> __device__ __forceinline__ void fmac_bcast(float &acc, float a, float b) {
   asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(J));
 }
-template <typename T, int K, int J> struct Chol16Upd {
-  static __device__ __forceinline__ void run(T (&x)[16], T (&y)[16], T nlx, T lx, T ly) {
-    fmac_bcast<J>(x[J], nlx, lx);
-    fmac_bcast<J>(y[J], nlx, ly);
-    Chol16Upd<T, K, J + 1>::run(x, y, nlx, lx, ly);
-  }
-};
-template <typename T, int K> struct Chol16Upd<T, K, 16> {
-  static __device__ __forceinline__ void run(T (&)[16], T (&)[16], T, T, T) {}
-};
-template <typename T, int K> struct Chol16Col {
-  static __device__ __forceinline__ void run(T (&x)[16], T (&y)[16], int q, bool &bad) {
-    const T d = lane_bcast(x[K], K);
-    bad = bad || !(d > (T)0);        // (off the chain; a non-positive pivot turns the block into NaNs, the flag says so)
-    const T inv = chain_rsqrt(d);
-    // no mask on the chain: entries above the diagonal (lanes q < K) hold garbage that only ever flows into other
-    // entries above the diagonal -- a broadcast L(J, K) comes from lane J > K, the pivot from lane K; the caller zeroes
-    // them when it stores L
-    const T lx = x[K] * inv, ly = y[K] * inv;
-    x[K] = lx;
-    y[K] = ly;
-    T nlx = -lx;
-    asm volatile("s_nop 1" : "+v"(nlx));   // VALU write -> DPP read of the same register
-    Chol16Upd<T, K, K + 1>::run(x, y, nlx, lx, ly);
-    Chol16Col<T, K + 1>::run(x, y, q, bad);
-  }
-};
-template <typename T> struct Chol16Col<T, 16> {
-  static __device__ __forceinline__ void run(T (&)[16], T (&)[16], int, bool &) {}
-};
-// 16 x 16 Cholesky AND inverse, rows in lanes: lane q (of every 16-lane row of the wave; the four rows of lanes do the
-// same work) holds row q of the block in x and row q of an identity in y.  The column sweep that turns the block into L
-// turns the identity into L^-T: on return x[c] = L(q, c) for c <= q (GARBAGE above the diagonal), y[c] = W(c, q).  Against chol16_invert:
-// the broadcast of L(j, k) to the row is folded into the multiply-add (one instruction per entry instead of three in
-// fp64), at the price of the identity rows in registers of the same lanes instead of in lanes 16..31.
-template <typename T> __device__ __forceinline__ bool chol16_dpp(T (&x)[16], T (&y)[16], int q) {
-  bool bad = false;
-  Chol16Col<T, 0>::run(x, y, q, bad);
-  return bad;
-}
-
 // ---- the same sweep with the identity rows in the NEXT 16-lane row instead of in registers of the same lanes (the layout
 // of chol16_invert: lanes 0..15 of every 32 hold the rows of the block, lanes 16..31 the rows of an identity): one
 // multiply-add per column entry serves both, and the wave needs 16 registers per lane, not 32 -- the kernels that run
@@ -1340,74 +1243,6 @@ template <typename T> __device__ __forceinline__ bool chol16_dpp2(T (&x)[16], in
   return bad;
 }
 
-// Diagonal block k0 (nb <= 16 columns) of the panel P with the DPP sweep (chol16_dpp): every 16-lane row of the wave
-// holds the block's rows (lane q = row q; a partial block is padded with an identity), W = L^-1 goes to
-// wscr[q * 17 + c] = W(c, q) FIRST (the triangular solves of the other waves wait for it), then L in place with
-// zeros above the diagonal.  r04: 1.9 -> 1.1 us per block in fp64 against chol16_invert (profiles/EXPERIMENTS.md).
-template <typename T>
-__device__ __forceinline__ void diag16_dpp(T *P, int M, int k0, int nb, int *err, T *wscr) {
-  const int lane = threadIdx.x & 63, q = lane & 15;
-  T x[16], y[16];
-  const T *src = P + k0 * M + k0 + min(q, nb - 1);
-  if (nb == 16) {
-#pragma unroll
-    for (int c = 0; c < 16; c++) x[c] = src[c * M];
-  } else {
-#pragma unroll
-    for (int c = 0; c < 16; c++) {
-      const T v = pin(src[min(c, nb - 1) * M]);
-      x[c] = (q < nb && c < nb) ? v : (q == c ? (T)1 : (T)0);
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < 16; c++) y[c] = q == c ? (T)1 : (T)0;
-  const bool bad = chol16_dpp<T>(x, y, q);
-  T *ws = wscr + q * 17;
-#pragma unroll
-  for (int c = 0; c < 16; c++) ws[c] = y[c];
-  if (bad && lane == 0) atomicOr(err, DEVERR_NOT_SPD);
-  if (q < nb) {
-    T *pw = P + k0 * M + k0 + q;
-#pragma unroll
-    for (int c = 0; c < 16; c++)
-      if (c < nb) pw[c * M] = c <= q ? x[c] : (T)0;
-  }
-}
-
-// Diagonal block k0 (nb <= 16 columns) of the panel P, by the calling wave: L11 in place and
-// W = L11^-1 to the LDS scratch as wscr[j * 17 + c] = W(c, j) and, for the back substitution, to
-// wout[block][c * 16 + j].  A partial block is padded with an identity.  All loads unconditional (clamped), two divergent store regions instead of a branch per store.
-template <typename T>
-__device__ __forceinline__ void diag16_factor_invert(T *P, int M, int k0, int nb, int *err, T *wscr, T *wout) {
-  const int lane = threadIdx.x & 63, ll = lane & 31, q = lane & 15;
-  const bool rowlane = ll < 16;
-  T x[16];
-  const T *prow = P + k0 + min(q, nb - 1);
-#pragma unroll
-  for (int c = 0; c < 16; c++) {
-    const T v = pin(prow[(k0 + min(c, nb - 1)) * M]);
-    x[c] = rowlane ? ((q < nb && c < nb) ? (c <= q ? v : (T)0) : (q == c ? (T)1 : (T)0)) : (q == c ? (T)1 : (T)0);
-  }
-  const bool bad = chol16_invert<T>(x, ll);
-  if (bad && lane == 0) atomicOr(err, DEVERR_NOT_SPD);
-  if (rowlane) {
-    if (q < nb) {
-      T *pw = P + k0 + q;
-#pragma unroll
-      for (int c = 0; c < 16; c++)
-        if (c < nb) pw[(k0 + c) * M] = c <= q ? x[c] : (T)0;   // zeros above the diagonal
-    }
-  } else {
-#pragma unroll
-    for (int c = 0; c < 16; c++) wscr[q * 17 + c] = x[c];      // W(c, q)
-    if (wout && lane < 32) {   // kept for the back substitution: wout[c * 16 + q] = W(c, q)
-      T *wo = wout + (k0 >> 4) * 256 + q;
-#pragma unroll
-      for (int c = 0; c < 16; c++) wo[c * 16] = x[c];
-    }
-  }
-}
-
 // The same for a FULL block whose strict upper triangle in P is zero (fronts are zeroed before assembly
 // and every later store is to i >= j) and with a 16 x 16 identity at wscr + 16 * 17: lanes 0..15 stream
 // the rows of the block, lanes 16..31 the rows of the identity, through ONE per-lane (base, stride) pair
@@ -1424,11 +1259,7 @@ __device__ __forceinline__ void diag16_factor_invert_full(T *P, int M, int k0, i
   T x[16];
 #pragma unroll
   for (int c = 0; c < 16; c++) x[c] = src[c * sstride];
-#if RRPGO_DPP_SWEEP == 2
   const bool bad = chol16_dpp2<T>(x);   // (leaves garbage above the diagonal of the factored block: nothing reads it)
-#else
-  const bool bad = chol16_invert<T>(x, ll);
-#endif
   if (bad && lane == 0) atomicOr(err, DEVERR_NOT_SPD);
   T *dst = rowlane ? P + k0 * M + k0 + q : wscr + q * 17;              // L(q, c) in place | W(c, q)
   const int dstride = rowlane ? M : 1;
@@ -1453,11 +1284,7 @@ __device__ __forceinline__ void diag16_factor_invert_part(T *P, int M, int k0, i
     const T *pc = (prow && c >= nb) ? ident + 1 : src + c * sstride;
     x[c] = *pc;
   }
-#if RRPGO_DPP_SWEEP == 2
   const bool bad = chol16_dpp2<T>(x, nb);
-#else
-  const bool bad = chol16_invert<T>(x, ll);
-#endif
   if (bad && lane == 0) atomicOr(err, DEVERR_NOT_SPD);
   T *dump = wscr + 16;
   T *dst = prow ? P + k0 * M + k0 + q : rowlane ? dump : wscr + q * 17;
@@ -1538,13 +1365,9 @@ __device__ __forceinline__ void panel_factor(T *P, int M, int nc, int *err, T *w
     RRPGO_ACC_BEGIN();
     constexpr bool fast = FAST;
     auto diag = [&] {
-      if (!FAST) diag16_factor_invert<T>(P, M, k0, nb, err, wscr, wout);
-#if RRPGO_DPP_SWEEP == 1
-      else diag16_dpp<T>(P, M, k0, nb, err, wscr);
-#else
-      else if (nb == NB) diag16_factor_invert_full<T>(P, M, k0, err, wscr);
+      static_assert(FAST, "the general diagonal-block form (fronts factored in place in global memory by this routine) was retired in r05");
+      if (nb == NB) diag16_factor_invert_full<T>(P, M, k0, err, wscr);
       else diag16_factor_invert_part<T>(P, M, k0, nb, err, wscr);
-#endif
     };
     if (NW == 1) {
       if (pend_k0 >= 0) rest_update(pend_k0, 0, 1);
@@ -1606,331 +1429,6 @@ __device__ __forceinline__ void panel_factor(T *P, int M, int nc, int *err, T *w
   }
 }
 
-
-// ===== panel_flow: the partial Cholesky of a front in LDS as a DATAFLOW between the waves of the workgroup (r04) =====
-//
-// panel_factor (above) walks the pivot blocks with two workgroup barriers per 16 columns, and the wave that carries the
-// chain of diagonal blocks passes through LDS four times per block (diagonal block in, L and W out, W in, the updated
-// next diagonal block out): 3.8 us per block on intel.g2o's fronts, of which 1.9 are the 16 x 16 sweep itself
-// (profiles/r04_intel_critical_path.txt).  Here every 16-row block of the front has an OWNER wave (block i -> wave
-// i mod NW) that keeps that block's 16 x 16 tiles of the pivot columns up to date and turns them into L,
-//     X_ik = T_ik W_k^T              when W_k (the inverse of diagonal block k) arrives,
-//     T_i(k+1) -= X_ik X_(k+1)k^T    at once (the pivot row block k + 1 publishes its X before it factors),
-//     T_ic -= X_i(k-1) X_c(k-1)^T    for the later block columns c one step behind (all of block column k - 1 is in LDS
-//                                    by then), and likewise the tiles of the update matrix below the pivot block,
-// so that a tile has every term but the newest when its turn comes.  What travels between waves are W_k (three LDS
-// slots) and X blocks, behind monotone LDS counters instead of barriers:
-//     wdone    = number of diagonal blocks whose W is published
-//     pdone    = k + 1 once the pivot row block k + 1 has stored X_(k+1)k
-//     xcnt[k]  = row blocks that have stored their X block of pivot block column k (and are done reading W_k)
-// The chain hops from owner to owner: when W_k arrives the owner of row block k + 1 forms X = T W_k^T and
-// D = A - X X^T on the matrix cores WITHOUT leaving registers (accumulator layout = operand layout, Mfma16<T>::row),
-// turns D by one LDS transpose into the row-per-lane form of the register sweep (chol16_dpp), publishes W_(k+1) -- and
-// only then stores L, which nobody waits for.  Between two sweeps the chain costs one LDS flag hop, 8 MFMAs and the
-// transpose.  The last block column's term of the update matrix is applied by all waves after the panel (the caller).
-// A wave may own several row blocks (fronts of more than 16 NW rows, small workgroups): it handles them step by step
-// in ascending order, the chain block first -- every wait is for something produced in an EARLIER step of another
-// wave's sequence (or earlier in the same step by the chain block's owner, who never waits for this wave), so the
-// scheme cannot deadlock for any NW.
-constexpr int PANEL_W = 16 * 17;                 // one W slot (W(c, q) at [q * 17 + c]); also the transpose scratch of the next sweep
-constexpr int PANEL_NW = 3;                      // W slots: W_k's slot is reused for W_(k+3), once every row block is done with W_k
-constexpr int PANEL_SCR = PANEL_NW * PANEL_W + 256;   // LDS scalars: the W slots | 16 x 16 identity
-constexpr int PANEL_FLAGS = 2 + 16;              // LDS ints: wdone, pdone, xcnt[16]
-template <typename T> __device__ __forceinline__ void panel_scr_init(T *scr, int tid, int nthreads) {
-  for (int t = tid; t < 256; t += nthreads) scr[PANEL_NW * PANEL_W + t] = (t >> 4) == (t & 15) ? (T)1 : (T)0;
-}
-__device__ __forceinline__ int lds_flag_ld(const int *p) { return __hip_atomic_load(const_cast<int *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void lds_flag_st(int *p, int v) {   // after this wave's LDS stores
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-template <bool URGENT> __device__ __forceinline__ void lds_wait_ge(const int *p, int v) {
-  while (lds_flag_ld(p) < v) {
-    if (URGENT) __builtin_amdgcn_s_sleep(0);
-    else __builtin_amdgcn_s_sleep(2);
-  }
-  asm volatile("" ::: "memory");
-}
-
-#ifdef RRPGO_STAMPS
-#define RRPGO_PTRACE(blk, slot)                                                                                   \
-  do {                                                                                                             \
-    if (ptrace && lane == 0 && (blk) < 16) { __builtin_amdgcn_sched_barrier(0); ptrace[(blk) * 8 + (slot)] = clock64(); __builtin_amdgcn_sched_barrier(0); } \
-  } while (0)
-#else
-#define RRPGO_PTRACE(blk, slot) do { } while (0)
-#endif
-#if defined(RRPGO_STAMPS) && defined(RRPGO_WAVE_TRACE)
-#define RRPGO_WTRACE(k, slot)                                                                                      \
-  do {                                                                                                             \
-    if (lane == 0 && (k) < 8 && wave < 16) { __builtin_amdgcn_sched_barrier(0); rrpgo_wtr[(wave * 8 + (k)) * 8 + (slot)] = clock64(); __builtin_amdgcn_sched_barrier(0); } \
-  } while (0)
-__shared__ unsigned long long rrpgo_wtr[16 * 8 * 8];   // per wave and step, kept in LDS while the panel runs (a global store per stamp disturbs what it measures)
-#else
-#define RRPGO_WTRACE(k, slot) do { } while (0)
-#endif
-// ptrace + 128 (diagnostic builds): per wave and step 8 stamps -- 0 step begun (first owned row block), 1 W seen,
-// 2 X stored + counted, 3 immediate update: X of the next pivot rows seen, 4 immediate done, 5 lagged: block column complete
-// seen, 6 lagged done (last owned row block of the step)
-// ptrace (diagnostic builds, else null): per pivot block 8 shader-clock stamps of the chain wave that factors it --
-// 0 W of the previous block seen, 1 X formed, 2 X published, 3 diagonal block complete, 4 slot free, 5 rows loaded,
-// 6 sweep done, 7 W published
-// nu / uaddr: the front's update matrix (rows nc.. of the panel are its operand), updated here block column by block
-// column except for the last one (the caller); nu == 0: left to the caller entirely.
-template <typename T, int THREADS, typename UAddr>
-__device__ __forceinline__ void panel_flow(T *P, int M, int nc, int *err, T *scr, int *flg, T *wout, int nu, UAddr uaddr,
-                                           unsigned long long *ptrace = nullptr) {
-  using MM = Mfma16<T>;
-  using Acc = typename MM::Acc;
-  constexpr int NW = THREADS / 64;
-  const int wave = wave_index(), lane = threadIdx.x & 63, li = lane & 15;
-  const int nblk = (nc + 15) >> 4;
-  const int nrb = nblk + ((M - nc + 15) >> 4);   // pivot row blocks, then the blocks of the rows below (from row nc on; the last holds the rhs row)
-  int kr[4];
-#pragma unroll
-  for (int r = 0; r < 4; r++) kr[r] = MM::row(lane, r);
-  auto row0 = [&](int i) { return i < nblk ? 16 * i : nc + 16 * (i - nblk); };
-  auto rows = [&](int i) { return i < nblk ? min(16, nc - 16 * i) : min(16, M - (nc + 16 * (i - nblk))); };
-  // Who owns row block i.  Eight waves sit two to a SIMD (wave w on SIMD w mod 4), and the sweep of a diagonal block
-  // keeps its SIMD's vector pipe busy: the wave next to it crawls, and the matrix-core pipe of that SIMD is the one the
-  // chain's own eight MFMAs per step need.  So the pivot row blocks -- the chain -- alternate between SIMDs 0 and 1
-  // (waves 0, 1, 4, 5: consecutive chain steps never share a SIMD, a wave's turn comes every fourth step), and the
-  // blocks of the rows below, which carry most of the trailing work, go to the waves of SIMDs 2 and 3.
-  auto owner = [&](int i) {
-    if (NW == 8) {
-      const int t = i < nblk ? i & 3 : (i - nblk) & 3;
-      return (i < nblk ? 0 : 2) + (t & 1) + 4 * (t >> 1);
-    }
-    return i % NW;
-  };
-  // every row block below pivot block k stores one X block of that column (and reads W_k once)
-  auto readers = [&](int k) { return nrb - 1 - k; };
-  int *xcnt = flg + 2;
-  // tile (row block i, pivot block column c) in accumulator layout: lane = row of the block, register r = column kr[r]
-  auto tile_ld = [&](int r0, int rn, int c, int cw) {
-    Acc t;
-    const int rl = min(li, rn - 1);
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const T v = P[(16 * c + min(kr[r], cw - 1)) * M + r0 + rl];
-      t[r] = kr[r] < cw ? v : (T)0;
-    }
-    return t;
-  };
-  auto tile_st = [&](int r0, int rn, int c, int cw, const Acc &t) {
-    if (rn == 16 && cw == 16) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) P[(16 * c + kr[r]) * M + r0 + li] = t[r];
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; r++)
-        if (li < rn && kr[r] < cw) P[(16 * c + kr[r]) * M + r0 + li] = t[r];
-    }
-  };
-  // the X block of pivot row block c in block column kc as the a-operand of  T_ic -= X_i X_c^T : lane = row of block c
-  auto xop_ld = [&](int c, int cn, int kc, T (&xo)[4]) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const T v = P[(16 * kc + kr[r]) * M + 16 * c + min(li, cn - 1)];
-      xo[r] = li < cn ? -v : (T)0;
-    }
-  };
-  // ---- the chain duty of the owner of pivot row block i: D (accumulator layout, symmetric, final) -> W_i, L_ii
-  auto chain_factor = [&](int i, Acc D) {
-    const int nb = rows(i);
-    T *slot = scr + (i % PANEL_NW) * PANEL_W;
-    RRPGO_PTRACE(i, 3);
-    if (i >= PANEL_NW) lds_wait_ge<true>(xcnt + (i - PANEL_NW), readers(i - PANEL_NW));   // the slot still holds W_(i-3): every row block must be done with it
-    RRPGO_PTRACE(i, 4);
-    // transpose through the slot: accumulator (kr[r], li) -> row per lane
-#pragma unroll
-    for (int r = 0; r < 4; r++) slot[kr[r] * 17 + li] = D[r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int q = li;
-    const bool prow = q < nb;   // lanes that hold a row of the block; the others stream identity rows
-    const T *ident = scr + PANEL_NW * PANEL_W;
-    const T *src = prow ? slot + q : ident + q;
-    const int sstride = prow ? 17 : 16;
-    T x[16], y[16];
-    if (nb == 16) {
-#pragma unroll
-      for (int c = 0; c < 16; c++) x[c] = slot[c * 17 + q];
-    } else {
-#pragma unroll
-      for (int c = 0; c < 16; c++) {
-        const T *pc = (prow && c >= nb) ? ident + 1 : src + c * sstride;   // columns past a partial block: zeros
-        x[c] = *pc;
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 16; c++) y[c] = q == c ? (T)1 : (T)0;
-#ifdef RRPGO_STAMPS
-#pragma unroll
-    for (int c = 0; c < 16; c++) asm volatile("" : "+v"(x[c]));
-#endif
-    RRPGO_PTRACE(i, 5);
-    const bool bad = chol16_dpp<T>(x, y, q);
-#ifdef RRPGO_STAMPS
-#pragma unroll
-    for (int c = 0; c < 16; c++) asm volatile("" : "+v"(y[c]));
-#endif
-    RRPGO_PTRACE(i, 6);
-    // W(c, q) -> the slot (every row of lanes stores the same values) and out; then, off the chain, row q of L -> P in place
-    T *ws = slot + q * 17;
-#pragma unroll
-    for (int c = 0; c < 16; c++) ws[c] = y[c];
-    if (lane == 0) lds_flag_st(flg + 0, i + 1);   // (a wave's LDS operations complete in order: lane 0's flag follows every lane's stores after the waitcnt)
-    RRPGO_PTRACE(i, 7);
-    if (bad && lane == 0) atomicOr(err, DEVERR_NOT_SPD);
-    if (q < nb) {
-      T *pw = P + (16 * i) * M + 16 * i + q;
-#pragma unroll
-      for (int c = 0; c < 16; c++)
-        if (c < nb) pw[c * M] = c <= q ? x[c] : (T)0;   // zeros above the diagonal (the sweep leaves garbage there)
-    }
-  };
-  // ---- update matrix: U -= X X^T over the rows below the pivot block, as BACKGROUND work.  Every tile belongs to ONE
-  // wave for the whole panel (its read-modify-write needs no ordering between waves).  A wave works on its tiles while it
-  // waits for the next W, one tile at a time (a tile is ~0.3 us: the X blocks that W releases are late by at most that),
-  // in passes: a pass applies the block columns [ua, ub) that were complete when it began to every tile of the wave --
-  // several block columns in one read-modify-write when the wave has fallen behind.
-  const int unt = (nu + 15) >> 4, utiles = nu > 0 ? unt * (unt + 1) / 2 : 0;
-  const int uend = nblk - 1;                   // block columns [0, uend) here; the last one is the caller's (all waves)
-  int u_done = 0, u_avail = 0, ua = 0, ub = 0, ucur = utiles;   // ucur == utiles: no pass open
-  auto u_step = [&]() -> bool {                // one tile; false: nothing to do right now
-    if (ucur >= utiles) {
-      while (u_avail < uend && lds_flag_ld(xcnt + u_avail) >= readers(u_avail)) u_avail++;
-      if (u_avail <= u_done || wave >= utiles) return false;
-      ua = u_done; ub = u_avail; ucur = wave;
-    }
-    int jb = 0, rem = ucur;
-    while (rem >= unt - jb) { rem -= unt - jb; jb++; }
-    tile_rank_update<T>(P + nc, M, 16 * (jb + rem), 16 * jb, nu, nu, 16 * ua, 16 * ub, uaddr);
-    ucur += NW;
-    if (ucur >= utiles) { u_done = ub; ucur = utiles; }
-    return true;
-  };
-  if (wave == owner(0)) {
-    __builtin_amdgcn_s_setprio(RRPGO_CHAIN_PRIO);
-    // diagonal block 0 as assembled: lower triangle of P, mirrored
-    const int nb = rows(0);
-    Acc D;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int a = max(kr[r], li), b = min(kr[r], li);   // (row a, column b), a >= b
-      const T v = P[min(b, nb - 1) * M + min(a, nb - 1)];
-      D[r] = (a < nb) ? v : (T)0;
-    }
-    chain_factor(0, D);
-    __builtin_amdgcn_s_setprio(0);
-  }
-  for (int k = 0; k < nblk; k++) {
-    const int kw = min(16, nc - 16 * k);            // columns of pivot block k
-    for (int i = k + 1; i < nrb; i++) {
-      if (owner(i) != wave) continue;
-      const bool pivot = i < nblk, chain = pivot && i == k + 1;   // chain: this wave factors the next diagonal block
-      if (chain) __builtin_amdgcn_s_setprio(RRPGO_CHAIN_PRIO);
-      const int r0 = row0(i), rn = rows(i);
-      RRPGO_WTRACE(k, 0);
-      // ---- X_ik = T_ik W_k^T: the tile has every earlier term already
-      const Acc Tt = tile_ld(r0, rn, k, kw);
-      Acc Dn = {0, 0, 0, 0};
-      if (pivot) {   // the block's own diagonal tile, symmetric: stored full by this wave at the earlier steps (as assembled: lower triangle, mirrored)
-        if (k == 0) {
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int a = max(kr[r], li), b = min(kr[r], li);
-            const T v = P[(16 * i + min(b, rn - 1)) * M + 16 * i + min(a, rn - 1)];
-            Dn[r] = (a < rn) ? v : (T)0;
-          }
-        } else {
-          Dn = tile_ld(r0, rn, i, rn);
-        }
-      }
-      if (chain || (pivot && i == k + 2) || NW < 4) {
-        lds_wait_ge<true>(flg + 0, k + 1);     // this wave carries the chain now or next: nothing else in between
-      } else {
-        while (lds_flag_ld(flg + 0) < k + 1)
-          if (!u_step()) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
-      }
-      if (chain) RRPGO_PTRACE(i, 0);
-      RRPGO_WTRACE(k, 1);
-      const T *slot = scr + (k % PANEL_NW) * PANEL_W;
-      T wa[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) wa[r] = slot[kr[r] * 17 + li];   // W_k(c = li, j = kr[r])
-      Acc X = {0, 0, 0, 0};
-#pragma unroll
-      for (int r = 0; r < 4; r++) X = MM::mma(wa[r], Tt[r], X);
-#ifdef RRPGO_STAMPS
-      if (chain) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) asm volatile("" : "+v"(X[r]));
-        RRPGO_PTRACE(i, 1);
-      }
-#endif
-      tile_st(r0, rn, k, kw, X);
-      // rows past a partial block and columns past a partial pivot block would poison the products below
-      Acc Xz;
-#pragma unroll
-      for (int r = 0; r < 4; r++) Xz[r] = (li < rn && kr[r] < kw) ? X[r] : (T)0;
-      if (pivot) {
-        // the diagonal tile's term straight from the registers (the matrix cores work under the drain of the stores)
-#pragma unroll
-        for (int r = 0; r < 4; r++) Dn = MM::mma(-Xz[r], Xz[r], Dn);
-        if (chain) {
-          if (lane == 0) lds_flag_st(flg + 1, k + 1);   // X_(k+1)k is in LDS
-          RRPGO_PTRACE(i, 2);
-          chain_factor(i, Dn);
-          __builtin_amdgcn_s_setprio(0);
-        } else {
-          tile_st(r0, rn, i, rn, Dn);   // (full tile, both triangles: only this wave reads it again)
-        }
-      }
-      if (i == nrb - 1 && wout) copy_w16<T>(slot, wout + k * 256);   // kept for the back substitution (one coalesced copy per block)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this row block's X block is in LDS, its reads of W_k are done
-      if (lane == 0) atomicAdd(xcnt + k, 1);
-      RRPGO_WTRACE(k, 2);
-      // ---- the tile of the NEXT block column takes this step's term at once: the pivot row block k + 1 publishes its X
-      // block before it factors, so the tile is complete when W_(k+1) arrives
-      const int cmax = min(i, nblk);   // this row block has tiles in the block columns c < cmax
-      if (k + 1 < cmax) {
-        lds_wait_ge<false>(flg + 1, k + 1);
-        RRPGO_WTRACE(k, 3);
-        const int cw1 = min(16, nc - 16 * (k + 1));   // (the last pivot block may be a partial one)
-        T xo[4];
-        xop_ld(k + 1, cw1, k, xo);
-        Acc Tn = tile_ld(r0, rn, k + 1, cw1);
-#pragma unroll
-        for (int r = 0; r < 4; r++) Tn = MM::mma(xo[r], Xz[r], Tn);
-        tile_st(r0, rn, k + 1, cw1, Tn);
-        RRPGO_WTRACE(k, 4);
-      }
-      // ---- the later block columns, one step behind: the term of block column k - 1
-      if (k >= 1 && k + 1 < cmax) {
-        lds_wait_ge<false>(xcnt + (k - 1), readers(k - 1));
-        RRPGO_WTRACE(k, 5);
-        T xi[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) xi[r] = P[(16 * (k - 1) + kr[r]) * M + r0 + min(li, rn - 1)];   // X_i(k-1)
-        for (int c = k + 1; c < cmax; c++) {
-          const int cw = min(16, nc - 16 * c);
-          T xo[4];
-          xop_ld(c, cw, k - 1, xo);
-          Acc Tc = tile_ld(r0, rn, c, cw);
-#pragma unroll
-          for (int r = 0; r < 4; r++) Tc = MM::mma(xo[r], xi[r], Tc);
-          tile_st(r0, rn, c, cw, Tc);
-        }
-        RRPGO_WTRACE(k, 6);
-      }
-    }
-  }
-  // what is left of the update matrix (but the last block column)
-  while (wave < utiles && u_done < uend)
-    if (!u_step()) __builtin_amdgcn_s_sleep(1);
-}
 
 // Assemble, factor and publish one front.  P is the M x nc pivot panel
 // (column-major, ld M), U the (nr+1) x (nr+1) update matrix (packed lower when
@@ -2106,9 +1604,6 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
       }
     }
   }
-#if RRPGO_PANEL_FLOW
-  if (!IN_PLACE && tid < PANEL_FLAGS) reinterpret_cast<int *>(dinv + PANEL_SCR)[tid] = 0;   // counters of panel_flow
-#endif
   __syncthreads();
   RRPGO_STAMP(a, s, 3);
   // ---- partial factorisation + Schur complement
@@ -2124,28 +1619,7 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
   auto uaddr = [&](int i, int j) {   // 32-bit index arithmetic for the packed triangle in LDS
     return IN_PLACE ? U + ((int64_t)j * uld + i) : U + (j * nu - ((j * (j - 1)) >> 1) + (i - j));
   };
-#if RRPGO_PANEL_FLOW
-  constexpr bool panel_dataflow = !IN_PLACE;
-#else
-  constexpr bool panel_dataflow = false;
-#endif
-  if constexpr (panel_dataflow) {
-    // the pivot panel as a dataflow between the waves (panel_flow); the update matrix in one pass over all pivot columns below
-#ifdef RRPGO_STAMPS
-    if (tid == 0 && a.stamps) { a.stamps[(int64_t)s * 12 + 7] = 0; a.stamps[(int64_t)s * 12 + 8] = 0; a.stamps[(int64_t)s * 12 + 9] = 0; }
-#endif
-#ifdef RRPGO_STAMPS
-    panel_flow<T, THREADS>(P, M, nc, a.err, dinv, reinterpret_cast<int *>(dinv + PANEL_SCR), a.winv + (int64_t)m.wblk * 256, defer_u ? 0 : nu, uaddr,
-                           a.ptrace ? a.ptrace + (int64_t)s * 1280 : nullptr);
-#ifdef RRPGO_WAVE_TRACE
-    __syncthreads();
-    if (a.ptrace) for (int t = tid; t < 1024; t += THREADS) { a.ptrace[(int64_t)s * 1280 + 128 + t] = rrpgo_wtr[t]; rrpgo_wtr[t] = 0; }
-#endif
-#else
-    panel_flow<T, THREADS>(P, M, nc, a.err, dinv, reinterpret_cast<int *>(dinv + PANEL_SCR), a.winv + (int64_t)m.wblk * 256, defer_u ? 0 : nu, uaddr);
-#endif
-    __syncthreads();
-  } else {
+  {
 #ifdef RRPGO_STAMPS
   if (tid == 0 && a.stamps) { a.stamps[(int64_t)s * 12 + 7] = 0; a.stamps[(int64_t)s * 12 + 8] = 0; a.stamps[(int64_t)s * 12 + 9] = 0; }
   panel_factor<T, THREADS, !IN_PLACE>(P, M, nc, a.err, dinv, a.winv + (int64_t)m.wblk * 256, a.stamps ? a.stamps + (int64_t)s * 12 : nullptr, nu, uaddr, defer_u);
@@ -2209,15 +1683,9 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
 template <typename T, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_factor_tasks(FactorArgs<T> a) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-#if RRPGO_PANEL_FLOW
-  __shared__ __align__(16) T dinv[PANEL_SCR + (PANEL_FLAGS * sizeof(int) + sizeof(T) - 1) / sizeof(T)];   // panel_flow: two W slots | identity | counters
-  T *smem = reinterpret_cast<T *>(smem_raw);
-  panel_scr_init<T>(dinv, threadIdx.x, THREADS);   // process_front has barriers before the first use
-#else
   __shared__ T dinv[W16_SCR];   // inverse of the current 16 x 16 diagonal block + an identity (diag16_factor_invert_full)
   T *smem = reinterpret_cast<T *>(smem_raw);
   init_w16_identity<T>(dinv, threadIdx.x, THREADS);   // process_front has barriers before the first use
-#endif
   // the wave that carries every diagonal block shares its SIMD's issue slots with waves 4, 8, 12 of the workgroup:
   // it is served first (measured: intel.g2o +0.7 %, M3500 +0.9 %)
   if (THREADS > 256 && wave_index() == 0) __builtin_amdgcn_s_setprio(RRPGO_CHAIN_PRIO);
@@ -2448,13 +1916,9 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
 #pragma unroll
     for (int c = 0; c < 16; c++) x[c] = src[c * sstride];
   }
-#if RRPGO_DPP_SWEEP == 2
   bad = chol16_dpp2<T>(x, min(nb, 16));   // (leaves garbage above the diagonal of L: zeroed on the way out, the images below rely on it)
 #pragma unroll
   for (int c = 0; c < 16; c++) x[c] = (rowlane && c > q) ? (T)0 : x[c];
-#else
-  bad = chol16_invert<T>(x, ll);
-#endif
 #pragma unroll
   for (int c = 0; c < 16; c++) Sh[rowlane ? c * 33 + q : WOFF + q * 33 + c] = x[c];   // L11(q, c) | W11(c, q)
   sync();
@@ -2490,13 +1954,9 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
 #pragma unroll
     for (int c = 0; c < 16; c++) x[c] = src[c * sstride];
   }
-#if RRPGO_DPP_SWEEP == 2
   bad = chol16_dpp2<T>(x, max(nb - 16, 0)) || bad;
 #pragma unroll
   for (int c = 0; c < 16; c++) x[c] = (rowlane && c > q) ? (T)0 : x[c];
-#else
-  bad = chol16_invert<T>(x, ll) || bad;
-#endif
   if (bad && lane == 0) atomicOr(err, DEVERR_NOT_SPD);
 #pragma unroll
   for (int c = 0; c < 16; c++) Sh[rowlane ? (16 + c) * 33 + 16 + q : WOFF + (16 + q) * 33 + 16 + c] = x[c];
@@ -2790,11 +2250,15 @@ template <typename T> struct TileGather {
   const int32_t *scat;
   const T *lvals, *uvals, *xch;
 };
-template <typename T, int NT, int DEPTH = 1, bool SC1 = false, bool LONGK = false>
+// Gate (LONGK only): called with s before the first operand load of the columns [128 s, 128 s + 128) -- k_big_schur_flow
+// (flow.hip.h) runs beside the launch that is still producing those columns and waits for their flags there.
+struct NoGate { static constexpr bool on = false; __device__ __forceinline__ void operator()(int) const {} };
+template <typename T, int NT, int DEPTH = 1, bool SC1 = false, bool LONGK = false, typename Gate = NoGate>
 __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int jmax, int I0, int J0, T *smem,
                                                 typename Mfma16<T>::Acc (&acc)[NT][NT], unsigned long long *trace = nullptr, bool pm = false,
                                                 const TileGather<T> gather = TileGather<T>{nullptr, -1, nullptr, nullptr, nullptr, nullptr},
-                                                int tid_in = -1 /* k_big_flow: the caller's own copy of threadIdx.x */) {
+                                                int tid_in = -1 /* k_big_flow: the caller's own copy of threadIdx.x */, const Gate gate = Gate{}) {
+  static_assert(!Gate::on || LONGK, "only the one-pass Schur form is gated");
   struct { unsigned long long *trace; } a{trace};   // for RRPGO_PHASE_MARK (diagnostic builds)
   (void)a; (void)pm;
   using MM = Mfma16<T>;
@@ -2858,6 +2322,7 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
   };
   const int nchunks = (nk + KC - 1) / KC;
   constexpr int MAXCH = BIG_SUPER / KC;   // K <= 128
+  if constexpr (Gate::on) gate(0);
 #pragma unroll
   for (int d = 0; d < DEPTH; d++)
     if (d < nchunks) fetch(d, ra[d], rb[d]);   // requested BEFORE the C tile: a gathered tile pays two dependent round trips of its own
@@ -3026,7 +2491,11 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
       }
       if (c + 1 < nchunks) {
         stash(buf ^ 1, ra[0], rb[0]);
-        if (c + 2 < nchunks) fetch(c + 2, ra[0], rb[0]);
+        if (c + 2 < nchunks) {
+          if constexpr (Gate::on)
+            if (((c + 2) * KC) % BIG_SUPER == 0) gate((c + 2) * KC / BIG_SUPER);   // uniform: the next super-panel's first chunk
+          fetch(c + 2, ra[0], rb[0]);
+        }
       }
       __syncthreads();
     }

@@ -48,18 +48,10 @@ __device__ __forceinline__ int lds_flow_ticket(unsigned *ticket, int *slot) {
 template <typename T, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_factor_flow(FactorArgs<T> a, const LdsFlowTask *tasks, int n_tasks, unsigned *ticket) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-#if RRPGO_PANEL_FLOW
-  __shared__ __align__(16) T dinv[PANEL_SCR + (PANEL_FLAGS * sizeof(int) + sizeof(T) - 1) / sizeof(T)];   // panel_flow: two W slots | identity | counters
-#else
   __shared__ T dinv[W16_SCR];   // inverse of the current 16 x 16 diagonal block + an identity (diag16_factor_invert_full)
-#endif
   __shared__ int ticket_slot[2];
   T *smem = reinterpret_cast<T *>(smem_raw);
-#if RRPGO_PANEL_FLOW
-  panel_scr_init<T>(dinv, threadIdx.x, THREADS);
-#else
   init_w16_identity<T>(dinv, threadIdx.x, THREADS);
-#endif
   if (THREADS > 256 && wave_index() == 0) __builtin_amdgcn_s_setprio(RRPGO_CHAIN_PRIO);
   for (int round = 0;; round++) {
     const int tk = lds_flow_ticket(ticket, &ticket_slot[round & 1]);

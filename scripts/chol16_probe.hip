@@ -2,10 +2,75 @@
 // and checked against a host Cholesky: chol16_invert (rows in registers, v_readlane broadcasts) and chol16_mfma (the block in
 // MFMA accumulator layout, one rank-1 MFMA per column).  Exit code 0 = both within tolerance.
 #include "../rustrobotics_amd/csrc/kernels.hip.h"
+using namespace rrpgo;
+// The two retired forms the probe compares chol16_dpp2 with (removed from kernels.hip.h in r05, kept here as the reference):
+// 16 x 16 Cholesky AND inverse in the registers of one wave: lanes 0..15 hold the rows of the block,
+// lanes 16..31 the rows of an identity, so the column sweep that turns the block into L turns the
+// identity into L^-T (v_readlane broadcasts, rsqrt + Newton, no LDS and no barrier on the chain).
+// `lane` is the lane index modulo 32 (lanes 32..63 mirror 0..31).
+template <typename T> __device__ __forceinline__ bool chol16_invert(T (&x)[16], int lane) {
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    T d = lane_bcast(x[k], k);
+    if (!(d > (T)0)) { bad = true; d = (T)1; }
+    const T inv = chain_rsqrt(d);
+    const T lik = lane >= k ? x[k] * inv : (T)0;
+    x[k] = lik;
+#pragma unroll
+    for (int j = k + 1; j < 16; j++) x[j] -= lik * lane_bcast(lik, j);
+  }
+  return bad;
+}
+
+// 16 x 16 Cholesky AND inverse on the matrix cores, the block in ACCUMULATOR layout: register r of lane l holds
+// element (MM::row(l, r), l & 15) of a 16 x 16 matrix -- what a trailing-update tile leaves behind, so the diagonal
+// block goes from the update into the factorisation without an LDS round trip.
+//   D   in: the SYMMETRIC block (both triangles)             destroyed
+//   Lt  out: L^T  (element (k, i) = L(i, k), zero for i < k)
+//   W   out: L^-1 (element (k, i) = W(k, i), zero for i > k)
+// Column k: row k of D lives in ONE register of the 16 lanes of one lane group -- by symmetry it is column k, i.e. in the
+// a / b operand position of an MFMA for k-slot (lane >> 4): the rank-1 update D -= l l^T is ONE v_mfma (the other three
+// k-slots multiply zeros), and so is the forward substitution that carries the inverse along, F -= l w_k^T (F starts as
+// the identity; w_k = row k of F over L_kk is row k of L^-1).  On the chain of a column: v_readlane of the pivot, rsqrt,
+// one multiply, one MFMA -- the 15 - k (v_readlane, v_readlane, FMA) triples per column of the register sweep
+// (chol16_invert) are gone.  Columns nb.. (a partial last block) are skipped: Lt and W are zero there.
+template <typename T>
+__device__ __forceinline__ bool chol16_mfma(typename Mfma16<T>::Acc &D, typename Mfma16<T>::Acc &Lt, typename Mfma16<T>::Acc &W, int nb) {
+  using MM = Mfma16<T>;
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  typename MM::Acc F;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    F[r] = MM::row(lane, r) == li ? (T)1 : (T)0;
+    Lt[r] = 0;
+    W[r] = 0;
+  }
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    constexpr bool f64 = sizeof(T) == 8;
+    const int gk = f64 ? (k & 3) : (k >> 2), rk = f64 ? (k >> 2) : (k & 3);   // lane group and register of row k
+    if (k < nb) {
+      T d = lane_bcast(D[rk], 16 * gk + k);
+      if (!(d > (T)0)) { bad = true; d = (T)1; }
+      const T vk = (lk == gk && li >= k) ? D[rk] : (T)0;   // row k = column k, from the diagonal down (off the chain: D is there before 1/sqrt)
+      const T fk = lk == gk ? F[rk] : (T)0;
+      const T inv = chain_rsqrt(d);
+      const T l = vk * inv, w = fk * inv;
+      D = MM::mma(l, -l, D);
+      F = MM::mma(l, -w, F);
+      Lt[rk] += l;
+      W[rk] += w;
+    }
+  }
+  return bad;
+}
+
+
 #include <cmath>
 #include <cstdio>
 #include <vector>
-using namespace rrpgo;
 template <typename T> __global__ void __launch_bounds__(64) probe_regs(T *buf, long long *st) {
   const int lane = threadIdx.x;
   T x[16];

@@ -62,30 +62,3 @@ print('  hop = last child\'s flag -> extend-add of that child done (poll + sc1 l
 # per-phase means over all fronts
 ph = np.diff(st[:, 0:7], axis=1)
 print('all fronts, mean us per phase [zero, asm, extadd, panel, schur, store]:', np.round(ph.mean(0), 2))
-
-# chain stamps of panel_flow on the critical path's fronts (shader clocks -> ns at 2.4 GHz)
-if hasattr(L, 'rr_pgo_debug_ptrace'):
-    raw = np.zeros((S, 1280))
-    L.rr_pgo_debug_ptrace(g._h, raw.ctypes.data_as(C.POINTER(C.c_double)))
-    pt = raw[:, :128].reshape(S, 16, 8)
-    if not pt.any(): sys.exit(0)   # (a build without panel_flow: no chain stamps)
-    wt = raw[:, 128:1152].reshape(S, 16, 8, 8)
-    names = ['W seen', 'X formed', 'X publ', 'D done', 'slot free', 'rows in', 'sweep', 'W publ']
-    print('panel_flow chain, per pivot block (ns since the previous block\'s W was published; block 0: since its own D):')
-    for s in path[-4:]:
-        nb = (nc[s] + 15) // 16
-        print(f' front {s} nc={nc[s]} nr={nr[s]}')
-        for b in range(min(nb, 16)):
-            t = pt[s, b] / 2.4
-            ref = pt[s, b - 1, 7] / 2.4 if b > 0 else t[3]
-            print(f'   block {b}: ' + '  '.join(f'{n} {t[q] - ref:7.0f}' for q, n in enumerate(names) if (b > 0 or q >= 3)))
-    s = path[-1] if len(sys.argv) < 3 else int(sys.argv[2])
-    nb = (nc[s] + 15) // 16
-    print(f'per wave and step of front {s} (ns since W_0 was published): begun | W seen | X counted | imm: X seen, done | lagged: seen, done')
-    ref = pt[s, 0, 7] / 2.4
-    for k in range(min(nb, 8)):
-        print(f'  step {k}: W_{k} published at {pt[s, k, 7] / 2.4 - ref:7.0f}')
-        for w in range(16):
-            t = wt[s, w, k] / 2.4
-            if t[1] == 0: continue
-            print(f'     wave {w:2d}: ' + ' '.join(f'{(v - ref) if v > 0 else float("nan"):7.0f}' for v in t[:7]))

@@ -5,6 +5,7 @@
 //   hipcc --offload-arch=gfx950 -O3 scripts/handoff_probe.hip -o handoff_probe && ./handoff_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 constexpr int LINES = 32, ELEMS = LINES * 32, PASSES = ELEMS / 64;
@@ -108,7 +109,88 @@ template <int LOADF, int STOREF, bool ACQ, bool REL> void run(const char *name, 
   hipFree(buf); hipFree(flags); hipFree(stale); hipFree(tmo); hipFree(xcc); hipFree(lat);
 }
 
-int main() {
+int main8(int rounds);
+
+// ---- r05: the payload-as-flag hand-off of k_solve_flow (kernels.hip.h, x_wait) for 8-BYTE payloads --------------------------
+// An entry of x goes from "pending" to its value in ONE aligned 8-byte sc1 store; the consumer polls the entry itself.  x_wait
+// trusts that such a store is single-copy atomic (a poll never sees one 32-bit half new and the other half old).  Here every
+// round r writes (hi, lo) = (H | r, L ^ r) over round r - 1's pair; the consumer polls until the HIGH word is round r's and
+// counts entries whose LOW word is still round r - 1's (torn).  FORM 0: __hip_atomic_store / load (global_store_dwordx2 sc1),
+// FORM 1: raw buffer store / load b64 with the sc1 bit (Sc1Buf).  WIDE: the producer writes its 512 entries as 64 lanes x 8
+// passes (one entry per lane and store, as solve_front does).
+typedef unsigned pr_u2 __attribute__((ext_vector_type(2)));
+template <int FORM> __device__ __forceinline__ void st8(double *base, int i, unsigned hi, unsigned lo) {
+  if (FORM == 0) __hip_atomic_store(base + i, __hiloint2double((int)hi, (int)lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else {
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 512 * 8, 0x00020000);
+    const pr_u2 w = {lo, hi};
+    __builtin_amdgcn_raw_buffer_store_b64(w, r, i * 8, 0, 16);
+  }
+}
+template <int FORM> __device__ __forceinline__ void ld8(const double *base, int i, unsigned &hi, unsigned &lo) {
+  if (FORM == 0) {
+    const double v = __hip_atomic_load(const_cast<double *>(base) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    hi = (unsigned)__double2hiint(v); lo = (unsigned)__double2loint(v);
+  } else {
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base), 0, 512 * 8, 0x00020000);
+    const pr_u2 w = __builtin_amdgcn_raw_buffer_load_b64(r, i * 8, 0, 16);
+    hi = w.y; lo = w.x;
+  }
+}
+template <int FORM>
+__global__ void __launch_bounds__(64) k_probe8(double *buf, unsigned *go, unsigned long long *torn, unsigned long long *seen, unsigned *tmo, int rounds, int stride) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int g2 = b / (2 * stride), rem = b % (2 * stride);
+  const int role = rem / stride, g = g2 * stride + rem % stride;   // role 0 consumer, 1 producer
+  double *reg = buf + (size_t)g * 512;
+  unsigned *fl = go + (size_t)g * 32;
+  constexpr unsigned H = 0x40100000u, L = 0x5a5a0000u;
+  unsigned long long bad = 0, n = 0;
+  for (int r = 1; r <= rounds; r++) {
+    if (role == 1) {
+      // the consumer has checked round r - 1 (otherwise a fast producer would overwrite what is being polled)
+      if (!wait_flag(fl, (unsigned)(r - 1), tmo)) return;
+      for (int p = 0; p < 8; p++) st8<FORM>(reg, p * 64 + lane, H | (unsigned)r, L ^ (unsigned)r);
+    } else {
+      for (int p = 0; p < 8; p++) {
+        unsigned hi, lo;
+        unsigned s = 0;
+        do { asm volatile("" ::: "memory"); ld8<FORM>(reg, p * 64 + lane, hi, lo); } while (hi != (H | (unsigned)r) && ++s < SPIN_MAX);   // (the clobber: a raw buffer load is no volatile access, the compiler may hoist it out of a poll)
+        if (s >= SPIN_MAX) { if (lane == 0) atomicAdd(tmo, 1u); return; }
+        bad += lo != (L ^ (unsigned)r);
+        n++;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) st_flag(fl, (unsigned)r);
+    }
+  }
+  if (role == 0) { atomicAdd(torn, bad); atomicAdd(seen, n); }
+}
+template <int FORM> void run8(const char *name, int stride, int rounds) {
+  const int nb = 240, groups = nb / 2;
+  double *buf; unsigned *go, *tmo; unsigned long long *torn, *seen;
+  hipMalloc(&buf, 8 * 512 * groups); hipMemset(buf, 0, 8 * 512 * groups);
+  hipMalloc(&go, 128 * groups); hipMemset(go, 0, 128 * groups);
+  hipMalloc(&torn, 8); hipMemset(torn, 0, 8); hipMalloc(&seen, 8); hipMemset(seen, 0, 8);
+  hipMalloc(&tmo, 4); hipMemset(tmo, 0, 4);
+  hipLaunchKernelGGL((k_probe8<FORM>), dim3(nb), dim3(64), 0, 0, buf, go, torn, seen, tmo, rounds, stride);
+  hipError_t e = hipDeviceSynchronize();
+  unsigned long long ht = 0, hs = 0; unsigned hto = 0;
+  hipMemcpy(&ht, torn, 8, hipMemcpyDeviceToHost); hipMemcpy(&hs, seen, 8, hipMemcpyDeviceToHost); hipMemcpy(&hto, tmo, 4, hipMemcpyDeviceToHost);
+  printf("8-byte payload-as-flag, %-44s stride %d: torn %llu of %llu hand-offs  timeouts %u  (%s)\n", name, stride, ht, hs, hto, hipGetErrorString(e));
+  hipFree(buf); hipFree(go); hipFree(torn); hipFree(seen); hipFree(tmo);
+}
+int main8(int rounds) {
+  for (int stride : {1, 8}) {
+    run8<0>("atomic store / load, agent scope (dwordx2 sc1)", stride, rounds);
+    run8<1>("raw buffer store / load b64, sc1", stride, rounds);
+  }
+  return 0;
+}
+
+int main(int argc, char **argv) {
+  if (argc > 1) return main8(atoi(argv[1]));   // ./handoff_probe ROUNDS: the 8-byte payload-as-flag probe only (122880 hand-offs per round)
   for (int stride : {1, 8}) {
     run<1, 1, false, false>("sc1 stores, sc1 loads, no fence", stride);
     run<2, 1, false, false>("sc1 stores, sc0 sc1 loads, no fence", stride);
