@@ -35,7 +35,10 @@ struct FlowFront {       // one front of a flow level: where its flags live (ind
   int32_t wf;            // wf[b]: W of 32-column block b is in winv (and every row the chain read for it is in F)
   int32_t pf, pstride;   // pf[b * pstride + rb]: X of row block rb of block b is in F
   int32_t uf, ustride;   // uf[sp * ustride + bx (bx + 1) / 2 + by]: tile (bx, by) of super-panel sp's update is in F (tiles of 64 or 128: FlowLevel::nt)
-  int32_t pad[3];
+  // cross-level form (ONE launch for every level, r05; -1 / 0 otherwise):
+  int32_t bf, nbuild;    // bf: counter of finished BUILD tasks of this front; the one that counts to nbuild sets the flag word bf + 1, which the
+                         // front's DIAG0 and PANEL tasks wait for (its UPDATE tasks wait for PANEL flags: nothing to add)
+  int32_t done;          // counter of finished UPDATE tasks: the parent's BUILD tasks wait for it (FlowArgs::child_done holds word and target)
 };
 static_assert(sizeof(FlowFront) == 32, "FlowFront is one 32-byte record");
 
@@ -43,7 +46,8 @@ struct FlowTask {        // 16 bytes, one scalar load
   int32_t kind_front;    // kind << 24 | front slot of the level
   int32_t p0, p1, p2;    // PANEL: kb, first row block, K0;  UPDATE: K0, bx, by;  DIAG0: -
 };
-constexpr int FLOW_PANEL = 0, FLOW_UPDATE = 1, FLOW_DIAG0 = 2;
+constexpr int FLOW_PANEL = 0, FLOW_UPDATE = 1, FLOW_DIAG0 = 2, FLOW_BUILD = 3;   // BUILD(front, first column): cross-level form only
+constexpr int FLOW_BUILD_COLS = 4;   // pivot columns per BUILD task: one per wave, k_big_build's decomposition
 constexpr int FLOW_GROUP = 4;   // row blocks per PANEL task (one per wave)
 
 struct alignas(128) FlowRec {   // what a workgroup loads per ticket: the task and its front's records in ONE 128-byte line
@@ -70,6 +74,10 @@ template <typename T> struct FlowArgs {   // everything the launch reads: a slim
   int *err;
   unsigned long long wait_ticks;   // bound of one wait, 100 MHz wall-clock ticks (RR_PGO_FLOW_TIMEOUT_MS; default 2 s)
   unsigned long long *trace;   // diagnostic build (-DRRPGO_FLOW_TRACE): [ticket][wave][4] wall-clock stamps, else null
+  // cross-level form: what the BUILD tasks read (k_big_build's arguments)
+  const int2 *child_done;      // per child_meta entry: (word of the child's `done` counter, UPDATE tasks it has), (-1, 0): factored by an earlier launch
+  const int32_t *fasm_colptr, *fasm_dst, *fasm_src, *perm;
+  const T *hvals, *b;
 };
 
 // stamps of a task's wave: 0 = ticket drawn, 1 = dependencies met, 2 = X / tile stored, 3 = flags set (100 MHz wall clock)
@@ -106,6 +114,26 @@ __device__ __forceinline__ bool flow_wait(const unsigned *p, int *err, unsigned 
     __builtin_amdgcn_s_sleep(1);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the payload loads below the poll
+  return ok;
+}
+// wait until a counter has reached `need` (wave-uniform word).  Bounded like flow_wait.
+__device__ __forceinline__ bool flow_wait_ge(const unsigned *word, unsigned need, int *err, unsigned long long max_ticks) {
+  bool ok = true;
+  unsigned long long t0 = 0;
+  for (unsigned spins = 0;; spins++) {
+    if (flow_flag_ld(word) >= need) break;
+    if ((spins & 63u) == 63u) {
+      if (t0 == 0) t0 = wall_clock64();
+      const int e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e != 0 || wall_clock64() - t0 > max_ticks) {
+        if (e == 0) atomicOr(err, DEVERR_FLOW_TIMEOUT);
+        ok = false;
+        break;
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   return ok;
 }
 // the mark k_flow_reset leaves in a W block that is not there yet (see there)
@@ -148,6 +176,76 @@ __device__ __forceinline__ void flow_diag0_wave(const FlowArgs<T> &fa, const Flo
   if (lane == 0) flow_flag_set(fa.flags + ff.wf);
 }
 
+// ---- BUILD (cross-level form): FLOW_BUILD_COLS pivot columns of a front, one per wave -- k_big_build's arithmetic (the sum, in
+// child order, of what the children hold for every entry, then the column's H entries and its right-hand-side entry on top),
+// with the children's entries read past L1 and the column written through: children and parent are fronts of ONE launch.  The
+// task waits for the `done` counters of the children that are fronts of this launch (the others were factored by k_factor_flow,
+// an earlier launch), and counts itself in the front's build counter when its columns are in memory.
+template <typename T>
+__device__ __forceinline__ void flow_build_task(const FlowArgs<T> &fa, const FlowFront &ff, const SnMeta &m, int j0, int tid, int ticket) {
+  const int M = m.nc + m.nr + 1;
+  T *F = fa.lvals + m.loff;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const ChildMeta *cm = fa.child_meta + m.child_begin;
+  if (wave == 0) {
+    for (int q0 = 0; q0 < m.child_count; q0 += 64) {   // (a front has a handful of children: one pass)
+      const int q = q0 + lane;
+      int2 cd = make_int2(-1, 0);
+      if (q < m.child_count) cd = fa.child_done[m.child_begin + q];
+      // lanes poll their own child's counter; the wave goes on when every lane's has reached its target
+      bool ok = true;
+      unsigned long long t0 = 0;
+      for (unsigned spins = 0;; spins++) {
+        const bool there = cd.x < 0 || flow_flag_ld(fa.flags + cd.x) >= (unsigned)cd.y;
+        if (__all(there)) break;
+        if ((spins & 63u) == 63u) {
+          if (t0 == 0) t0 = wall_clock64();
+          const int e = __hip_atomic_load(fa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (e != 0 || wall_clock64() - t0 > fa.wait_ticks) {
+            if (e == 0 && lane == 0) atomicOr(fa.err, DEVERR_FLOW_TIMEOUT);
+            ok = false;
+            break;
+          }
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      (void)ok;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  __syncthreads();
+  RRPGO_FLOW_MARK(fa, ticket, wave, 1);
+  const int Jend = big_built_cols(m.nc, M);
+  const int J = j0 + wave;
+  if (J < Jend) {
+    T *col = F + (int64_t)J * M;
+    if (m.child_count <= 2) big_build_column<T, 2, true, FlowArgs<T>>(fa, cm, m.child_count, M, J, col, lane);
+    else big_build_column<T, 4, true, FlowArgs<T>>(fa, cm, m.child_count, M, J, col, lane);
+    if (J < m.nc) {
+      // the column's H entries and its right-hand-side entry on top of what this wave's other lanes have just stored
+      // (k_big_build, with_h: the same sums)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int t0 = fa.fasm_colptr[m.col0 + J], t1 = fa.fasm_colptr[m.col0 + J + 1];
+      for (int t = t0 + lane; t < t1; t += 64) {
+        T *p = F + fa.fasm_dst[t];
+        mem_st<true>(p, mem_ld<true>(p) + fa.hvals[fa.fasm_src[t]]);
+      }
+      if (lane == 0) {
+        T *p = F + (int64_t)J * M + (M - 1);
+        mem_st<true>(p, mem_ld<true>(p) + fa.b[fa.perm[m.col0 + J]]);
+      }
+    }
+  }
+  flow_drain();
+  __syncthreads();
+  if (tid == 0) {
+    // every BUILD task drains its stores before it counts itself: whoever counts last knows all the front's pivot columns are in memory
+    const unsigned before = __hip_atomic_fetch_add(fa.flags + ff.bf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (before + 1u == (unsigned)ff.nbuild) flow_flag_set(fa.flags + ff.bf + 1);
+  }
+  RRPGO_FLOW_MARK(fa, ticket, wave, 3);
+}
+
 // ---- PANEL: one wave = 32 rows below the block at kb (k_big_panel32's arithmetic, sc1 accesses, flags).
 // The order of work is the chain's schedule.  Everything that does not depend on the diagonal block being factored
 // right now comes first -- the left-looking update from the super-panel's earlier blocks, oldest first, each block's
@@ -158,7 +256,7 @@ __device__ __forceinline__ void flow_diag0_wave(const FlowArgs<T> &fa, const Flo
 // with the first half running under the previous step's factor-and-invert.
 template <typename T, int TS /* edge of a trailing-update tile: 64 or 128 */>
 __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const FlowFront &ff, const SnMeta &m, int kb,
-                                                int K0raw, int rowblk, T *Sh, int tid, int ticket) {
+                                                int K0raw, int rowblk, T *Sh, int tid, int ticket, const unsigned *built = nullptr) {
   static_assert(BIG_NB == 32 && BIG_SUPER == 128, "written for 32-column blocks in 128-column super-panels");
   using MM = Mfma16<T>;
   const int nb = min(BIG_NB, m.nc - kb);
@@ -199,6 +297,8 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
     } else if (lane == 3 * (FLOW_MAX_BACK - 1) + 2) {
       const int d = (kn - K0) / TS;   // the update before the next block's range (a later range: look_tile below)
       if (look && skip == 0 && K0 > 0) fp = fa.flags + ff.uf + (K0 / BIG_SUPER - 1) * ff.ustride + flow_tri(d, d);
+    } else if (lane == 63) {
+      fp = built;   // cross-level form: the front's pivot columns (the C tiles below are read from them)
     }
     flow_wait(fp, fa.err, fa.wait_ticks);
   }
@@ -432,7 +532,11 @@ __global__ void __launch_bounds__(256) k_flow_reset(unsigned *words, int64_t n, 
 // them in flight), 4 -> 128 x 128 (levels with thousands of tiles: the flow kernel runs two workgroups per CU, and at
 // that occupancy only the large tile -- sixteen accumulators per wave, four times the MFMAs per staged chunk -- keeps
 // the matrix cores fed while the next chunk is on its way)
-template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? RRPGO_FLOW_WAVES : 1)) k_big_flow(FlowArgs<T> fa) {
+// XL: the cross-level form (r05) -- the list holds the tasks of EVERY level of fronts beyond LDS, level after level: BUILD tasks
+// form a front's pivot columns once its children (fronts of earlier levels, earlier tickets) are done, a front's other tasks
+// wait for its BUILD tasks, and whatever is gathered from a child is read past L1.  One launch instead of three per level;
+// graphs of a few dozen big fronts (sphere2500: 46 in six levels) -- what k_factor_flow did for the LDS fronts.
+template <typename T, int NT, bool XL = false> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? RRPGO_FLOW_WAVES : 1)) k_big_flow(FlowArgs<T> fa) {
   using MM = Mfma16<T>;
   using UT = UpdTile<T, NT>;
   constexpr int TS = UT::TILE;
@@ -457,12 +561,23 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
     const int kind = tk.kind_front >> 24;
     const SnMeta m = rec.m;
     const FlowFront ff = rec.ff;
+    if constexpr (XL) {
+      if (kind == FLOW_BUILD) {
+        flow_build_task<T>(fa, ff, m, tk.p0, tid, t);
+        continue;
+      }
+    }
+    // (cross-level form: the flag that says the front's pivot columns are built -- a PANEL wave reads them before any other wait)
+    const unsigned *built = XL ? fa.flags + ff.bf + 1 : nullptr;
     if (kind == FLOW_PANEL) {
-      flow_panel_wave<T, TS>(fa, ff, m, tk.p0, tk.p2, tk.p1 + wave, smem, tid, t);
+      flow_panel_wave<T, TS>(fa, ff, m, tk.p0, tk.p2, tk.p1 + wave, smem, tid, t, built);
       continue;
     }
     if (kind == FLOW_DIAG0) {
-      if (wave == 0) flow_diag0_wave<T>(fa, ff, m, smem, tid);
+      if (wave == 0) {
+        if constexpr (XL) flow_wait(lane == 0 ? built : nullptr, fa.err, fa.wait_ticks);
+        flow_diag0_wave<T>(fa, ff, m, smem, tid);
+      }
       RRPGO_FLOW_MARK(fa, t, wave, 3);
       continue;
     }
@@ -506,11 +621,14 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
     typename MM::Acc acc[NT][NT];
     TileGather<T> tg{nullptr, -1, nullptr, nullptr, nullptr, nullptr};
     if (fa.gather && K0 == 0 && J0 >= big_built_cols(m.nc, M)) tg = TileGather<T>{fa.child_meta + m.child_begin, m.child_count, fa.scat, fa.lvals, fa.uvals, fa.xch};
-    const bool have = big_update_tile<T, NT, RRPGO_FLOW_DEPTH, true>(F, M, K0, ke, jmax, I0, J0, smem, acc, nullptr, false, tg, tid);
+    const bool have = big_update_tile<T, NT, RRPGO_FLOW_DEPTH, true, false, NoGate, XL>(F, M, K0, ke, jmax, I0, J0, smem, acc, nullptr, false, tg, tid);
     RRPGO_FLOW_MARK(fa, t, wave, 2);
     flow_drain();
     __syncthreads();   // every wave's part of the tile is in memory
-    if (tid == 64) flow_flag_set(fa.flags + ff.uf + sp * ff.ustride + flow_tri(bx, by));
+    if (tid == 64) {
+      flow_flag_set(fa.flags + ff.uf + sp * ff.ustride + flow_tri(bx, by));
+      if constexpr (XL) __hip_atomic_fetch_add(fa.flags + ff.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one more of the front's UPDATE tasks: its parent counts them
+    }
     // exact mode, tile (0, 0): its first wave holds the next super-panel's first diagonal block: factor and invert it here
     if (fa.exact && bx == 0 && by == 0 && t0 < m.nc && wave == 0 && have) {
       T *Sh = smem;
@@ -544,6 +662,9 @@ template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) 
 // k_big_flow's workgroups find room beside these: the launch pads its LDS so that at most three of these workgroups (84 VGPRs,
 // 46 KB) fit a compute unit, which always leaves registers (260 per lane and SIMD) and LDS (22 KB) for one workgroup of
 // k_big_flow, whoever else shares the chip; operands are read with sc1 loads (the producer is running: flow_panel_wave).
+#ifndef RRPGO_SCHUR_POLL
+#define RRPGO_SCHUR_POLL 32   // s_sleep between two polls of a waiting Schur tile, in units of 64 clocks
+#endif
 struct SchurGate {
   const unsigned *flags;
   int pf, pstride, nc, M, I0, J0, tile;
@@ -551,18 +672,37 @@ struct SchurGate {
   unsigned long long wait_ticks;
   static constexpr bool on = true;
   __device__ __forceinline__ void operator()(int sp) const {
+    // ONE wave polls, slowly (these workgroups are in no hurry, and thousands of waves polling every few hundred clocks slow the
+    // flag lines down for the chain they wait for: r05, +0.2 ms on the two top levels of the lattice); the others sleep at the barrier.
     // lane = block of the super-panel (4) x strip (2) x row block (up to 8): as the UPDATE tasks of k_big_flow wait
-    const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const unsigned *fp = nullptr;
-    const int qq = lane >> 4, strip = (lane >> 3) & 1, k = lane & 7;
-    const int kb = sp * BIG_SUPER + 32 * qq;
-    if (kb < min(sp * BIG_SUPER + BIG_SUPER, nc)) {
-      const int nbq = min(BIG_NB, nc - kb), r0 = kb + nbq;
-      const int lo = strip ? J0 : I0, hi = min(lo + tile - 1, M - 1);
-      const int rb = (lo - r0) / 32 + k;
-      if (rb <= (hi - r0) / 32) fp = flags + pf + (kb / BIG_NB) * pstride + rb;
+    if (wave_index() == 0) {
+      const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      const unsigned *fp = nullptr;
+      const int qq = lane >> 4, strip = (lane >> 3) & 1, k = lane & 7;
+      const int kb = sp * BIG_SUPER + 32 * qq;
+      if (kb < min(sp * BIG_SUPER + BIG_SUPER, nc)) {
+        const int nbq = min(BIG_NB, nc - kb), r0 = kb + nbq;
+        const int lo = strip ? J0 : I0, hi = min(lo + tile - 1, M - 1);
+        const int rb = (lo - r0) / 32 + k;
+        if (rb <= (hi - r0) / 32) fp = flags + pf + (kb / BIG_NB) * pstride + rb;
+      }
+      unsigned long long t0 = 0;
+      for (unsigned spins = 0;; spins++) {
+        const unsigned v = fp ? flow_flag_ld(fp) : 1u;
+        if (__all(v != 0u)) break;
+        if ((spins & 15u) == 15u) {
+          if (t0 == 0) t0 = wall_clock64();
+          const int e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (e != 0 || wall_clock64() - t0 > wait_ticks) {
+            if (e == 0 && lane == 0) atomicOr(err, DEVERR_FLOW_TIMEOUT);
+            break;
+          }
+        }
+        __builtin_amdgcn_s_sleep(RRPGO_SCHUR_POLL);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    flow_wait(fp, err, wait_ticks);
+    __syncthreads();
   }
 };
 template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? 6 : 2))   // <= 80 VGPRs in fp32: three of these + one of k_big_flow (240) per SIMD

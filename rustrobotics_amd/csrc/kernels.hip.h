@@ -1766,8 +1766,10 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_assemble(Fact
 // column J are cleared too (the diagonal-block kernels read whole squares).
 // QB children per batch: all their index loads are requested before the first value load, so a batch pays two
 // dependent round trips; a child without this column (jq < 0) is read at a clamped address and masked.
-template <typename T, int QB>
-__device__ __forceinline__ void big_build_column(const FactorArgs<T> &a, const ChildMeta *cm, int nkids, int M, int J, T *col, int lane) {
+// Args: any argument block with scat, lvals, uvals, xch (FactorArgs, FlowArgs).  SC1 (k_big_flow's cross-level form: children
+// and parent are fronts of ONE launch): the children's entries are read past this CU's L1 and the column is written through.
+template <typename T, int QB, bool SC1 = false, typename Args = FactorArgs<T>>
+__device__ __forceinline__ void big_build_column(const Args &a, const ChildMeta *cm, int nkids, int M, int J, T *col, int lane) {
   for (int r0 = (J & ~63) + lane; r0 < M; r0 += 256) {
     T acc[4] = {0, 0, 0, 0};
     for (int q0 = 0; q0 < nkids; q0 += QB) {
@@ -1790,7 +1792,7 @@ __device__ __forceinline__ void big_build_column(const FactorArgs<T> &a, const C
 #pragma unroll
       for (int qq = 0; qq < QB; qq++)
 #pragma unroll
-        for (int u = 0; u < 4; u++) uv[qq][u] = ucol[qq][max(iq[qq][u], max(jq[qq], 0))];   // rows above the column map below jq
+        for (int u = 0; u < 4; u++) uv[qq][u] = mem_ld<SC1>(ucol[qq] + max(iq[qq][u], max(jq[qq], 0)));   // rows above the column map below jq
 #pragma unroll
       for (int qq = 0; qq < QB; qq++)
 #pragma unroll
@@ -1799,7 +1801,7 @@ __device__ __forceinline__ void big_build_column(const FactorArgs<T> &a, const C
     }
 #pragma unroll
     for (int u = 0; u < 4; u++)
-      if (r0 + 64 * u < M) col[r0 + 64 * u] = acc[u];
+      if (r0 + 64 * u < M) mem_st<SC1>(col + r0 + 64 * u, acc[u]);
   }
 }
 
@@ -2253,7 +2255,8 @@ template <typename T> struct TileGather {
 // Gate (LONGK only): called with s before the first operand load of the columns [128 s, 128 s + 128) -- k_big_schur_flow
 // (flow.hip.h) runs beside the launch that is still producing those columns and waits for their flags there.
 struct NoGate { static constexpr bool on = false; __device__ __forceinline__ void operator()(int) const {} };
-template <typename T, int NT, int DEPTH = 1, bool SC1 = false, bool LONGK = false, typename Gate = NoGate>
+// GSC1: the gathered children are fronts of the SAME launch (k_big_flow's cross-level form): their entries are read past L1.
+template <typename T, int NT, int DEPTH = 1, bool SC1 = false, bool LONGK = false, typename Gate = NoGate, bool GSC1 = false>
 __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int jmax, int I0, int J0, T *smem,
                                                 typename Mfma16<T>::Acc (&acc)[NT][NT], unsigned long long *trace = nullptr, bool pm = false,
                                                 const TileGather<T> gather = TileGather<T>{nullptr, -1, nullptr, nullptr, nullptr, nullptr},
@@ -2375,7 +2378,7 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
             for (int r = 0; r < 4; r++) {
               const int jc = max(jq[r], 0);
 #pragma unroll
-              for (int ib = 0; ib < NT; ib++) v[r][ib] = Uc[co[r] + max(iq[ib], jc)];   // clamped into the column
+              for (int ib = 0; ib < NT; ib++) v[r][ib] = mem_ld<GSC1>(Uc + co[r] + max(iq[ib], jc));   // clamped into the column
             }
             // an entry of the lower triangle exists in the child iff its row AND its column do (monotone maps);
             // entries above the diagonal of a diagonal tile take whatever falls out, they are never stored.  The

@@ -290,6 +290,15 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
                                     // to 64 fronts; with W polled in place and no tile on the chain every level does (limits 64 / 128 / 256 /
                                     // none: 4.57 / 4.54 / 4.53 / 4.52 ms) -- the launch sequence (k_big_panel32 + k_big_update) remains as the
                                     // parity alternative (RR_PGO_FLOW=0)
+  // cross-level form of k_big_flow (flow.hip.h, XL): graphs of a few dozen fronts beyond LDS (sphere2500: 46 in six levels) run ALL
+  // their levels as ONE launch -- BUILD tasks in place of k_big_build, Schur complements as UPDATE tasks, parent waits for child by counter
+  bool xl_ = false;                 // RR_PGO_FLOW_XL=0: one build + one flow launch per level (the r03 / r04 form; bit-identical)
+  int xl_max_fronts_ = 256;         // RR_PGO_FLOW_XL=<n>: graphs of at most n fronts beyond LDS
+  DevBuf<FlowRec> xl_recs_;
+  std::vector<FlowRec> xl_host_;
+  DevBuf<int2> xl_child_done_;
+  DevBuf<unsigned long long> xl_trace_;   // diagnostic builds only
+  int64_t xl_ticket_word_ = 0;
   bool fused_assembly_ = true;      // RR_PGO_SPLIT_ASSEMBLY=1: H entries and rhs of the fronts beyond LDS by a k_big_assemble launch per level
   bool flow_deep_ = true;           // RR_PGO_FLOW_DEEP=0: no look-back over the previous super-panel (fast mode; see build_flow_levels)
   bool flow_exact_ = false;         // RR_PGO_FLOW_EXACT=1: bit-identical to the launch sequence (tile (0, 0) forms the next super-panel's first block)
@@ -299,7 +308,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   int flow_schur_min_ = 512;        // RR_PGO_FLOW_SCHUR_MIN=<n>: flow levels with at least n Schur tiles leave them to k_big_schur
   int flow_grid_ = 0;               // persistent workgroups of a flow launch (RR_PGO_FLOW_GRID; default CUs x RRPGO_FLOW_WAVES)
   // k_big_schur_flow (flow.hip.h): levels of at most schur_overlap_nf_ fronts form their Schur complements beside the flow launch
-  int schur_overlap_nf_ = 32;       // RR_PGO_SCHUR_OVERLAP=<n> (0: never -- k_big_schur behind the flow launch, the r03 / r04 form; bit-identical)
+  int schur_overlap_nf_ = 0;        // RR_PGO_SCHUR_OVERLAP=<n>: levels of at most n fronts (default 0: never -- k_big_schur behind the flow launch; bit-identical either way).  Measured slower at every n (profiles/r05_schur_overlap_*.txt): beside each other both launches lose more than the overlap gains
   int flow_overlap_grid_ = 0;       // workgroups of the flow launch of such a level: one per CU, so that the Schur workgroups find room (RR_PGO_FLOW_OVERLAP_GRID)
   PooledStream stream2_;            // the second stream (acquired with the first overlapped level)
   std::vector<std::unique_ptr<EventHolder>> fork_ev_, join_ev_;   // per step: fronts built -> stream2_; Schur complements done -> stream_
@@ -339,6 +348,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   std::vector<int> step_solve_lds_;  // scalars of LDS the back-solve of each step needs
   PinnedBuf<double> host_pair_;      // pinned: chi2, |dx|, and (as an int in slot 2) the device error flag
   int n_lin_blocks_ = 0, n_upd_blocks_ = 0;
+  bool no_graph_ = false, force_graph_ = false;   // RR_PGO_NO_GRAPH=1 / RR_PGO_FORCE_GRAPH=1 (read when the handle is created): plain launches / replays of the captured hipGraph everywhere
   bool edge_lin_ = false;           // RR_PGO_EDGE_LINEARIZE=1: k_linearize_edges (one thread per edge, atomics) instead of the pull form
   int host_counter_ = 0;             // mirrors the device slot counter
 
@@ -501,15 +511,16 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       for (const Step &st : sym.steps) any_big = any_big || st.kind != STEP_TASKS;
       gemv_part_.alloc(any_big ? (size_t)kGemvSlices * g.dim : 4);
     }
-    // LDS fronts: 16-wave workgroups for fronts of more than 128 rows (RR_PGO_FACTOR_512=1 / RR_PGO_FACTOR_256=1: 8 / 4 waves;
+    // LDS fronts: 16-wave workgroups for fronts of more than 128 rows (RR_PGO_FACTOR_512=1: 8 waves;
     // intel.g2o r04: 4318 / 4134 it/s with 16 / 8 waves)
     factor_threads_max_ = getenv("RR_PGO_FACTOR_512") ? 512 : 1024;
-    if (getenv("RR_PGO_FACTOR_256")) factor_threads_max_ = 256;
     if (const char *e = getenv("RR_PGO_SOLVE_THREADS")) solve_threads_max_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_SP_SOLVE_MIN")) sp_solve_min_nc_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_XCD_REMAP")) xcd_remap_ = std::atoi(e) != 0;
     if (const char *e = getenv("RR_PGO_SCHUR_SPLIT")) schur_split_ = std::atoi(e) != 0;
     gather_update_ = getenv("RR_PGO_NO_GATHER_UPDATE") == nullptr;
+    no_graph_ = getenv("RR_PGO_NO_GRAPH") != nullptr;
+    force_graph_ = getenv("RR_PGO_FORCE_GRAPH") != nullptr && !no_graph_;
     fused_assembly_ = getenv("RR_PGO_SPLIT_ASSEMBLY") == nullptr;
     if (const char *e = getenv("RR_PGO_FLOW")) flow_max_nf_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_FLOW_EXACT")) flow_exact_ = std::atoi(e) != 0;
@@ -699,8 +710,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     for (const Step &st : sym.steps)
       n_launches_per_iter += st.kind == STEP_BIG ? count_big_launches(st) + count_big_solve_launches(st) : 2;
     if (lds_flow_) {   // linearise, k_factor_flow, the levels of fronts beyond LDS, k_solve_flow, update
-      n_launches_per_iter = 4;
-      for (size_t si = 1; si < sym.steps.size(); si++) n_launches_per_iter += count_big_launches(sym.steps[si]) + count_big_solve_launches(sym.steps[si]);
+      n_launches_per_iter = 4 + (xl_ ? 1 : 0);
+      for (size_t si = 1; si < sym.steps.size(); si++) n_launches_per_iter += (xl_ ? 0 : count_big_launches(sym.steps[si])) + count_big_solve_launches(sym.steps[si]);
     }
   }
 
@@ -732,6 +743,22 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (const char *e = getenv("RR_PGO_FLOW_OVERLAP_GRID")) flow_overlap_grid_ = std::max(1, std::atoi(e));
     fork_ev_.resize(sym_.steps.size());
     join_ev_.resize(sym_.steps.size());
+    {
+      // the cross-level form: every front beyond LDS sits above the LDS fronts (the dataflow schedule's condition), few of them,
+      // none with parallel-edge blocks (k_big_assemble_dup has no task form), no gauge term on the root, default flow limits
+      if (const char *e = getenv("RR_PGO_FLOW_XL")) xl_max_fronts_ = std::atoi(e);
+      int n_big = 0;
+      bool dup = false;
+      for (const Step &st : sym_.steps)
+        if (st.kind == STEP_BIG)
+          for (int t = st.task_begin; t < st.task_end; t++) {
+            const int sn = sym_.task_sn[sym_.task_ptr[t]];
+            n_big++;
+            dup = dup || sym_.fdup_ptr[sn + 1] > sym_.fdup_ptr[sn];
+          }
+      xl_ = lds_flow_ && !sharded_ && world_ == 1 && gather_update_ && fused_assembly_ && !gauge_ok_ && !dup && n_big > 0 && n_big <= xl_max_fronts_ &&
+            flow_max_nf_ >= (1 << 20) && flow_max_tasks_ >= (1 << 20);
+    }
     // first W block of every supernode in winv (as the SnMeta table lays them out), for the marks k_flow_reset writes
     std::vector<int64_t> sn_wblk(sym_.S + 1, 0);
     for (int f = 0; f < sym_.S; f++)
@@ -765,6 +792,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       // few fronts: the chains bound the launch and the Schur complements are formed beside it (k_big_schur_flow), whatever their number
       lvl->overlap = schur_split_ && schur_overlap_nf_ > 0 && nf <= schur_overlap_nf_ && schur_tiles > 0 && sizeof(T) == 4;
       if (lvl->overlap) lvl->schur_split = true;
+      if (xl_) { lvl->schur_split = false; lvl->overlap = false; }   // one launch: the Schur complements are UPDATE tasks
       std::vector<FlowTask> tasks;
       std::vector<FlowFront> fronts(nf);
       double level_end = 0, busy_us = 0;
@@ -802,6 +830,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         ff.wf = (int32_t)words; words += nblk + 1;
         ff.pf = (int32_t)words; ff.pstride = pstride; words += (int64_t)nblk * pstride;
         ff.uf = (int32_t)words; ff.ustride = ustride; words += (int64_t)nsp * ustride;
+        ff.bf = -1; ff.nbuild = 0; ff.done = -1;
+        if (xl_) {   // build counter + "built" flag, and the counter of finished UPDATE tasks, on a line of their own
+          words = (words + 31) & ~(int64_t)31;
+          ff.bf = (int32_t)words; ff.done = (int32_t)words + 2; words += 3;
+          ff.nbuild = (big_built_cols(nc, M) + FLOW_BUILD_COLS - 1) / FLOW_BUILD_COLS;
+        }
         words = (words + 31) & ~(int64_t)31;
         if (words > 0x7fffff00LL) throw ApiError(RR_PGO_EUNSUPPORTED, "too many flow flags");
         const int wf = (int)(ff.wf - flag0), pf = (int)(ff.pf - flag0), uf = (int)(ff.uf - flag0);
@@ -972,12 +1006,23 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       }
       };   // plan
       plan();
-      if (!too_many && lvl->schur_split && !lvl->overlap && busy_us + schur_in_flow_us <= 0.6 * flow_grid_ * level_end) {
+      if (!too_many && !xl_ && lvl->schur_split && !lvl->overlap && busy_us + schur_in_flow_us <= 0.6 * flow_grid_ * level_end) {
         lvl->schur_split = false;
         plan();
         if (too_many) { too_many = false; lvl->schur_split = true; plan(); }
       }
       if (too_many) { words = lvl->ticket_word; continue; }   // throughput-bound level: launch sequence (its flag words are given back)
+      if (xl_) {
+        // BUILD tasks ahead of the level's other tasks, chunk by chunk over all fronts (every front's first columns first)
+        std::vector<FlowTask> bt;
+        int max_nb = 0;
+        for (int z = 0; z < nf; z++) max_nb = std::max(max_nb, fronts[z].nbuild);
+        for (int k = 0; k < max_nb; k++)
+          for (int z = 0; z < nf; z++)
+            if (k < fronts[z].nbuild) bt.push_back(FlowTask{(FLOW_BUILD << 24) | z, k * FLOW_BUILD_COLS, 0, 0});
+        bt.insert(bt.end(), tasks.begin(), tasks.end());
+        tasks.swap(bt);
+      }
       lvl->n_tasks = (int)tasks.size();
       lvl->est_us = level_end;
       lvl->wfill_begin = (int)(wfill.size() / 2);
@@ -1067,6 +1112,46 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         flow_levels_[si]->trace.zero();
 #endif
       }
+    if (xl_) {
+      // the cross-level list: every level's records, level after level (children have smaller tickets than their parents), and
+      // per child_meta entry where the child's `done` counter lives and how many UPDATE tasks it counts
+      std::vector<int32_t> sn_done(sym_.S, -1), sn_nupd(sym_.S, 0);
+      for (size_t si = 0; si < sym_.steps.size(); si++) {
+        if (!flow_levels_[si]) { if (sym_.steps[si].kind == STEP_BIG) xl_ = false; continue; }
+        const Step &st = sym_.steps[si];
+        for (const FlowTask &t : all_tasks[si]) {
+          const int slot = t.kind_front & 0xffffff, sn = sym_.task_sn[sym_.task_ptr[st.task_begin + slot]];
+          sn_done[sn] = all_fronts[si][slot].done;
+          if ((t.kind_front >> 24) == FLOW_UPDATE) sn_nupd[sn]++;
+        }
+      }
+      if (!xl_) throw ApiError(RR_PGO_EUNSUPPORTED, "internal: a level of fronts beyond LDS without a dataflow task list in the cross-level form");
+      std::vector<int2> cd(sym_.child_list.size(), int2{-1, 0});
+      for (size_t q = 0; q < cd.size(); q++) {
+        const int c = sym_.child_list[q];
+        if (sn_done[c] >= 0) cd[q] = int2{sn_done[c], sn_nupd[c]};
+      }
+      xl_child_done_.upload(cd);
+      bool first = true;
+      for (size_t si = 0; si < sym_.steps.size(); si++) {
+        if (!flow_levels_[si]) continue;
+        if (first) { xl_ticket_word_ = flow_levels_[si]->ticket_word; first = false; }
+        const Step &st = sym_.steps[si];
+        for (const FlowTask &t : all_tasks[si]) {
+          const int slot = t.kind_front & 0xffffff;
+          FlowRec r{};
+          r.t = t;
+          r.ff = all_fronts[si][slot];
+          r.m = host_task_meta_[st.task_begin + slot];
+          xl_host_.push_back(r);
+        }
+      }
+      xl_recs_.upload(xl_host_);
+#ifdef RRPGO_FLOW_TRACE
+      xl_trace_.alloc(xl_host_.size() * 16);
+      xl_trace_.zero();
+#endif
+    }
   }
   // k_big_update's and k_big_schur's grids: per level of the launch sequence the list of real tiles, front after front
   // -- per super-panel the tiles left of the Schur origin (schur_split_: the Schur complement is ONE pass of k_big_schur
@@ -1127,15 +1212,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     const size_t si = (size_t)(&st - sym_.steps.data());
     return si < flow_levels_.size() ? flow_levels_[si].get() : nullptr;
   }
-  void launch_flow(const Step &st, const FlowLevel &lvl) {
+  FlowArgs<T> flow_args() {
     FlowArgs<T> fa;
-    fa.tasks = lvl.tasks.p;
-    fa.ticket = flow_flags_.p + lvl.ticket_word;
     fa.flags = flow_flags_.p;
-    fa.n_tasks = lvl.n_tasks;
     fa.gather = gather_update_ ? 1 : 0;
     fa.exact = flow_exact_ ? 1 : 0;
-    fa.schur_tile = lvl.schur_split ? schur_tile_ : 0;
     fa.child_meta = child_meta_.p;
     fa.scat = scat_.p;
     fa.lvals = lvals_.p;
@@ -1144,9 +1225,36 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     fa.winv = winv_.p;
     fa.err = err_.p;
     fa.wait_ticks = wait_ticks_;
+    fa.trace = nullptr;
+    fa.child_done = xl_child_done_.p;
+    fa.fasm_colptr = fasm_colptr_.p;
+    fa.fasm_dst = fasm_dst_.p;
+    fa.fasm_src = fasm_src_.p;
+    fa.perm = perm_.p;
+    fa.hvals = hvals_.p;
+    fa.b = b_.p;
+    return fa;
+  }
+  void launch_flow(const Step &st, const FlowLevel &lvl) {
+    FlowArgs<T> fa = flow_args();
+    fa.tasks = lvl.tasks.p;
+    fa.ticket = flow_flags_.p + lvl.ticket_word;
+    fa.n_tasks = lvl.n_tasks;
+    fa.schur_tile = lvl.schur_split ? schur_tile_ : 0;
     fa.trace = lvl.trace.p;
     hipLaunchKernelGGL((k_big_flow<T, 2>), dim3((unsigned)std::min(lvl.n_tasks, lvl.overlap ? flow_overlap_grid_ : flow_grid_)), dim3(256), 0, stream_, fa);
     check_launch("k_big_flow");
+  }
+  // every level of fronts beyond LDS as ONE launch (the cross-level form: BUILD tasks, Schur complements inside, counters between levels)
+  void launch_flow_xl() {
+    FlowArgs<T> fa = flow_args();
+    fa.tasks = xl_recs_.p;
+    fa.ticket = flow_flags_.p + xl_ticket_word_;
+    fa.n_tasks = (int)xl_host_.size();
+    fa.schur_tile = 0;
+    fa.trace = xl_trace_.p;
+    hipLaunchKernelGGL((k_big_flow<T, 2, true>), dim3((unsigned)std::min(fa.n_tasks, flow_grid_)), dim3(256), 0, stream_, fa);
+    check_launch("k_big_flow (cross-level)");
   }
 
   // Gauge transfer applies to a single-precision factor (T = float) of an SE(2) graph whose root front is
@@ -1178,7 +1286,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       const double *wi = &g_.edge_info[g_.edge_info_off[k]];
       w = std::max(w, std::fabs(wi[0]));
     }
-    if (const char *e = getenv("RR_PGO_GAUGE_W")) w = std::atof(e);
     gauge_mu_t_ = w;
     gauge_mu_r_ = w / std::max(1.0, ext * ext);
     gauge_root_ = root;
@@ -1401,6 +1508,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       check_launch("k_factor_flow");
       pend(RR_PGO_K_FACTOR);
       from = 1;
+    }
+    if (xl_ && from == 1 && to == sym_.steps.size()) {
+      pbegin();
+      launch_flow_xl();
+      pend(RR_PGO_K_BIG_FLOW);
+      return;
     }
     for (size_t si = from; si < to; si++) {
       const Step &st = sym_.steps[si];
@@ -1818,7 +1931,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       // benches/graph_slam.rs:9-10, is ONE new() + optimize(10)).  Graphs of dozens of launches replay a captured graph.
       // (optimize() reads two scalars back after every iteration, so the enqueueing is not hidden behind the device as it is
       // in iterate_async: dozens of launches stay one graph launch here.)  RR_PGO_FORCE_GRAPH=1: always the graph.
-      const bool eager = n_launches_per_iter <= 8 && !gn_exec_ && !std::getenv("RR_PGO_FORCE_GRAPH");
+      const bool eager = (no_graph_ || n_launches_per_iter <= 8) && !gn_exec_ && !force_graph_;
       if (!eager) ensure_gn_graph();
       reset_counter();
       int done = 0;
@@ -1919,13 +2032,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (sharded_) throw ApiError(RR_PGO_EUNSUPPORTED, "sharded handle: drive it with rr_pgo_stage + the two collectives");
     // RR_PGO_NO_GRAPH=1: plain launches (rocprofv3 --kernel-trace crashes on replays of graphs
     // with thousands of nodes; profiling runs of the large workloads use this switch)
-    static const bool no_graph = std::getenv("RR_PGO_NO_GRAPH") != nullptr;
     // plain launches queue back to back while consecutive graph launches leave the GPU idle for ~8 us each (rocprofv3
     // --kernel-trace, scripts/kernel_gaps.py), and the host stays far ahead of the device even at 67 launches per iteration
     // (the 1M-edge lattice: ~0.2 ms of enqueueing against 4.4 ms of kernels).  Measured: intel + 2 %, sphere2500 + 0.8 %,
     // lattice + 0.7 %.  RR_PGO_FORCE_GRAPH=1: replays of the captured hipGraph (r01 - r03's form).
-    static const bool force_graph = std::getenv("RR_PGO_FORCE_GRAPH") != nullptr;
-    if (no_graph || !force_graph) {
+    if (no_graph_ || !force_graph_) {
       for (int i = 0; i < iters; i++) enqueue_gn_iteration();
       return;
     }
@@ -1947,6 +2058,27 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   }
   // diagnostic builds: the task list and the stamps of the `level`-th flow level (-1: no such level)
   int flow_trace(int level, std::vector<int32_t> &tasks, std::vector<unsigned long long> &stamps, int *nf, double *est_us) override {
+    if (xl_) {
+      // the cross-level list as "level 0": the front slot of every task replaced by its SUPERNODE (slots repeat from level to level)
+      if (level != 0) return -1;
+      tasks.resize(xl_host_.size() * 4);
+      size_t i = 0;
+      for (size_t si = 0; si < flow_levels_.size(); si++) {
+        if (!flow_levels_[si]) continue;
+        const Step &st = sym_.steps[si];
+        for (int k2 = 0; k2 < flow_levels_[si]->n_tasks; k2++, i++) {
+          const FlowTask &t = xl_host_[i].t;
+          const int sn = sym_.task_sn[sym_.task_ptr[st.task_begin + (t.kind_front & 0xffffff)]];
+          tasks[4 * i] = (t.kind_front & ~0xffffff) | sn;
+          tasks[4 * i + 1] = t.p0; tasks[4 * i + 2] = t.p1; tasks[4 * i + 3] = t.p2;
+        }
+      }
+      stamps.resize(xl_trace_.n);
+      if (xl_trace_.n) HIPCHK(hipMemcpy(stamps.data(), xl_trace_.p, xl_trace_.n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      *nf = sym_.S;
+      *est_us = 0;
+      return (int)xl_host_.size();
+    }
     int k = 0;
     for (size_t si = 0; si < flow_levels_.size(); si++) {
       if (!flow_levels_[si]) continue;
@@ -2024,8 +2156,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   void stage(int stg, double lambda, int lm) override {
     if (!sharded_) throw ApiError(RR_PGO_EINVAL, "handle is not sharded");
     if (stg < 0 || stg > 2) throw ApiError(RR_PGO_EINVAL, "stage must be 0, 1 or 2");
-    static const bool no_graph = std::getenv("RR_PGO_NO_GRAPH") != nullptr;
-    if (stg == 2 || lm || no_graph) { enqueue_stage(stg, lambda, lm); return; }
+    if (stg == 2 || lm || no_graph_) { enqueue_stage(stg, lambda, lm); return; }
     if (!stage_exec_[stg]) {   // Gauss-Newton stages replay a captured graph like the unsharded iteration
       hipGraph_t graph = nullptr;
       if (stg == 1) gauge_now_ = gauge_ok_;   // what stage 0 (lm == 0) set; the capture must not depend on call order
@@ -2074,7 +2205,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         withheld_parent_ = -1;
       }
       if (withheld_level_ >= 0) {
-        HIPCHK(hipMemcpy(flow_levels_[withheld_level_]->tasks.p + withheld_task_, &withheld_rec_, sizeof(FlowRec), hipMemcpyHostToDevice));
+        FlowRec *dst = withheld_level_ == (1 << 30) ? xl_recs_.p : flow_levels_[withheld_level_]->tasks.p;
+        HIPCHK(hipMemcpy(dst + withheld_task_, &withheld_rec_, sizeof(FlowRec), hipMemcpyHostToDevice));
         withheld_level_ = -1;
       }
       return;
@@ -2101,6 +2233,20 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           return;
         }
       throw ApiError(RR_PGO_EUNSUPPORTED, "no front waits for a parent of another task");
+    }
+    if (mode == 3 && xl_) {
+      for (size_t t = 0; t < xl_host_.size(); t++)
+        if ((xl_host_[t].t.kind_front >> 24) == FLOW_PANEL) {
+          withheld_level_ = 1 << 30;   // (the cross-level list)
+          withheld_task_ = (int)t;
+          withheld_rec_ = xl_host_[t];
+          FlowRec bad = xl_host_[t];
+          bad.ff.pf = (int32_t)((int64_t)flow_flags_.n - kDeadFlagWords);
+          bad.ff.pstride = 1;
+          HIPCHK(hipMemcpy(xl_recs_.p + t, &bad, sizeof(FlowRec), hipMemcpyHostToDevice));
+          return;
+        }
+      throw ApiError(RR_PGO_EUNSUPPORTED, "no PANEL task in the cross-level list");
     }
     if (mode == 3) {
       for (size_t si = 0; si < flow_levels_.size(); si++) {
@@ -2228,7 +2374,6 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
   so.lds_flow = opt.world_size <= 1 && !opt.sharded;
   if (const char *e = std::getenv("RR_PGO_LDS_FLOW")) so.lds_flow = so.lds_flow && std::atoi(e) != 0;
   if (const char *e = std::getenv("RR_PGO_TASK_US")) so.task_us = std::atof(e);
-  if (const char *e = std::getenv("RR_PGO_THREADS_SHIFT")) so.threads_shift = std::atoi(e);
   if (std::getenv("RR_PGO_NO_GEO")) so.geo_nd = false;
   if (const char *e = std::getenv("RR_PGO_LDS_PIECES")) so.max_lds_pieces = std::max(1, std::atoi(e));
   if (std::getenv("RR_PGO_JOIN_SEPARATORS")) so.split_separators = false;
@@ -2236,7 +2381,6 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
   if (const char *e = std::getenv("RR_PGO_BALANCE_BLOCKS")) { so.balance_blocks = std::atoi(e) != 0; if (std::atoi(e) > 1) so.balance_max_rem = std::atoi(e); }
   if (const char *e = std::getenv("RR_PGO_MERGE_CHAIN")) { so.merge_chain_nc = std::atoi(e); if (const char *c = std::strchr(e, ',')) so.merge_chain_gain_us = std::atof(c + 1); }
   if (const char *e = std::getenv("RR_PGO_AMALG_NP")) so.amalg_np = std::atoi(e);
-  if (const char *e = std::getenv("RR_PGO_AMALG_FRAC")) so.amalg_frac = std::atof(e);
   double t0 = now_ms();
   std::string err;
   if (h->g.n_nodes() <= 6000 && opt.world_size <= 1 && !opt.sharded && !(std::getenv("RR_PGO_ND_LEAF") && std::getenv("RR_PGO_AMALG_NP"))) {
@@ -2602,6 +2746,19 @@ int rr_pgo_stage_scalars(rr_pgo *h, double *chi2, double *norm_dx) {
   return guarded([&] { h->engine->read_last_scalars(chi2, norm_dx); });
 }
 #ifdef RRPGO_FLOW_TRACE
+// Diagnostic build only: per supernode (parent, pivot columns, rows below, step) -- out[S][4]
+extern "C" int32_t rr_pgo_debug_sn_info(rr_pgo *h, int32_t *out) {
+  if (!h) return -1;
+  const Symbolic &y = h->sym;
+  if (out) {
+    std::vector<int> step_of(y.S, -1);
+    for (size_t si = 0; si < y.steps.size(); si++)
+      for (int t = y.steps[si].task_begin; t < y.steps[si].task_end; t++)
+        for (int q = y.task_ptr[t]; q < y.task_ptr[t + 1]; q++) step_of[y.task_sn[q]] = (int)si;
+    for (int s2 = 0; s2 < y.S; s2++) { out[4 * s2] = y.sn_parent[s2]; out[4 * s2 + 1] = y.sn_ncols[s2]; out[4 * s2 + 2] = y.sn_nrows[s2]; out[4 * s2 + 3] = step_of[s2]; }
+  }
+  return y.S;
+}
 // Diagnostic build only (make ../librr_pgo_trace.so): task list (4 ints per task) and stamps (4 waves x 4 per task) of a flow level
 extern "C" int64_t rr_pgo_debug_flow_trace(rr_pgo *h, int32_t level, int32_t *tasks, unsigned long long *stamps, int64_t cap_tasks, int32_t *nf, double *est_us) {
   if (!h) return -1;

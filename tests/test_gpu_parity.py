@@ -523,7 +523,8 @@ def test_levenberg_marquardt_through_the_big_front_path(api, oracle):
 @pytest.mark.parametrize("env", ["RR_PGO_FLOW=0", "RR_PGO_FLOW_TASKS=100000000", "RR_PGO_FLOW_EXACT", "RR_PGO_NO_GATHER_UPDATE",
                                  "RR_PGO_SCHUR_SPLIT=0", "RR_PGO_XCD_REMAP=0", "RR_PGO_SOLVE_FLOW=0", "RR_PGO_EDGE_LINEARIZE",
                                  "RR_PGO_FLOW_DEEP=0", "RR_PGO_FLOW_SCHUR_MIN=100000000", "RR_PGO_FLOW_SLOTS=1000000",
-                                 "RR_PGO_SPLIT_ASSEMBLY", "RR_PGO_FLOW_GRID=1", "RR_PGO_FLOW_GRID=7"])
+                                 "RR_PGO_SPLIT_ASSEMBLY", "RR_PGO_FLOW_GRID=1", "RR_PGO_FLOW_GRID=7", "RR_PGO_SP_SOLVE_MIN=100000",
+                                 "RR_PGO_SP_SOLVE_MIN=1", "RR_PGO_NO_GRAPH", "RR_PGO_FORCE_GRAPH"])
 def test_alternate_big_front_launch_sequences_agree(api, env, monkeypatch):
     """The switches read when a handle is created that change WHICH kernels run: the launch-per-step sequence for every
     level (RR_PGO_FLOW=0) or the dataflow launch for every level of at most 64 fronts (RR_PGO_FLOW_TASKS), its exact mode,
@@ -534,7 +535,10 @@ def test_alternate_big_front_launch_sequences_agree(api, env, monkeypatch):
     steps that never look back over the previous super-panel, Schur complements always inside the launch, tickets in
     the order of earliest starts instead of the list schedule's), and the H entries of the fronts beyond LDS added by a
     k_big_assemble launch per level instead of by k_big_build's own waves; and the dataflow launches with ONE workgroup or
-    seven instead of two per CU -- tasks wait only for smaller tickets, so any grid must finish, with the same bits.  Each must give the default path's answer on the 100 x 100 lattice (same arithmetic up to the order
+    seven instead of two per CU -- tasks wait only for smaller tickets, so any grid must finish, with the same bits; the back
+    substitution of the fronts beyond LDS by k_solve_mid everywhere / by k_big_solve_flow everywhere (RR_PGO_SP_SOLVE_MIN); and
+    the iteration as plain launches / as replays of one captured hipGraph (optimize() picks by the launch count otherwise).
+    Each must give the default path's answer on the 100 x 100 lattice (same arithmetic up to the order
     of the block operations).  (The r01 / r02 alternatives of the big-front path were removed in r03 after losing every
     measurement: profiles/EXPERIMENTS.md.)"""
     from rustrobotics_amd import synthetic_grid_arrays
@@ -547,7 +551,8 @@ def test_alternate_big_front_launch_sequences_agree(api, env, monkeypatch):
     monkeypatch.delenv(env)
     ealt = alt.optimize(3)
     np.testing.assert_allclose(ealt, eref, rtol=1e-9)
-    if env in ("RR_PGO_SCHUR_SPLIT", "RR_PGO_XCD_REMAP", "RR_PGO_NO_GATHER_UPDATE", "RR_PGO_SOLVE_FLOW", "RR_PGO_SPLIT_ASSEMBLY", "RR_PGO_FLOW_GRID"):
+    if env in ("RR_PGO_SCHUR_SPLIT", "RR_PGO_XCD_REMAP", "RR_PGO_NO_GATHER_UPDATE", "RR_PGO_SOLVE_FLOW", "RR_PGO_SPLIT_ASSEMBLY", "RR_PGO_FLOW_GRID",
+               "RR_PGO_NO_GRAPH", "RR_PGO_FORCE_GRAPH"):
         # placement, one pass or one per super-panel, gathered or built: the same chunks in the same order -- the same bits
         assert np.array_equal(ealt, eref) and np.array_equal(np.array(alt.state()), np.array(ref.state()))
     assert _state_diff_se2(alt.state(), ref.state()) <= 1e-8
@@ -677,7 +682,10 @@ def test_lds_dataflow_launches_are_bit_identical_to_the_level_schedule(api, name
     ref = api[0].new(g2o_path(name))
     eref, sref = np.array(ref.optimize(4)), np.array(ref.state())
     # (RR_PGO_FORCE_GRAPH: the iterations as replays of the captured hipGraph instead of plain launches)
-    for env, val in (("RR_PGO_LDS_FLOW", "0"), ("RR_PGO_LDS_FLOW_GRID", "1"), ("RR_PGO_LDS_FLOW_GRID", "7"), ("RR_PGO_TASK_US", "60"), ("RR_PGO_FORCE_GRAPH", "1")):
+    # (RR_PGO_FACTOR_512 / RR_PGO_SOLVE_THREADS: smaller workgroups for the same fronts -- the sums of a front do not depend on the
+    # workgroup size, kernels.hip.h, solve_front)
+    for env, val in (("RR_PGO_LDS_FLOW", "0"), ("RR_PGO_LDS_FLOW_GRID", "1"), ("RR_PGO_LDS_FLOW_GRID", "7"), ("RR_PGO_TASK_US", "60"), ("RR_PGO_FORCE_GRAPH", "1"),
+                     ("RR_PGO_NO_GRAPH", "1"), ("RR_PGO_FACTOR_512", "1"), ("RR_PGO_SOLVE_THREADS", "256")):
         monkeypatch.setenv(env, val)
         alt = api[0].new(g2o_path(name))
         monkeypatch.delenv(env)
@@ -708,6 +716,108 @@ def test_chain_passes_of_the_analysis_change_the_tree_not_the_answer(api, name, 
         # (dlr's chi2 is 3.7e8 on entry and moves by factors per iteration: 8e-9 relative between two partitions, measured)
         np.testing.assert_allclose(np.array(alt.optimize(5)), eref, rtol=1e-7)
         np.testing.assert_allclose(np.array(alt.state()), sref, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", ["lattice100-f32", "lattice100-mixed", "lattice400x250-f32"])
+def test_schur_complements_beside_the_flow_launch_are_bit_identical(api, case, monkeypatch):
+    """r05: on levels of few fronts the Schur complements are formed by k_big_schur_flow on a second stream WHILE k_big_flow
+    runs (a tile's k loop waits, super-panel by super-panel, for the X flags of its operand strips) instead of by k_big_schur
+    behind it (RR_PGO_SCHUR_OVERLAP=0): the same chunks in the same order, so chi2 and state must agree to the last bit -- a
+    tile that read an X block early would show here.  Also with every level overlapped, and with the flow launch squeezed into
+    one workgroup / spread over more than the default (RR_PGO_FLOW_OVERLAP_GRID): the Schur tiles only ever wait for the flow
+    launch, never the other way round, so any grid finishes.  Replaces umfpack.factorize, pose_graph_optimization.rs:138."""
+    from rustrobotics_amd import synthetic_grid_arrays
+    name, prec = case.rsplit("-", 1)
+    w, h = (100, 100) if name == "lattice100" else (400, 250)
+    arrays = synthetic_grid_arrays(w, h, 1000000 if w == 400 else 0)
+    iters = 3
+    monkeypatch.setenv("RR_PGO_SCHUR_OVERLAP", "0")
+    ref = api[0].from_arrays(*arrays, precision=prec)
+    monkeypatch.delenv("RR_PGO_SCHUR_OVERLAP")
+    eref, sref = np.array(ref.optimize(iters)), np.array(ref.state())
+    del ref
+    alts = [{}, {"RR_PGO_SCHUR_OVERLAP": "100000"}]
+    if w == 100:
+        alts += [{"RR_PGO_SCHUR_OVERLAP": "100000", "RR_PGO_FLOW_OVERLAP_GRID": "1"}, {"RR_PGO_FLOW_OVERLAP_GRID": "1000"},
+                 {"RR_PGO_SCHUR_OVERLAP": "100000", "RR_PGO_FORCE_GRAPH": "1"}, {"RR_PGO_SCHUR_OVERLAP": "100000", "RR_PGO_NO_GRAPH": "1"}]
+    for env in alts:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        alt = api[0].from_arrays(*arrays, precision=prec)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert np.array_equal(np.array(alt.optimize(iters)), eref), env
+        assert np.array_equal(np.array(alt.state()), sref), env
+        del alt
+
+
+@pytest.mark.parametrize("name,prec", [("sphere2500", "f64"), ("torus3D", "f64"), ("sphere2500", "mixed"), ("lattice60x40", "f64"), ("lattice60x40", "f32")])
+def test_cross_level_flow_launch_is_bit_identical_to_one_launch_per_level(api, name, prec, monkeypatch):
+    """r05: graphs of a few dozen fronts beyond LDS (sphere2500: 46 in six levels) run ALL their levels as ONE k_big_flow launch
+    (flow.hip.h, XL): BUILD tasks in place of k_big_build, the Schur complements as UPDATE tasks, a parent's BUILD tasks wait for
+    their children's counters, everything gathered from a child is read past L1.  RR_PGO_FLOW_XL=0 keeps one build + one flow
+    launch per level: the same device functions, the same order of every sum -- chi2 and state must agree to the last bit; a child
+    read before it was complete, or a pivot column read before it was built, would show here.  Also with ONE workgroup drawing
+    every ticket in turn (a parent only ever waits for smaller tickets), and through the captured graph."""
+    from rustrobotics_amd import synthetic_grid_arrays
+
+    def make():
+        if name.startswith("lattice"):
+            return api[0].from_arrays(*synthetic_grid_arrays(60, 40), precision=prec)
+        return api[0].new(g2o_path(name), precision=prec)
+
+    monkeypatch.setenv("RR_PGO_FLOW_XL", "0")
+    ref = make()
+    monkeypatch.delenv("RR_PGO_FLOW_XL")
+    assert ref.stats()["n_big_fronts"] > 0
+    eref, sref = np.array(ref.optimize(4)), np.array(ref.state())
+    xl = make()
+    if prec != "f32":   # (a single-precision factor of an SE(2) graph puts the gauge term on the root front: no cross-level form there)
+        assert xl.stats()["n_launches_per_iter"] < ref.stats()["n_launches_per_iter"]   # the cross-level form really is on
+    for env in ({}, {"RR_PGO_FLOW_GRID": "1"}, {"RR_PGO_FLOW_GRID": "5"}, {"RR_PGO_FORCE_GRAPH": "1"}, {"RR_PGO_FLOW_EXACT": "1", "_ref_exact": "1"}):
+        exact = env.pop("_ref_exact", None)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        alt = make()
+        if exact:   # the exact mode's sums differ from the fast mode's: compare with the exact mode of the per-level form
+            monkeypatch.setenv("RR_PGO_FLOW_XL", "0")
+            r2 = make()
+            monkeypatch.delenv("RR_PGO_FLOW_XL")
+            e2, s2 = np.array(r2.optimize(4)), np.array(r2.state())
+        else:
+            e2, s2 = eref, sref
+        for k in env:
+            monkeypatch.delenv(k)
+        assert np.array_equal(np.array(alt.optimize(4)), e2), env
+        assert np.array_equal(np.array(alt.state()), s2), env
+
+
+@pytest.mark.parametrize("env", ["RR_PGO_NO_GEO", "RR_PGO_JOIN_SEPARATORS", "RR_PGO_LDS_PIECES=1", "RR_PGO_ND_LEAF=24"])
+def test_other_orderings_of_a_large_graph_give_the_same_answer(api, oracle, env, monkeypatch):
+    """Switches of the symbolic phase for graphs beyond 6000 poses: breadth-first separators only (no coordinate cuts), a
+    region's last separator chained into its parent's supernode, supernodes beyond the LDS budget never cut into pieces,
+    smaller dissection leaves -- other elimination trees for the same matrix: the trajectory agrees with the oracle's."""
+    from rustrobotics_amd import synthetic_grid_arrays
+    arrays = synthetic_grid_arrays(100, 100)
+    k, _, v = env.partition("=")
+    monkeypatch.setenv(k, v or "1")
+    g = api[0].from_arrays(*arrays)
+    monkeypatch.delenv(k)
+    eo = oracle.from_arrays(*arrays).optimize(3)
+    np.testing.assert_allclose(g.optimize(3), eo, rtol=1e-9)
+
+
+def test_single_precision_factor_with_the_reference_prior(api, monkeypatch):
+    """RR_PGO_GAUGE=0: the fp32 factor keeps the reference's 1e7 anchor prior (pose_graph_optimization.rs:330-336) instead
+    of the gauge transfer: the same minimum to 1e-5 (cond(H) ~ 1e10 eats the rest)."""
+    from rustrobotics_amd import synthetic_grid_arrays
+    arrays = synthetic_grid_arrays(100, 100)
+    monkeypatch.setenv("RR_PGO_GAUGE", "0")
+    g32 = api[0].from_arrays(*arrays, precision="f32")
+    monkeypatch.delenv("RR_PGO_GAUGE")
+    g64 = api[0].from_arrays(*arrays)
+    e32, e64 = g32.optimize(6), g64.optimize(6)
+    assert abs(min(e32) - e64[-1]) <= 1e-4 * e64[-1]
 
 
 def test_fronts_beyond_lds_f32_reaches_the_f64_minimum(api):
