@@ -621,7 +621,7 @@ template <typename T, int NT, bool XL = false> __global__ void __launch_bounds__
     typename MM::Acc acc[NT][NT];
     TileGather<T> tg{nullptr, -1, nullptr, nullptr, nullptr, nullptr};
     if (fa.gather && K0 == 0 && J0 >= big_built_cols(m.nc, M)) tg = TileGather<T>{fa.child_meta + m.child_begin, m.child_count, fa.scat, fa.lvals, fa.uvals, fa.xch};
-    const bool have = big_update_tile<T, NT, RRPGO_FLOW_DEPTH, true, false, NoGate, XL>(F, M, K0, ke, jmax, I0, J0, smem, acc, nullptr, false, tg, tid);
+    const bool have = big_update_tile<T, NT, RRPGO_FLOW_DEPTH, true, false, XL>(F, M, K0, ke, jmax, I0, J0, smem, acc, nullptr, false, tg, tid);
     RRPGO_FLOW_MARK(fa, t, wave, 2);
     flow_drain();
     __syncthreads();   // every wave's part of the tile is in memory
@@ -649,91 +649,6 @@ template <typename T, int NT, bool XL = false> __global__ void __launch_bounds__
     }
     RRPGO_FLOW_MARK(fa, t, wave, 3);
   }
-}
-
-// ---- k_big_schur_flow: the Schur complements of a flow level, formed WHILE the level's k_big_flow launch runs (r05) -------------
-// On the levels of few fronts k_big_flow is bound by its panel chains and most of the chip idles, and the level's Schur
-// complements (k_big_schur: one pass over all pivot columns, K = nc) used to follow as a launch of their own -- 0.62 ms of dense
-// MFMA work per iteration of the 1M-edge lattice waiting behind chains (levels of 32 ... 4 fronts).  This kernel is k_big_schur
-// with a gate: it is launched on a SECOND stream right after the level's fronts are built, and a tile's k loop waits, super-panel
-// by super-panel, for the X blocks of its two operand strips (the flags the PANEL waves of k_big_flow set).  Same chunks in the
-// same order, tile read (or gathered) once and written once: bit-identical to k_big_schur.
-// The dependency is one-way -- k_big_flow never waits for a Schur tile of its own level -- so the pair cannot deadlock as long as
-// k_big_flow's workgroups find room beside these: the launch pads its LDS so that at most three of these workgroups (84 VGPRs,
-// 46 KB) fit a compute unit, which always leaves registers (260 per lane and SIMD) and LDS (22 KB) for one workgroup of
-// k_big_flow, whoever else shares the chip; operands are read with sc1 loads (the producer is running: flow_panel_wave).
-#ifndef RRPGO_SCHUR_POLL
-#define RRPGO_SCHUR_POLL 32   // s_sleep between two polls of a waiting Schur tile, in units of 64 clocks
-#endif
-struct SchurGate {
-  const unsigned *flags;
-  int pf, pstride, nc, M, I0, J0, tile;
-  int *err;
-  unsigned long long wait_ticks;
-  static constexpr bool on = true;
-  __device__ __forceinline__ void operator()(int sp) const {
-    // ONE wave polls, slowly (these workgroups are in no hurry, and thousands of waves polling every few hundred clocks slow the
-    // flag lines down for the chain they wait for: r05, +0.2 ms on the two top levels of the lattice); the others sleep at the barrier.
-    // lane = block of the super-panel (4) x strip (2) x row block (up to 8): as the UPDATE tasks of k_big_flow wait
-    if (wave_index() == 0) {
-      const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-      const unsigned *fp = nullptr;
-      const int qq = lane >> 4, strip = (lane >> 3) & 1, k = lane & 7;
-      const int kb = sp * BIG_SUPER + 32 * qq;
-      if (kb < min(sp * BIG_SUPER + BIG_SUPER, nc)) {
-        const int nbq = min(BIG_NB, nc - kb), r0 = kb + nbq;
-        const int lo = strip ? J0 : I0, hi = min(lo + tile - 1, M - 1);
-        const int rb = (lo - r0) / 32 + k;
-        if (rb <= (hi - r0) / 32) fp = flags + pf + (kb / BIG_NB) * pstride + rb;
-      }
-      unsigned long long t0 = 0;
-      for (unsigned spins = 0;; spins++) {
-        const unsigned v = fp ? flow_flag_ld(fp) : 1u;
-        if (__all(v != 0u)) break;
-        if ((spins & 15u) == 15u) {
-          if (t0 == 0) t0 = wall_clock64();
-          const int e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (e != 0 || wall_clock64() - t0 > wait_ticks) {
-            if (e == 0 && lane == 0) atomicOr(err, DEVERR_FLOW_TIMEOUT);
-            break;
-          }
-        }
-        __builtin_amdgcn_s_sleep(RRPGO_SCHUR_POLL);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    __syncthreads();
-  }
-};
-template <typename T, int NT> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? 6 : 2))   // <= 80 VGPRs in fp32: three of these + one of k_big_flow (240) per SIMD
-k_big_schur_flow(FactorArgs<T> a, int gather, const int32_t *tile_map, int n_tiles, int xcd_remap, const FlowFront *fronts, const unsigned *flags) {
-  using MM = Mfma16<T>;
-  using UT = UpdTile<T, NT>;
-  constexpr int TILE = UT::TILE;
-  __shared__ T smem[UT::SMEM];
-  unsigned v = blockIdx.x;
-  if (xcd_remap) {
-    const unsigned total = (unsigned)n_tiles, c = v & 7u, base = total >> 3, rem = total & 7u;
-    v = c * base + min(c, rem) + (v >> 3);
-  }
-  const int packed = tile_map[v];
-  const unsigned zq = (unsigned)packed >> 16;
-  const int t = packed & 0xffff;
-  int bx = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-  while (bx * (bx + 1) / 2 > t) bx--;
-  while ((bx + 1) * (bx + 2) / 2 <= t) bx++;
-  const int by = t - bx * (bx + 1) / 2;
-  const SnMeta m = a.task_meta[a.task_begin + zq];
-  const FlowFront ff = fronts[zq];
-  const int M = m.nc + m.nr + 1;
-  const int o = big_schur_origin(m.nc, TILE);
-  const int I0 = o + bx * TILE, J0 = o + by * TILE;
-  if (I0 >= M || J0 >= M) return;
-  typename MM::Acc acc[NT][NT];
-  TileGather<T> tg{nullptr, -1, nullptr, nullptr, nullptr, nullptr};
-  if (gather && J0 >= big_built_cols(m.nc, M)) tg = TileGather<T>{a.child_meta + m.child_begin, m.child_count, a.scat, a.lvals, a.uvals, a.xch};
-  const SchurGate gate{flags, ff.pf, ff.pstride, m.nc, M, I0, J0, TILE, a.err, a.wait_ticks};
-  big_update_tile<T, NT, 1, true, true, SchurGate>(a.lvals + m.loff, M, 0, m.nc, M, I0, J0, smem, acc, nullptr, false, tg, -1, gate);
 }
 
 // ---- k_big_solve_flow: the back substitution of a level's WIDE pivot blocks as ONE launch ---------------------------

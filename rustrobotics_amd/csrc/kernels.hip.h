@@ -2252,16 +2252,12 @@ template <typename T> struct TileGather {
   const int32_t *scat;
   const T *lvals, *uvals, *xch;
 };
-// Gate (LONGK only): called with s before the first operand load of the columns [128 s, 128 s + 128) -- k_big_schur_flow
-// (flow.hip.h) runs beside the launch that is still producing those columns and waits for their flags there.
-struct NoGate { static constexpr bool on = false; __device__ __forceinline__ void operator()(int) const {} };
 // GSC1: the gathered children are fronts of the SAME launch (k_big_flow's cross-level form): their entries are read past L1.
-template <typename T, int NT, int DEPTH = 1, bool SC1 = false, bool LONGK = false, typename Gate = NoGate, bool GSC1 = false>
+template <typename T, int NT, int DEPTH = 1, bool SC1 = false, bool LONGK = false, bool GSC1 = false>
 __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int jmax, int I0, int J0, T *smem,
                                                 typename Mfma16<T>::Acc (&acc)[NT][NT], unsigned long long *trace = nullptr, bool pm = false,
                                                 const TileGather<T> gather = TileGather<T>{nullptr, -1, nullptr, nullptr, nullptr, nullptr},
-                                                int tid_in = -1 /* k_big_flow: the caller's own copy of threadIdx.x */, const Gate gate = Gate{}) {
-  static_assert(!Gate::on || LONGK, "only the one-pass Schur form is gated");
+                                                int tid_in = -1 /* k_big_flow: the caller's own copy of threadIdx.x */) {
   struct { unsigned long long *trace; } a{trace};   // for RRPGO_PHASE_MARK (diagnostic builds)
   (void)a; (void)pm;
   using MM = Mfma16<T>;
@@ -2325,7 +2321,6 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
   };
   const int nchunks = (nk + KC - 1) / KC;
   constexpr int MAXCH = BIG_SUPER / KC;   // K <= 128
-  if constexpr (Gate::on) gate(0);
 #pragma unroll
   for (int d = 0; d < DEPTH; d++)
     if (d < nchunks) fetch(d, ra[d], rb[d]);   // requested BEFORE the C tile: a gathered tile pays two dependent round trips of its own
@@ -2494,11 +2489,7 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
       }
       if (c + 1 < nchunks) {
         stash(buf ^ 1, ra[0], rb[0]);
-        if (c + 2 < nchunks) {
-          if constexpr (Gate::on)
-            if (((c + 2) * KC) % BIG_SUPER == 0) gate((c + 2) * KC / BIG_SUPER);   // uniform: the next super-panel's first chunk
-          fetch(c + 2, ra[0], rb[0]);
-        }
+        if (c + 2 < nchunks) fetch(c + 2, ra[0], rb[0]);
       }
       __syncthreads();
     }

@@ -276,8 +276,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     int64_t ticket_word = 0;   // index of the level's ticket in flow_flags_
     int wfill_begin = 0, wfill_end = 0;   // the level's entries in flow_wfill_
     double est_us = 0;         // critical path of the cost model that orders the tasks
-    bool overlap = false;      // the level's Schur complements are formed by k_big_schur_flow on the second stream WHILE the flow launch runs
-    DevBuf<FlowFront> fronts;  // (overlap) where each front's flags live, by front slot
   };
   std::vector<std::unique_ptr<FlowLevel>> flow_levels_;   // per step of sym_.steps (null: launch sequence)
   std::vector<SnMeta> host_task_meta_;   // host copy of task_meta_ (one record per task = per front of a big level)
@@ -307,12 +305,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   bool solve_flow_on_ = true;       // RR_PGO_SOLVE_FLOW=0: one k_big_solve_sp launch per 128 columns
   int flow_schur_min_ = 512;        // RR_PGO_FLOW_SCHUR_MIN=<n>: flow levels with at least n Schur tiles leave them to k_big_schur
   int flow_grid_ = 0;               // persistent workgroups of a flow launch (RR_PGO_FLOW_GRID; default CUs x RRPGO_FLOW_WAVES)
-  // k_big_schur_flow (flow.hip.h): levels of at most schur_overlap_nf_ fronts form their Schur complements beside the flow launch
-  int schur_overlap_nf_ = 0;        // RR_PGO_SCHUR_OVERLAP=<n>: levels of at most n fronts (default 0: never -- k_big_schur behind the flow launch; bit-identical either way).  Measured slower at every n (profiles/r05_schur_overlap_*.txt): beside each other both launches lose more than the overlap gains
-  int flow_overlap_grid_ = 0;       // workgroups of the flow launch of such a level: one per CU, so that the Schur workgroups find room (RR_PGO_FLOW_OVERLAP_GRID)
-  PooledStream stream2_;            // the second stream (acquired with the first overlapped level)
-  std::vector<std::unique_ptr<EventHolder>> fork_ev_, join_ev_;   // per step: fronts built -> stream2_; Schur complements done -> stream_
-  static constexpr int kSchurFlowLdsPad = 46 * 1024;   // total LDS of a k_big_schur_flow workgroup: three per CU, never four (see the kernel)
   // k_factor_flow / k_solve_flow (lds_flow.hip.h): every front in LDS, the factorisation and the back substitution ONE launch each
   bool lds_flow_ = false;
   DevBuf<int32_t> child_dep_, parent_dep_;
@@ -528,7 +520,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (const char *e = getenv("RR_PGO_FLOW_TASKS")) flow_max_tasks_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_SOLVE_FLOW")) solve_flow_on_ = std::atoi(e) != 0;
     if (const char *e = getenv("RR_PGO_FLOW_SCHUR_MIN")) flow_schur_min_ = std::atoi(e);
-    if (const char *e = getenv("RR_PGO_SCHUR_OVERLAP")) schur_overlap_nf_ = std::atoi(e);
     n_lin_blocks_ = (int)(((int64_t)n_list_ * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
     edge_lin_ = getenv("RR_PGO_EDGE_LINEARIZE") != nullptr && !is3d_ && !sharded_ && g_.n_edges() > 0;
     if (edge_lin_) n_lin_blocks_ = std::max(1, (g_.n_edges() + LIN_THREADS - 1) / LIN_THREADS);
@@ -739,10 +730,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     flow_grid_ = std::max(cus, 1) * (sizeof(T) == 4 ? RRPGO_FLOW_WAVES : 1);
     if (const char *e = getenv("RR_PGO_FLOW_GRID")) flow_grid_ = std::max(1, std::atoi(e));
-    flow_overlap_grid_ = std::min(flow_grid_, std::max(cus, 1));
-    if (const char *e = getenv("RR_PGO_FLOW_OVERLAP_GRID")) flow_overlap_grid_ = std::max(1, std::atoi(e));
-    fork_ev_.resize(sym_.steps.size());
-    join_ev_.resize(sym_.steps.size());
     {
       // the cross-level form: every front beyond LDS sits above the LDS fronts (the dataflow schedule's condition), few of them,
       // none with parallel-edge blocks (k_big_assemble_dup has no task form), no gauge term on the root, default flow limits
@@ -789,10 +776,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         }
       }
       lvl->schur_split = schur_split_ && schur_tiles >= flow_schur_min_;
-      // few fronts: the chains bound the launch and the Schur complements are formed beside it (k_big_schur_flow), whatever their number
-      lvl->overlap = schur_split_ && schur_overlap_nf_ > 0 && nf <= schur_overlap_nf_ && schur_tiles > 0 && sizeof(T) == 4;
-      if (lvl->overlap) lvl->schur_split = true;
-      if (xl_) { lvl->schur_split = false; lvl->overlap = false; }   // one launch: the Schur complements are UPDATE tasks
+      if (xl_) lvl->schur_split = false;   // one launch: the Schur complements are UPDATE tasks
       std::vector<FlowTask> tasks;
       std::vector<FlowFront> fronts(nf);
       double level_end = 0, busy_us = 0;
@@ -1006,7 +990,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       }
       };   // plan
       plan();
-      if (!too_many && !xl_ && lvl->schur_split && !lvl->overlap && busy_us + schur_in_flow_us <= 0.6 * flow_grid_ * level_end) {
+      if (!too_many && !xl_ && lvl->schur_split && busy_us + schur_in_flow_us <= 0.6 * flow_grid_ * level_end) {
         lvl->schur_split = false;
         plan();
         if (too_many) { too_many = false; lvl->schur_split = true; plan(); }
@@ -1097,14 +1081,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
             std::memset(recs[i].pad, 0, sizeof(recs[i].pad));
           }
           flow_levels_[si]->tasks.upload(recs);
-          if (flow_levels_[si]->overlap) {
-            flow_levels_[si]->fronts.upload(all_fronts[si]);
-            fork_ev_[si] = std::make_unique<EventHolder>();
-            join_ev_[si] = std::make_unique<EventHolder>();
-            fork_ev_[si]->create(hipEventDisableTiming);
-            join_ev_[si]->create(hipEventDisableTiming);
-            stream2_.acquire();
-          }
         }
 #ifdef RRPGO_FLOW_TRACE
         flow_levels_[si]->host_tasks = all_tasks[si];
@@ -1242,7 +1218,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     fa.n_tasks = lvl.n_tasks;
     fa.schur_tile = lvl.schur_split ? schur_tile_ : 0;
     fa.trace = lvl.trace.p;
-    hipLaunchKernelGGL((k_big_flow<T, 2>), dim3((unsigned)std::min(lvl.n_tasks, lvl.overlap ? flow_overlap_grid_ : flow_grid_)), dim3(256), 0, stream_, fa);
+    hipLaunchKernelGGL((k_big_flow<T, 2>), dim3((unsigned)std::min(lvl.n_tasks, flow_grid_)), dim3(256), 0, stream_, fa);
     check_launch("k_big_flow");
   }
   // every level of fronts beyond LDS as ONE launch (the cross-level form: BUILD tasks, Schur complements inside, counters between levels)
@@ -1598,33 +1574,13 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (do_launch) pend(RR_PGO_K_BIGFRONT);   // closes the build / assemble segment
     if (const FlowLevel *lvl = flow_of(st)) {
       // the whole panel chain and every trailing update of the level: ONE launch of ticket-ordered tasks
-      const size_t si = (size_t)(&st - sym_.steps.data());
-      const UpdMap &sm = schur_maps_[si];
-      const bool ov = lvl->overlap && sm.n_tiles > 0;
       if (do_launch) {
-        if (ov) {
-          // the level's Schur complements on the second stream, gated tile by tile on the flags of the flow launch
-          HIPCHK(hipEventRecord(*fork_ev_[si], stream_));
-          HIPCHK(hipStreamWaitEvent(stream2_, *fork_ev_[si], 0));
-          constexpr int kStage = (int)(UpdTile<T, 2>::SMEM * sizeof(T));
-          static_assert((kSchurFlowLdsPad > kStage), "padding on top of the staging buffers");
-          hipLaunchKernelGGL((k_big_schur_flow<T, 2>), dim3((unsigned)sm.n_tiles), dim3(256), (size_t)(kSchurFlowLdsPad - kStage), stream2_, a,
-                             gather_update_ ? 1 : 0, (const int32_t *)upd_map_buf_.p + sm.offset, sm.n_tiles, xcd_remap_ ? 1 : 0,
-                             (const FlowFront *)lvl->fronts.p, (const unsigned *)flow_flags_.p);
-          check_launch("k_big_schur_flow");
-          HIPCHK(hipEventRecord(*join_ev_[si], stream2_));
-        }
         pbegin();
         launch_flow(st, *lvl);
         pend(RR_PGO_K_BIG_FLOW);
-        if (ov) {
-          pbegin();
-          HIPCHK(hipStreamWaitEvent(stream_, *join_ev_[si], 0));
-          pend(RR_PGO_K_BIG_UPDATE);   // (profiling: what of the Schur pass outlasts the flow launch)
-        }
       }
       n++;
-      n += ov ? 1 : launch_schur(st, a, do_launch);
+      n += launch_schur(st, a, do_launch);
       if (do_launch) pbegin();   // re-arm: the caller closes the level with pend(BIGFRONT)
       return n;
     }

@@ -718,39 +718,6 @@ def test_chain_passes_of_the_analysis_change_the_tree_not_the_answer(api, name, 
         np.testing.assert_allclose(np.array(alt.state()), sref, rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("case", ["lattice100-f32", "lattice100-mixed", "lattice400x250-f32"])
-def test_schur_complements_beside_the_flow_launch_are_bit_identical(api, case, monkeypatch):
-    """r05: on levels of few fronts the Schur complements are formed by k_big_schur_flow on a second stream WHILE k_big_flow
-    runs (a tile's k loop waits, super-panel by super-panel, for the X flags of its operand strips) instead of by k_big_schur
-    behind it (RR_PGO_SCHUR_OVERLAP=0): the same chunks in the same order, so chi2 and state must agree to the last bit -- a
-    tile that read an X block early would show here.  Also with every level overlapped, and with the flow launch squeezed into
-    one workgroup / spread over more than the default (RR_PGO_FLOW_OVERLAP_GRID): the Schur tiles only ever wait for the flow
-    launch, never the other way round, so any grid finishes.  Replaces umfpack.factorize, pose_graph_optimization.rs:138."""
-    from rustrobotics_amd import synthetic_grid_arrays
-    name, prec = case.rsplit("-", 1)
-    w, h = (100, 100) if name == "lattice100" else (400, 250)
-    arrays = synthetic_grid_arrays(w, h, 1000000 if w == 400 else 0)
-    iters = 3
-    monkeypatch.setenv("RR_PGO_SCHUR_OVERLAP", "0")
-    ref = api[0].from_arrays(*arrays, precision=prec)
-    monkeypatch.delenv("RR_PGO_SCHUR_OVERLAP")
-    eref, sref = np.array(ref.optimize(iters)), np.array(ref.state())
-    del ref
-    alts = [{}, {"RR_PGO_SCHUR_OVERLAP": "100000"}]
-    if w == 100:
-        alts += [{"RR_PGO_SCHUR_OVERLAP": "100000", "RR_PGO_FLOW_OVERLAP_GRID": "1"}, {"RR_PGO_FLOW_OVERLAP_GRID": "1000"},
-                 {"RR_PGO_SCHUR_OVERLAP": "100000", "RR_PGO_FORCE_GRAPH": "1"}, {"RR_PGO_SCHUR_OVERLAP": "100000", "RR_PGO_NO_GRAPH": "1"}]
-    for env in alts:
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        alt = api[0].from_arrays(*arrays, precision=prec)
-        for k in env:
-            monkeypatch.delenv(k)
-        assert np.array_equal(np.array(alt.optimize(iters)), eref), env
-        assert np.array_equal(np.array(alt.state()), sref), env
-        del alt
-
-
 @pytest.mark.parametrize("name,prec", [("sphere2500", "f64"), ("torus3D", "f64"), ("sphere2500", "mixed"), ("lattice60x40", "f64"), ("lattice60x40", "f32")])
 def test_cross_level_flow_launch_is_bit_identical_to_one_launch_per_level(api, name, prec, monkeypatch):
     """r05: graphs of a few dozen fronts beyond LDS (sphere2500: 46 in six levels) run ALL their levels as ONE k_big_flow launch
