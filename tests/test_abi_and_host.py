@@ -371,3 +371,17 @@ def test_offline_pmc_traffic_names_kernels_of_the_newest_kernel_stats():
         assert ran, (key, e["kernel"], sorted(names))
         # the counters' view of the dominant kernel agrees with the byte model to within what a cache hierarchy can do
         assert e["traffic_bytes_per_launch"] > 0 and e["launches_sampled"] > 0
+
+
+def test_the_sharded_c_client_compiles_against_the_header(tmp_path):
+    """tests/native/shard_client.c (the torch-free driver of the sharded protocol; run on a GPU by tests/test_gpu_parity.py) builds
+    with -Werror against include/rr_pgo.h and links the library alone: RCCL is found with dlopen at run time."""
+    import shutil
+    import subprocess
+    from rustrobotics_amd import _lib
+    exe = tmp_path / "shard_client"
+    subprocess.check_call([shutil.which("gcc") or "gcc", "-std=c99", "-D_DEFAULT_SOURCE", "-Wall", "-Wextra", "-Werror",
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "shard_client.c"),
+                           _lib.LIB_PATH, "-ldl", f"-Wl,-rpath,{os.path.dirname(_lib.LIB_PATH)}", "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 1 and "usage" in r.stderr

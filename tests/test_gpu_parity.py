@@ -457,6 +457,42 @@ def test_c_client_of_the_abi_matches_the_python_mirror(api, tmp_path):
         assert np.array_equal(state, np.array(g.state()))
 
 
+@pytest.mark.parametrize("what,prec,iters", [("grid:60x40", "f64", 10), ("grid:100x100", "mixed", 6), ("sphere2500", "f64", 12)])
+def test_c_client_drives_the_sharded_protocol_over_rccl_without_python(api, tmp_path, what, prec, iters):
+    """tests/native/shard_client.c: ONE rank of a sharded graph from plain C -- rr_pgo_stage(0), ncclAllGather, rr_pgo_stage(1),
+    ncclAllReduce on the handle's own stream, RCCL found with dlopen, no Python and no torch in that process (missing
+    item 2: a Rust caller of PoseGraph::optimize, pose_graph_optimization.rs:247-303, can shard through the C ABI alone).  A
+    one-rank communicator is all a one-GPU box allows; the chi2 list, the |dx| list and the state must be the bits the Python
+    drivers of the same stages produce."""
+    import shutil
+    import subprocess
+    from rustrobotics_amd import _lib, sharding, synthetic_grid_arrays
+    exe, out = tmp_path / "shard_client", tmp_path / "out.bin"
+    subprocess.check_call([shutil.which("gcc") or "gcc", "-std=c99", "-D_DEFAULT_SOURCE", "-Wall", "-Wextra", "-Werror",
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "shard_client.c"),
+                           _lib.LIB_PATH, "-ldl", f"-Wl,-rpath,{os.path.dirname(_lib.LIB_PATH)}", "-o", str(exe)])
+    arg = what if what.startswith("grid:") else g2o_path(what)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([str(exe), arg, prec, str(iters), str(out)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = (tmp_path / "out.bin.0").read_bytes()
+    ne, sl = np.frombuffer(raw[:8], np.int32)
+    errors = np.frombuffer(raw[8:8 + 8 * ne], np.float64)
+    norms = np.frombuffer(raw[8 + 8 * ne:8 + 8 * (2 * ne - 1)], np.float64)
+    state = np.frombuffer(raw[8 + 8 * (2 * ne - 1):], np.float64)
+    if what.startswith("grid:"):
+        w, h = (int(x) for x in what[5:].split("x"))
+        arrays = synthetic_grid_arrays(w, h)
+    else:
+        arrays = api[0].new(arg).graph_arrays()
+    shards, coll = sharding.emulate(arrays, 1, prec)
+    eref, nref = sharding.gauss_newton(shards, iters, coll)
+    assert len(state) == sl
+    assert np.array_equal(errors, np.array(eref)), (errors, eref)
+    assert np.array_equal(norms, np.array(nref)), (norms, nref)
+    assert np.array_equal(state, np.array(shards[0].state()))
+
+
 # ---- synthetic lattice (BASELINE config 4 generator) ------------------------------------------
 
 def test_synthetic_small_matches_oracle_f64(api, oracle):
