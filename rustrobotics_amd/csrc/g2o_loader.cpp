@@ -16,7 +16,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string_view>
+#include <thread>
 #include <unordered_map>
 
 #include "host_graph.h"
@@ -118,27 +120,27 @@ std::string HostGraph::finalize() {
   return "";
 }
 
-std::string load_g2o(const char *path, HostGraph &g, bool &io_error) {
-  io_error = false;
-  std::string text;
-  if (!read_file(path, text)) {
-    io_error = true;
-    return std::string("cannot read '") + path + "'";
-  }
-  g = HostGraph();
-  std::unordered_map<uint32_t, int32_t> index_of;  // id -> dense index (lut + nodes maps of the reference)
-  std::vector<uint32_t> from_id, to_id;
-  std::vector<std::string_view> tok;
-  size_t pos = 0;
-  long lineno = 0;
-  auto fail = [&](const std::string &m) { return "line " + std::to_string(lineno) + ": " + m; };
+namespace {
 
-  while (pos < text.size()) {
-    size_t eol = text.find('\n', pos);
-    if (eol == std::string::npos) eol = text.size();
-    std::string_view line(text.data() + pos, eol - pos);
+// what one thread parses: a run of whole lines
+struct ParsedPart {
+  std::vector<int32_t> node_kind, edge_kind, node_line;
+  std::vector<uint32_t> node_id, from_id, to_id;
+  std::vector<double> node_state, edge_meas, edge_info;
+  long lines = 0;        // lines consumed (up to and including the failing one)
+  std::string error;     // first failure of this part, without the line prefix
+};
+
+void parse_part(const char *text, size_t begin, size_t end, ParsedPart &out) {
+  std::vector<std::string_view> tok;
+  size_t pos = begin;
+  auto fail = [&](const std::string &m) { out.error = m; };
+  while (pos < end) {
+    const char *nl = (const char *)std::memchr(text + pos, '\n', end - pos);
+    const size_t eol = nl ? (size_t)(nl - text) : end;
+    std::string_view line(text + pos, eol - pos);
     pos = eol + 1;
-    lineno++;
+    out.lines++;
     if (!line.empty() && line.back() == '\r') line.remove_suffix(1);
     tok.clear();
     for (size_t i = 0; i < line.size();) {
@@ -170,21 +172,76 @@ std::string load_g2o(const char *path, HostGraph &g, bool &io_error) {
       if (!to_f64(tok[first + i], v[i])) return fail("bad number '" + std::string(tok[first + i]) + "'");
 
     if (!is_edge) {
+      out.node_kind.push_back(kind);
+      out.node_id.push_back(id0);
+      out.node_line.push_back((int32_t)out.lines);
+      out.node_state.insert(out.node_state.end(), v, v + nvals);
+    } else {
+      out.edge_kind.push_back(kind);
+      out.from_id.push_back(id0);
+      out.to_id.push_back(id1);
+      const int nm = edge_meas_len(kind);
+      out.edge_meas.insert(out.edge_meas.end(), v, v + nm);
+      out.edge_info.insert(out.edge_info.end(), v + nm, v + nvals);
+    }
+  }
+}
+
+}  // namespace
+
+// The text is cut into a few runs of whole lines, parsed by one thread each (the numbers are the cost: ~50 000 from_chars calls
+// for intel.g2o, 1 ms of the 7 ms closure the reference's bench times, benches/graph_slam.rs:9-10) and put together in file
+// order: vertex order, edge order, the first failure in file order and its line number are those of a sequential pass.
+std::string load_g2o(const char *path, HostGraph &g, bool &io_error) {
+  io_error = false;
+  std::string text;
+  if (!read_file(path, text)) {
+    io_error = true;
+    return std::string("cannot read '") + path + "'";
+  }
+  g = HostGraph();
+  int nparts = (int)std::min<size_t>(4, text.size() / (96u << 10) + 1);
+  nparts = std::max(1, std::min<int>(nparts, (int)std::thread::hardware_concurrency()));
+  std::vector<size_t> cut(nparts + 1, text.size());
+  cut[0] = 0;
+  for (int k = 1; k < nparts; k++) {
+    size_t p = text.size() * (size_t)k / (size_t)nparts;
+    p = std::max(p, cut[k - 1]);
+    const size_t nl = text.find('\n', p);
+    cut[k] = nl == std::string::npos ? text.size() : nl + 1;
+  }
+  std::vector<ParsedPart> parts(nparts);
+  {
+    std::vector<std::thread> pool;
+    for (int k = 1; k < nparts; k++) pool.emplace_back([&, k] { parse_part(text.data(), cut[k], cut[k + 1], parts[k]); });
+    parse_part(text.data(), cut[0], cut[1], parts[0]);
+    for (std::thread &t : pool) t.join();
+  }
+  std::unordered_map<uint32_t, int32_t> index_of;  // id -> dense index (lut + nodes maps of the reference)
+  std::vector<uint32_t> from_id, to_id;
+  size_t nn = 0, ne = 0;
+  for (const ParsedPart &p : parts) { nn += p.node_kind.size(); ne += p.edge_kind.size(); }
+  index_of.reserve(nn * 2);
+  g.node_kind.reserve(nn); g.node_id.reserve(nn);
+  g.edge_kind.reserve(ne); from_id.reserve(ne); to_id.reserve(ne);
+  long line0 = 0;
+  for (const ParsedPart &p : parts) {
+    for (size_t i = 0; i < p.node_kind.size(); i++) {
       // The reference would silently overwrite the hash-map entry and leave the
       // previous offset's rows empty (a singular system): rejected here.
-      if (!index_of.emplace(id0, (int32_t)g.node_kind.size()).second)
-        return fail("duplicate vertex id " + std::to_string(id0));
-      g.node_kind.push_back(kind);
-      g.node_id.push_back(id0);
-      g.node_state.insert(g.node_state.end(), v, v + nvals);
-    } else {
-      g.edge_kind.push_back(kind);
-      from_id.push_back(id0);
-      to_id.push_back(id1);
-      const int nm = edge_meas_len(kind);
-      g.edge_meas.insert(g.edge_meas.end(), v, v + nm);
-      g.edge_info.insert(g.edge_info.end(), v + nm, v + nvals);
+      if (!index_of.emplace(p.node_id[i], (int32_t)g.node_kind.size()).second)
+        return "line " + std::to_string(line0 + p.node_line[i]) + ": duplicate vertex id " + std::to_string(p.node_id[i]);
+      g.node_kind.push_back(p.node_kind[i]);
+      g.node_id.push_back(p.node_id[i]);
     }
+    if (!p.error.empty()) return "line " + std::to_string(line0 + p.lines) + ": " + p.error;
+    g.node_state.insert(g.node_state.end(), p.node_state.begin(), p.node_state.end());
+    g.edge_kind.insert(g.edge_kind.end(), p.edge_kind.begin(), p.edge_kind.end());
+    from_id.insert(from_id.end(), p.from_id.begin(), p.from_id.end());
+    to_id.insert(to_id.end(), p.to_id.begin(), p.to_id.end());
+    g.edge_meas.insert(g.edge_meas.end(), p.edge_meas.begin(), p.edge_meas.end());
+    g.edge_info.insert(g.edge_info.end(), p.edge_info.begin(), p.edge_info.end());
+    line0 += p.lines;
   }
   const size_t E = g.edge_kind.size();
   g.edge_from.resize(E);

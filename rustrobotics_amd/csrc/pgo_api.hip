@@ -53,6 +53,41 @@ static thread_local std::string g_last_error;
 // synchronise): a caller that builds a graph, runs ten iterations and drops it -- the reference's own
 // criterion bench -- would spend more time there than iterating.  Buffers are carved out of a few large
 // chunks owned by the engine instead; a DevBuf only calls hipMalloc itself when no arena is active.
+// Chunks of dropped handles are kept per device and handed to the next handle (hipFree synchronises the device and costs
+// ~0.1 ms per chunk: "drop" was 0.4 - 0.5 ms of the 7 ms closure the reference's bench times, benches/graph_slam.rs:9-10, a
+// loop of new + optimize(10) + drop).  Only small chunks, and only a bounded total: the arenas of the large graphs are freed.
+// Nothing reads memory it has not written (scripts/gpu_soak.py rebuilds handles on poisoned memory), so a recycled chunk needs no clearing.
+struct ChunkPool {
+  struct Idle { int dev; char *base; size_t cap; };
+  std::mutex mu;
+  std::vector<Idle> idle;
+  size_t idle_bytes = 0;
+  static constexpr size_t kMaxChunk = 64u << 20, kMaxIdle = 256u << 20;
+  char *take(size_t min_bytes, size_t *cap) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t best = idle.size();
+    for (size_t i = 0; i < idle.size(); i++)
+      if (idle[i].dev == dev && idle[i].cap >= min_bytes && idle[i].cap <= 4 * min_bytes + (1u << 20) && (best == idle.size() || idle[i].cap < idle[best].cap)) best = i;
+    if (best == idle.size()) return nullptr;
+    char *p = idle[best].base;
+    *cap = idle[best].cap;
+    idle_bytes -= idle[best].cap;
+    idle.erase(idle.begin() + (long)best);
+    return p;
+  }
+  void put(char *base, size_t cap) {
+    int dev = 0;
+    if (cap <= kMaxChunk && hipGetDevice(&dev) == hipSuccess) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (idle_bytes + cap <= kMaxIdle) { idle.push_back(Idle{dev, base, cap}); idle_bytes += cap; return; }
+    }
+    (void)hipFree(base);
+  }
+};
+static ChunkPool &chunk_pool() { static ChunkPool *p = new ChunkPool; return *p; }   // leaked on purpose, like the stream pool
+
 struct DeviceArena {
   struct Chunk { char *base; size_t cap, used; };
   std::vector<Chunk> chunks;
@@ -60,7 +95,8 @@ struct DeviceArena {
   DeviceArena() = default;
   DeviceArena(const DeviceArena &) = delete;
   DeviceArena &operator=(const DeviceArena &) = delete;
-  ~DeviceArena() { for (Chunk &c : chunks) (void)hipFree(c.base); }
+  // (the engine's stream was synchronised when it went back to its pool: declared after the arena, destroyed before it)
+  ~DeviceArena() { for (Chunk &c : chunks) chunk_pool().put(c.base, c.cap); }
   void reserve(size_t bytes) { next_chunk = std::max(next_chunk, bytes); }
   void *take(size_t bytes) {
     for (Chunk &c : chunks) {
@@ -68,7 +104,8 @@ struct DeviceArena {
       if (off + bytes <= c.cap) { c.used = off + bytes; return c.base + off; }
     }
     Chunk c{nullptr, std::max(next_chunk, bytes + 256), 0};
-    HIPCHK(hipMalloc((void **)&c.base, c.cap));
+    if (char *p = chunk_pool().take(c.cap, &c.cap)) c.base = p;
+    else HIPCHK(hipMalloc((void **)&c.base, c.cap));
     next_chunk = std::max<size_t>(8u << 20, c.cap / 4);
     c.used = bytes;
     chunks.push_back(c);
