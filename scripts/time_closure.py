@@ -6,6 +6,8 @@ from rustrobotics_amd import PoseGraph
 name = sys.argv[1] if len(sys.argv) > 1 else 'intel'
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests/golden/g2o', name + '.g2o')
 g = PoseGraph.new(path); g.optimize(10); del g      # warm: module load, first-use initialisation of the runtime
+# RR_PGO_ANALYSIS_CACHE=0 in the environment: every construction analysed afresh (what a FIRST construction costs); default: the
+# steady state of the reference's bench loop, the analysis of the structurally identical graph reused
 for rep in range(3):
     sys.stderr.write('--- rep %d\n' % rep)
     t0 = time.perf_counter(); g = PoseGraph.new(path); t1 = time.perf_counter(); e = g.optimize(10); t2 = time.perf_counter()

@@ -957,6 +957,25 @@ def test_properties_at_full_size(api, name):
     assert np.abs(st[g.anchor_node] - st0[g.anchor_node]).max() < 1e-6
 
 
+def test_analysis_cache_hands_out_the_same_tables(api, monkeypatch):
+    """A second handle on a structurally identical graph reuses the first one's symbolic analysis (pgo_api.hip, analysis cache: the
+    reference's bench is a loop of PoseGraph::new + optimize(10), benches/graph_slam.rs:9-10); RR_PGO_ANALYSIS_CACHE=0 analyses
+    afresh.  Same tables either way: same bits; another switch of the analysis is another cache entry, not a stale hit."""
+    a = api[0].new(g2o_path("intel"))
+    ea, sa = np.array(a.optimize(6)), np.array(a.state())
+    b = api[0].new(g2o_path("intel"))
+    assert b.stats()["analyze_ms"] < 0.5 * a.stats()["analyze_ms"] or a.stats()["analyze_ms"] < 0.5    # (a itself may have hit an entry of an earlier test)
+    assert np.array_equal(np.array(b.optimize(6)), ea) and np.array_equal(np.array(b.state()), sa)
+    monkeypatch.setenv("RR_PGO_ANALYSIS_CACHE", "0")
+    c = api[0].new(g2o_path("intel"))
+    monkeypatch.delenv("RR_PGO_ANALYSIS_CACHE")
+    assert np.array_equal(np.array(c.optimize(6)), ea) and np.array_equal(np.array(c.state()), sa)
+    monkeypatch.setenv("RR_PGO_MERGE_CHAIN", "0")
+    d = api[0].new(g2o_path("intel"))
+    monkeypatch.delenv("RR_PGO_MERGE_CHAIN")
+    assert d.stats()["n_supernodes"] != a.stats()["n_supernodes"]    # the other partition, not the cached one
+
+
 def test_iterate_async_equals_optimize_without_break(api):
     g1, g2 = api[0].new(g2o_path("intel")), api[0].new(g2o_path("intel"))
     g1.iterate_async(4); g1.sync()
