@@ -71,6 +71,7 @@ template <typename T> struct FlowArgs {   // everything the launch reads: a slim
   const ChildMeta *child_meta;
   const int32_t *scat;
   T *lvals, *uvals, *xch, *winv;
+  T *xnew;      // per 32-column block of a flow front (laid out like winv): the chain wave's X block, polled in place by the next step (see flow_panel_wave)
   int *err;
   unsigned long long wait_ticks;   // bound of one wait, 100 MHz wall-clock ticks (RR_PGO_FLOW_TIMEOUT_MS; default 2 s)
   unsigned long long *trace;   // diagnostic build (-DRRPGO_FLOW_TRACE): [ticket][wave][4] wall-clock stamps, else null
@@ -328,8 +329,50 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
       d += kstep;
     }
   };
-  auto wait_newest = [&] {   // X of block blk - 1: my rows and the diagonal block's rows
-    flow_wait(lane < 3 ? block_flag(1, lane) : nullptr, fa.err, fa.wait_ticks);
+  // The newest block's operand from the DIAGONAL block's rows is the X block the previous step's chain wave has just formed: the one
+  // hand-off every wave of this step waits for.  It does not come through F (store, drain, flag, poll, load) but through a copy the
+  // chain wave stores FIRST (xnew, below) and that is polled in place like W: k_flow_reset marked it, each entry goes from the mark
+  // to its value in one store (r05: the drain + flag hop were ~1.7 us of every chain step).
+  const Sc1Buf<T> xbuf(fa.xnew + (int64_t)m.wblk * 256 + (int64_t)max(blk - 1, 0) * 1024, 1024u * SZ);
+  auto fetch_newest = [&](int b, T (*xa)[2], T (*xb)[2]) {
+    uint32_t d = (uint32_t)(b * 8) * kstep;
+#pragma unroll
+    for (int s4 = 0; s4 < 8; s4++) {
+      xb[s4][0] = fbuf.ld(ob0 + d);
+      xb[s4][1] = fbuf.ld(ob1 + d);
+      d += kstep;
+    }
+    const uint32_t r0 = (uint32_t)min(li, nb - 1), r1 = (uint32_t)min(16 + li, nb - 1);
+    unsigned long long xt0 = 0;
+    for (unsigned spins = 0;; spins++) {
+      bool unset = false;
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int s4 = 0; s4 < 8; s4++) {
+        const uint32_t c = (uint32_t)(4 * s4 + lk) * 32u;
+        xa[s4][0] = xbuf.ld((c + r0) * SZ);
+        xa[s4][1] = xbuf.ld((c + r1) * SZ);
+        unset = unset || flow_w_unset(xa[s4][0]) || flow_w_unset(xa[s4][1]);
+      }
+      if (!__any(unset)) break;
+      if ((spins & 63u) == 63u) {
+        if (xt0 == 0) xt0 = wall_clock64();
+        const int e = __hip_atomic_load(fa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e != 0 || wall_clock64() - xt0 > fa.wait_ticks) {
+          if (e == 0 && lane == 0) atomicOr(fa.err, DEVERR_FLOW_TIMEOUT);
+          break;
+        }
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 8; s4++) {
+      xa[s4][0] *= am0;
+      xa[s4][1] *= am1;
+    }
+  };
+  auto wait_newest = [&] {   // X of block blk - 1, my rows (the diagonal block's rows: fetch_newest)
+    flow_wait(lane < 2 ? block_flag(1, lane) : nullptr, fa.err, fa.wait_ticks);
   };
   // a range of more than three blocks reaches into the previous super-panel: its blocks are there long before block
   // blk - 2 is, and at ~2 us of loads per block the pre-work has to start on them at once to stay off the chain
@@ -345,8 +388,8 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
 #pragma unroll
       for (int ib = 0; ib < 2; ib++) acc[ib][jb][r] = ldF(kb + min(j, nb - 1), irow[ib]);
     }
-  if (nblk == 1) wait_newest();
-  if (nblk > 0) fetch(0, av[0], bv[0]);
+  if (nblk == 1) { wait_newest(); fetch_newest(0, av[0], bv[0]); }
+  else if (nblk > 0) fetch(0, av[0], bv[0]);
   auto load_next_diag = [&] {
 #pragma unroll
     for (int jb = 0; jb < 2; jb++)
@@ -381,7 +424,8 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
       if (b + 1 < nblk) {   // the next block's operands are in flight under this block's MFMAs
         if (b + 2 == nblk) wait_newest();
         if (b + 3 == nblk) wait_second();
-        fetch(b + 1, av[slot ^ 1], bv[slot ^ 1]);
+        if (b + 2 == nblk) fetch_newest(b + 1, av[slot ^ 1], bv[slot ^ 1]);
+        else fetch(b + 1, av[slot ^ 1], bv[slot ^ 1]);
       }
       if (look && skip > 0 && b + 1 == skip) {
         // the next diagonal block's range starts with the next block; the tile of the update before it that holds the
@@ -466,6 +510,18 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
         }
   }
   unsigned *pflag = fa.flags + ff.pf + blk * ff.pstride + rowblk;
+  if (look) {
+    // the copy the next step polls (all 1024 entries: rows past the front's end hold clamped, finite values nobody uses unmasked)
+    const Sc1Buf<T> xout(fa.xnew + (int64_t)m.wblk * 256 + (int64_t)blk * 1024, 1024u * SZ);
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t co = (uint32_t)((16 * cb + MM::row(lane, r)) * 32 + li) * SZ;
+        xout.st(co, (T)out[0][cb][r]);
+        xout.st(co + 16u * SZ, (T)out[1][cb][r]);
+      }
+  }
   if (!look) {
     flow_drain();
     if (lane == 0) flow_flag_set(pflag);
@@ -484,15 +540,18 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
   const int nbn = min(BIG_NB, m.nc - kn);
   sh_image_from_acc<T>(Sh, nxt, nbn);
   diag32_init_tables<T>(Sh);
-  // X of this row block is what the NEXT step's pre-work reads (these rows are its diagonal block's): publish it now,
-  // before the factorisation -- its stores have been draining under the MFMAs and LDS writes above
-  flow_drain();
-  if (lane == 0) flow_flag_set(pflag);
+  // X of this row block is what the NEXT step's pre-work reads (these rows are its diagonal block's): it is published from INSIDE the
+  // factorisation, after the first 16 x 16 sweep -- its stores (written through to memory: ~1 us) have landed by then, and the chain
+  // has not stood still for them (r05: the drain used to sit here, in front of the factorisation)
   wave_sync();
+  auto publish_x = [&] {
+    flow_drain();
+    if (lane == 0) flow_flag_set(pflag);
+  };
   // the factored block itself is not stored: nothing reads a diagonal block of L once its W exists (the back
   // substitution works with the inverses), and across a super-panel's end tile (0, 0) of the update still owns it
-  diag32_factor_invert<T, false, true>(Sh, nbn, F + (int64_t)kn * M + kn, M, fa.winv + (int64_t)m.wblk * 256 + (kn / BIG_NB) * 1024, fa.err,
-                                       false, true);
+  diag32_factor_invert<T, false, true, decltype(publish_x)>(Sh, nbn, F + (int64_t)kn * M + kn, M, fa.winv + (int64_t)m.wblk * 256 + (kn / BIG_NB) * 1024, fa.err,
+                                                            false, true, publish_x);
   flow_drain();   // W is in memory
   if (lane == 0) flow_flag_set(fa.flags + ff.wf + blk + 1);
   RRPGO_FLOW_MARK(fa, ticket, tid >> 6, 3);
@@ -509,7 +568,7 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
 // (hardware NaNs are 0x7fc00000 / propagated payloads of the operands); every store of a W block writes all of its
 // 1024 entries, each entry goes from the mark to its value in one store, so a block without a mark is complete.
 template <typename T>
-__global__ void __launch_bounds__(256) k_flow_reset(unsigned *words, int64_t n, int flag_wgs, T *winv, const int64_t *wfill) {
+__global__ void __launch_bounds__(256) k_flow_reset(unsigned *words, int64_t n, int flag_wgs, T *winv, const int64_t *wfill, T *xnew) {
   if ((int)blockIdx.x < flag_wgs) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)flag_wgs * 256) words[i] = 0u;
   } else {
@@ -517,8 +576,8 @@ __global__ void __launch_bounds__(256) k_flow_reset(unsigned *words, int64_t n, 
     const int e = (int)blockIdx.x - flag_wgs;
     const int64_t off = wfill[2 * e], cnt = wfill[2 * e + 1];
     using U = typename std::conditional<sizeof(T) == 4, unsigned, unsigned long long>::type;
-    U *w = reinterpret_cast<U *>(winv + off);
-    for (int64_t i = threadIdx.x; i < cnt; i += 256) w[i] = ~(U)0;
+    U *w = reinterpret_cast<U *>(winv + off), *xw = reinterpret_cast<U *>(xnew + off);
+    for (int64_t i = threadIdx.x; i < cnt; i += 256) { w[i] = ~(U)0; xw[i] = ~(U)0; }   // (the chain waves' X blocks are polled in place like W)
   }
 }
 #ifndef RRPGO_FLOW_DEPTH

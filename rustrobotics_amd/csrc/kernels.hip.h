@@ -1893,9 +1893,12 @@ __device__ __forceinline__ void sh_image_from_acc(T *Sh, const typename Mfma16<T
       }
 }
 
-template <typename T, bool WG_IS_ONE_WAVE = true, bool SC1 = false>
+// Mid: called once by every lane after the first 16 x 16 sweep (~1 us into the ~2.7 us): k_big_flow's chain wave publishes the X
+// block it stored just before the call there -- by then those stores have landed, and the factorisation has not waited for them.
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+template <typename T, bool WG_IS_ONE_WAVE = true, bool SC1 = false, typename Mid = NoMid>
 __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int M, T *Wt, int *err, bool store_l = true,
-                                                     bool store_w = true) {
+                                                     bool store_w = true, const Mid mid = Mid{}) {
   // orders this wave's LDS writes before its later reads: a workgroup barrier where the workgroup IS the
   // wave, a wave-level fence where other waves of the workgroup have already left
   auto sync = [] {
@@ -1924,6 +1927,7 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
 #pragma unroll
   for (int c = 0; c < 16; c++) Sh[rowlane ? c * 33 + q : WOFF + q * 33 + c] = x[c];   // L11(q, c) | W11(c, q)
   sync();
+  mid();
   // ---- L21(i, c) = sum_j A21(i, j) W11(c, j): tile rows = c, tile columns = i
   typename MM::Acc l21 = {0, 0, 0, 0};
 #pragma unroll

@@ -365,7 +365,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<int64_t> pack_list_;       // (front, exchange offset) of the in-place boundary fronts this rank owns
   int n_pack_ = 0, pack_max_nu_ = 0;
   // numeric
-  DevBuf<T> hvals_, b_, x_, dx_ref_, lvals_, uvals_, winv_, gemv_part_;
+  DevBuf<T> hvals_, b_, x_, dx_ref_, lvals_, uvals_, winv_, xnew_, gemv_part_;
   static constexpr int kGemvSlices = 16;   // row slices of the multi-workgroup L21^T x product
   DevBuf<double> chi_partial_, norm_partial_, hist_;
   DevBuf<int> counter_, err_, blocks_done_;
@@ -634,6 +634,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       if (wblk_total > 0x7fffff00LL) throw ApiError(RR_PGO_EUNSUPPORTED, "too many diagonal blocks");
       winv_.alloc((size_t)wblk_total * 256 + 4);
       winv_.zero();
+      {
+        bool any_big = false;
+        for (const Step &st : sym.steps) any_big = any_big || st.kind == STEP_BIG;
+        xnew_.alloc(any_big ? (size_t)wblk_total * 256 + 4 : 4);   // the chain waves' X blocks of the flow fronts (laid out like winv; flow.hip.h)
+        xnew_.zero();
+      }
       child_meta_.upload(cm);
       if (const char *e = getenv("RR_PGO_FLOW_TIMEOUT_MS")) wait_ticks_ = (unsigned long long)std::max(1.0, std::atof(e) * 1e5);
       if (sym.lds_flow) {
@@ -1236,6 +1242,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     fa.uvals = uvals_.p;
     fa.xch = xch_;
     fa.winv = winv_.p;
+    fa.xnew = xnew_.p;
     fa.err = err_.p;
     fa.wait_ticks = wait_ticks_;
     fa.trace = nullptr;
@@ -1501,7 +1508,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         if (flow_levels_[si]) { if (e1 == 0) e0 = flow_levels_[si]->wfill_begin; e1 = flow_levels_[si]->wfill_end; }
       const int flag_wgs = (int)std::min<int64_t>(((int64_t)flow_flags_.n + 255) / 256, 256);
       hipLaunchKernelGGL(k_flow_reset<T>, dim3((unsigned)(flag_wgs + std::max(e1 - e0, 0))), dim3(256), 0, stream_, flow_flags_.p, (int64_t)flow_flags_.n, flag_wgs,
-                         winv_.p, flow_wfill_.p + 2 * e0);
+                         winv_.p, flow_wfill_.p + 2 * e0, xnew_.p);
       check_launch("k_flow_reset");
     }
     if (lds_flow_ && from == 0 && to > 0) {
