@@ -139,7 +139,13 @@ __device__ __forceinline__ bool flow_wait_ge(const unsigned *word, unsigned need
 }
 // the mark k_flow_reset leaves in a W block that is not there yet (see there)
 __device__ __forceinline__ bool flow_w_unset(float v) { return __float_as_uint(v) == 0xffffffffu; }
-__device__ __forceinline__ bool flow_w_unset(double v) { return (unsigned long long)__double_as_longlong(v) == ~0ull; }
+// fp64: EITHER half still holding the mark counts as not there (an aligned 8-byte sc1 store was never seen torn on this chip --
+// scripts/handoff_probe.hip, 0 of 1e9 -- but the poll does not rest on it).  A finished value whose low word happens to be all ones
+// (one in 2^32; the high word cannot be: that is a NaN) keeps the poll going for flow_w_patience polls, then it is taken as read.
+__device__ __forceinline__ bool flow_w_unset(double v) { return (unsigned)__double2hiint(v) == 0xffffffffu || (unsigned)__double2loint(v) == 0xffffffffu; }
+__device__ __forceinline__ bool flow_w_hi_unset(float v) { return flow_w_unset(v); }
+__device__ __forceinline__ bool flow_w_hi_unset(double v) { return (unsigned)__double2hiint(v) == 0xffffffffu; }
+constexpr unsigned flow_w_patience = 16;   // polls with only low words at the mark before the values are accepted
 // after this wave's payload stores: drain them, then the caller sets its flags
 __device__ __forceinline__ void flow_drain() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -344,8 +350,9 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
     }
     const uint32_t r0 = (uint32_t)min(li, nb - 1), r1 = (uint32_t)min(16 + li, nb - 1);
     unsigned long long xt0 = 0;
+    unsigned low_only = 0;
     for (unsigned spins = 0;; spins++) {
-      bool unset = false;
+      bool unset = false, hi_unset = false;
       asm volatile("" ::: "memory");
 #pragma unroll
       for (int s4 = 0; s4 < 8; s4++) {
@@ -353,8 +360,10 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
         xa[s4][0] = xbuf.ld((c + r0) * SZ);
         xa[s4][1] = xbuf.ld((c + r1) * SZ);
         unset = unset || flow_w_unset(xa[s4][0]) || flow_w_unset(xa[s4][1]);
+        hi_unset = hi_unset || flow_w_hi_unset(xa[s4][0]) || flow_w_hi_unset(xa[s4][1]);
       }
       if (!__any(unset)) break;
+      if (!__any(hi_unset) && ++low_only > flow_w_patience) break;
       if ((spins & 63u) == 63u) {
         if (xt0 == 0) xt0 = wall_clock64();
         const int e = __hip_atomic_load(fa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -454,8 +463,9 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
   // (polled in place: k_flow_reset marked the block, see there; bounded like flow_wait)
   T wv[3][4];
   unsigned long long wt0 = 0;
+  unsigned low_only = 0;
   for (unsigned spins = 0;; spins++) {
-    bool unset = false;
+    bool unset = false, hi_unset = false;
     asm volatile("" ::: "memory");   // the raw buffer loads below are not volatile accesses: nothing else keeps them inside the poll
 #pragma unroll
     for (int t = 0; t < 3; t++)
@@ -464,8 +474,10 @@ __device__ __forceinline__ void flow_panel_wave(const FlowArgs<T> &fa, const Flo
         const int cb = t == 0 ? 0 : 1, jb = t == 2 ? 1 : 0;
         wv[t][r] = wbuf.ld((uint32_t)((16 * jb + MM::row(lane, r)) * 32 + 16 * cb + li) * SZ);
         unset = unset || flow_w_unset(wv[t][r]);
+        hi_unset = hi_unset || flow_w_hi_unset(wv[t][r]);
       }
     if (!__any(unset)) break;
+    if (!__any(hi_unset) && ++low_only > flow_w_patience) break;
     if ((spins & 63u) == 63u) {
       if (wt0 == 0) wt0 = wall_clock64();
       const int e = __hip_atomic_load(fa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
