@@ -273,6 +273,102 @@ def test_parallel_edges_and_reversed_edges(api, oracle):
     assert np.abs(g.state() - o.state()).max() <= 1e-8
 
 
+def _random_graph(rng, n_pose, n_lm, n_extra, se3=False):
+    """A connected random graph in rr_pgo_graph_desc packing: a random spanning tree over the poses (so that the one prior on the
+    from-node of the first pose-pose edge, :330-336, reaches everything), `n_extra` loop closures between random pose pairs
+    (parallel edges and both directions allowed), `n_lm` landmarks seen from one to three random poses each (SE(2) only), full
+    random SPD information matrices, measurements = ground truth relative poses + noise, initial state = ground truth + noise."""
+    def spd(d):
+        a = rng.normal(size=(d, d))
+        m = a @ a.T + d * np.eye(d)
+        return m * rng.uniform(0.5, 50.0)
+    if se3:
+        def q_mul(a, b):
+            ax, ay, az, aw = a; bx, by, bz, bw = b
+            return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                             aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+        def q_rot(q, v):
+            qv = np.array([*v, 0.0]); qc = np.array([-q[0], -q[1], -q[2], q[3]])
+            return q_mul(q_mul(q, qv), qc)[:3]
+        def rq():
+            q = rng.normal(size=4); return q / np.linalg.norm(q) * np.sign(q[3] if q[3] != 0 else 1.0)
+        T = [(rng.uniform(-5, 5, 3), rq()) for _ in range(n_pose)]
+        pairs = [(int(rng.integers(0, i)), i) for i in range(1, n_pose)] + [tuple(int(x) for x in rng.choice(n_pose, 2, replace=False)) for _ in range(n_extra)]
+        rng.shuffle(pairs[1:])
+        nk = np.full(n_pose, 2, np.int32)
+        ns = np.concatenate([np.concatenate([t + rng.normal(scale=0.05, size=3), (lambda q: q / np.linalg.norm(q))(q + rng.normal(scale=0.02, size=4))]) for t, q in T])
+        ek, ef, et, em, ei = [], [], [], [], []
+        for a, b in pairs:
+            (ta, qa), (tb, qb) = T[a], T[b]
+            qai = np.array([-qa[0], -qa[1], -qa[2], qa[3]])
+            tz, qz = q_rot(qai, tb - ta), q_mul(qai, qb)
+            qz = (qz + rng.normal(scale=0.01, size=4)); qz /= np.linalg.norm(qz)
+            ek.append(2); ef.append(a); et.append(b)
+            em.append(np.concatenate([tz + rng.normal(scale=0.02, size=3), qz]))
+            ei.append(spd(6)[np.triu_indices(6)])
+        return nk, ns, np.array(ek, np.int32), np.array(ef, np.int32), np.array(et, np.int32), np.concatenate(em), np.concatenate(ei)
+    X = np.column_stack([rng.uniform(-10, 10, n_pose), rng.uniform(-10, 10, n_pose), rng.uniform(-np.pi, np.pi, n_pose)])
+    Lm = rng.uniform(-10, 10, (n_lm, 2))
+    pairs = [(int(rng.integers(0, i)), i) for i in range(1, n_pose)] + [tuple(int(x) for x in rng.choice(n_pose, 2, replace=False)) for _ in range(n_extra)]
+    first, rest = pairs[:1], pairs[1:]
+    sights = [(int(p), n_pose + l) for l in range(n_lm) for p in rng.choice(n_pose, int(rng.integers(1, 4)), replace=False)]
+    rest = rest + sights
+    order = rng.permutation(len(rest))
+    edges = first + [rest[i] for i in order]          # (the first edge stays a pose-pose edge: the prior's anchor)
+    nk = np.concatenate([np.zeros(n_pose, np.int32), np.ones(n_lm, np.int32)])
+    ns = np.concatenate([(X + rng.normal(scale=[0.1, 0.1, 0.03], size=X.shape)).ravel(), (Lm + rng.normal(scale=0.1, size=Lm.shape)).ravel()])
+    ek, ef, et, em, ei = [], [], [], [], []
+    for a, b in edges:
+        xa = X[a]
+        c, s_ = np.cos(xa[2]), np.sin(xa[2])
+        Rt = np.array([[c, s_], [-s_, c]])
+        if b < n_pose:
+            xb = X[b]
+            z = np.concatenate([Rt @ (xb[:2] - xa[:2]), [xb[2] - xa[2]]]) + rng.normal(scale=[0.05, 0.05, 0.01])
+            ek.append(0); em.append(z); ei.append(spd(3)[np.triu_indices(3)])
+        else:
+            z = Rt @ (Lm[b - n_pose] - xa[:2]) + rng.normal(scale=0.05, size=2)
+            ek.append(1); em.append(z); ei.append(spd(2)[np.triu_indices(2)])
+        ef.append(a); et.append(b)
+    return nk, ns, np.array(ek, np.int32), np.array(ef, np.int32), np.array(et, np.int32), np.concatenate(em), np.concatenate(ei)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_ragged_graphs_match_the_oracle(api, oracle, seed):
+    """Seeded random graphs the datasets do not contain: 2 .. 70 poses, trees with random loop closures (parallel edges, both
+    directions), landmarks seen from one to three poses mixed into the edge order, full (not diagonal) random SPD information
+    matrices.  chi2 (:537-574), every block of H and b (:165-212, :305-369) with and without the LM term, the first step
+    (:371-373) and a five-iteration Gauss-Newton and LM trajectory against the oracle."""
+    from oracle.oracle import LEVENBERG_MARQUARDT
+    rng = np.random.default_rng(1000 + seed)
+    n_pose = int(rng.integers(2, 70))
+    arrays = _random_graph(rng, n_pose, int(rng.integers(0, 25)) if seed % 3 else 0, int(rng.integers(0, 2 * n_pose)))
+    g, o = api[0].from_arrays(*arrays), oracle.from_arrays(*arrays)
+    assert abs(g.global_error() - o.global_error()) <= 1e-12 * max(1.0, o.global_error())
+    for lm in (False, True):
+        _assert_system_matches_oracle(g, o, "random", lm, 1e-12, 1e-11)
+    dx, odx = g.linearize_and_solve(), o.linearize_and_solve()
+    assert np.abs(dx - odx).max() <= 1e-8 * max(1.0, np.abs(odx).max())
+    np.testing.assert_allclose(g.optimize(5), o.optimize(5), rtol=1e-8)
+    assert np.abs(g.state() - o.state()).max() <= 1e-7
+    glm, olm = api[0].from_arrays(*arrays, solver=api[1].LevenbergMarquardt), oracle.from_arrays(*arrays)
+    np.testing.assert_allclose(glm.optimize(5), olm.optimize(5, LEVENBERG_MARQUARDT), rtol=1e-8)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_se3_graphs_match_the_oracle(api, oracle, seed):
+    """The same for SE(3) pose graphs (build-defined maths; the oracle is the definition): random trees with loop
+    closures, random unit quaternions, full 6 x 6 SPD information matrices."""
+    rng = np.random.default_rng(2000 + seed)
+    n_pose = int(rng.integers(3, 40))
+    arrays = _random_graph(rng, n_pose, 0, int(rng.integers(0, n_pose)), se3=True)
+    g, o = api[0].from_arrays(*arrays), oracle.from_arrays(*arrays)
+    assert abs(g.global_error() - o.global_error()) <= 1e-11 * max(1.0, o.global_error())
+    dx, odx = g.linearize_and_solve(), o.linearize_and_solve()
+    assert np.abs(dx - odx).max() <= 1e-7 * max(1.0, np.abs(odx).max())
+    np.testing.assert_allclose(g.optimize(4), o.optimize(4), rtol=1e-7)
+
+
 def test_not_positive_definite_is_reported(api):
     """A graph with a component that no prior reaches is singular: the reference returns Err from
     umfpack.factorize (:138); here RR_PGO_ENOTSPD."""
