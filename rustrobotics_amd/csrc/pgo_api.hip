@@ -77,9 +77,8 @@ struct ChunkPool {
     idle.erase(idle.begin() + (long)best);
     return p;
   }
-  void put(char *base, size_t cap) {
-    int dev = 0;
-    if (cap <= kMaxChunk && hipGetDevice(&dev) == hipSuccess) {
+  void put(int dev, char *base, size_t cap) {   // dev: the device the chunk was allocated on (the caller's current device may be another by now)
+    if (cap <= kMaxChunk && dev >= 0) {
       std::lock_guard<std::mutex> lk(mu);
       if (idle_bytes + cap <= kMaxIdle) { idle.push_back(Idle{dev, base, cap}); idle_bytes += cap; return; }
     }
@@ -89,21 +88,22 @@ struct ChunkPool {
 static ChunkPool &chunk_pool() { static ChunkPool *p = new ChunkPool; return *p; }   // leaked on purpose, like the stream pool
 
 struct DeviceArena {
-  struct Chunk { char *base; size_t cap, used; };
+  struct Chunk { char *base; size_t cap, used; int dev; };
   std::vector<Chunk> chunks;
   size_t next_chunk = 8u << 20;
   DeviceArena() = default;
   DeviceArena(const DeviceArena &) = delete;
   DeviceArena &operator=(const DeviceArena &) = delete;
   // (the engine's stream was synchronised when it went back to its pool: declared after the arena, destroyed before it)
-  ~DeviceArena() { for (Chunk &c : chunks) chunk_pool().put(c.base, c.cap); }
+  ~DeviceArena() { for (Chunk &c : chunks) chunk_pool().put(c.dev, c.base, c.cap); }
   void reserve(size_t bytes) { next_chunk = std::max(next_chunk, bytes); }
   void *take(size_t bytes) {
     for (Chunk &c : chunks) {
       const size_t off = (c.used + 255) & ~(size_t)255;
       if (off + bytes <= c.cap) { c.used = off + bytes; return c.base + off; }
     }
-    Chunk c{nullptr, std::max(next_chunk, bytes + 256), 0};
+    Chunk c{nullptr, std::max(next_chunk, bytes + 256), 0, -1};
+    if (hipGetDevice(&c.dev) != hipSuccess) c.dev = -1;
     if (char *p = chunk_pool().take(c.cap, &c.cap)) c.base = p;
     else HIPCHK(hipMalloc((void **)&c.base, c.cap));
     next_chunk = std::max<size_t>(8u << 20, c.cap / 4);
@@ -2352,7 +2352,7 @@ struct AnalysisCacheEntry {
   std::shared_ptr<const Symbolic> sym;
 };
 static std::mutex g_analysis_mu;
-static std::vector<AnalysisCacheEntry> g_analysis_cache;   // most recent last; at most four graphs of at most 200 000 edges
+static std::vector<AnalysisCacheEntry> g_analysis_cache;   // most recent last; at most four graphs of at most 50 000 edges
 extern "C" char **environ;
 static std::string analysis_env() {   // every RR_PGO_* switch of the process (the analysis reads a dozen of them)
   std::string e;
@@ -2367,7 +2367,7 @@ static uint64_t fnv(uint64_t h, const void *data, size_t n) {
 }
 static uint64_t analysis_cache_key(const HostGraph &g, const rr_pgo_options &opt) {
   if (const char *e = std::getenv("RR_PGO_ANALYSIS_CACHE")) if (std::atoi(e) == 0) return 0;
-  if (g.n_edges() > 200000 || g.n_edges() == 0) return 0;
+  if (g.n_edges() > 50000 || g.n_edges() == 0) return 0;   // (the reference's datasets: at most 17 605 edges; the tables of a large graph are not worth keeping)
   uint64_t h = 1469598103934665603ull;
   const int32_t o[4] = {opt.precision, opt.rank, opt.world_size, opt.sharded};
   h = fnv(h, o, sizeof o);

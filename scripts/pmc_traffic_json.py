@@ -40,7 +40,7 @@ doc = {"_comment": f"HBM-side traffic per launch of the dominant kernel class, f
 doc["_tag"] = tag   # tests/test_abi_and_host.py: must be the tag of the newest profiles/*_kernel_stats_*.csv, whose kernels these entries name
 doc["intel:f64"] = entry("intel", ["k_factor_flow"], "k_factor_flow") or entry("intel", ["k_factor_tasks"], "k_factor_tasks")
 doc["grid:400x250:1000000:f32"] = entry("grid", ["k_big_flow"], "k_big_flow", grid_iters)
-doc["grid:400x250:1000000:f32:k_big_update"] = entry("grid", ["k_big_update", "k_big_schur", "k_big_schur_flow"], "k_big_update+k_big_schur+k_big_schur_flow", grid_iters)
+doc["grid:400x250:1000000:f32:k_big_update"] = entry("grid", ["k_big_update", "k_big_schur"], "k_big_update+k_big_schur", grid_iters)
 doc["grid:400x250:1000000:f32:k_big_update"]["note"] = (
     "r02 (profiles/r02z_grid_*_SIZE.txt): k_big_update 48 launches per step x 160.6 MB = 7.7 GB per step, plus 177 k_big_panel32 launches x 14.7 MB "
     "= 2.6 GB. r03: the panel steps and per-super-panel updates of every level are tasks of k_big_flow (entry above), the Schur "
