@@ -2430,6 +2430,10 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
   if (const char *e = std::getenv("RR_PGO_LDS_FLOW")) so.lds_flow = so.lds_flow && std::atoi(e) != 0;
   if (const char *e = std::getenv("RR_PGO_TASK_US")) so.task_us = std::atof(e);
   if (std::getenv("RR_PGO_NO_GEO")) so.geo_nd = false;
+  // small graphs (trajectories with loop closures): the multilevel bisection finds separators less than half the size of the
+  // level sets / coordinate cuts (symbolic.cpp, MultilevelBisection); the lattice's straight cuts are already the best there are
+  so.ml_nd = h->g.n_nodes() <= 6000;
+  if (const char *e = std::getenv("RR_PGO_ML_ND")) so.ml_nd = std::atoi(e) != 0;
   if (const char *e = std::getenv("RR_PGO_LDS_PIECES")) so.max_lds_pieces = std::max(1, std::atoi(e));
   if (std::getenv("RR_PGO_JOIN_SEPARATORS")) so.split_separators = false;
   if (const char *e = std::getenv("RR_PGO_ND_LEAF")) so.nd_leaf = std::atoi(e);
@@ -2457,13 +2461,15 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
     // the estimated critical path picks the leaf size and the amalgamation width.  Below 2400 nodes no cut ever won.
     // The candidates are independent host computations: one thread each (r04: the six analyses in sequence were 35 ms
     // of M3500's and 55 ms of dlr's constructor on the GPU box, against 2 - 3 ms of optimize(10)).
-    static const int kLeaf[] = {1 << 30, 3000, 2000, 1400, 1000, 700};
+    static const int kLeafLevelSets[] = {1 << 30, 3000, 2000, 1400, 1000, 700};
+    static const int kLeafMultilevel[] = {1 << 30, 1400, 700, 500, 350, 250, 150};
     struct Cand { int leaf, np; };
     const bool np_fixed = std::getenv("RR_PGO_AMALG_NP") != nullptr;
     std::vector<Cand> cl;
-    for (int leaf : kLeaf) {
+    for (int li = 0; li < (so.ml_nd ? 7 : 6); li++) {
+      int leaf = so.ml_nd ? kLeafMultilevel[li] : kLeafLevelSets[li];
       if (std::getenv("RR_PGO_ND_LEAF")) { if (leaf != (1 << 30)) continue; leaf = so.nd_leaf; }
-      else if (leaf != (1 << 30) && (h->g.n_nodes() < 2400 || leaf >= h->g.n_nodes())) continue;   // (a leaf size >= the graph is no cut at all)
+      else if (leaf != (1 << 30) && ((!so.ml_nd && h->g.n_nodes() < 2400) || leaf >= h->g.n_nodes())) continue;   // (a leaf size >= the graph is no cut at all)
       cl.push_back({leaf, np_fixed ? so.amalg_np : 16});   // the narrow rule first: it wins wherever every front lives in LDS
     }
     Symbolic best;

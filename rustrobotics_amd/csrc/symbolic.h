@@ -22,6 +22,7 @@ namespace rrpgo {
 struct SymbolicOptions {
   bool split_separators = false;     // do not chain a region's last separator into its parent separator's supernode
   bool geo_nd = true;                // nested dissection may cut along a coordinate axis (pose graphs are spatial)
+  bool ml_nd = false;                // nested dissection also tries a multilevel bisection with a minimum-cover separator (small graphs)
   int threads_shift = 1;             // workgroup size classes: front size is shifted left by this before the lookup
   int max_lds_pieces = 2;            // a supernode beyond the LDS budget is cut into at most this many LDS-sized pieces, else it stays ONE front
                                      // beyond LDS (r03, 1M-edge lattice: 54-column supernodes just over the budget were cut into three 18-column
