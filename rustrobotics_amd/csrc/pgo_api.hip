@@ -2462,7 +2462,7 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
     // The candidates are independent host computations: one thread each (r04: the six analyses in sequence were 35 ms
     // of M3500's and 55 ms of dlr's constructor on the GPU box, against 2 - 3 ms of optimize(10)).
     static const int kLeafLevelSets[] = {1 << 30, 3000, 2000, 1400, 1000, 700};
-    static const int kLeafMultilevel[] = {1 << 30, 1400, 700, 500, 350, 250, 150};
+    static const int kLeafMultilevel[] = {1 << 30, 500, 250, 150, 100, 70, 50};
     struct Cand { int leaf, np; };
     const bool np_fixed = std::getenv("RR_PGO_AMALG_NP") != nullptr;
     std::vector<Cand> cl;
