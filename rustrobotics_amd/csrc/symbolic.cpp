@@ -12,6 +12,8 @@
 #include <functional>
 #include <numeric>
 #include <queue>
+#include <thread>
+#include <atomic>
 
 namespace rrpgo {
 
@@ -488,15 +490,16 @@ struct NestedDissection {
   std::vector<char> ordered;
   std::vector<int32_t> order;    // output: order[pos] = node
   std::vector<int32_t> part;     // owner partition, -1 shared
-  std::vector<int32_t> level, queue, local_id;
+  std::vector<int32_t> level, queue;
   std::vector<int8_t> side;      // scratch of the coordinate bisection
   std::vector<int32_t> sep_of;   // separator a node belongs to (-1: inside a leaf)
   const HostGraph *hg = nullptr; // node positions for coordinate bisection (optional)
-  int next_set = 1, part_depth = 0;
+  std::atomic<int> next_set{1};  // (ids only ever compared for equality: the two halves of a split may be dissected by two threads)
+  int part_depth = 0;
 
   NestedDissection(const Adj &a, const std::vector<int32_t> &ww, const SymbolicOptions &o)
       : adj(a), w(ww), opt(o), N((int)ww.size()), set_id(N, 0), ordered(N, 0), part(N, -1),
-        level(N, -1), local_id(N, -1), side(N, -1), sep_of(N, -1) {
+        level(N, -1), side(N, -1), sep_of(N, -1) {
     order.reserve(N);
     queue.reserve(N);
     while ((1 << part_depth) < opt.n_parts) part_depth++;
@@ -523,7 +526,8 @@ struct NestedDissection {
     return nlev;
   }
 
-  void order_leaf(const std::vector<int32_t> &S) {
+  // `out`: where the order of this part of the graph is collected; `local_id`: scratch of the calling thread, all -1 between calls
+  void order_leaf(const std::vector<int32_t> &S, std::vector<int32_t> &out, std::vector<int32_t> &local_id) {
     // local graph: S first, then not-yet-ordered outside neighbours (ancestor separators)
     const int ne = (int)S.size();
     std::vector<int32_t> verts(S);
@@ -551,7 +555,7 @@ struct NestedDissection {
     std::vector<int32_t> lo;
     constrained_min_degree(ne, nt, A, lw, lo);
     for (int l : lo) {
-      order.push_back(verts[l]);
+      out.push_back(verts[l]);
       ordered[verts[l]] = 1;
     }
     for (int v : verts) local_id[v] = -1;
@@ -652,7 +656,7 @@ struct NestedDissection {
   // The multilevel bisection of S (see MultilevelBisection) with its minimum-cover separator; same score as the
   // other two searches.
   double ml_split(const std::vector<int32_t> &S, int sid, std::vector<int32_t> &left,
-                  std::vector<int32_t> &right, std::vector<int32_t> &sep) {
+                  std::vector<int32_t> &right, std::vector<int32_t> &sep, std::vector<int32_t> &local_id) {
     const int n = (int)S.size();
     MlGraph g;
     g.n = n;
@@ -676,8 +680,9 @@ struct NestedDissection {
     std::vector<int8_t> sd;
     std::vector<char> in_sep;
     std::vector<int32_t> tl, tr, ts;
-    for (int t = 0; t < 3; t++) {
-      MultilevelBisection::bisect(g, hier, (int64_t)(kMinSide[t] * n), sd);
+    const bool three = n >= 200;   // (below 200 nodes the middle setting alone: same estimates, a third less time)
+    for (int t = 0; t < (three ? 3 : 1); t++) {
+      MultilevelBisection::bisect(g, hier, (int64_t)(kMinSide[three ? t : 1] * n), sd);
       MultilevelBisection::cover_separator(g, sd, in_sep);
       tl.clear(); tr.clear(); ts.clear();
       int64_t ws = 0;
@@ -693,12 +698,12 @@ struct NestedDissection {
     return best;
   }
 
-  void dissect(std::vector<int32_t> &S, int depth, int path) {
+  void dissect(std::vector<int32_t> &S, int depth, int path, std::vector<int32_t> &out, std::vector<int32_t> &local_id) {
     const int n = (int)S.size();
     if (n == 0) return;
     if (depth == part_depth || (depth < part_depth && n <= opt.nd_leaf)) assign_part(S, depth, path);
     if (n <= opt.nd_leaf) {
-      order_leaf(S);
+      order_leaf(S, out, local_id);
       return;
     }
     const int sid = set_id[S[0]];
@@ -745,7 +750,7 @@ struct NestedDissection {
       if (nlev < 3) {  // no usable level separator: treat as a leaf
         for (int v : S) level[v] = -1;
         if (depth < part_depth) assign_part(S, depth, path);
-        order_leaf(S);
+        order_leaf(S, out, local_id);
         return;
       }
       std::vector<int64_t> cnt(nlev, 0), wsum(nlev, 0);
@@ -786,7 +791,7 @@ struct NestedDissection {
         double cur_score = bfs_score;
         if (gscore >= 0 && gscore < bfs_score) { left.swap(gl); right.swap(gr); sep.swap(gs); cur_score = gscore; }
         if (opt.ml_nd) {
-          const double mscore = ml_split(S, sid, gl, gr, gs);
+          const double mscore = ml_split(S, sid, gl, gr, gs, local_id);
           if (mscore >= 0 && mscore < cur_score) { left.swap(gl); right.swap(gr); sep.swap(gs); }
         }
       }
@@ -803,15 +808,26 @@ struct NestedDissection {
     }
     if (depth < part_depth)
       for (int v : sep) part[v] = -1;
-    const int lid = next_set++, rid = next_set++, zid = next_set++;
-    for (int v : left) set_id[v] = lid;
-    for (int v : right) set_id[v] = rid;
+    const int left_id = next_set++, right_id = next_set++, zid = next_set++;
+    for (int v : left) set_id[v] = left_id;
+    for (int v : right) set_id[v] = right_id;
     for (int v : sep) set_id[v] = zid;
     std::vector<int32_t>().swap(S);
-    dissect(left, depth + 1, path * 2);
-    dissect(right, depth + 1, path * 2 + 1);
+    // No edge joins the two halves, so their dissections touch disjoint entries of the per-node arrays (the scratch that maps
+    // separator nodes of the ancestors is per thread): the top two levels of a small graph's multilevel dissection -- three
+    // quarters of the time of its analysis -- run on up to four threads.  Same order as the sequential run: left, right, separator.
+    if (opt.ml_nd && depth < 2 && left.size() >= 150 && right.size() >= 150) {
+      std::vector<int32_t> out_right, scratch_right(N, -1);
+      std::thread other([&] { dissect(right, depth + 1, path * 2 + 1, out_right, scratch_right); });
+      dissect(left, depth + 1, path * 2, out, local_id);
+      other.join();
+      out.insert(out.end(), out_right.begin(), out_right.end());
+    } else {
+      dissect(left, depth + 1, path * 2, out, local_id);
+      dissect(right, depth + 1, path * 2 + 1, out, local_id);
+    }
     for (int v : sep) {
-      order.push_back(v);
+      out.push_back(v);
       ordered[v] = 1;
       sep_of[v] = zid;
     }
@@ -911,7 +927,8 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
     nd.hg = &g;
     std::vector<int32_t> all(N);
     std::iota(all.begin(), all.end(), 0);
-    nd.dissect(all, 0, 0);
+    std::vector<int32_t> scratch(N, -1);
+    nd.dissect(all, 0, 0, nd.order, scratch);
     order.swap(nd.order);
     sym.node_part.swap(nd.part);
     node_sep.swap(nd.sep_of);
