@@ -1697,6 +1697,12 @@ std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sy
       for (int q = sym.child_ptr[f]; q < sym.child_ptr[f + 1]; q++) {
         int c = sym.child_list[q];
         if (!top[c]) continue;
+        // Sharded runs: the levels of the SHARED fronts must not depend on the rank.  Every rank factors them redundantly and
+        // keeps its own copy of the shared poses, so the copies only stay equal if the ranks batch (and therefore sum) alike;
+        // the depth of a rank's own subtrees under the task threshold IT picked is not the same on every rank.  (r05: rank 4
+        // of 8 on sphere2500 batched the five top fronts 2 + 3 + 1 instead of 4 + 1 + 1, its copies of the shared poses drifted
+        // from the others' by 1e-7 over six iterations and the converged state sat 4e-8 off the oracle's.)
+        if (opt.n_parts > 1 && sym.sn_owner[f] < 0 && sym.sn_owner[c] >= 0) continue;
         if (lvl[c] > L) { L = lvl[c]; nmax = 1; cmax = c; }
         else if (lvl[c] == L) nmax++;
       }

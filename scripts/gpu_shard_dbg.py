@@ -1,0 +1,31 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from rustrobotics_amd import PoseGraph, sharding
+p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests/golden/g2o/sphere2500.g2o")
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+g = PoseGraph.new(p); g.optimize(1); s1 = np.asarray(g.state()).reshape(-1, 7)
+ref = PoseGraph.new(p)
+shards, coll = sharding.emulate(ref.graph_arrays(), P)
+sharding.gauss_newton(shards, 1, coll)
+owner = np.asarray(shards[0].node_owner())
+states = [np.asarray(s.state()).reshape(-1, 7) for s in shards]
+print("nodes per owner", {int(o): int((owner == o).sum()) for o in np.unique(owner)})
+gs = sharding.gather_state(shards).reshape(-1, 7)
+d = np.abs(gs - s1).max(1)
+bad = np.where(d > 1e-10)[0]
+print("nodes off by > 1e-10 after one iteration:", len(bad), "max", d.max())
+for i in bad[:20]:
+    print("  node", i, "owner", owner[i], "diff %.2e" % d[i])
+# shared nodes must agree on every rank
+sh = np.where(owner < 0)[0]
+spread = np.zeros(len(sh))
+for r in range(1, P):
+    spread = np.maximum(spread, np.abs(states[r][sh] - states[0][sh]).max(1))
+print("shared nodes", len(sh), "max spread across ranks %.2e" % (spread.max() if len(sh) else 0))
+# own nodes on the owner vs unsharded
+for r in range(P):
+    m = owner == r
+    print("rank", r, "own nodes", int(m.sum()), "max diff vs unsharded %.2e" % np.abs(states[r][m] - s1[m]).max())
+print("shared max diff vs unsharded (rank 0 copy) %.2e" % (np.abs(states[0][sh] - s1[sh]).max() if len(sh) else 0))
+print("stats rank0", {k: shards[0].stats()[k] for k in ("n_supernodes", "n_big_fronts", "n_levels", "max_front")})

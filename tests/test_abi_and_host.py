@@ -332,15 +332,17 @@ def test_algorithmic_bytes_follow_survey_8d(lib):
     """SURVEY.md 8(d), worked totals for intel.g2o in fp64: linearise 0.90 MB, solve 0.43 + 3 x 1.24 + 0.17 = 4.3 MB with
     nnzblk(L) = 17 193 [probe], update 0.12 MB -- 5.4 MB per iteration with chi2 fused into the linearisation.  The
     statistics bench.py's roofline divides by must be THAT figure (every datum moved once, the factor at its nonzeros), not
-    the padded storage of the supernodal panels (r03 reported 7.17 MB)."""
+    the padded storage of the supernodal panels (r03 reported 7.17 MB).  r05: the multilevel dissection trades fill for a shorter
+    critical path -- 18 985 blocks in L against 17 767 for the minimum-degree tree of r01 - r04 and the probe's 17 193 -- so the
+    factor / solve figures sit 4 - 7 % above the survey's; the bounds below still exclude padded storage by a wide margin."""
     from rustrobotics_amd import PoseGraph
     s = PoseGraph.analyze(g2o_path("intel"))
     assert s["abi_version"] == 4
     assert s["n_supernodes"] > 0 and s["n_big_fronts"] == 0 and s["n_launches_per_iter"] == 0   # (no device: no engine)
     total = s["bytes_linearize"] + s["bytes_chi2"] + s["bytes_factor"] + s["bytes_solve"] + s["bytes_update"]
-    assert abs(total - 5.4e6) <= 0.05 * 5.4e6, total
+    assert abs(total - 5.4e6) <= 0.08 * 5.4e6, total
     assert abs(s["bytes_linearize"] - 0.90e6) <= 0.06 * 0.90e6
-    assert abs(s["bytes_factor"] + s["bytes_solve"] - 4.3e6) <= 0.05 * 4.3e6
+    assert abs(s["bytes_factor"] + s["bytes_solve"] - 4.3e6) <= 0.09 * 4.3e6
     assert abs(s["bytes_update"] - 0.12e6) <= 0.05 * 0.12e6
     assert s["stored_factor_bytes"] > s["bytes_factor"] - 0.45e6   # padding only ever adds
     # fp32 halves every scalar but not the 8 index bytes per edge
