@@ -2472,6 +2472,11 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
       else if (leaf != (1 << 30) && ((!so.ml_nd && h->g.n_nodes() < 2400) || leaf >= h->g.n_nodes())) continue;   // (a leaf size >= the graph is no cut at all)
       cl.push_back({leaf, np_fixed ? so.amalg_np : 16});   // the narrow rule first: it wins wherever every front lives in LDS
     }
+    const size_t n_depths = cl.size();
+    // the deepest dissections once more with mid-sized fronts merged up to 32 columns (intel, r05: the model's and the measured best)
+    if (so.ml_nd && !np_fixed && !std::getenv("RR_PGO_ND_LEAF"))
+      for (int leaf : {70, 50})
+        if (leaf < h->g.n_nodes()) cl.push_back({leaf, 32});
     Symbolic best;
     double best_crit = -1.0;
     int best_leaf = 0;
@@ -2507,6 +2512,7 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
     // fronts beyond LDS (sphere2500, torus3D: 6 x 6 blocks): there the r01 rule -- mid-sized fronts merge up to 72 columns --
     // still pays, and with another depth than the narrow rule's (torus3D): a second round of the same depths decides
     if (err.empty() && !np_fixed && best.n_big > 0) {
+      cl.resize(n_depths);
       for (Cand &c : cl) c.np = 72;
       run(cl);
     }

@@ -21,6 +21,10 @@ done
 # the cross-level launch of the small graphs with fronts beyond LDS, A/B against one launch per level
 for W in sphere2500 torus3D; do timeout -k 10 200 python scripts/gpu_env_ab.py $W f64 RR_PGO_FLOW_XL=0 - ; done > gpurun_out/xl_ab_$TAG.txt 2>&1
 for N in intel input_M3500_g2o dlr sphere2500; do RR_PGO_ANALYZE_TIMES=1 timeout -k 10 120 python scripts/time_closure.py $N > gpurun_out/closure_${N}_$TAG.txt 2>&1; done
+for N in intel input_M3500_g2o dlr sphere2500; do RR_PGO_ANALYSIS_CACHE=0 RR_PGO_ANALYZE_TIMES=1 timeout -k 10 120 python scripts/time_closure.py $N > gpurun_out/closure_uncached_${N}_$TAG.txt 2>&1; done
+# the dissection of the small graphs: level sets / coordinate cuts only (RR_PGO_ML_ND=0, r01 - r04) against the multilevel bisection
+( echo "# GN it/s, fp64: RR_PGO_ML_ND=0 = the level-set / coordinate-cut dissection of r01 - r04, '-' = the default (multilevel bisection with a minimum-cover separator); scripts/gpu_env_ab.py"
+  for W in intel input_M3500_g2o dlr parking-garage sphere2500 torus3D; do timeout -k 10 200 python scripts/gpu_env_ab.py $W f64 RR_PGO_ML_ND=0 - 2>&1 | grep -v amdgpu.ids; done ) > gpurun_out/ml_nd_ab_$TAG.txt
 timeout -k 10 300 python bench.py --workload grid:400x250:1000000 --precision f32 --steps 50 --warmup 5 --no-secondary > gpurun_out/bench_grid_f32_$TAG.json 2> gpurun_out/bench_grid_$TAG.err
 rm -rf /tmp/prof_grid
 ( cd /tmp && RR_PGO_NO_GRAPH=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_grid -- python3 $GRAFT_REPO_ROOT/scripts/gpu_grid_prof.py 400 250 1000000 f32 5 > /tmp/prof_grid.log 2>&1 )
