@@ -45,6 +45,8 @@ int main(int argc, char **argv) {
   if (getenv("MERGE_GAIN")) opt.merge_chain_gain_us = atof(getenv("MERGE_GAIN"));
   if (getenv("BALANCE")) { opt.balance_blocks = atoi(getenv("BALANCE")) != 0; if (atoi(getenv("BALANCE")) > 1) opt.balance_max_rem = atoi(getenv("BALANCE")); }
   if (getenv("AMALG_NP")) opt.amalg_np = atoi(getenv("AMALG_NP"));
+  if (getenv("ML")) opt.ml_nd = true;   // the multilevel bisection with a minimum-cover separator (graphs of up to 6000 nodes in the engine)
+  if (getenv("PIN")) opt.pin_node = g.anchor_node;   // sharded runs of the engine: the anchor joins the top separator
   Symbolic y;
   std::string e = analyze(g, opt, y);
   if (!e.empty()) { printf("analyze error: %s\n", e.c_str()); return 2; }
@@ -121,6 +123,24 @@ int main(int argc, char **argv) {
       if (yp.l_elems != y.l_elems || yp.xch_elems != y.xch_elems || yp.S != y.S) { printf("FAIL: rank layouts differ\n"); return 1; }
       for (int s = 0; s < S; s++)
         if (yp.sn_owner[s] != y.sn_owner[s]) { printf("FAIL: owners differ between ranks\n"); return 1; }
+      // every rank factors the SHARED fronts itself: their part of the schedule (which fronts share a step, in which order)
+      // must be the same on every rank, or the ranks' copies of the shared poses drift apart by rounding (r05, sphere2500 over 8)
+      {
+        auto shared_part = [](const Symbolic &z) {
+          std::vector<int32_t> v;
+          for (size_t i = (size_t)z.n_local_steps; i < z.steps.size(); i++) {
+            v.push_back(-1 - z.steps[i].kind);
+            for (int t = z.steps[i].task_begin; t < z.steps[i].task_end; t++) {
+              v.push_back(-100);
+              for (int q = z.task_ptr[t]; q < z.task_ptr[t + 1]; q++) v.push_back(z.task_sn[q]);
+            }
+          }
+          return v;
+        };
+        static std::vector<int32_t> first;
+        if (p == 0) first = shared_part(yp);
+        else if (shared_part(yp) != first) { printf("FAIL: rank %d schedules the shared fronts differently from rank 0\n", p); return 1; }
+      }
       run_steps(yp, 0, (size_t)yp.n_local_steps);
       if (p == opt.n_parts - 1) run_steps(yp, (size_t)yp.n_local_steps, yp.steps.size());
     }
