@@ -2462,11 +2462,11 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
     // The candidates are independent host computations: one thread each (r04: the six analyses in sequence were 35 ms
     // of M3500's and 55 ms of dlr's constructor on the GPU box, against 2 - 3 ms of optimize(10)).
     static const int kLeafLevelSets[] = {1 << 30, 3000, 2000, 1400, 1000, 700};
-    static const int kLeafMultilevel[] = {1 << 30, 500, 250, 150, 100, 70, 50};
+    static const int kLeafMultilevel[] = {1 << 30, 250, 150, 100, 70, 50};   // (500 never won on any graph of the test set)
     struct Cand { int leaf, np; };
     const bool np_fixed = std::getenv("RR_PGO_AMALG_NP") != nullptr;
     std::vector<Cand> cl;
-    for (int li = 0; li < (so.ml_nd ? 7 : 6); li++) {
+    for (int li = 0; li < 6; li++) {
       int leaf = so.ml_nd ? kLeafMultilevel[li] : kLeafLevelSets[li];
       if (std::getenv("RR_PGO_ND_LEAF")) { if (leaf != (1 << 30)) continue; leaf = so.nd_leaf; }
       else if (leaf != (1 << 30) && ((!so.ml_nd && h->g.n_nodes() < 2400) || leaf >= h->g.n_nodes())) continue;   // (a leaf size >= the graph is no cut at all)
