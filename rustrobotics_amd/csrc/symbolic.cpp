@@ -676,30 +676,19 @@ struct NestedDissection {
     MultilevelBisection::Hierarchy hier;
     MultilevelBisection::build_hierarchy(g, hier);
     static const double kMinSide[3] = {0.30, 0.38, 0.46};
-    const bool three = n >= 200;   // (below 200 nodes the middle setting alone: same estimates, a third less time)
-    const int n_try = three ? 3 : 1;
-    struct Try { std::vector<int8_t> sd; std::vector<char> in_sep; };
-    Try tries[3];
-    auto run = [&](int t) {
-      MultilevelBisection::bisect(g, hier, (int64_t)(kMinSide[three ? t : 1] * n), tries[t].sd);
-      MultilevelBisection::cover_separator(g, tries[t].sd, tries[t].in_sep);
-    };
-    if (n >= 600) {   // the top splits of a graph: the three settings side by side (they only read the graph and the hierarchy)
-      std::thread t1([&] { run(1); }), t2([&] { run(2); });
-      run(0);
-      t1.join();
-      t2.join();
-    } else {
-      for (int t = 0; t < n_try; t++) run(t);
-    }
     double best = -1.0;
+    std::vector<int8_t> sd;
+    std::vector<char> in_sep;
     std::vector<int32_t> tl, tr, ts;
-    for (int t = 0; t < n_try; t++) {   // (in the order of the settings, whichever thread finished first: the first best wins)
+    const bool three = n >= 200;   // (below 200 nodes the middle setting alone: same estimates, a third less time)
+    for (int t = 0; t < (three ? 3 : 1); t++) {
+      MultilevelBisection::bisect(g, hier, (int64_t)(kMinSide[three ? t : 1] * n), sd);
+      MultilevelBisection::cover_separator(g, sd, in_sep);
       tl.clear(); tr.clear(); ts.clear();
       int64_t ws = 0;
       for (int i = 0; i < n; i++) {
-        if (tries[t].in_sep[i]) { ts.push_back(S[i]); ws += w[S[i]]; }
-        else (tries[t].sd[i] == 0 ? tl : tr).push_back(S[i]);
+        if (in_sep[i]) { ts.push_back(S[i]); ws += w[S[i]]; }
+        else (sd[i] == 0 ? tl : tr).push_back(S[i]);
       }
       if (tl.empty() || tr.empty() || ts.empty()) continue;
       const double imb = std::fabs((double)tl.size() - (double)tr.size()) / (double)n;
