@@ -2435,7 +2435,10 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
   so.ml_nd = h->g.n_nodes() <= 6000;
   if (const char *e = std::getenv("RR_PGO_ML_ND")) so.ml_nd = std::atoi(e) != 0;
   if (const char *e = std::getenv("RR_PGO_LDS_PIECES")) so.max_lds_pieces = std::max(1, std::atoi(e));
-  if (std::getenv("RR_PGO_JOIN_SEPARATORS")) so.split_separators = false;
+  // RR_PGO_JOIN_SEPARATORS=1: a region's last separator always chained into its parent separator's supernode; =0: never (small graphs:
+  // no longer a choice of the candidates below)
+  const char *join_env = std::getenv("RR_PGO_JOIN_SEPARATORS");
+  if (join_env) so.split_separators = std::atoi(join_env) == 0 && join_env[0] == '0';
   if (const char *e = std::getenv("RR_PGO_ND_LEAF")) so.nd_leaf = std::atoi(e);
   if (const char *e = std::getenv("RR_PGO_BALANCE_BLOCKS")) { so.balance_blocks = std::atoi(e) != 0; if (std::atoi(e) > 1) so.balance_max_rem = std::atoi(e); }
   if (const char *e = std::getenv("RR_PGO_MERGE_CHAIN")) { so.merge_chain_nc = std::atoi(e); if (const char *c = std::strchr(e, ',')) so.merge_chain_gain_us = std::atof(c + 1); }
@@ -2463,20 +2466,28 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
     // of M3500's and 55 ms of dlr's constructor on the GPU box, against 2 - 3 ms of optimize(10)).
     static const int kLeafLevelSets[] = {1 << 30, 3000, 2000, 1400, 1000, 700};
     static const int kLeafMultilevel[] = {1 << 30, 250, 150, 100, 70, 50};   // (500 never won on any graph of the test set)
-    struct Cand { int leaf, np; };
+    struct Cand { int leaf, np; bool split; };
     const bool np_fixed = std::getenv("RR_PGO_AMALG_NP") != nullptr;
     std::vector<Cand> cl;
     for (int li = 0; li < 6; li++) {
       int leaf = so.ml_nd ? kLeafMultilevel[li] : kLeafLevelSets[li];
       if (std::getenv("RR_PGO_ND_LEAF")) { if (leaf != (1 << 30)) continue; leaf = so.nd_leaf; }
       else if (leaf != (1 << 30) && ((!so.ml_nd && h->g.n_nodes() < 2400) || leaf >= h->g.n_nodes())) continue;   // (a leaf size >= the graph is no cut at all)
-      cl.push_back({leaf, np_fixed ? so.amalg_np : 16});   // the narrow rule first: it wins wherever every front lives in LDS
+      cl.push_back({leaf, np_fixed ? so.amalg_np : 16, so.split_separators});   // the narrow rule first: it wins wherever every front lives in LDS
     }
     const size_t n_depths = cl.size();
     // the deepest dissections once more with mid-sized fronts merged up to 32 columns (intel, r05: the model's and the measured best)
     if (so.ml_nd && !np_fixed && !std::getenv("RR_PGO_ND_LEAF"))
       for (int leaf : {70, 50})
-        if (leaf < h->g.n_nodes()) cl.push_back({leaf, 32});
+        if (leaf < h->g.n_nodes()) cl.push_back({leaf, 32, so.split_separators});
+    // ... and the deeper dissections with a region's last separator NOT chained into its parent separator's supernode (the rule of the
+    // large graphs, symbolic.cpp step 4): the sibling separator then runs beside it instead of before it.  Measured (r05, same kernels):
+    // sphere2500 1539 -> 1697 it/s, torus3D 1066 -> 1191, dlr 7369 -> 7852, intel 7382 -> 6962 -- and the estimates say so beforehand
+    // (-8 %, -5 %, -3 %, +7 %), so the candidates carry both forms and the model picks.
+    const bool split_free = so.ml_nd && !join_env && !std::getenv("RR_PGO_ND_LEAF");
+    if (split_free)
+      for (int leaf : {100, 70, 50})
+        if (leaf < h->g.n_nodes()) cl.push_back({leaf, np_fixed ? so.amalg_np : 16, true});
     Symbolic best;
     double best_crit = -1.0;
     int best_leaf = 0;
@@ -2490,12 +2501,14 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
             SymbolicOptions o = so;
             o.nd_leaf = list[c].leaf;
             o.amalg_np = list[c].np;
+            o.split_separators = list[c].split;
             try { errs[c] = analyze(h->g, o, cands[c]); } catch (const std::exception &e) { errs[c] = e.what(); }
           });
         {
           SymbolicOptions o = so;
           o.nd_leaf = list[0].leaf;
           o.amalg_np = list[0].np;
+          o.split_separators = list[0].split;
           errs[0] = analyze(h->g, o, cands[0]);
         }
         for (std::thread &t : pool) t.join();
@@ -2503,8 +2516,8 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
       for (size_t c = 0; c < list.size(); c++) {
         if (!errs[c].empty()) { err = errs[c]; return; }
         if (std::getenv("RR_PGO_ANALYZE_TIMES"))
-          std::fprintf(stderr, "analyze: nd_leaf %d, amalgamation up to %d columns -> estimated critical path %.1f us (%d big fronts, %d supernodes)\n", list[c].leaf,
-                       list[c].np, cands[c].est_critical_us, cands[c].n_big, cands[c].S);
+          std::fprintf(stderr, "analyze: nd_leaf %d, amalgamation up to %d columns, separators %s -> estimated critical path %.1f us (%d big fronts, %d supernodes)\n", list[c].leaf,
+                       list[c].np, list[c].split ? "apart" : "chained", cands[c].est_critical_us, cands[c].n_big, cands[c].S);
         // a tree with a front beyond LDS below an LDS front loses the dataflow launches (one launch per level instead, and no
         // cross-level launch for its big fronts): the estimate does not see that, the measurement does (torus3D, r05: the
         // candidate with the smallest estimate ran 40 launches per iteration and 2 % slower than r04's tree)
@@ -2518,6 +2531,9 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
     if (err.empty() && !np_fixed && best.n_big > 0) {
       cl.resize(n_depths);
       for (Cand &c : cl) c.np = 72;
+      if (split_free)
+        for (size_t i = 0; i < n_depths; i++)
+          if (cl[i].leaf != (1 << 30)) cl.push_back({cl[i].leaf, 72, true});
       run(cl);
     }
     (void)best_leaf;

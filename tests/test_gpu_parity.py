@@ -842,17 +842,17 @@ def test_the_tree_the_product_picks_is_inside_the_bit_identity_net(api, name, mo
     eref, xref = np.array(ref.optimize(4)), np.array(ref.state())
     key = lambda st: (st["n_supernodes"], st["nnz_l_scalars"], st["factor_flops"], st["max_front"], st["n_levels"])
     found = None
-    for leaf in ("1000000", "250", "150", "100", "70", "50"):
-        for npc in ("16", "32", "72"):
-            monkeypatch.setenv("RR_PGO_ND_LEAF", leaf)
-            monkeypatch.setenv("RR_PGO_AMALG_NP", npc)
-            h = api[0].new(g2o_path(name))
-            if key(h.stats()) == key(sref) and np.array_equal(np.array(h.optimize(4)), eref) and np.array_equal(np.array(h.state()), xref):
-                found = (leaf, npc)
-                break
-        if found:
+    # (the third choice: whether a region's last separator is chained into its parent separator's supernode or kept apart)
+    import itertools
+    for leaf, npc, join in itertools.product(("1000000", "250", "150", "100", "70", "50"), ("16", "32", "72"), ("1", "0")):
+        monkeypatch.setenv("RR_PGO_ND_LEAF", leaf)
+        monkeypatch.setenv("RR_PGO_AMALG_NP", npc)
+        monkeypatch.setenv("RR_PGO_JOIN_SEPARATORS", join)
+        h = api[0].new(g2o_path(name))
+        if key(h.stats()) == key(sref) and np.array_equal(np.array(h.optimize(4)), eref) and np.array_equal(np.array(h.state()), xref):
+            found = (leaf, npc, join)
             break
-    assert found, "no pinned (dissection leaf, amalgamation width) reproduces the product's analysis"
+    assert found, "no pinned (dissection leaf, amalgamation width, separator rule) reproduces the product's analysis"
     monkeypatch.setenv("RR_PGO_LDS_FLOW", "0")      # (the pins are still set)
     lvl = api[0].new(g2o_path(name))
     monkeypatch.delenv("RR_PGO_LDS_FLOW")
