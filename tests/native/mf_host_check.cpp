@@ -179,7 +179,21 @@ int main(int argc, char **argv) {
     printf("dataflow schedule: %d tasks, model %.1f + %.1f us\n", nt, y.est_factor_us, y.est_solve_us);
   }
 
-  // ---- numeric multifrontal, same data flow as the kernels
+  // ---- the longest chain of the supernode tree in pivot columns (what a small graph's iteration time follows): a guard on the
+  // quality of the dissection -- CHAIN_MAX=<columns> fails the run when the chain is longer
+  {
+    std::vector<int64_t> chain(S, 0);
+    int64_t longest = 0;
+    for (int s2 = 0; s2 < S; s2++) {   // (children precede parents)
+      chain[s2] += y.sn_ncols[s2];
+      longest = std::max(longest, chain[s2]);
+      const int p2 = y.sn_parent[s2];
+      if (p2 >= 0) chain[p2] = std::max(chain[p2], chain[s2]);
+    }
+    printf("longest chain: %lld pivot columns\n", (long long)longest);
+    if (getenv("CHAIN_MAX") && longest > atoll(getenv("CHAIN_MAX"))) { printf("FAIL: the chain is longer than %s columns\n", getenv("CHAIN_MAX")); return 1; }
+  }
+
   std::vector<double> L((size_t)y.l_elems + 4, 0.0), Uv((size_t)y.u_elems + 4, 0.0), x(dim, 0.0);
   std::vector<double> P, Uloc;
   for (int s : order) {
