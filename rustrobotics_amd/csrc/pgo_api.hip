@@ -2491,6 +2491,18 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
     Symbolic best;
     double best_crit = -1.0;
     int best_leaf = 0;
+    // the candidates differ in where they STOP dissecting, not in how a set is split: the deepest dissection runs once (its halves on
+    // threads of their own) and records its splits, every candidate replays them (symbolic.h, NdSplitTable)
+    NdSplitTable splits;
+    bool shared_splits = false;
+    if (so.ml_nd && cl.size() > 1) {
+      SymbolicOptions o = so;
+      o.nd_leaf = 1 << 30;
+      for (const Cand &c : cl) o.nd_leaf = std::min(o.nd_leaf, c.leaf);
+      o.nd_record = &splits;
+      err = dissect_only(h->g, o);
+      shared_splits = err.empty();
+    }
     auto run = [&](const std::vector<Cand> &list) {
       std::vector<Symbolic> cands(list.size());
       std::vector<std::string> errs(list.size());
@@ -2502,6 +2514,7 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
             o.nd_leaf = list[c].leaf;
             o.amalg_np = list[c].np;
             o.split_separators = list[c].split;
+            if (shared_splits) o.nd_replay = &splits;
             try { errs[c] = analyze(h->g, o, cands[c]); } catch (const std::exception &e) { errs[c] = e.what(); }
           });
         {
@@ -2509,6 +2522,7 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
           o.nd_leaf = list[0].leaf;
           o.amalg_np = list[0].np;
           o.split_separators = list[0].split;
+          if (shared_splits) o.nd_replay = &splits;
           errs[0] = analyze(h->g, o, cands[0]);
         }
         for (std::thread &t : pool) t.join();
@@ -2525,7 +2539,7 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
         if (best_crit < 0 || eff < best_crit) { best_crit = eff; best_leaf = list[c].leaf; best = std::move(cands[c]); }
       }
     };
-    run(cl);
+    if (err.empty()) run(cl);
     // fronts beyond LDS (sphere2500, torus3D: 6 x 6 blocks): there the r01 rule -- mid-sized fronts merge up to 72 columns --
     // still pays, and with another depth than the narrow rule's (torus3D): a second round of the same depths decides
     if (err.empty() && !np_fixed && best.n_big > 0) {

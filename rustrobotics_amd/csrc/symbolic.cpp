@@ -707,94 +707,113 @@ struct NestedDissection {
       return;
     }
     const int sid = set_id[S[0]];
-    // connected components
-    std::vector<int32_t> visit, comp_of_start, comp_sizes;
-    std::vector<std::vector<int32_t>> comps;
-    for (int v : S)
-      if (level[v] < 0) {
-        bfs(v, sid, visit);
-        comps.emplace_back(visit);
-      }
-    for (int v : S) level[v] = -1;
+    // The split of a set is a function of the set alone (not of the leaf size the caller stops at): when several dissection depths of
+    // one graph are analysed side by side (the engine's candidates), the deepest is dissected once, recording, and the others replay.
     std::vector<int32_t> left, right, sep;
-    if (comps.size() > 1) {
-      std::sort(comps.begin(), comps.end(),
-                [](const auto &a, const auto &b) { return a.size() > b.size(); });
-      size_t nl = 0, nr = 0;
-      for (auto &c : comps) {
-        auto &dst = nl <= nr ? left : right;
-        (nl <= nr ? nl : nr) += c.size();
-        dst.insert(dst.end(), c.begin(), c.end());
-      }
-    } else {
-      // pseudo-peripheral root
-      int root = S[0], nlev = 0;
-      for (int it = 0; it < 6; it++) {
-        int nl = bfs(root, sid, visit);
-        int far = visit.back(), best_deg = 1 << 30;
-        for (size_t i = visit.size(); i-- > 0 && level[visit[i]] == nl - 1;) {
-          int d = adj.deg(visit[i]);
-          if (d < best_deg) { best_deg = d; far = visit[i]; }
+    bool replayed = false;
+    if (opt.nd_replay)
+      if (const NdSplit *sp = opt.nd_replay->find(depth, S[0], n)) {
+        if (sp->as_leaf) {
+          if (depth < part_depth) assign_part(S, depth, path);
+          order_leaf(S, out, local_id);
+          return;
         }
-        bool grew = nl > nlev;
-        nlev = nl;
-        if (!grew && it > 0) break;
-        if (it < 5) {
-          for (int v : visit) level[v] = -1;
-          root = far;
-        }
+        left = sp->left;
+        right = sp->right;
+        sep = sp->sep;
+        replayed = true;
       }
-      // make sure levels correspond to `root`
+    if (!replayed) {
+      // connected components
+      std::vector<int32_t> visit, comp_of_start, comp_sizes;
+      std::vector<std::vector<int32_t>> comps;
+      for (int v : S)
+        if (level[v] < 0) {
+          bfs(v, sid, visit);
+          comps.emplace_back(visit);
+        }
       for (int v : S) level[v] = -1;
-      nlev = bfs(root, sid, visit);
-      if (nlev < 3) {  // no usable level separator: treat as a leaf
-        for (int v : S) level[v] = -1;
-        if (depth < part_depth) assign_part(S, depth, path);
-        order_leaf(S, out, local_id);
-        return;
-      }
-      std::vector<int64_t> cnt(nlev, 0), wsum(nlev, 0);
-      for (int v : visit) { cnt[level[v]]++; wsum[level[v]] += w[v]; }
-      int64_t total = n, acc = 0;
-      int best = -1;
-      double best_score = 1e300;
-      for (int j = 0; j < nlev; j++) {
-        int64_t l = acc, r = total - acc - cnt[j];
-        acc += cnt[j];
-        if (j == 0 || j == nlev - 1) continue;
-        double imb = std::fabs((double)l - (double)r) / (double)total;
-        double score = (double)wsum[j] * (1.0 + 4.0 * imb * imb) + (imb > 0.6 ? 1e6 * imb : 0.0);
-        if (score < best_score) { best_score = score; best = j; }
-      }
-      for (int v : visit) {
-        int lv = level[v];
-        if (lv < best) left.push_back(v);
-        else if (lv > best) right.push_back(v);
-        else {
-          bool touches_right = false;
-          for (int p = adj.ptr[v]; p < adj.ptr[v + 1] && !touches_right; p++) {
-            int u = adj.idx[p];
-            touches_right = set_id[u] == sid && level[u] == best + 1;
+      if (comps.size() > 1) {
+        std::sort(comps.begin(), comps.end(),
+                  [](const auto &a, const auto &b) { return a.size() > b.size(); });
+        size_t nl = 0, nr = 0;
+        for (auto &c : comps) {
+          auto &dst = nl <= nr ? left : right;
+          (nl <= nr ? nl : nr) += c.size();
+          dst.insert(dst.end(), c.begin(), c.end());
+        }
+      } else {
+        // pseudo-peripheral root
+        int root = S[0], nlev = 0;
+        for (int it = 0; it < 6; it++) {
+          int nl = bfs(root, sid, visit);
+          int far = visit.back(), best_deg = 1 << 30;
+          for (size_t i = visit.size(); i-- > 0 && level[visit[i]] == nl - 1;) {
+            int d = adj.deg(visit[i]);
+            if (d < best_deg) { best_deg = d; far = visit[i]; }
           }
-          (touches_right ? sep : left).push_back(v);
+          bool grew = nl > nlev;
+          nlev = nl;
+          if (!grew && it > 0) break;
+          if (it < 5) {
+            for (int v : visit) level[v] = -1;
+            root = far;
+          }
+        }
+        // make sure levels correspond to `root`
+        for (int v : S) level[v] = -1;
+        nlev = bfs(root, sid, visit);
+        if (nlev < 3) {  // no usable level separator: treat as a leaf
+          for (int v : S) level[v] = -1;
+          if (opt.nd_record) opt.nd_record->store(depth, S[0], n, true, left, right, sep);
+          if (depth < part_depth) assign_part(S, depth, path);
+          order_leaf(S, out, local_id);
+          return;
+        }
+        std::vector<int64_t> cnt(nlev, 0), wsum(nlev, 0);
+        for (int v : visit) { cnt[level[v]]++; wsum[level[v]] += w[v]; }
+        int64_t total = n, acc = 0;
+        int best = -1;
+        double best_score = 1e300;
+        for (int j = 0; j < nlev; j++) {
+          int64_t l = acc, r = total - acc - cnt[j];
+          acc += cnt[j];
+          if (j == 0 || j == nlev - 1) continue;
+          double imb = std::fabs((double)l - (double)r) / (double)total;
+          double score = (double)wsum[j] * (1.0 + 4.0 * imb * imb) + (imb > 0.6 ? 1e6 * imb : 0.0);
+          if (score < best_score) { best_score = score; best = j; }
+        }
+        for (int v : visit) {
+          int lv = level[v];
+          if (lv < best) left.push_back(v);
+          else if (lv > best) right.push_back(v);
+          else {
+            bool touches_right = false;
+            for (int p = adj.ptr[v]; p < adj.ptr[v + 1] && !touches_right; p++) {
+              int u = adj.idx[p];
+              touches_right = set_id[u] == sid && level[u] == best + 1;
+            }
+            (touches_right ? sep : left).push_back(v);
+          }
+        }
+        for (int v : S) level[v] = -1;
+        {
+          // the straight cut, if the graph has positions and it is the lighter separator
+          int64_t ws = 0;
+          for (int v : sep) ws += w[v];
+          const double imb = std::fabs((double)left.size() - (double)right.size()) / (double)n;
+          const double bfs_score = (double)ws * (1.0 + 4.0 * imb * imb) + (imb > 0.6 ? 1e6 * imb : 0.0);
+          std::vector<int32_t> gl, gr, gs;
+          const double gscore = geo_split(S, sid, gl, gr, gs);
+          double cur_score = bfs_score;
+          if (gscore >= 0 && gscore < bfs_score) { left.swap(gl); right.swap(gr); sep.swap(gs); cur_score = gscore; }
+          if (opt.ml_nd) {
+            const double mscore = ml_split(S, sid, gl, gr, gs, local_id);
+            if (mscore >= 0 && mscore < cur_score) { left.swap(gl); right.swap(gr); sep.swap(gs); }
+          }
         }
       }
-      for (int v : S) level[v] = -1;
-      {
-        // the straight cut, if the graph has positions and it is the lighter separator
-        int64_t ws = 0;
-        for (int v : sep) ws += w[v];
-        const double imb = std::fabs((double)left.size() - (double)right.size()) / (double)n;
-        const double bfs_score = (double)ws * (1.0 + 4.0 * imb * imb) + (imb > 0.6 ? 1e6 * imb : 0.0);
-        std::vector<int32_t> gl, gr, gs;
-        const double gscore = geo_split(S, sid, gl, gr, gs);
-        double cur_score = bfs_score;
-        if (gscore >= 0 && gscore < bfs_score) { left.swap(gl); right.swap(gr); sep.swap(gs); cur_score = gscore; }
-        if (opt.ml_nd) {
-          const double mscore = ml_split(S, sid, gl, gr, gs, local_id);
-          if (mscore >= 0 && mscore < cur_score) { left.swap(gl); right.swap(gr); sep.swap(gs); }
-        }
-      }
+      if (opt.nd_record) opt.nd_record->store(depth, S[0], n, false, left, right, sep);
     }
     if (depth == 0 && opt.pin_node >= 0 && part_depth > 0) {
       // sharded runs: the anchor joins the top separator, so that every rank holds its solution entries
@@ -907,6 +926,20 @@ struct PhaseTimer {
     t0 = t1;
   }
 };
+
+std::string dissect_only(const HostGraph &g, const SymbolicOptions &opt) {
+  const int N = g.n_nodes();
+  if (N == 0) return "graph has no vertices";
+  std::vector<int32_t> w(N);
+  for (int i = 0; i < N; i++) w[i] = node_dim(g.node_kind[i]);
+  const Adj adj = build_adjacency(g);
+  NestedDissection nd(adj, w, opt);
+  nd.hg = &g;
+  std::vector<int32_t> all(N), scratch(N, -1);
+  std::iota(all.begin(), all.end(), 0);
+  nd.dissect(all, 0, 0, nd.order, scratch);
+  return (int)nd.order.size() == N ? "" : "internal: ordering lost nodes";
+}
 
 std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sym) {
   sym = Symbolic();

@@ -14,12 +14,43 @@
 #pragma once
 #include <cstdint>
 #include <vector>
+#include <unordered_map>
+#include <mutex>
 
 #include "host_graph.h"
 
 namespace rrpgo {
 
+// The splits of one nested dissection, for the candidates of one graph that differ in where they STOP dissecting (pgo_api.hip):
+// recorded by the deepest, replayed by the others.  A split is looked up by (depth, first node, size) of its set -- unique within one
+// dissection, and checked against what was stored.
+struct NdSplit {
+  int32_t depth = 0, first = 0, n = 0;
+  bool as_leaf = false;              // the search found no usable separator: the set is ordered as a leaf
+  std::vector<int32_t> left, right, sep;
+};
+struct NdSplitTable {
+  std::unordered_map<uint64_t, NdSplit> map;
+  std::mutex mu;                     // (the two halves of a top split are dissected by two threads)
+  static uint64_t key(int depth, int first, int n) {
+    return (uint64_t)depth * 0x9E3779B97F4A7C15ull ^ (uint64_t)(uint32_t)first * 0xC2B2AE3D27D4EB4Full ^ (uint64_t)(uint32_t)n * 0x165667B19E3779F9ull;
+  }
+  void store(int depth, int first, int n, bool as_leaf, const std::vector<int32_t> &l, const std::vector<int32_t> &r, const std::vector<int32_t> &s) {
+    std::lock_guard<std::mutex> lock(mu);
+    NdSplit &sp = map[key(depth, first, n)];
+    sp.depth = depth; sp.first = first; sp.n = n; sp.as_leaf = as_leaf;
+    sp.left = l; sp.right = r; sp.sep = s;
+  }
+  const NdSplit *find(int depth, int first, int n) const {
+    auto it = map.find(key(depth, first, n));
+    if (it == map.end() || it->second.depth != depth || it->second.first != first || it->second.n != n) return nullptr;
+    return &it->second;
+  }
+};
+
 struct SymbolicOptions {
+  NdSplitTable *nd_record = nullptr;        // the dissection stores every split it computes here ...
+  const NdSplitTable *nd_replay = nullptr;  // ... and takes the splits it finds here instead of searching (both: see NdSplitTable)
   bool split_separators = false;     // do not chain a region's last separator into its parent separator's supernode
   bool geo_nd = true;                // nested dissection may cut along a coordinate axis (pose graphs are spatial)
   bool ml_nd = false;                // nested dissection also tries a multilevel bisection with a minimum-cover separator (small graphs)
@@ -147,5 +178,8 @@ struct Symbolic {
 
 // Returns "" or an error message.
 std::string analyze(const HostGraph &g, const SymbolicOptions &opt, Symbolic &sym);
+
+// The ordering phase alone (nested dissection down to opt.nd_leaf), for its side effect on opt.nd_record.
+std::string dissect_only(const HostGraph &g, const SymbolicOptions &opt);
 
 }  // namespace rrpgo

@@ -338,6 +338,17 @@ def test_symbolic_tables_drive_a_correct_factorization(mfcheck, args, env):
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
 
 
+def test_replayed_dissections_are_the_computed_ones(tmp_path):
+    """The candidates of one graph share ONE nested dissection (recorded by the deepest, replayed by the others: symbolic.h NdSplitTable,
+    pgo_api.hip): at every depth the engine tries, the analysis that replays must equal the analysis that computes -- ordering,
+    supernodes, tree, schedule, estimate (tests/native/nd_replay_check.cpp)."""
+    exe = tmp_path / "nd_replay_check"
+    srcs = [os.path.join(ROOT, "tests", "native", "nd_replay_check.cpp")] + [os.path.join(CSRC, f) for f in ("symbolic.cpp", "g2o_loader.cpp", "synth_grid.cpp")]
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", CSRC, *srcs, "-lpthread", "-o", str(exe)])
+    out = subprocess.run([str(exe), g2o_path("intel"), g2o_path("dlr"), g2o_path("sphere2500"), g2o_path("simulation-pose-landmark")], capture_output=True, text=True)
+    assert out.returncode == 0 and "replayed == computed for every depth" in out.stdout, out.stdout + out.stderr
+
+
 def test_algorithmic_bytes_follow_survey_8d(lib):
     """SURVEY.md 8(d), worked totals for intel.g2o in fp64: linearise 0.90 MB, solve 0.43 + 3 x 1.24 + 0.17 = 4.3 MB with
     nnzblk(L) = 17 193 [probe], update 0.12 MB -- 5.4 MB per iteration with chi2 fused into the linearisation.  The
