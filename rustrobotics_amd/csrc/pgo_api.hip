@@ -2473,6 +2473,9 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
       int leaf = so.ml_nd ? kLeafMultilevel[li] : kLeafLevelSets[li];
       if (std::getenv("RR_PGO_ND_LEAF")) { if (leaf != (1 << 30)) continue; leaf = so.nd_leaf; }
       else if (leaf != (1 << 30) && ((!so.ml_nd && h->g.n_nodes() < 2400) || leaf >= h->g.n_nodes())) continue;   // (a leaf size >= the graph is no cut at all)
+      // (with the multilevel bisection the undissected tree lost on every graph of 1000+ nodes by 30 - 60 % of the estimate, and its
+      // minimum-degree pass over the whole graph is the slowest of the candidate analyses: 5.8 ms on dlr)
+      if (so.ml_nd && leaf == (1 << 30) && h->g.n_nodes() >= 1000 && !std::getenv("RR_PGO_ND_LEAF")) continue;
       cl.push_back({leaf, np_fixed ? so.amalg_np : 16, so.split_separators});   // the narrow rule first: it wins wherever every front lives in LDS
     }
     const size_t n_depths = cl.size();
@@ -2500,8 +2503,10 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
       o.nd_leaf = 1 << 30;
       for (const Cand &c : cl) o.nd_leaf = std::min(o.nd_leaf, c.leaf);
       o.nd_record = &splits;
+      const double td = now_ms();
       err = dissect_only(h->g, o);
       shared_splits = err.empty();
+      if (std::getenv("RR_PGO_ANALYZE_TIMES")) std::fprintf(stderr, "analyze: shared dissection down to %d nodes: %.3f ms (%zu splits)\n", o.nd_leaf, now_ms() - td, splits.map.size());
     }
     auto run = [&](const std::vector<Cand> &list) {
       std::vector<Symbolic> cands(list.size());

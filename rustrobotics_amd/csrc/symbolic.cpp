@@ -494,6 +494,7 @@ struct NestedDissection {
   std::vector<int8_t> side;      // scratch of the coordinate bisection
   std::vector<int32_t> sep_of;   // separator a node belongs to (-1: inside a leaf)
   const HostGraph *hg = nullptr; // node positions for coordinate bisection (optional)
+  bool splits_only = false;      // dissect_only(): the caller wants the recorded splits, not the order -- leaves are not ordered
   std::atomic<int> next_set{1};  // (ids only ever compared for equality: the two halves of a split may be dissected by two threads)
   int part_depth = 0;
 
@@ -528,6 +529,10 @@ struct NestedDissection {
 
   // `out`: where the order of this part of the graph is collected; `local_id`: scratch of the calling thread, all -1 between calls
   void order_leaf(const std::vector<int32_t> &S, std::vector<int32_t> &out, std::vector<int32_t> &local_id) {
+    if (splits_only) {
+      for (int v : S) { out.push_back(v); ordered[v] = 1; }
+      return;
+    }
     // local graph: S first, then not-yet-ordered outside neighbours (ancestor separators)
     const int ne = (int)S.size();
     std::vector<int32_t> verts(S);
@@ -676,19 +681,33 @@ struct NestedDissection {
     MultilevelBisection::Hierarchy hier;
     MultilevelBisection::build_hierarchy(g, hier);
     static const double kMinSide[3] = {0.30, 0.38, 0.46};
-    double best = -1.0;
-    std::vector<int8_t> sd;
-    std::vector<char> in_sep;
-    std::vector<int32_t> tl, tr, ts;
     const bool three = n >= 200;   // (below 200 nodes the middle setting alone: same estimates, a third less time)
-    for (int t = 0; t < (three ? 3 : 1); t++) {
-      MultilevelBisection::bisect(g, hier, (int64_t)(kMinSide[three ? t : 1] * n), sd);
-      MultilevelBisection::cover_separator(g, sd, in_sep);
+    const int n_try = three ? 3 : 1;
+    struct Try { std::vector<int8_t> sd; std::vector<char> in_sep; };
+    Try tries[3];
+    auto run = [&](int t) {
+      MultilevelBisection::bisect(g, hier, (int64_t)(kMinSide[three ? t : 1] * n), tries[t].sd);
+      MultilevelBisection::cover_separator(g, tries[t].sd, tries[t].in_sep);
+    };
+    if (splits_only && n >= 400) {
+      // the recording dissection has the host to itself (the candidate analyses start when it is done): the three settings of its
+      // large splits side by side -- they only read the graph and the hierarchy.  (Beside eight candidate analyses this
+      // oversubscribed the host: 6.7 against 4.7 ms, r05.)
+      std::thread t1([&] { run(1); }), t2([&] { run(2); });
+      run(0);
+      t1.join();
+      t2.join();
+    } else {
+      for (int t = 0; t < n_try; t++) run(t);
+    }
+    double best = -1.0;
+    std::vector<int32_t> tl, tr, ts;
+    for (int t = 0; t < n_try; t++) {   // (in the order of the settings, whichever thread finished first: the first best wins)
       tl.clear(); tr.clear(); ts.clear();
       int64_t ws = 0;
       for (int i = 0; i < n; i++) {
-        if (in_sep[i]) { ts.push_back(S[i]); ws += w[S[i]]; }
-        else (sd[i] == 0 ? tl : tr).push_back(S[i]);
+        if (tries[t].in_sep[i]) { ts.push_back(S[i]); ws += w[S[i]]; }
+        else (tries[t].sd[i] == 0 ? tl : tr).push_back(S[i]);
       }
       if (tl.empty() || tr.empty() || ts.empty()) continue;
       const double imb = std::fabs((double)tl.size() - (double)tr.size()) / (double)n;
@@ -835,7 +854,7 @@ struct NestedDissection {
     // No edge joins the two halves, so their dissections touch disjoint entries of the per-node arrays (the scratch that maps
     // separator nodes of the ancestors is per thread): the top two levels of a small graph's multilevel dissection -- three
     // quarters of the time of its analysis -- run on up to four threads.  Same order as the sequential run: left, right, separator.
-    if (opt.ml_nd && depth < 2 && left.size() >= 150 && right.size() >= 150) {
+    if (opt.ml_nd && depth < (splits_only ? 3 : 2) && left.size() >= 150 && right.size() >= 150) {   // (alone on the host when only recording: one level more)
       std::vector<int32_t> out_right, scratch_right(N, -1);
       std::thread other([&] { dissect(right, depth + 1, path * 2 + 1, out_right, scratch_right); });
       dissect(left, depth + 1, path * 2, out, local_id);
@@ -935,6 +954,7 @@ std::string dissect_only(const HostGraph &g, const SymbolicOptions &opt) {
   const Adj adj = build_adjacency(g);
   NestedDissection nd(adj, w, opt);
   nd.hg = &g;
+  nd.splits_only = true;
   std::vector<int32_t> all(N), scratch(N, -1);
   std::iota(all.begin(), all.end(), 0);
   nd.dissect(all, 0, 0, nd.order, scratch);
