@@ -1,3 +1,5 @@
+"""Diagnostic (r05, the rank-dependent shared schedule): sphere2500 over P emulated ranks after ONE Gauss-Newton iteration against the
+unsharded handle -- which nodes are off, who owns them, how far the ranks' copies of the shared poses are apart.  usage: gpu_shard_dbg.py [P]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

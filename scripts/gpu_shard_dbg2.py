@@ -1,3 +1,6 @@
+"""Diagnostic (r05, the rank-dependent shared schedule): sphere2500 over P emulated ranks, iteration by iteration -- distance of the gathered
+state from the unsharded handle's, by owner, and the spread of the ranks' copies of the shared poses (must be 0.0: every rank computes them
+itself, bit for bit alike).  usage: gpu_shard_dbg2.py [P]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
