@@ -338,6 +338,45 @@ def test_symbolic_tables_drive_a_correct_factorization(mfcheck, args, env):
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
 
 
+@pytest.mark.parametrize("shape", ["star", "chain", "two-components", "dense", "hubs", "random-loops", "three-nodes"])
+def test_multilevel_dissection_on_awkward_graphs(mfcheck, tmp_path, shape):
+    """The multilevel bisection on graphs that are not trajectories: a star (every separator is the hub), a bare chain, two components,
+    a dense random graph (no small separator exists), a chain with three hubs, a chain with random long loop closures, three nodes --
+    unsharded and over four ranks the tables must still drive a correct factorisation (tests/native/mf_host_check.cpp)."""
+    import random
+    rnd = random.Random(5)
+    n = 400
+    chain = [(i, i + 1) for i in range(n - 1)]
+    if shape == "star":
+        edges = [(0, i) for i in range(1, n)]
+    elif shape == "chain":
+        edges = chain
+    elif shape == "two-components":
+        edges = [(i, i + 1) for i in range(n // 2 - 1)] + [(i, i + 1) for i in range(n // 2, n - 1)]
+    elif shape == "dense":
+        n = 90
+        edges = [(i, j) for i in range(n) for j in range(i + 1, n) if rnd.random() < 0.5]
+    elif shape == "hubs":
+        edges = chain + [(h, i) for h in (5, 200, 390) for i in range(0, n, 3) if abs(i - h) > 1]
+    elif shape == "random-loops":
+        edges = list(chain)
+        while len(edges) < 1000:
+            a, b = rnd.randrange(n), rnd.randrange(n)
+            if abs(a - b) > 1:
+                edges.append((a, b))
+    else:
+        n, edges = 3, [(0, 1), (1, 2)]
+    path = tmp_path / (shape + ".g2o")
+    with open(path, "w") as f:
+        for i in range(n):
+            f.write("VERTEX_SE2 %d %.4f %.4f %.4f\n" % (i, rnd.random() * 10, rnd.random() * 10, rnd.random()))
+        for a, b in edges:
+            f.write("EDGE_SE2 %d %d 1.0 0.1 0.01 100 0 0 100 0 400\n" % (a, b))
+    for env in ({"LEAF": "8", "ML": "1"}, {"LEAF": "16", "ML": "1", "PARTS": "4", "PIN": "1"}):
+        out = subprocess.run([mfcheck, str(path)], env={**os.environ, **env}, capture_output=True, text=True)
+        assert out.returncode == 0 and out.stdout.strip().endswith("OK"), (env, out.stdout + out.stderr)
+
+
 def test_replayed_dissections_are_the_computed_ones(tmp_path):
     """The candidates of one graph share ONE nested dissection (recorded by the deepest, replayed by the others: symbolic.h NdSplitTable,
     pgo_api.hip): at every depth the engine tries, the analysis that replays must equal the analysis that computes -- ordering,
