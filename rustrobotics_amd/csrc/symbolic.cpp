@@ -173,9 +173,10 @@ void constrained_min_degree(int ne, int nt, std::vector<std::vector<int32_t>> &A
 // vertex separator the edge bisection admits -- a minimum vertex cover of its cut edges (Koenig's theorem on the
 // bipartite graph of the two boundaries).  Everything is integer arithmetic with index tie-breaks: the same graph
 // gives the same split on every host.  Measured against the breadth-first level sets and coordinate cuts of
-// NestedDissection on the trajectory graphs (r05): intel's top separator 26 -> 12 nodes, the separators on its
-// heaviest root path 97 -> ~45 nodes (a Fiedler-vector bisection with the same cover step, computed offline with
-// scipy, gives 12 and 42).
+// NestedDissection on the trajectory graphs (r05, intel down to leaves of 100 nodes): the separators on the heaviest
+// root path add up to 60 nodes instead of 97 (top separator 20 instead of 26, the two below it 7 and 11 instead of
+// 13 and 38); a Fiedler-vector bisection with the same cover step, computed offline with scipy, gives 71 (its top
+// separator is 12 nodes at a 55 : 45 split -- the score below prefers the better balanced 20).
 struct MlGraph {
   int n = 0;
   std::vector<int32_t> ptr, idx, ew, vw;
