@@ -608,6 +608,7 @@ __global__ void __launch_bounds__(256) k_flow_reset(unsigned *words, int64_t n, 
 // wait for its BUILD tasks, and whatever is gathered from a child is read past L1.  One launch instead of three per level;
 // graphs of a few dozen big fronts (sphere2500: 46 in six levels) -- what k_factor_flow did for the LDS fronts.
 template <typename T, int NT, bool XL = false> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? RRPGO_FLOW_WAVES : 1)) k_big_flow(FlowArgs<T> fa) {
+  if (opt_stopped(fa.err)) return;   // rr_pgo_optimize: enqueued behind the iteration that met the stop rule
   using MM = Mfma16<T>;
   using UT = UpdTile<T, NT>;
   constexpr int TS = UT::TILE;
@@ -758,6 +759,7 @@ __device__ __forceinline__ bool solve_flow_wait(const unsigned *word, unsigned n
 template <typename T> __global__ void __launch_bounds__(1024) k_big_solve_flow(FactorArgs<T> a, const T *part, int64_t N, int R, unsigned *flags,
                                                                              const SolveFlowFront *fronts, const SolveFlowTask *tasks, int n_tasks,
                                                                              unsigned *ticket) {
+  if (opt_stopped(a.err)) return;
   __shared__ T xf[BIG_SUPER];              // this super-panel: t, then x
   __shared__ T Ws[4 * 32 * 33];            // the super-panel's four W_b, staged transposed
   __shared__ unsigned s_ticket;

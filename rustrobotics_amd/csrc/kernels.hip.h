@@ -98,6 +98,43 @@ __device__ __forceinline__ int wave_index() { return __builtin_amdgcn_readfirstl
 // device-side error flags (sticky, read by the host at sync points)
 enum : int { DEVERR_NOT_SPD = 1, DEVERR_FLOW_TIMEOUT = 2 };
 
+// ---- the loop state of ONE rr_pgo_optimize call, on the device (reference pose_graph_optimization.rs:247-303).
+// The host enqueues iterations ahead of the device and never synchronises inside the loop: the stop rule (:298-300), the
+// Levenberg-Marquardt accept / reject (:275-282) and the failure of a factorisation (:271) are decided here, by the
+// kernel that finishes an iteration, which also publishes the iteration's (chi2, |dx|) in a ring the host polls
+// (pinned, host-coherent memory).  The STOP WORD is the int behind the sticky error flag (err[1]): once it is set,
+// every later launch of the same call returns at its first instruction (the compute kernels) or leaves the state alone
+// (k_update), so an iteration that was enqueued before the host saw the stop costs a handful of empty launches.
+struct OptCtrl {
+  double lambda;        // :254; x 2 on reject, / 2 on accept
+  double last_error;    // :255, :284
+  double tolerance;     // :253
+  unsigned long long seq;   // items of this call published so far
+  int reject;           // Levenberg-Marquardt: the step just applied is to be undone (:276-279); read by the undo launch
+  int pad;
+};
+struct alignas(32) OptSlot {   // one published item; `seq` (1-based index of the item) is stored last, system-scope release
+  double chi2, norm;
+  int flags, pad;
+  unsigned long long seq;
+};
+enum : int { OPT_RING = 8 };
+enum : int { OPT_STOP = 1,      // the stop rule fired in this item: it is the last iteration of the call
+             OPT_SKIPPED = 2,   // the item found the stop word set: only its chi2 (of the final state) means anything
+             OPT_ERR_SHIFT = 8  // flags >> 8 = the device error flag (DEVERR_*) when the item's factorisation failed
+};
+__device__ __forceinline__ void opt_publish(OptCtrl *c, OptSlot *ring, double chi2, double norm, int flags) {
+  const unsigned long long n = c->seq + 1;
+  OptSlot *s = ring + (n - 1) % OPT_RING;
+  s->chi2 = chi2;
+  s->norm = norm;
+  s->flags = flags;
+  __hip_atomic_store(&s->seq, n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  c->seq = n;
+}
+// the stop word of the running rr_pgo_optimize call (0 outside one): `err` is the engine's two-int error block
+__device__ __forceinline__ bool opt_stopped(const int *err) { return err && err[1] != 0; }
+
 
 // TC = type of the state, the measurements and all factor arithmetic; T = type H and b are stored in
 // (TC == T, or TC = double with T = float: "mixed" mode, exact gradient + single-precision factor)
@@ -138,7 +175,28 @@ template <typename T, typename TC = T> struct LinArgs {
   int n_zero_words;                      // one launch ahead of their first use (0: none)
   unsigned *fill_words;                  // the solution vector of k_solve_flow: every word set to X_PENDING_WORD here (a front
   int n_fill_words;                      // of that launch waits for its ancestors' entries themselves, x_wait) (0: none)
+  OptCtrl *ctrl;                         // rr_pgo_optimize's device-side loop state (null outside one) ...
+  int lambda_from_ctrl;                  // ... 1: lambda = ctrl->lambda (Levenberg-Marquardt: the host does not know it)
+  int reset_ctrl;                        // ... 1: the first launch of a call: its first thread resets the loop state
+  double reset_lambda, reset_tolerance;  //      (:253-254) and the stop word err[1] -- nothing in this launch reads either
+  int *err;
+  int publish;                           // ... 1: a Gauss-Newton iteration's linearisation: when the stop word is set, its LAST
+                                         //      workgroup publishes chi2 (of the final state: the call's last error entry) at once --
+                                         //      the host returns while the iteration's other launches drain empty;
+                                         //      2: a chi2-only item: always published from here (and kept as OptCtrl::last_error)
+  OptSlot *ring_host;
+  int *blocks_done;                      // zero between launches
 };
+template <typename A> __device__ __forceinline__ void opt_reset_in_first_thread(const A &a) {
+  if (a.reset_ctrl && blockIdx.x == 0 && threadIdx.x == 0) {
+    a.ctrl->lambda = a.reset_lambda;
+    a.ctrl->tolerance = a.reset_tolerance;
+    a.ctrl->last_error = 0.0;
+    a.ctrl->seq = 0ull;
+    a.ctrl->reject = 0;
+    a.err[1] = 0;
+  }
+}
 
 // ---------------------------------------------------------------- factor maths
 
@@ -212,6 +270,9 @@ struct FinArgs {
   int *counter;                // slot counter, advanced when `advance`
   int advance, ring;
   int *blocks_done;            // zero between launches
+  OptCtrl *ctrl;               // rr_pgo_optimize without host round trips: the device-side loop state (null: none) ...
+  OptSlot *ring_host;          // ... and the host-visible ring the iteration is published in
+  int *err;                    // the engine's error block: [0] sticky error flag, [1] stop word
 };
 template <int THREADS>
 __device__ __forceinline__ void finalize_in_last_block(const FinArgs &f, const double *norm_partial, int n_norm, double *red) {
@@ -234,6 +295,85 @@ __device__ __forceinline__ void finalize_in_last_block(const FinArgs &f, const d
     f.hist[2 * slot + 1] = sqrt(nt);
     if (f.advance) *f.counter = *f.counter + 1;
     *f.blocks_done = 0;
+    if (f.ctrl) {
+      // Gauss-Newton inside rr_pgo_optimize: ct = chi2 of the state BEFORE this step (errors[i], :286), sqrt(nt) = |dx| (:273)
+      const int e = f.err[0];
+      if (f.err[1]) {
+        // enqueued behind the iteration that met the stop rule: this item's linearisation has published chi2 of the final state
+      } else {
+        const double nrm = sqrt(nt);
+        const bool stop = e != 0 || nrm < f.ctrl->tolerance;   // :298-300; a failed factorisation ends the call (:271)
+        if (stop) f.err[1] = 1;
+        opt_publish(f.ctrl, f.ring_host, ct, nrm, (stop && !e ? OPT_STOP : 0) | (e << OPT_ERR_SHIFT));
+      }
+    }
+  }
+}
+
+// rr_pgo_optimize's items that are not a Gauss-Newton iteration (one workgroup of 256; the sums in k_finalize_slot's order):
+//   mode 0   chi2 of the current state (the linearisation before this launch wrote the partials): Gauss-Newton's entry behind
+//            the last iteration when the stop rule never fired; Levenberg-Marquardt's initial error (:255) -> last_error
+//   mode 1   the end of a Levenberg-Marquardt iteration (:274-300): error = chi2 of the state AFTER the step, |dx| from the
+//            update's partials; reject (last_error < error) => `reject` for the undo launch behind this one, lambda x 2, else
+//            lambda / 2; last_error = error either way (:284); the stop rule
+struct OptItemArgs {
+  const double *chi_partial, *norm_partial;
+  int n_chi, n_norm, mode;
+  OptCtrl *ctrl;
+  OptSlot *ring;
+  int *err;
+};
+__global__ void __launch_bounds__(256) k_opt_item(OptItemArgs a) {
+  __shared__ double red[4];
+  double c = 0.0, n = 0.0;
+  for (int i = threadIdx.x; i < a.n_chi; i += 256) c += a.chi_partial[i];
+  for (int i = threadIdx.x; i < a.n_norm; i += 256) n += a.norm_partial[i];
+  const double ct = block_sum<double, 256>(c, red);
+  const double nt = block_sum<double, 256>(n, red);
+  if (threadIdx.x != 0) return;
+  OptCtrl *k = a.ctrl;
+  k->reject = 0;
+  if (a.err[1]) { opt_publish(k, a.ring, ct, 0.0, OPT_SKIPPED); return; }
+  if (a.mode == 0) {
+    k->last_error = ct;
+    opt_publish(k, a.ring, ct, 0.0, 0);
+    return;
+  }
+  const int e = a.err[0];
+  if (e) {   // the step was not applied (k_update saw the flag): no decision to take, the call ends
+    a.err[1] = 1;
+    opt_publish(k, a.ring, ct, 0.0, e << OPT_ERR_SHIFT);
+    return;
+  }
+  const double nrm = sqrt(nt);
+  if (k->last_error < ct) { k->reject = 1; k->lambda *= 2.0; }   // :276-279
+  else k->lambda /= 2.0;                                           // :281
+  k->last_error = ct;                                              // :284
+  const bool stop = nrm < k->tolerance;
+  if (stop) a.err[1] = 1;
+  opt_publish(k, a.ring, ct, nrm, stop ? OPT_STOP : 0);
+}
+
+// (the sum in k_finalize_slot's order: 256 threads, stride 256, block_sum)
+template <typename A> __device__ __forceinline__ void opt_publish_chi2_in_last_block(const A &a, double *red) {
+  if (!a.publish) return;
+  const bool stopped = !a.reset_ctrl && a.err[1] != 0;   // (the call's first launch resets the word: never stopped)
+  if (a.publish == 1 && !stopped) return;
+  __shared__ int is_last;
+  if (threadIdx.x == 0) {
+    __threadfence();
+    is_last = atomicAdd(a.blocks_done, 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  double c = 0.0;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += LIN_THREADS) c += a.chi2_partial[i];
+  const double ct = block_sum<double, LIN_THREADS>(c, red);
+  if (threadIdx.x == 0) {
+    *a.blocks_done = 0;
+    if (!stopped) a.ctrl->last_error = ct;
+    opt_publish(a.ctrl, a.ring_host, ct, 0.0, stopped ? OPT_SKIPPED : 0);
   }
 }
 
@@ -249,6 +389,8 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<TO, T> a) {
   const int gid = blockIdx.x * LIN_THREADS + threadIdx.x;
   for (int i = gid; i < a.n_zero_words; i += gridDim.x * LIN_THREADS) a.zero_words[i] = 0u;
   for (int i = gid; i < a.n_fill_words; i += gridDim.x * LIN_THREADS) a.fill_words[i] = X_PENDING_WORD;
+  opt_reset_in_first_thread(a);
+  const T lambda = a.lambda_from_ctrl ? (T)a.ctrl->lambda : a.lambda;
   const int slot = gid / LIN_GROUP, sub = gid % LIN_GROUP;
   const int node = slot < a.n_nodes ? (a.node_list ? a.node_list[slot] : slot) : -1;
   double chi = 0.0;
@@ -331,7 +473,7 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<TO, T> a) {
 #pragma unroll
     for (int t = 0; t < 3; t++) bv[t] = group_sum8(bv[t]);
     if (node >= 0 && sub == 0) {
-      T add = a.lambda;
+      T add = lambda;
       if (node == a.anchor) add += (T)10000000.0;
       if (a.adds_diag && !a.adds_diag[node]) add = 0;
       TO *d = a.hvals + a.diag_off[node];
@@ -349,6 +491,7 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<TO, T> a) {
   }
   double tot = block_sum<double, LIN_THREADS>(chi, red);
   if (threadIdx.x == 0) a.chi2_partial[blockIdx.x] = tot;
+  opt_publish_chi2_in_last_block(a, red);
 }
 
 // ---- the EDGE-PARALLEL form of the same linearisation (the north star's wording; RR_PGO_EDGE_LINEARIZE=1) ----
@@ -520,6 +663,13 @@ template <typename T, typename TC = T> struct LinArgs3 {
   int n_zero_words;
   unsigned *fill_words;                 // as LinArgs::fill_words
   int n_fill_words;
+  OptCtrl *ctrl;                        // as LinArgs::ctrl ...
+  int lambda_from_ctrl, reset_ctrl;
+  double reset_lambda, reset_tolerance;
+  int *err;
+  int publish;
+  OptSlot *ring_host;
+  int *blocks_done;
 };
 
 template <typename T> __device__ __forceinline__ void q_mul(const T a[4], const T b[4], T r[4]) {
@@ -606,6 +756,8 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize_se3(LinArgs3<TO, T> a
   const int gid = blockIdx.x * LIN_THREADS + threadIdx.x;
   for (int i = gid; i < a.n_zero_words; i += gridDim.x * LIN_THREADS) a.zero_words[i] = 0u;
   for (int i = gid; i < a.n_fill_words; i += gridDim.x * LIN_THREADS) a.fill_words[i] = X_PENDING_WORD;
+  opt_reset_in_first_thread(a);
+  const T lambda = a.lambda_from_ctrl ? (T)a.ctrl->lambda : a.lambda;
   const int slot = gid / LIN_GROUP, sub = gid % LIN_GROUP;
   const int node = slot < a.n_nodes ? (a.node_list ? a.node_list[slot] : slot) : -1;
   double chi = 0.0;
@@ -706,7 +858,7 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize_se3(LinArgs3<TO, T> a
 #pragma unroll
     for (int t = 0; t < 6; t++) bv[t] = group_sum8(bv[t]);
     if (node >= 0 && sub == 0) {
-      T add = a.lambda;
+      T add = lambda;
       if (node == a.anchor) add += (T)10000000.0;
       if (a.adds_diag && !a.adds_diag[node]) add = 0;
       TO *d = a.hvals + a.diag_off[node];
@@ -726,6 +878,7 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize_se3(LinArgs3<TO, T> a
   }
   double tot = block_sum<double, LIN_THREADS>(chi, red);
   if (threadIdx.x == 0) a.chi2_partial[blockIdx.x] = tot;
+  opt_publish_chi2_in_last_block(a, red);
 }
 
 template <typename T, typename TC = T> struct UpdArgs3 {
@@ -740,6 +893,7 @@ template <typename T, typename TC = T> struct UpdArgs3 {
   const int *err;      // sticky device error flag: a failed factorisation must not touch the state
   const int32_t *node_list;    // sharded runs: the nodes this rank updates (own + shared), n_nodes = its length
   const uint8_t *norm_counts;  // sharded runs: per node, 1 = this rank adds the node's |dx|^2 (every node counted once)
+  const int *gate;             // as UpdArgs::gate
   FinArgs fin;
 };
 
@@ -750,7 +904,8 @@ __global__ void __launch_bounds__(UPD_THREADS) k_update_se3(UpdArgs3<TO, T> a) {
   const int slot = blockIdx.x * UPD_THREADS + threadIdx.x;
   const int node = slot < a.n_nodes ? (a.node_list ? a.node_list[slot] : slot) : -1;
   double nrm = 0.0;
-  const bool failed = a.err && *a.err != 0;
+  if (a.gate && *a.gate == 0) return;
+  const bool failed = a.err && (a.err[0] != 0 || a.err[1] != 0);   // as k_update
   if (node >= 0 && !failed) {
     T d[6];
     const TO *src = a.dx_ref_in ? a.dx_ref_in + a.node_offset[node] : a.x + a.node_pcol[node];
@@ -1745,6 +1900,7 @@ __device__ __host__ __forceinline__ int big_built_cols(int nc, int M) {
 // add == 0: plain stores into the zeroed front (before the extend-adds); add == 1: on top of what k_big_build
 // gathered from the children (every destination appears once in the list, so neither form needs atomics)
 template <typename T> __global__ void __launch_bounds__(256) k_big_assemble(FactorArgs<T> a, int add) {
+  if (opt_stopped(a.err)) return;   // rr_pgo_optimize: enqueued behind the iteration that met the stop rule
   const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
   T *F = a.lvals + m.loff;
   const int M = m.nc + m.nr + 1;
@@ -1812,6 +1968,7 @@ __device__ __forceinline__ void big_build_column(const Args &a, const ChildMeta 
 // the stores are drained first (write-through: they are in L2 then) and the values read back past the CU's L1, which
 // may still hold the previous iteration's line.  Same sums as k_big_assemble: bit-identical.
 template <typename T> __global__ void __launch_bounds__(256) k_big_build(FactorArgs<T> a, int pivot_only, int with_h) {
+  if (opt_stopped(a.err)) return;   // rr_pgo_optimize: enqueued behind the iteration that met the stop rule
   const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
   const int M = m.nc + m.nr + 1;
   T *F = a.lvals + m.loff;
@@ -1840,6 +1997,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_build(FactorA
 
 // blocks of parallel edges (rare): serial, after the plain stores
 template <typename T> __global__ void k_big_assemble_dup(FactorArgs<T> a) {
+  if (opt_stopped(a.err)) return;   // rr_pgo_optimize: enqueued behind the iteration that met the stop rule
   const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
   T *F = a.lvals + m.loff;
   if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -2012,6 +2170,7 @@ __device__ __forceinline__ void diag32_factor_invert(T *Sh, int nb, T *Fblk, int
 // Loads go to clamped addresses (no branch per load); rows past the front only feed results that are
 // never stored.
 template <typename T> __global__ void __launch_bounds__(64) k_big_panel32(FactorArgs<T> a, int kb, int K0, int first) {
+  if (opt_stopped(a.err)) return;   // rr_pgo_optimize: enqueued behind the iteration that met the stop rule
   static_assert(BIG_NB == 32, "the left-looking panel kernels are written for 32-column blocks");
   using MM = Mfma16<T>;
   __shared__ T Sh[DIAG32_LDS];
@@ -2533,6 +2692,7 @@ __device__ __forceinline__ bool big_update_tile(T *F, int M, int ka, int ke, int
 // workgroup; tile t = bx (bx + 1) / 2 + by of a front's lower triangle of tiles.  gather: the launch for a front's FIRST super-panel forms the
 // tiles right of big_built_cols from the children instead of loading them (k_big_build was told to leave them out).
 template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_update(FactorArgs<T> a, int kb, int gather, const int32_t *tile_map, int n_tiles, int xcd_remap, int schur_split) {
+  if (opt_stopped(a.err)) return;   // rr_pgo_optimize: enqueued behind the iteration that met the stop rule
   using MM = Mfma16<T>;
   using UT = UpdTile<T, NT>;
   constexpr int TILE = UT::TILE;
@@ -2603,6 +2763,7 @@ template <typename T, int NT, int DEPTH = 1> __global__ void __launch_bounds__(2
 // instead of 8, and the sums are the same chunks in the same order: results are bit-identical to the pass-per-super-panel
 // form.  Same grid as k_big_update: the level's real tiles, XCD c takes the c-th contiguous eighth.
 template <typename T, int NT> __global__ void __launch_bounds__(256, (NT == 4 ? (sizeof(T) == 4 ? 2 : 1) : sizeof(T) == 4 ? RRPGO_UPD_WAVES : 2)) k_big_schur(FactorArgs<T> a, int gather, const int32_t *tile_map, int n_tiles, int xcd_remap) {
+  if (opt_stopped(a.err)) return;   // rr_pgo_optimize: enqueued behind the iteration that met the stop rule
   using MM = Mfma16<T>;
   using UT = UpdTile<T, NT>;
   constexpr int TILE = UT::TILE;
@@ -3073,6 +3234,7 @@ __global__ void __launch_bounds__(THREADS) k_solve_tasks(FactorArgs<T> a) {
 // R row slices, lanes along the rows (coalesced), a wave 4 columns at a time.  Partial sums go to
 // part[by][col0 + j] (fixed slots, summed in order by the solve kernels: deterministic).
 template <typename T> __global__ void __launch_bounds__(256) k_big_gemv_partial(FactorArgs<T> a, T *part, int64_t N, int R) {
+  if (opt_stopped(a.err)) return;   // rr_pgo_optimize: enqueued behind the iteration that met the stop rule
   __shared__ T xs[1024];
   const SnMeta m = a.task_meta[a.task_begin + blockIdx.z];
   const int nc = m.nc, nr = m.nr, M = nc + nr + 1;
@@ -3294,6 +3456,7 @@ __device__ void solve_big_front(const FactorArgs<T> &a, const SnMeta &m, T *work
 // t = y1 - sum of the row slices of k_big_gemv_partial.  Every column is owned by one workgroup per launch and
 // the launches are ordered: plain read-modify-write, fixed summation order.
 template <typename T> __global__ void __launch_bounds__(1024) k_big_solve_sp(FactorArgs<T> a, int ell, const T *part, int64_t N, int R) {
+  if (opt_stopped(a.err)) return;   // rr_pgo_optimize: enqueued behind the iteration that met the stop rule
   __shared__ T xf[BIG_SUPER];              // this super-panel: t, then x
   __shared__ T Ws[4 * 32 * 33];            // the super-panel's four W_b, staged transposed
   const SnMeta m = a.task_meta[a.task_begin + blockIdx.y];
@@ -3421,6 +3584,7 @@ template <typename T> __global__ void __launch_bounds__(1024) k_big_solve_sp(Fac
 
 template <typename T, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_solve_mid(FactorArgs<T> a, int w32, const T *part, int64_t N, int R) {
+  if (opt_stopped(a.err)) return;   // rr_pgo_optimize: enqueued behind the iteration that met the stop rule
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int s = a.task_sn[a.task_ptr[a.task_begin + blockIdx.x]];
   // w32: the front was factored by the 32-column block kernels (inverse diagonal blocks in winv); it also sums
@@ -3542,6 +3706,8 @@ template <typename T, typename TC = T> struct UpdArgs {
   const int *err;      // sticky device error flag: a failed factorisation must not touch the state
   const int32_t *node_list;    // sharded runs: the nodes this rank updates (own + shared), n_nodes = its length
   const uint8_t *norm_counts;  // sharded runs: per node, 1 = this rank adds the node's |dx|^2 (every node counted once)
+  const int *gate;             // non-null: the launch does nothing unless *gate != 0 (Levenberg-Marquardt's undo inside
+                               // rr_pgo_optimize: OptCtrl::reject, decided on the device by the launch before this one)
   FinArgs fin;
 };
 
@@ -3553,7 +3719,9 @@ __global__ void __launch_bounds__(UPD_THREADS) k_update(UpdArgs<TO, T> a) {
   const int slot = blockIdx.x * UPD_THREADS + threadIdx.x;
   const int node = slot < a.n_nodes ? (a.node_list ? a.node_list[slot] : slot) : -1;
   double nrm = 0.0;
-  const bool failed = a.err && *a.err != 0;
+  if (a.gate && *a.gate == 0) return;
+  // a failed factorisation, or a launch enqueued behind the iteration that met the stop rule (:298-300): the state stays
+  const bool failed = a.err && (a.err[0] != 0 || a.err[1] != 0);
   if (node >= 0 && !failed) {
     const int nd = a.node_dim[node];
     T d[3] = {0, 0, 0};

@@ -51,11 +51,13 @@ __global__ void __launch_bounds__(THREADS) k_factor_flow(FactorArgs<T> a, const 
   __shared__ T dinv[W16_SCR];   // inverse of the current 16 x 16 diagonal block + an identity (diag16_factor_invert_full)
   __shared__ int ticket_slot[2];
   T *smem = reinterpret_cast<T *>(smem_raw);
+  const bool stopped = opt_stopped(a.err);   // rr_pgo_optimize: enqueued behind the iteration that met the stop rule (the load is
+                                             // back before the first ticket is: nothing waits for it)
   init_w16_identity<T>(dinv, threadIdx.x, THREADS);
   if (THREADS > 256 && wave_index() == 0) __builtin_amdgcn_s_setprio(RRPGO_CHAIN_PRIO);
   for (int round = 0;; round++) {
     const int tk = lds_flow_ticket(ticket, &ticket_slot[round & 1]);
-    if (tk >= n_tasks) break;
+    if (tk >= n_tasks || stopped) break;
     const LdsFlowTask tr = tasks[tk];
     int snext = tr.sn;
     SnMeta mnext = tr.m;
@@ -76,9 +78,10 @@ __global__ void __launch_bounds__(THREADS) k_solve_flow(FactorArgs<T> a, const L
   extern __shared__ __align__(16) unsigned char smem_raw[];
   __shared__ int ticket_slot[2];
   T *smem = reinterpret_cast<T *>(smem_raw);
+  const bool stopped = opt_stopped(a.err);   // as k_factor_flow
   for (int round = 0;; round++) {
     const int tk = lds_flow_ticket(ticket, &ticket_slot[round & 1]);
-    if (tk >= n_tasks) break;
+    if (tk >= n_tasks || stopped) break;
     const LdsFlowTask tr = tasks[tk];
     int snext = tr.sn;
     SnMeta mnext = tr.m;
@@ -98,6 +101,11 @@ __global__ void __launch_bounds__(THREADS) k_solve_flow(FactorArgs<T> a, const L
 // iteration: LinArgs::zero_words, fill_words; the edge-parallel linearisation launches this instead)
 __global__ void __launch_bounds__(256) k_fill_words(unsigned *w, int n, unsigned v) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) w[i] = v;
+}
+
+// rr_pgo_set_state with the state of the previous call: the poses come back from their device-side copy (16-byte words)
+__global__ void __launch_bounds__(256) k_copy_words16(const uint4 *src, uint4 *dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
 }
 
 }  // namespace rrpgo

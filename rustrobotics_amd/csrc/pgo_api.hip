@@ -167,7 +167,11 @@ template <typename U> struct PinnedBuf {
   PinnedBuf(const PinnedBuf &) = delete;
   PinnedBuf &operator=(const PinnedBuf &) = delete;
   ~PinnedBuf() { if (p) (void)hipHostFree(p); }
-  void alloc(size_t n) { HIPCHK(hipHostMalloc((void **)&p, n * sizeof(U))); }
+  // coherent (fine-grained): a kernel's system-scope stores are visible to the polling host while the kernel runs
+  void alloc(size_t n, bool coherent = true) {
+    if (p) { (void)hipHostFree(p); p = nullptr; }
+    HIPCHK(hipHostMalloc((void **)&p, n * sizeof(U), coherent ? (hipHostMallocMapped | hipHostMallocCoherent) : hipHostMallocDefault));
+  }
   U &operator[](size_t i) const { return p[i]; }
   operator U *() const { return p; }
 };
@@ -375,7 +379,22 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<SnMeta> sn_meta_, task_meta_;
   DevBuf<ChildMeta> child_meta_;
   std::vector<int> step_solve_lds_;  // scalars of LDS the back-solve of each step needs
-  PinnedBuf<double> host_pair_;      // pinned: chi2, |dx|, and (as an int in slot 2) the device error flag
+  PinnedBuf<double> host_pair_;      // pinned: chi2, |dx|, and (as an int in slot 2) the device error flag; behind them (32-byte
+                                     // aligned) the OPT_RING slots rr_pgo_optimize's device-side loop publishes its iterations in
+  PinnedBuf<V4> state_stage_;        // rr_pgo_set_state's staging buffer (made on first use) and the event behind its last copy
+  EventHolder state_stage_ev_;
+  std::vector<double> state_in_;     // ... and the state that call was given
+  DevBuf<V4> pose_saved_;            // ... and its device-side copy
+  OptSlot *opt_ring_ = nullptr;      // = host_pair_ + 4: host-coherent, written by the device, polled by optimize_pipelined
+  DevBuf<OptCtrl> opt_ctrl_;         // the loop state of the running rr_pgo_optimize call (kernels.hip.h, OptCtrl)
+  bool opt_active_ = false;          // launches enqueued now belong to a pipelined rr_pgo_optimize call ...
+  bool opt_first_ = false;           // ... and the next linearisation is the call's first launch: it resets the loop state
+  bool opt_lambda_dev_ = false;      // ... Levenberg-Marquardt: the linearisation reads lambda from the loop state
+  int opt_publish_ = 0;              // ... LinArgs::publish of the next linearisation
+  double opt_lambda0_ = 0.01;
+  bool stop_dirty_ = false;          // the stop word err_[1] may be set: cleared before the next launch outside such a call
+  bool sync_optimize_ = false;       // RR_PGO_SYNC_OPTIMIZE=1: rr_pgo_optimize with one host round trip per iteration (the r01 - r05
+                                     // form, bit-identical: the parity alternative; handles without the LDS dataflow launches always)
   int n_lin_blocks_ = 0, n_upd_blocks_ = 0;
   bool no_graph_ = false, force_graph_ = false;   // RR_PGO_NO_GRAPH=1 / RR_PGO_FORCE_GRAPH=1 (read when the handle is created): plain launches / replays of the captured hipGraph everywhere
   bool edge_lin_ = false;           // RR_PGO_EDGE_LINEARIZE=1: k_linearize_edges (one thread per edge, atomics) instead of the pull form
@@ -400,7 +419,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     arena_.reserve((size_t)(sym.l_elems + sym.u_elems + sym.n_hvals + 8 * (int64_t)g.dim + sym.xch_elems) * sizeof(T) + (4u << 20));
     stream_.acquire();
     cmark("stream");
-    host_pair_.alloc(3);
+    host_pair_.alloc(4 + OPT_RING * sizeof(OptSlot) / sizeof(double));
+    opt_ring_ = reinterpret_cast<OptSlot *>(host_pair_.p + 4);
     cmark("pinned");
     const int N = g.n_nodes(), E = g.n_edges();
     // ---- graph arrays
@@ -567,9 +587,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     hist_.zero();
     counter_.alloc(1);
     counter_.zero();
-    err_.alloc(1);
+    err_.alloc(2);   // [0] sticky error flag, [1] stop word of the running rr_pgo_optimize call (kernels.hip.h, OptCtrl)
     err_.zero();
-    blocks_done_.alloc(1);
+    opt_ctrl_.alloc(1);
+    opt_ctrl_.zero();
+    sync_optimize_ = getenv("RR_PGO_SYNC_OPTIMIZE") != nullptr;
+    blocks_done_.alloc(2);   // [0] k_update's last-workgroup counter, [1] k_linearize's
     blocks_done_.zero();
     cmark("numeric");
     // ---- symbolic tables
@@ -1385,7 +1408,22 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     a.n_zero_words = lds_flow_ ? 2 * sym_.S + 64 : 0;
     a.fill_words = lds_flow_ ? reinterpret_cast<unsigned *>(x_ptr_) : nullptr;
     a.n_fill_words = lds_flow_ ? (int)((size_t)g_.dim * sizeof(T) / 4) : 0;
+    opt_lin_fields(a, lm);
     return a;
+  }
+  // what a linearisation inside a pipelined rr_pgo_optimize call carries: the reset of the loop state (first launch of
+  // the call), lambda from the device (Levenberg-Marquardt)
+  template <typename A> void opt_lin_fields(A &a, int lm) {
+    a.ctrl = opt_active_ ? opt_ctrl_.p : nullptr;
+    a.err = err_.p;
+    a.lambda_from_ctrl = (opt_active_ && opt_lambda_dev_ && lm) ? 1 : 0;
+    a.reset_ctrl = (opt_active_ && opt_first_) ? 1 : 0;
+    a.reset_lambda = opt_lambda0_;
+    a.reset_tolerance = 1e-4;   // :253
+    a.publish = opt_active_ ? opt_publish_ : 0;
+    a.ring_host = opt_ring_;
+    a.blocks_done = blocks_done_.p + 1;
+    opt_first_ = false;
   }
 
   FactorArgs<T> factor_args(int task_begin) {
@@ -1453,6 +1491,11 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   }
 
   void launch_linearize(double lambda, int lm, int write_system, bool reference_prior = false) {
+    if (stop_dirty_ && !opt_active_) {
+      // a pipelined rr_pgo_optimize call may have left its stop word set: every path outside such a call starts here
+      HIPCHK(hipMemsetAsync(err_.p + 1, 0, sizeof(int), stream_));
+      stop_dirty_ = false;
+    }
     pbegin();
     if (!is3d_ && edge_lin_) {
       // the edge-parallel form (experiment knob RR_PGO_EDGE_LINEARIZE): clear + prior, one thread per edge, mirror
@@ -1492,6 +1535,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       a.n_zero_words = lds_flow_ ? 2 * sym_.S + 64 : 0;
       a.fill_words = lds_flow_ ? reinterpret_cast<unsigned *>(x_ptr_) : nullptr;
       a.n_fill_words = lds_flow_ ? (int)((size_t)g_.dim * sizeof(T) / 4) : 0;
+      opt_lin_fields(a, lm);
       hipLaunchKernelGGL((k_linearize_se3<T, S>), dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_, a);
     }
     check_launch("k_linearize");
@@ -1760,11 +1804,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     }
   }
 
-  void launch_update(const T *dx_ref_in, double sign, bool write_ref, bool export_only = false, bool fused_finalize = false) {
+  void launch_update(const T *dx_ref_in, double sign, bool write_ref, bool export_only = false, bool fused_finalize = false, const int *gate = nullptr) {
     FinArgs fin{};
     if (fused_finalize) {
       fin.enabled = 1; fin.chi_partial = chi_partial_.p; fin.n_chi = n_lin_blocks_; fin.hist = hist_.p; fin.counter = counter_.p;
       fin.advance = 1; fin.ring = HIST; fin.blocks_done = blocks_done_.p;
+      if (opt_active_) { fin.ctrl = opt_ctrl_.p; fin.ring_host = opt_ring_; fin.err = err_.p; }
     }
     pbegin();
     if (!is3d_) {
@@ -1784,6 +1829,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       u.gauge_anchor = (!dx_ref_in && gauge_now_) ? g_.anchor_node : -1;
       u.export_only = export_only ? 1 : 0;
       u.err = dx_ref_in ? nullptr : err_.p;
+      u.gate = gate;
       u.fin = fin;
       hipLaunchKernelGGL((k_update<T, S>), dim3(n_upd_blocks_), dim3(UPD_THREADS), 0, stream_, u);
     } else {
@@ -1801,6 +1847,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       u.norm_partial = norm_partial_.p;
       u.export_only = export_only ? 1 : 0;
       u.err = dx_ref_in ? nullptr : err_.p;
+      u.gate = gate;
       u.fin = fin;
       hipLaunchKernelGGL((k_update_se3<T, S>), dim3(n_upd_blocks_), dim3(UPD_THREADS), 0, stream_, u);
     }
@@ -1920,6 +1967,10 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   // optimize(), pose_graph_optimization.rs:247-303
   void optimize(int solver, int iters, double *errors, int *n_errors, double *norms) override {
     if (sharded_) throw ApiError(RR_PGO_EUNSUPPORTED, "sharded handle: drive it with rr_pgo_stage + the two collectives");
+    if (lds_flow_ && !edge_lin_ && !sync_optimize_ && !prof_.on) {
+      optimize_pipelined(solver, iters, errors, n_errors, norms);
+      return;
+    }
     const double tolerance = 1e-4;  // :253
     int ne = 0;
     if (solver == RR_PGO_GAUSS_NEWTON) {
@@ -1978,6 +2029,108 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     *n_errors = ne;
   }
 
+  // ---- rr_pgo_optimize without a host round trip per iteration (graphs on the LDS dataflow launches: an iteration is a few
+  // launches of 0.1 - 0.6 ms altogether, and a stream synchronisation + two copies per iteration were ~25 us of idle device).
+  // The loop of :247-303 is cut into ITEMS, each a fixed sequence of launches whose last kernel publishes (chi2, |dx|, flags)
+  // in the host-coherent ring and -- on the device -- takes the decisions the reference takes on the host: the stop rule
+  // (:298-300, the stop word err[1]: every later launch of the call is empty or leaves the state alone), Levenberg-
+  // Marquardt's accept / reject and lambda (:275-282), the end of the call after a failed factorisation (:271).
+  //   Gauss-Newton          item k < n: iteration k (k_linearize ... k_update; chi2 of the state BEFORE the step and |dx|);
+  //                         item n: chi2 of the final state.  After a stop in iteration k, item k + 1 IS that chi2 (its
+  //                         linearisation runs, the rest is skipped): the errors are the reference's list, shifted by one
+  //   Levenberg-Marquardt   item 0: the initial error (:255); item k: iteration k - 1 = step, chi2, decision, gated undo
+  // The host keeps ONE item queued behind the one that is running (enqueueing an item takes a fraction of its run time), polls
+  // the ring, and stops enqueueing when it sees the stop: optimize(100) that stops after 6 iterations pays one skipped item.
+  void enqueue_opt_item(bool lm, long k, int iters) {
+    OptItemArgs oi{};
+    oi.chi_partial = chi_partial_.p; oi.norm_partial = norm_partial_.p; oi.n_chi = n_lin_blocks_; oi.n_norm = 0; oi.mode = 0;
+    oi.ctrl = opt_ctrl_.p; oi.ring = opt_ring_; oi.err = err_.p;
+    struct Pub { int &p; ~Pub() { p = 0; } } pub{opt_publish_};
+    if (!lm) {
+      // an iteration: its linearisation publishes only when the stop word is set (then the rest of the item is empty
+      // launches); the item behind the last iteration: chi2 only, published by the linearisation's last workgroup
+      opt_publish_ = k < iters ? 1 : 2;
+      if (k < iters) enqueue_gn_iteration();
+      else launch_linearize(0.0, 0, 0);
+      return;
+    }
+    if (k == 0) {
+      launch_linearize(0.0, 0, 0);
+      hipLaunchKernelGGL(k_opt_item, dim3(1), dim3(256), 0, stream_, oi);
+      check_launch("k_opt_item");
+      return;
+    }
+    launch_linearize(0.0, 1, 1);   // lambda: OptCtrl::lambda
+    launch_factor();
+    launch_solve();
+    launch_update(nullptr, 1.0, true);
+    launch_linearize(0.0, 0, 0);
+    oi.n_norm = n_upd_blocks_; oi.mode = 1;
+    hipLaunchKernelGGL(k_opt_item, dim3(1), dim3(256), 0, stream_, oi);
+    check_launch("k_opt_item");
+    launch_update(dx_ref_.p, -1.0, false, false, false, &opt_ctrl_.p->reject);   // :277, when the device decided so
+  }
+  // the slot of item `idx` (0-based); false: the stream went idle or failed without publishing it
+  bool wait_opt_slot(long idx, OptSlot *out) {
+    volatile OptSlot *s = opt_ring_ + idx % OPT_RING;
+    const unsigned long long want = (unsigned long long)idx + 1;
+    double t_query = now_ms();
+    for (unsigned spins = 0;; spins++) {
+      if (__atomic_load_n(const_cast<unsigned long long *>(&s->seq), __ATOMIC_ACQUIRE) == want) break;
+      __builtin_ia32_pause();
+      if ((spins & 1023u) == 1023u && now_ms() - t_query > 1.0) {
+        // every wait inside a launch is bounded, so the stream always drains: an idle stream without the slot is a lost launch
+        const hipError_t q = hipStreamQuery(stream_);
+        if (q == hipSuccess) {
+          if (__atomic_load_n(const_cast<unsigned long long *>(&s->seq), __ATOMIC_ACQUIRE) == want) break;
+          return false;
+        }
+        if (q != hipErrorNotReady) throw ApiError(RR_PGO_ENODEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+        t_query = now_ms();
+      }
+    }
+    out->chi2 = s->chi2; out->norm = s->norm; out->flags = s->flags; out->seq = want;
+    return true;
+  }
+  void optimize_pipelined(int solver, int iters, double *errors, int *n_errors, double *norms) {
+    const bool lm = solver != RR_PGO_GAUSS_NEWTON;
+    const long total = (long)iters + 1;
+    for (int i = 0; i < OPT_RING; i++) opt_ring_[i].seq = 0ull;   // (nothing of an earlier call is in flight: every call consumes what it enqueued)
+    struct Scope {   // whatever happens, the launches behind this call are plain ones again and know about the stop word
+      Engine *e;
+      ~Scope() { e->opt_active_ = false; e->opt_first_ = false; e->stop_dirty_ = true; }
+    } scope{this};
+    opt_active_ = true; opt_first_ = true; opt_lambda_dev_ = lm; opt_lambda0_ = 0.01;   // :254
+    long enq = 0, seen = 0;
+    int ne = 0, dev_err = 0;
+    bool stop_seen = false;
+    while (true) {
+      while (enq < total && enq < seen + 2 && !stop_seen) enqueue_opt_item(lm, enq++, iters);
+      if (seen >= enq) break;
+      OptSlot sl;
+      if (!wait_opt_slot(seen, &sl)) {
+        HIPCHK(hipStreamSynchronize(stream_));
+        check_device_error();
+        throw ApiError(RR_PGO_ENODEVICE, "internal: an item of rr_pgo_optimize was never published");
+      }
+      const long k = seen++;
+      const int e = sl.flags >> OPT_ERR_SHIFT;
+      if (e) { dev_err = e; stop_seen = true; continue; }
+      if (!lm) {
+        if (k == iters || (sl.flags & OPT_SKIPPED)) { if (!dev_err) errors[ne++] = sl.chi2; continue; }   // chi2 of the final state
+        errors[ne++] = sl.chi2;
+        if (norms) norms[k] = sl.norm;
+      } else {
+        if (sl.flags & OPT_SKIPPED) continue;
+        errors[ne++] = sl.chi2;
+        if (k > 0 && norms) norms[k - 1] = sl.norm;
+      }
+      if (sl.flags & OPT_STOP) stop_seen = true;
+    }
+    if (dev_err) throw_on_flag(dev_err);
+    *n_errors = ne;
+  }
+
   void get_state(double *out) override {
     const int N = g_.n_nodes();
     std::vector<V4> pose(pose_.n);
@@ -1996,9 +2149,32 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     }
   }
 
+  // (the poses go through a pinned staging buffer into a device-side copy, from there into the state, and the call does not
+  // wait for either copy; the state of the previous call is remembered, so setting the SAME state again -- restarting a run,
+  // what the benchmark does between two optimize() calls -- costs the host a comparison and one small launch instead of the
+  // conversion loop (a cosine and a sine per pose) and a host-to-device copy)
+  void restore_saved_state() {
+    const int64_t n16 = (int64_t)(pose_.n * sizeof(V4) / 16);
+    hipLaunchKernelGGL(k_copy_words16, dim3((unsigned)std::min<int64_t>((n16 + 255) / 256, 1024)), dim3(256), 0, stream_,
+                       reinterpret_cast<const uint4 *>(pose_saved_.p), reinterpret_cast<uint4 *>(pose_.p), n16);
+    check_launch("k_copy_words16");
+  }
   void set_state(const double *st) override {
     const int N = g_.n_nodes();
-    std::vector<V4> pose(pose_.n);
+    const size_t n_in = g_.node_state.size();
+    if (state_stage_.p && state_in_.size() == n_in && std::memcmp(state_in_.data(), st, n_in * sizeof(double)) == 0) {
+      restore_saved_state();
+      return;
+    }
+    if (!state_stage_.p) {
+      state_stage_.alloc(pose_.n, false);
+      state_stage_ev_.create(hipEventDisableTiming);
+      pose_saved_.alloc(pose_.n);
+    } else {
+      HIPCHK(hipEventSynchronize(state_stage_ev_));   // the previous copy out of the buffer has been made
+    }
+    state_in_.assign(st, st + n_in);
+    V4 *pose = state_stage_.p;
     for (int i = 0; i < N; i++) {
       if (is3d_) {
         const double n = std::sqrt(st[3] * st[3] + st[4] * st[4] + st[5] * st[5] + st[6] * st[6]);
@@ -2013,8 +2189,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         st += 2;
       }
     }
-    HIPCHK(hipMemcpyAsync(pose_.p, pose.data(), pose.size() * sizeof(V4), hipMemcpyHostToDevice, stream_));
-    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipMemcpyAsync(pose_saved_.p, pose, pose_.n * sizeof(V4), hipMemcpyHostToDevice, stream_));
+    HIPCHK(hipEventRecord(state_stage_ev_, stream_));
+    restore_saved_state();
   }
 
   void assemble(double lambda, int lm, std::vector<double> &hv, std::vector<double> &b) override {

@@ -184,6 +184,32 @@ class PoseGraph:
             return list(errors), list(norms[:n.value - 1])
         return list(errors)
 
+    def optimize_count(self, num_iterations):
+        """rr_pgo_optimize with the buffers of the previous call: the iterations it executed (len(errors) - 1).
+        What bench.py's timed loop calls -- optimize() itself, without this mirror's list building around it."""
+        buf = getattr(self, "_opt_buf", None)
+        if buf is None or len(buf[0]) < num_iterations + 1:
+            errors, norms, n = np.zeros(num_iterations + 1), np.zeros(max(num_iterations, 1)), C.c_int32()
+            buf = self._opt_buf = (errors, norms, n, _lib.load().rr_pgo_optimize, _dp(errors), C.byref(n), _dp(norms))
+        rc = buf[3](self._h, num_iterations, buf[4], buf[5], buf[6])
+        if rc != 0:
+            _check(rc)
+        done = buf[2].value - 1
+        self.iteration += done
+        return done
+
+    def restarter(self, state):
+        """A callable that puts the handle back into `state` (rr_pgo_set_state with everything bound once)."""
+        state = np.ascontiguousarray(state, np.float64).copy()
+        assert state.shape == (_lib.load().rr_pgo_state_len(self._h),)
+        fn, h, ptr = _lib.load().rr_pgo_set_state, self._h, _dp(state)
+
+        def restart(_keep=state):
+            rc = fn(h, ptr)
+            if rc != 0:
+                _check(rc)
+        return restart
+
     def state(self):
         out = np.zeros(_lib.load().rr_pgo_state_len(self._h))
         _check(_lib.load().rr_pgo_get_state(self._h, _dp(out)))

@@ -1129,6 +1129,48 @@ def test_iterate_async_equals_optimize_without_break(api):
     assert np.abs(g1.state() - g2.state()).max() <= 1e-12
 
 
+@pytest.mark.parametrize("solver", ["GaussNewton", "LevenbergMarquardt"])
+@pytest.mark.parametrize("name", SE2_FILES + ["sphere2500"])
+def test_optimize_with_the_stop_rule_on_the_device_is_bit_identical_to_the_host_loop(api, name, solver, monkeypatch):
+    """rr_pgo_optimize of the graphs on the LDS dataflow launches never synchronises inside the loop: the stop rule
+    (:298-300), the Levenberg-Marquardt accept / reject and lambda (:275-282) are taken on the device, iterations are
+    enqueued ahead and published through a host-coherent ring (pgo_api.hip, optimize_pipelined).  Errors, norms and the
+    state must be those of the loop with one host round trip per iteration (RR_PGO_SYNC_OPTIMIZE=1, the r01 - r05 form),
+    to the last bit: the stop at convergence, the iteration cap, a cap of zero, a second call on the converged state."""
+    Solver = getattr(api[1], solver)
+    fast = api[0].new(g2o_path(name), Solver)
+    monkeypatch.setenv("RR_PGO_SYNC_OPTIMIZE", "1")
+    slow = api[0].new(g2o_path(name), Solver)
+    monkeypatch.delenv("RR_PGO_SYNC_OPTIMIZE")
+    s0 = np.array(fast.state())
+    for iters in (0, 1, 3, 100 if solver == "GaussNewton" else 25, 4):
+        ef, nf = fast.optimize(iters, return_norms=True)
+        es, ns = slow.optimize(iters, return_norms=True)
+        assert np.array_equal(ef, es) and np.array_equal(nf, ns), (name, solver, iters, ef, es)
+        assert np.array_equal(np.array(fast.state()), np.array(slow.state()))
+    # the stop word of the last call does not leak into the other entry points of the handle
+    fast.set_state(s0); slow.set_state(s0)
+    assert np.array_equal(fast.linearize_and_solve(), slow.linearize_and_solve())
+    fast.iterate_async(2); fast.sync()
+    slow.iterate_async(2); slow.sync()
+    assert np.array_equal(np.array(fast.state()), np.array(slow.state()))
+    assert fast.global_error() == slow.global_error()
+
+
+def test_optimize_stops_enqueueing_when_the_device_reports_the_stop(api):
+    """optimize(100000) on intel converges in six iterations: the call must return after those (one skipped item behind
+    them), not after a hundred thousand empty launches."""
+    import time
+    g = api[0].new(g2o_path("intel"))
+    g.optimize(10)
+    s0 = np.array(g.state())
+    t0 = time.perf_counter()
+    e = g.optimize(100000)
+    dt = time.perf_counter() - t0
+    assert len(e) == 2 and dt < 0.05, (len(e), dt)
+    assert np.array_equal(np.array(g.state()), s0) or np.abs(np.array(g.state()) - s0).max() < 1e-6
+
+
 def test_handles_that_run_at_the_same_time_do_not_disturb_each_other(api):
     """Four handles with fronts beyond LDS iterate at the same time on their own streams: their dataflow launches
     (k_big_flow, k_big_solve_flow: workgroups that wait for flags inside a launch) share the chip with each other's, and no
