@@ -109,6 +109,19 @@ void rr_pgo_destroy(rr_pgo *h);
 /* message for the last failing call on this thread (Box<dyn Error> text) */
 const char *rr_pgo_last_error(void);
 
+/* Process-wide state the library keeps BETWEEN handles, and how to give it back (no counterpart in the reference, which
+ * keeps nothing between two PoseGraphs):
+ *   - device memory of destroyed handles (chunks of at most 64 MB, at most 256 MB in all), their HIP streams (at most 16)
+ *     and the symbolic analysis of the last four graph structures are kept for the next handle: the reference's bench
+ *     (benches/graph_slam.rs:9-10) is a loop of new + optimize(10) + drop, and hipMalloc / hipStreamCreate / the analysis
+ *     cost more than its ten iterations.  RR_PGO_ANALYSIS_CACHE=0 switches the last one off.
+ *   - rr_pgo_load_g2o / rr_pgo_create work on a few host threads of their own for the duration of the call (the parts of a
+ *     large file, the halves of the nested dissection, the candidate elimination trees): never more than the host has
+ *     cores, all joined before the call returns; a thread the host refuses is not used.
+ * rr_pgo_trim() frees everything of the first kind that no live handle is using (safe at any time from any thread; the
+ * next constructor pays for allocation and analysis again).  Returns RR_PGO_OK. */
+int rr_pgo_trim(void);
+
 /* ---- sizes / fields ------------------------------------------------------ */
 int32_t rr_pgo_num_nodes(const rr_pgo *h);  /* nodes.len()  */
 int32_t rr_pgo_num_edges(const rr_pgo *h);  /* edges.len()  */

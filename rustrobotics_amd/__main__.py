@@ -1,9 +1,10 @@
 """Non-interactive counterpart of the reference's example and bench for this path.
 
   python -m rustrobotics_amd <file.g2o> [--solver GaussNewton|LevenbergMarquardt] [--iterations 50]
-                                        [--precision f64|f32|mixed]
+                                        [--precision f64|f32|mixed] [--plot]
       = examples/mapping/pose_graph_optimization.rs:49-50   PoseGraph::new(file, solver)?.optimize(50, true, plot)
-        (the reference picks file / solver / plot from interactive menus; plotting is out of scope here)
+        (the reference picks file / solver / plot from interactive menus; --plot writes img/{name}-{iteration}-{solver}.svg
+        before the first and after every iteration, like :266-268, :294-296)
 
   python -m rustrobotics_amd <file.g2o> --bench [--repeats 20]
       = benches/graph_slam.rs:9-10   PoseGraph::new("dataset/g2o/intel.g2o", GaussNewton)?.optimize(10, false, false)
@@ -25,13 +26,14 @@ def main(argv=None):
     ap.add_argument("--solver", choices=[s.name for s in PoseGraphSolver], default="GaussNewton")
     ap.add_argument("--iterations", type=int, default=None, help="default 50 (example) / 10 (--bench)")
     ap.add_argument("--precision", choices=["f64", "f32", "mixed"], default="f64")
+    ap.add_argument("--plot", action="store_true", help="the example's third menu: write ./img/{name}-{iteration}-{solver}.svg")
     ap.add_argument("--bench", action="store_true", help="time new() + optimize(10, false, false) like benches/graph_slam.rs")
     ap.add_argument("--repeats", type=int, default=20)
     a = ap.parse_args(argv)
     solver = PoseGraphSolver[a.solver]
     if not a.bench:
         graph = PoseGraph.new(a.file, solver, precision=a.precision)
-        graph.optimize(50 if a.iterations is None else a.iterations, True, False)
+        graph.optimize(50 if a.iterations is None else a.iterations, True, a.plot)
         return 0
     iters = 10 if a.iterations is None else a.iterations
     PoseGraph.new(a.file, solver, precision=a.precision).optimize(iters, False, False)   # warm-up: library load, HIP context

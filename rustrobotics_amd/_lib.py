@@ -29,7 +29,7 @@ EXPORTS = (
     "rr_pgo_get_state", "rr_pgo_set_state", "rr_pgo_assemble", "rr_pgo_iterate_async", "rr_pgo_sync",
     "rr_pgo_get_stats", "rr_pgo_analyze_g2o", "rr_pgo_abi_version", "rr_pgo_debug_withhold", "rr_pgo_profile", "rr_pgo_synth_grid", "rr_pgo_synth_free",
     "rr_pgo_exchange_buffer", "rr_pgo_set_exchange_buffer", "rr_pgo_stage", "rr_pgo_stage_scalars", "rr_pgo_stream",
-    "rr_pgo_node_owner",
+    "rr_pgo_node_owner", "rr_pgo_trim",
 )
 
 

@@ -22,6 +22,7 @@
 #include <unordered_map>
 
 #include "host_graph.h"
+#include "host_threads.h"
 
 namespace rrpgo {
 
@@ -211,12 +212,7 @@ std::string load_g2o(const char *path, HostGraph &g, bool &io_error) {
     cut[k] = nl == std::string::npos ? text.size() : nl + 1;
   }
   std::vector<ParsedPart> parts(nparts);
-  {
-    std::vector<std::thread> pool;
-    for (int k = 1; k < nparts; k++) pool.emplace_back([&, k] { parse_part(text.data(), cut[k], cut[k + 1], parts[k]); });
-    parse_part(text.data(), cut[0], cut[1], parts[0]);
-    for (std::thread &t : pool) t.join();
-  }
+  parallel_indices(nparts, nparts, [&](int k) { parse_part(text.data(), cut[k], cut[k + 1], parts[k]); });
   std::unordered_map<uint32_t, int32_t> index_of;  // id -> dense index (lut + nodes maps of the reference)
   std::vector<uint32_t> from_id, to_id;
   size_t nn = 0, ne = 0;

@@ -28,6 +28,7 @@
 #include "flow.hip.h"
 #include "lds_flow.hip.h"
 #include "symbolic.h"
+#include "host_threads.h"
 
 #ifndef RRPGO_UPD_DEPTH
 #define RRPGO_UPD_DEPTH 1   // k-chunks of the trailing update requested ahead of the MFMAs
@@ -77,6 +78,12 @@ struct ChunkPool {
     idle.erase(idle.begin() + (long)best);
     return p;
   }
+  void trim() {
+    std::lock_guard<std::mutex> lk(mu);
+    for (Idle &c : idle) (void)hipFree(c.base);
+    idle.clear();
+    idle_bytes = 0;
+  }
   void put(int dev, char *base, size_t cap) {   // dev: the device the chunk was allocated on (the caller's current device may be another by now)
     if (cap <= kMaxChunk && dev >= 0) {
       std::lock_guard<std::mutex> lk(mu);
@@ -94,8 +101,16 @@ struct DeviceArena {
   DeviceArena() = default;
   DeviceArena(const DeviceArena &) = delete;
   DeviceArena &operator=(const DeviceArena &) = delete;
+  bool stream_failed = false;   // the engine's stream could not be synchronised when it was given back (a device fault, a launch that
+                                // never drained): work may still be touching the chunks -- they are freed (hipFree waits for the
+                                // device), not handed to the next handle
   // (the engine's stream was synchronised when it went back to its pool: declared after the arena, destroyed before it)
-  ~DeviceArena() { for (Chunk &c : chunks) chunk_pool().put(c.dev, c.base, c.cap); }
+  ~DeviceArena() {
+    for (Chunk &c : chunks) {
+      if (stream_failed) (void)hipFree(c.base);
+      else chunk_pool().put(c.dev, c.base, c.cap);
+    }
+  }
   void reserve(size_t bytes) { next_chunk = std::max(next_chunk, bytes); }
   void *take(size_t bytes) {
     for (Chunk &c : chunks) {
@@ -132,12 +147,18 @@ struct StreamPool {
     HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     return s;
   }
-  void put(hipStream_t s) {
+  bool put(hipStream_t s) {   // false: the stream could not be synchronised (it is destroyed, not pooled)
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipStreamDestroy(s); return; }
+    if (hipGetDevice(&dev) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipStreamDestroy(s); return false; }
     std::lock_guard<std::mutex> lk(mu);
     if (idle.size() < 16) idle.emplace_back(dev, s);
     else (void)hipStreamDestroy(s);
+    return true;
+  }
+  void trim() {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &p : idle) (void)hipStreamDestroy(p.second);
+    idle.clear();
   }
 };
 static StreamPool &stream_pool() { static StreamPool *p = new StreamPool; return *p; }   // leaked on purpose: outlives the runtime's teardown order
@@ -148,7 +169,8 @@ struct PooledStream {
   PooledStream() = default;
   PooledStream(const PooledStream &) = delete;
   PooledStream &operator=(const PooledStream &) = delete;
-  ~PooledStream() { if (s) stream_pool().put(s); }
+  bool *failed = nullptr;   // the arena's flag (DeviceArena::stream_failed)
+  ~PooledStream() { if (s && !stream_pool().put(s) && failed) *failed = true; }
   void acquire() { if (!s) s = stream_pool().get(); }
   operator hipStream_t() const { return s; }
 };
@@ -333,6 +355,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   // their levels as ONE launch -- BUILD tasks in place of k_big_build, Schur complements as UPDATE tasks, parent waits for child by counter
   bool xl_ = false;                 // RR_PGO_FLOW_XL=0: one build + one flow launch per level (the r03 / r04 form; bit-identical)
   int xl_max_fronts_ = 256;         // RR_PGO_FLOW_XL=<n>: graphs of at most n fronts beyond LDS
+  int xl_level_tasks_ = 1 << 20;    // RR_PGO_FLOW_XL_TASKS=<n>: ... none of whose levels has more than n tasks in that form
+  bool xl_refused_ = false;         // a level went over the task limit under the cross-level plan: planned again level by level
   DevBuf<FlowRec> xl_recs_;
   std::vector<FlowRec> xl_host_;
   DevBuf<int2> xl_child_done_;
@@ -417,6 +441,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     };
     // the factor storage dominates: one chunk sized for it and the value arrays, tables follow in 8 MB chunks
     arena_.reserve((size_t)(sym.l_elems + sym.u_elems + sym.n_hvals + 8 * (int64_t)g.dim + sym.xch_elems) * sizeof(T) + (4u << 20));
+    stream_.failed = &arena_.stream_failed;
     stream_.acquire();
     cmark("stream");
     host_pair_.alloc(4 + OPT_RING * sizeof(OptSlot) / sizeof(double));
@@ -786,6 +811,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   // A dependency always FINISHES (so also starts) before its dependant starts, hence the sorted list is a topological
   // order -- all the ticket scheme needs -- and roughly the order in which tasks become ready.
   void build_flow_levels() {
+    flow_levels_.clear();
     flow_levels_.resize(sym_.steps.size());
     solve_flow_.clear();
     solve_flow_.resize(sym_.steps.size());
@@ -810,7 +836,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
             dup = dup || sym_.fdup_ptr[sn + 1] > sym_.fdup_ptr[sn];
           }
       xl_ = lds_flow_ && !sharded_ && world_ == 1 && gather_update_ && fused_assembly_ && !gauge_ok_ && !dup && n_big > 0 && n_big <= xl_max_fronts_ &&
-            flow_max_nf_ >= (1 << 20) && flow_max_tasks_ >= (1 << 20);
+            flow_max_nf_ >= (1 << 20) && flow_max_tasks_ >= (1 << 20) && !xl_refused_;
+      if (const char *e = getenv("RR_PGO_FLOW_XL_TASKS")) xl_level_tasks_ = std::atoi(e);
     }
     // first W block of every supernode in winv (as the SnMeta table lays them out), for the marks k_flow_reset writes
     std::vector<int64_t> sn_wblk(sym_.S + 1, 0);
@@ -972,7 +999,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         }
       }
       const int n_gen = (int)gen.size();
-      if (n_gen > flow_max_tasks_) { too_many = true; return; }
+      if (n_gen > (xl_ ? std::min(flow_max_tasks_, xl_level_tasks_) : flow_max_tasks_)) { too_many = true; return; }
       const int n_flags = (int)(words - flag0);
       // who sets a flag, who waits for it
       std::vector<int> producer(n_flags, -1), cons_ptr(n_flags + 1, 0), cons;
@@ -1085,6 +1112,18 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       all_tasks[si] = std::move(tasks);
       all_fronts[si] = std::move(fronts);
       flow_levels_[si] = std::move(lvl);
+    }
+    if (xl_) {
+      // the cross-level form needs a task list for EVERY level of fronts beyond LDS (with all Schur tiles as UPDATE tasks a
+      // level has several times the tasks of its per-level plan): a level that went over the limit takes the whole graph back to
+      // one build + one flow launch per level, planned afresh with the per-level Schur split -- never a refused handle
+      bool complete = true;
+      for (size_t si = 0; si < sym_.steps.size(); si++) complete = complete && (sym_.steps[si].kind != STEP_BIG || flow_levels_[si]);
+      if (!complete) {
+        xl_refused_ = true;
+        build_flow_levels();
+        return;
+      }
     }
     // k_big_solve_flow (back substitution of wide pivot blocks as one launch per level): a ticket and counters per front in
     // the same zeroed block, and the level's task list: by step, the chain tasks first, then the folds, the groups nearest
@@ -2688,27 +2727,15 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
     auto run = [&](const std::vector<Cand> &list) {
       std::vector<Symbolic> cands(list.size());
       std::vector<std::string> errs(list.size());
-      {
-        std::vector<std::thread> pool;
-        for (size_t c = 1; c < list.size(); c++)
-          pool.emplace_back([&, c] {
-            SymbolicOptions o = so;
-            o.nd_leaf = list[c].leaf;
-            o.amalg_np = list[c].np;
-            o.split_separators = list[c].split;
-            if (shared_splits) o.nd_replay = &splits;
-            try { errs[c] = analyze(h->g, o, cands[c]); } catch (const std::exception &e) { errs[c] = e.what(); }
-          });
-        {
-          SymbolicOptions o = so;
-          o.nd_leaf = list[0].leaf;
-          o.amalg_np = list[0].np;
-          o.split_separators = list[0].split;
-          if (shared_splits) o.nd_replay = &splits;
-          errs[0] = analyze(h->g, o, cands[0]);
-        }
-        for (std::thread &t : pool) t.join();
-      }
+      // (one candidate per thread, never more threads than cores: host_threads.h)
+      parallel_indices((int)list.size(), (int)list.size(), [&](int c) {
+        SymbolicOptions o = so;
+        o.nd_leaf = list[c].leaf;
+        o.amalg_np = list[c].np;
+        o.split_separators = list[c].split;
+        if (shared_splits) o.nd_replay = &splits;
+        try { errs[c] = analyze(h->g, o, cands[c]); } catch (const std::exception &e) { errs[c] = e.what(); }
+      });
       for (size_t c = 0; c < list.size(); c++) {
         if (!errs[c].empty()) { err = errs[c]; return; }
         if (std::getenv("RR_PGO_ANALYZE_TIMES"))
@@ -2978,6 +3005,14 @@ int rr_pgo_sync(rr_pgo *h) {
 }
 
 int32_t rr_pgo_abi_version(void) { return RR_PGO_ABI_VERSION; }
+
+int rr_pgo_trim(void) {
+  chunk_pool().trim();
+  stream_pool().trim();
+  std::lock_guard<std::mutex> lk(g_analysis_mu);
+  g_analysis_cache.clear();
+  return RR_PGO_OK;
+}
 
 int rr_pgo_debug_withhold(rr_pgo *h, int32_t mode) {
   if (!h) { g_last_error = "null argument"; return RR_PGO_EINVAL; }

@@ -1,5 +1,6 @@
 // symbolic.cpp -- see symbolic.h.  Host only, runs once per graph.
 #include "symbolic.h"
+#include "host_threads.h"
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -694,10 +695,7 @@ struct NestedDissection {
       // the recording dissection has the host to itself (the candidate analyses start when it is done): the three settings of its
       // large splits side by side -- they only read the graph and the hierarchy.  (Beside eight candidate analyses this
       // oversubscribed the host: 6.7 against 4.7 ms, r05.)
-      std::thread t1([&] { run(1); }), t2([&] { run(2); });
-      run(0);
-      t1.join();
-      t2.join();
+      parallel_indices(3, 3, [&](int t) { run(t); });
     } else {
       for (int t = 0; t < n_try; t++) run(t);
     }
@@ -857,9 +855,8 @@ struct NestedDissection {
     // quarters of the time of its analysis -- run on up to four threads.  Same order as the sequential run: left, right, separator.
     if (opt.ml_nd && depth < (splits_only ? 3 : 2) && left.size() >= 150 && right.size() >= 150) {   // (alone on the host when only recording: one level more)
       std::vector<int32_t> out_right, scratch_right(N, -1);
-      std::thread other([&] { dissect(right, depth + 1, path * 2 + 1, out_right, scratch_right); });
-      dissect(left, depth + 1, path * 2, out, local_id);
-      other.join();
+      run_beside([&] { dissect(right, depth + 1, path * 2 + 1, out_right, scratch_right); },
+                 [&] { dissect(left, depth + 1, path * 2, out, local_id); });
       out.insert(out.end(), out_right.begin(), out_right.end());
     } else {
       dissect(left, depth + 1, path * 2, out, local_id);

@@ -4,9 +4,12 @@ C ABI of librr_pgo.so.  Same names, argument meaning and error behaviour:
 
   PoseGraph.new(file_path, solver)        pose_graph_optimization.rs:215-227
   PoseGraph.optimize(num_iterations, log, plot) -> list of chi2   :247-303
+  PoseGraph.plot()                        :375-431   img/{name}-{iteration}-{solver:?}.svg
 
-`plot` is accepted for signature parity and must be False (plotting is a side
-output of the reference, SURVEY.md L0, out of scope).
+`optimize(n, False, False)` is ONE rr_pgo_optimize call (the loop, its stop rule and the Levenberg-Marquardt decisions
+run on the device).  With `log` or `plot` the loop runs here, one iteration at a time through rr_pgo_linearize_solve /
+rr_pgo_update / rr_pgo_chi2 in the reference's order, so that the lines are printed and the figures written as the
+iterations complete (:258-268, :288-296).
 """
 import ctypes as C
 import enum
@@ -165,24 +168,104 @@ class PoseGraph:
 
     def optimize(self, num_iterations, log=False, plot=False, return_norms=False):
         """optimize(num_iterations, log, plot) -> Vec<f64> of chi2, :247-303"""
-        if plot:
-            raise PoseGraphError(_lib.EUNSUPPORTED, "plotting is out of scope of this backend")
+        if log or plot:
+            return self._optimize_stepwise(num_iterations, log, plot, return_norms)
         L = _lib.load()
         errors = np.zeros(num_iterations + 1)
         norms = np.zeros(max(num_iterations, 1))
         n = C.c_int32()
-        if log:  # :258-265
-            print(f"Loaded graph with {self.num_nodes} nodes and {self.num_edges} edges")
         _check(L.rr_pgo_optimize(self._h, num_iterations, _dp(errors), C.byref(n), _dp(norms)))
         errors = errors[:n.value]
         self.iteration += n.value - 1
-        if log:
-            print(f"initial error :{errors[0]:.5f}")
-            for i in range(n.value - 1):  # :288-293
-                print(f"step {i:3} : |dx| = {norms[i]:3.5f}, error = {errors[i + 1]:3.5f}")
         if return_norms:
             return list(errors), list(norms[:n.value - 1])
         return list(errors)
+
+    def _optimize_stepwise(self, num_iterations, log, plot, return_norms):
+        """:247-303 statement by statement, for the calls that print or plot between iterations."""
+        lm = self.solver == PoseGraphSolver.LevenbergMarquardt
+        tolerance, lam, norms = 1e-4, 0.01, []          # :253-255
+        last_error = self.global_error()
+        errors = [last_error]
+        if log:                                         # :258-265
+            print(f"Loaded graph with {self.num_nodes} nodes and {self.num_edges} edges")
+            print(f"initial error :{errors[-1]:.5f}", flush=True)
+        if plot:                                        # :266-268
+            self.plot()
+        for i in range(num_iterations):
+            self.iteration += 1
+            dx = self.linearize_and_solve(lam, lm)      # :271 (lambda reaches the diagonal only for Levenberg-Marquardt, :362-366)
+            self.update_nodes(dx)
+            norm_dx = float(np.sqrt(np.dot(dx, dx)))    # :273
+            error = self.global_error()
+            if lm:                                      # :275-282
+                if last_error < error:
+                    self.update_nodes(dx, -1.0)
+                    lam *= 2.0
+                else:
+                    lam /= 2.0
+            last_error = error
+            norms.append(norm_dx)
+            errors.append(error)
+            if log:                                     # :288-293
+                print(f"step {i:3} : |dx| = {norm_dx:3.5f}, error = {errors[-1]:3.5f}", flush=True)
+            if plot:                                    # :294-296
+                self.plot()
+            if norm_dx < tolerance:                     # :298-300
+                break
+        return (errors, norms) if return_norms else errors
+
+    # -- PoseGraph::plot, :375-431 -------------------------------------------------------
+    def plot_data(self):
+        """What the reference's figure shows: the poses (blue circles), the same poses joined in the order of their ids
+        (red line), the landmarks if there are any (red stars).  SE(3) graphs are `todo!()` in the reference (:398-399)."""
+        L = _lib.load()
+        d = _lib.GraphDesc()
+        _check(L.rr_pgo_get_graph(self._h, C.byref(d)))
+        n = d.n_nodes
+        kinds = np.ctypeslib.as_array(d.node_kind, (n,)) if n else np.zeros(0, np.int32)
+        if np.any(kinds == 2):
+            raise PoseGraphError(_lib.EUNSUPPORTED, "plot of an SE(3) graph: todo!() in the reference (pose_graph_optimization.rs:398-399)")
+        ids = np.ctypeslib.as_array(d.node_id, (n,)).astype(np.int64) if (n and d.node_id) else np.arange(n)
+        st = self.state()
+        offs = np.concatenate([[0], np.cumsum(np.where(kinds == 0, 3, 2))])[:-1]
+        xy = np.stack([st[offs], st[offs + 1]], 1) if n else np.zeros((0, 2))
+        pose = kinds == 0
+        order = np.argsort(ids[pose], kind="stable")
+        return {"poses": xy[pose], "poses_seq": xy[pose][order], "landmarks": xy[~pose],
+                "file": f"img/{self.name}-{self.iteration}-{self.solver.name}.svg"}
+
+    def plot(self, directory="."):
+        """Writes the figure as SVG (the reference goes through plotpy / matplotlib; here the file is written directly)."""
+        import os
+        pd = self.plot_data()
+        pts = [pd["poses"], pd["landmarks"]]
+        allp = np.concatenate([p for p in pts if len(p)]) if any(len(p) for p in pts) else np.zeros((1, 2))
+        lo, hi = allp.min(0), allp.max(0)
+        span = float(max(hi[0] - lo[0], hi[1] - lo[1], 1e-9))      # equal axes (:425)
+        size, margin = 640.0, 40.0
+        scale = (size - 2 * margin) / span
+
+        def px(p):
+            return margin + (p[0] - lo[0]) * scale, size - margin - (p[1] - lo[1]) * scale
+
+        out = [f'<svg xmlns="http://www.w3.org/2000/svg" width="{size:.0f}" height="{size:.0f}" viewBox="0 0 {size:.0f} {size:.0f}">',
+               '<rect width="100%" height="100%" fill="white"/>']
+        if len(pd["poses_seq"]):
+            path = " ".join(f"{x:.2f},{y:.2f}" for x, y in map(px, pd["poses_seq"]))
+            out.append(f'<polyline points="{path}" fill="none" stroke="red" stroke-width="1"/>')
+        for p in pd["poses"]:
+            x, y = px(p)
+            out.append(f'<circle cx="{x:.2f}" cy="{y:.2f}" r="2" fill="blue"/>')
+        for p in pd["landmarks"]:
+            x, y = px(p)
+            out.append(f'<text x="{x:.2f}" y="{y:.2f}" fill="red" font-size="12" text-anchor="middle" dominant-baseline="central">*</text>')
+        out.append("</svg>")
+        path = os.path.join(directory, pd["file"])
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write("\n".join(out) + "\n")
+        return path
 
     def optimize_count(self, num_iterations):
         """rr_pgo_optimize with the buffers of the previous call: the iterations it executed (len(errors) - 1).

@@ -1,17 +1,24 @@
 #!/bin/bash
-# HBM traffic counters (separate --pmc passes, kernel-trace only) for intel fp64 and the 1M-edge lattice fp32.
-TAG=${1:-r01}
-export TMPDIR=/tmp
+# HBM traffic counters (separate --pmc passes, kernel-trace only) of every BASELINE config: intel / M3500 / sphere2500 fp64
+# (scripts/prof_g2o.py: plain launches of whole iterations) and the 1M-edge lattice fp32 (scripts/gpu_grid_prof.py).
+# -> gpurun_out/pmc_<TAG>_<workload>_<COUNTER>.txt (scripts/pmc_summary.py), copied into profiles/<TAG>_<workload>_<COUNTER>.txt;
+# scripts/pmc_traffic_json.py TAG turns them into profiles/pmc_traffic.json.       usage: scripts/gpu_pmc.sh TAG
+TAG=${1:-r06z}
+export TMPDIR=/tmp RR_PGO_NO_GRAPH=1
 cd /tmp
 R=$GRAFT_REPO_ROOT
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_intel_$C -- python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 2 > /dev/null 2>&1
-  echo "pmc $C intel done"
-  python3 $R/scripts/pmc_summary.py $(find $R/gpurun_out/pmc_intel_$C -name "*counter_collection.csv" | head -1) > $R/gpurun_out/pmc_${TAG}_intel_$C.txt
-  RR_PGO_NO_GRAPH=1 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_grid_$C -- python3 $R/scripts/gpu_grid_prof.py 400 250 1000000 f32 3 > /dev/null 2>&1
+  for W in intel input_M3500_g2o sphere2500; do
+    S=${W/input_M3500_g2o/m3500}
+    rm -rf /tmp/pmc_$S
+    timeout -k 10 240 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_$S -- python3 $R/scripts/prof_g2o.py $W 8 > /dev/null 2>&1
+    python3 $R/scripts/pmc_summary.py $(find /tmp/pmc_$S -name "*counter_collection.csv" | head -1) > $R/gpurun_out/pmc_${TAG}_${S}_$C.txt
+    echo "pmc $C $S done"
+  done
+  rm -rf /tmp/pmc_grid
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_grid -- python3 $R/scripts/gpu_grid_prof.py 400 250 1000000 f32 3 > /dev/null 2>&1
+  python3 $R/scripts/pmc_summary.py $(find /tmp/pmc_grid -name "*counter_collection.csv" | head -1) > $R/gpurun_out/pmc_${TAG}_grid_$C.txt
   echo "pmc $C grid done"
-  python3 $R/scripts/pmc_summary.py $(find $R/gpurun_out/pmc_grid_$C -name "*counter_collection.csv" | head -1) > $R/gpurun_out/pmc_${TAG}_grid_$C.txt
-  rm -rf $R/gpurun_out/pmc_intel_$C $R/gpurun_out/pmc_grid_$C
 done
 cd $R
 head -8 gpurun_out/pmc_${TAG}_*.txt | cut -c1-170

@@ -139,6 +139,91 @@ def test_integration_md_rust_binding_matches_the_header():
         assert cfields == rfields, (sname, cfields, rfields)
 
 
+def test_loader_parses_large_files_in_parts_like_a_sequential_pass(lib, tmp_path):
+    """g2o_loader.cpp cuts files beyond 96 KB into up to four runs of whole lines parsed side by side (that
+    path had no test -- every failure case above is a one-line file).  A 1 MB file: the first failure IN FILE ORDER wins
+    with the line number a sequential pass would print, whichever part it sits in; CRLF line ends and a missing final
+    newline parse like the plain file (the reference reads with str::lines(), g2o.rs:52)."""
+    from rustrobotics_amd import _lib
+    n = 12000
+    verts = [f"VERTEX_SE2 {i} {i * 0.5:.6f} {(i % 7) * 0.25:.6f} {(i % 13) * 0.01:.6f}" for i in range(n)]
+    edges = [f"EDGE_SE2 {i} {i + 1} 0.500000 0.000000 0.010000 100.000000 0.000000 0.000000 100.000000 0.000000 400.000000" for i in range(n - 1)]
+    lines = verts + edges
+    assert sum(len(x) + 1 for x in lines) > 1000000
+    opt = _lib.Options()
+    lib.rr_pgo_default_options(C.byref(opt))
+    st = _lib.Stats()
+
+    def analyse(name, text_bytes):
+        p = tmp_path / name
+        p.write_bytes(text_bytes)
+        rc = lib.rr_pgo_analyze_g2o(str(p).encode(), C.byref(opt), C.byref(st))   # host only: parse + symbolic analysis
+        return rc, lib.rr_pgo_last_error().decode()
+
+    rc, msg = analyse("ok.g2o", ("\n".join(lines) + "\n").encode())
+    assert rc == 0, msg
+    blocks = st.nnz_h_blocks
+    assert blocks == n + (n - 1)
+    for name, data in (("crlf.g2o", ("\r\n".join(lines) + "\r\n").encode()), ("no_final_newline.g2o", "\n".join(lines).encode())):
+        rc, msg = analyse(name, data)
+        assert rc == 0 and st.nnz_h_blocks == blocks, (name, rc, msg)
+
+    def message_at_line_one(bad_line):
+        rc, msg = analyse("one.g2o", (bad_line + "\n").encode())
+        assert rc == _lib.EPARSE and msg.startswith("line 1:"), msg
+        return msg[len("line 1:"):]
+
+    bad_float = "VERTEX_SE2 999999 0 zero 0"
+    tail = message_at_line_one(bad_float)
+    for where in (10, len(lines) // 4 + 5, len(lines) // 2 + 7, len(lines) - 3):   # part 0 ... part 3
+        broken = list(lines)
+        broken[where] = bad_float
+        rc, msg = analyse("bad.g2o", ("\n".join(broken) + "\n").encode())
+        assert rc == _lib.EPARSE and msg == f"line {where + 1}:{tail}", (where, msg)
+    # two failures in different parts: the earlier line is reported; a duplicate vertex id late in the file, with its line
+    broken = list(lines)
+    broken[len(lines) - 100] = bad_float
+    broken[50] = bad_float
+    rc, msg = analyse("bad2.g2o", ("\n".join(broken) + "\n").encode())
+    assert rc == _lib.EPARSE and msg == f"line 51:{tail}", msg
+    broken = list(lines)
+    broken[n - 5] = verts[3]          # vertex id 3 again, in a later part than its first occurrence
+    rc, msg = analyse("dup.g2o", ("\n".join(broken) + "\n").encode())
+    assert rc == _lib.EPARSE and msg.startswith(f"line {n - 4}: duplicate vertex id 3"), msg
+    broken[20] = bad_float            # ... and a parse error in part 0 comes first
+    rc, msg = analyse("dup2.g2o", ("\n".join(broken) + "\n").encode())
+    assert rc == _lib.EPARSE and msg == f"line 21:{tail}", msg
+
+
+def test_integration_md_shim_keeps_the_reference_public_surface():
+    """SURVEY 8(b): the four public items of robotics::mapping on this path -- PoseGraphSolver, PoseGraph::new,
+    PoseGraph::optimize(num_iterations, log, plot), PoseGraph::plot -- with the reference's signatures
+    (pose_graph_optimization.rs:28-32, :215, :247-252, :375), in the Rust shim of INTEGRATION.md section 3 AND in the Python
+    mirror; the shim's stepping loop calls only entry points the extern block declares."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    shim = md[md.index("// src/mapping/pose_graph_optimization.rs"):]
+    shim = shim[:shim.index("```")]
+    flat = re.sub(r"\s+", " ", re.sub(r"//[^\n]*", "", shim))
+    assert "pub enum PoseGraphSolver { GaussNewton, LevenbergMarquardt }" in flat
+    assert "pub struct PoseGraph<'a>" in flat and "impl<'a> PoseGraph<'a>" in flat
+    assert "pub fn new(file_path: &str, solver: PoseGraphSolver) -> Result<PoseGraph, Box<dyn Error>>" in flat
+    assert "pub fn optimize(&mut self, num_iterations: usize, log: bool, plot: bool) -> Result<Vec<f64>, Box<dyn Error>>" in flat
+    assert "pub fn plot(&self) -> Result<(), Box<dyn Error>>" in flat
+    assert 'format!("img/{}-{}-{:?}.svg", self.name, self.iteration, self.solver)' in flat      # :428
+    sys_block = md[md.index("// src/mapping/rr_pgo_sys.rs"):]
+    declared = set(re.findall(r"pub fn (rr_pgo_\w+)", sys_block[:sys_block.index("```")]))
+    used = set(re.findall(r"sys::(rr_pgo_\w+)\(", shim))
+    assert used and used <= declared, used - declared
+    assert {"rr_pgo_optimize", "rr_pgo_linearize_solve", "rr_pgo_update", "rr_pgo_chi2", "rr_pgo_get_state", "rr_pgo_get_graph"} <= used
+    # the Python mirror: same names, same argument order
+    import inspect
+    from rustrobotics_amd import PoseGraph, PoseGraphSolver
+    assert [s.name for s in PoseGraphSolver] == ["GaussNewton", "LevenbergMarquardt"]
+    assert list(inspect.signature(PoseGraph.optimize).parameters)[:4] == ["self", "num_iterations", "log", "plot"]
+    assert list(inspect.signature(PoseGraph.new).parameters)[:2] == ["file_path", "solver"]
+    assert callable(PoseGraph.plot)
+
+
 def _load(lib, path):
     from rustrobotics_amd import _lib
     opt = _lib.Options()

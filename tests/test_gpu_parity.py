@@ -921,6 +921,24 @@ def test_cross_level_flow_launch_is_bit_identical_to_one_launch_per_level(api, n
         assert np.array_equal(np.array(alt.state()), s2), env
 
 
+@pytest.mark.parametrize("name", ["sphere2500", "torus3D"])
+def test_cross_level_plan_that_exceeds_the_task_limit_falls_back_to_one_launch_per_level(api, name, monkeypatch):
+    """The cross-level form turns every Schur tile into an UPDATE task, so a level can exceed the task limit that its per-level
+    plan respects: the handle must then be built with one build + one flow launch per level -- never refused --
+    and give the bits of RR_PGO_FLOW_XL=0.  RR_PGO_FLOW_XL_TASKS lowers the limit of the cross-level plan only."""
+    xl = api[0].new(g2o_path(name))
+    monkeypatch.setenv("RR_PGO_FLOW_XL_TASKS", "40")
+    fell_back = api[0].new(g2o_path(name))
+    monkeypatch.delenv("RR_PGO_FLOW_XL_TASKS")
+    monkeypatch.setenv("RR_PGO_FLOW_XL", "0")
+    per_level = api[0].new(g2o_path(name))
+    monkeypatch.delenv("RR_PGO_FLOW_XL")
+    assert fell_back.stats()["n_launches_per_iter"] == per_level.stats()["n_launches_per_iter"] > xl.stats()["n_launches_per_iter"]
+    e1, e2 = fell_back.optimize(4), per_level.optimize(4)
+    assert np.array_equal(e1, e2) and np.array_equal(np.array(fell_back.state()), np.array(per_level.state()))
+    assert np.array_equal(e1, xl.optimize(4))   # (and the cross-level launch is bit-identical to both)
+
+
 @pytest.mark.parametrize("name", ["intel", "dlr", "sphere2500"])
 def test_level_set_dissection_of_a_small_graph_gives_the_same_answer(api, oracle, name, monkeypatch):
     """RR_PGO_ML_ND=0: graphs of up to 6000 poses dissected by breadth-first level sets and coordinate cuts only (the r01 - r04
@@ -1504,6 +1522,43 @@ def test_cli_mirrors_the_reference_example_output():
     assert lines[1].startswith("initial error :3030.31304")
     assert lines[2].startswith("step   0 : |dx| = ") and "error = " in lines[2]
     assert lines[-1].split("error = ")[1].startswith("474.0995")
+    # the log lines come out as the iterations complete, each from the calls the reference makes in that place
+    # (linearize_and_solve, update_nodes, global_error): the list is the one rr_pgo_optimize returns
+    from rustrobotics_amd import PoseGraph
+    errs = PoseGraph.new(g2o_path("simulation-pose-landmark")).optimize(50)
+    assert len(lines) == 2 + len(errs) - 1
+    for line, e in zip(lines[2:], errs[1:]):
+        assert abs(float(line.split("error = ")[1]) - e) <= 1e-5 * max(1.0, abs(e)) + 6e-6
     b = subprocess.run([sys.executable, "-m", "rustrobotics_amd", g2o_path("intel"), "--bench", "--repeats", "3"],
                        capture_output=True, text=True, cwd=root, timeout=300)
     assert b.returncode == 0 and "final chi2 359.996" in b.stdout
+
+
+@pytest.mark.parametrize("solver", ["GaussNewton", "LevenbergMarquardt"])
+def test_optimize_with_log_and_plot_steps_like_the_reference(api, solver, tmp_path, monkeypatch, capsys):
+    """optimize(n, log = true, plot = true), :247-303 with :258-268 and :288-296: one figure before the first iteration
+    and one after every iteration, named img/{name}-{iteration}-{solver:?}.svg (:428), log lines in between; the errors
+    are those of the single rr_pgo_optimize call (same kernels; |dx| is summed on the host here, on the device there)."""
+    Solver = getattr(api[1], solver)
+    monkeypatch.chdir(tmp_path)
+    name = "simulation-pose-landmark"
+    g = api[0].new(g2o_path(name), Solver)
+    errs, norms = g.optimize(25, True, True, return_norms=True)
+    ref_e, ref_n = api[0].new(g2o_path(name), Solver).optimize(25, return_norms=True)
+    assert len(errs) == len(ref_e)
+    np.testing.assert_allclose(errs, ref_e, rtol=1e-9)
+    np.testing.assert_allclose(norms, ref_n, rtol=1e-9, atol=1e-12)
+    files = sorted(os.listdir(tmp_path / "img"), key=lambda f: int(f.split("-")[-2]))
+    assert files == [f"{name}-{i}-{solver}.svg" for i in range(len(errs))]
+    out = capsys.readouterr().out.strip().splitlines()
+    assert out[0] == "Loaded graph with 77 nodes and 297 edges" and out[1].startswith("initial error :3030.31304")
+    assert len(out) == 2 + len(errs) - 1 and out[2].startswith("step   0 : |dx| = ")
+    # the figure's content: 77 nodes = poses + landmarks, the pose sequence in id order, landmarks present in this file
+    pd = g.plot_data()
+    arrays = g.graph_arrays()
+    assert len(pd["poses"]) == int((arrays[0] == 0).sum()) and len(pd["landmarks"]) == int((arrays[0] == 1).sum()) > 0
+    assert sorted(map(tuple, pd["poses_seq"])) == sorted(map(tuple, pd["poses"]))
+    svg = open(tmp_path / "img" / files[-1]).read()
+    assert svg.count("<circle") == len(pd["poses"]) and svg.count(">*</text>") == len(pd["landmarks"]) and "<polyline" in svg
+    with pytest.raises(api[2]):   # SE(3): todo!() in the reference (:398-399)
+        api[0].new(g2o_path("sphere2500")).plot()
