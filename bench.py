@@ -246,14 +246,21 @@ class SetupFailed(RuntimeError):
 class Ctx:
     """torch / torch.distributed plumbing shared by every measurement of this process."""
 
-    def __init__(self, rank, local_rank, world):
+    def __init__(self, rank, local_rank, world, host_staged=False):
         import torch
         self.torch, self.rank, self.local_rank, self.world = torch, rank, local_rank, world
         self.dist = None
+        # host_staged (--collectives host-staged): the ranks share GPUs, RCCL cannot connect them -- the group is gloo, its
+        # control tensors live on the CPU, the data-path collectives go through host memory (sharding.HostStagedShardDriver)
+        self.host_staged = host_staged
+        self.ctl_device = "cpu" if host_staged else "cuda"
         if world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            if host_staged:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             self.dist = dist
 
     def barrier(self):
@@ -264,14 +271,14 @@ class Ctx:
         """True iff `ok` on every rank.  A collective: call it only where every rank arrives whatever happened."""
         if not self.dist:
             return bool(ok)
-        t = self.torch.tensor([0 if ok else 1], dtype=self.torch.int32, device="cuda")
+        t = self.torch.tensor([0 if ok else 1], dtype=self.torch.int32, device=self.ctl_device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return int(t.item()) == 0
 
     def all_max(self, x):
         if not self.dist:
             return x
-        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.ctl_device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -310,11 +317,14 @@ def measure_single(ctx, workload, precision, steps, warmup, through="optimize"):
 def measure_sharded(ctx, workload, precision, steps, warmup, force_collectives=False):
     """ONE graph sharded over the ranks: rr_pgo_stage + RCCL collectives issued on the library's own stream
     (rustrobotics_amd.sharding.TorchShardDriver); no host synchronisation inside an iteration."""
-    from rustrobotics_amd.sharding import TorchShardDriver
+    from rustrobotics_amd.sharding import HostStagedShardDriver, TorchShardDriver
     drv, err = None, None
     try:
-        drv = TorchShardDriver(workload_arrays(workload), precision, ctx.local_rank, ctx.rank, ctx.world,
-                               ctx.dist, force_collectives=force_collectives)
+        if ctx.host_staged and ctx.world > 1:
+            drv = HostStagedShardDriver(workload_arrays(workload), precision, ctx.local_rank, ctx.rank, ctx.world, ctx.dist)
+        else:
+            drv = TorchShardDriver(workload_arrays(workload), precision, ctx.local_rank, ctx.rank, ctx.world,
+                                   ctx.dist, force_collectives=force_collectives)
     except Exception as e:   # noqa: BLE001 -- agreed on below, before any rank enters a data-path collective
         err = e
     if not ctx.all_ok(err is None):
@@ -415,7 +425,7 @@ def secondary_entry(ctx, workload, precision, steps, warmup, sharded, with_cpu=T
     rec["norm_dx"] = [float(n) for n in norms]
     rec["chi2_final"] = float(errors[-1])
     rec["stopped_by_reference_rule"] = bool(len(norms) > 0 and norms[-1] < 1e-4)   # :298-300
-    if workload == LATTICE:
+    if workload.startswith("grid:"):
         rec["role"] = ("configs[3] primary: fp32 factor + solve with the fp64 gradient (meets the reference's stop rule)" if precision == "mixed"
                        else "configs[3] beside the primary: pure fp32 as BASELINE words it")
     gold = golden_chi2(workload)
@@ -458,6 +468,13 @@ def main():
                     help="with --shard on ONE GPU: P ranks emulated in this process (P handles, device copies as the two "
                          "collectives) -- exercises the N > 1 record shape and the sharded numerics; the time is P ranks "
                          "serialised on one GPU, not a scaling number")
+    ap.add_argument("--collectives", default="rccl", choices=["rccl", "host-staged"],
+                    help="N > 1 only.  rccl (default): one rank per GPU, torch.distributed backend nccl = RCCL over xGMI.  host-staged: the "
+                         "ranks may SHARE GPUs (rank r uses device r mod the number of devices): the group is gloo and the two "
+                         "collectives of the sharded legs go through host memory -- a rehearsal of the whole N > 1 plan on a box "
+                         "with fewer GPUs than ranks; its times are not scaling numbers and the record says so")
+    ap.add_argument("--lattice", default=LATTICE, metavar="grid:WxH[:E]",
+                    help="the lattice of the secondary legs (default: BASELINE configs[3]); tests shrink it")
     ap.add_argument("--shard", action="store_true",
                     help="shard ONE graph (--workload) over the ranks as the headline line (strong scaling); with one rank "
                          "the collectives still run, over a one-rank RCCL group")
@@ -478,6 +495,9 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    host_staged = args.collectives == "host-staged" and world > 1
+    if host_staged:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if args.shard and world == 1 and args.emulate <= 1:   # a one-rank RCCL group so that the collective path really executes
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -489,7 +509,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         ctx.dist = dist
     else:
-        ctx = Ctx(rank, local_rank, world)
+        ctx = Ctx(rank, local_rank, world, host_staged=host_staged)
 
     out = None
     if args.shard and args.emulate > 1:
@@ -605,6 +625,9 @@ def main():
                     out["speedup_vs_cpu_baseline_edges_iters"] = out["edges_iters_per_s"] / cb["edges_iters_per_s"]
         del g
 
+    if out is not None and host_staged:
+        out["rehearsal"] = (f"--collectives host-staged: {world} ranks on {torch.cuda.device_count()} GPU(s), gloo group, the sharded legs' "
+                            f"collectives staged through host memory -- the N > 1 plan end to end, NOT a scaling measurement")
     # ---- the other BASELINE configs, same contract (skipped when a non-default workload was asked for)
     if not args.no_secondary and not args.shard and args.workload == "intel" and args.precision == "f64":
         sec = []
@@ -630,11 +653,11 @@ def main():
         # 5e-3 .. 1e-2), mixed (fp64 state / gradient / chi2, fp32 factor and solve: the arithmetic that costs anything IS fp32)
         # does, at the same speed -- mixed is the config's primary record, pure fp32 stands beside it; each says which
         # (`stopped_by_reference_rule`, `role`)
-        plan = [("m3500", "f64", False), (LATTICE, "mixed", False), (LATTICE, "f32", False), ("sphere2500", "f64", False)]
+        plan = [("m3500", "f64", False), (args.lattice, "mixed", False), (args.lattice, "f32", False), ("sphere2500", "f64", False)]
         if world > 1:   # multi-GPU legs of configs[3] and configs[4]: ONE graph over all ranks
-            plan = [(LATTICE, "mixed", True), (LATTICE, "f32", True), ("sphere2500", "f64", True)]
+            plan = [(args.lattice, "mixed", True), (args.lattice, "f32", True), ("sphere2500", "f64", True)]
         elif os.environ.get("RR_PGO_BENCH_NCCL1", "1") != "0":
-            plan.append((LATTICE, "mixed", "nccl1"))
+            plan.append((args.lattice, "mixed", "nccl1"))
         for workload, precision, sharded in plan:
             if sharded == "nccl1":
                 # the sharded protocol over a ONE-rank RCCL group: same stages and collectives as at N > 1, so the

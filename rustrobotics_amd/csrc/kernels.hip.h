@@ -274,6 +274,17 @@ struct FinArgs {
   OptSlot *ring_host;          // ... and the host-visible ring the iteration is published in
   int *err;                    // the engine's error block: [0] sticky error flag, [1] stop word
 };
+// Gauss-Newton inside rr_pgo_optimize (one thread): ct = chi2 of the state BEFORE this step (errors[i], :286), sqrt(nt) = |dx|
+// (:273); the stop rule, and the end of the call after a failed factorisation
+__device__ __forceinline__ void finalize_publish(const FinArgs &f, double ct, double nt) {
+  if (!f.ctrl) return;
+  const int e = f.err[0];
+  if (f.err[1]) return;   // enqueued behind the iteration that met the stop rule: this item's linearisation has published chi2 of the final state
+  const double nrm = sqrt(nt);
+  const bool stop = e != 0 || nrm < f.ctrl->tolerance;   // :298-300; a failed factorisation ends the call (:271)
+  if (stop) f.err[1] = 1;
+  opt_publish(f.ctrl, f.ring_host, ct, nrm, (stop && !e ? OPT_STOP : 0) | (e << OPT_ERR_SHIFT));
+}
 template <int THREADS>
 __device__ __forceinline__ void finalize_in_last_block(const FinArgs &f, const double *norm_partial, int n_norm, double *red) {
   __shared__ int is_last;
@@ -295,18 +306,7 @@ __device__ __forceinline__ void finalize_in_last_block(const FinArgs &f, const d
     f.hist[2 * slot + 1] = sqrt(nt);
     if (f.advance) *f.counter = *f.counter + 1;
     *f.blocks_done = 0;
-    if (f.ctrl) {
-      // Gauss-Newton inside rr_pgo_optimize: ct = chi2 of the state BEFORE this step (errors[i], :286), sqrt(nt) = |dx| (:273)
-      const int e = f.err[0];
-      if (f.err[1]) {
-        // enqueued behind the iteration that met the stop rule: this item's linearisation has published chi2 of the final state
-      } else {
-        const double nrm = sqrt(nt);
-        const bool stop = e != 0 || nrm < f.ctrl->tolerance;   // :298-300; a failed factorisation ends the call (:271)
-        if (stop) f.err[1] = 1;
-        opt_publish(f.ctrl, f.ring_host, ct, nrm, (stop && !e ? OPT_STOP : 0) | (e << OPT_ERR_SHIFT));
-      }
-    }
+    finalize_publish(f, ct, nt);
   }
 }
 
@@ -3713,6 +3713,46 @@ template <typename T, typename TC = T> struct UpdArgs {
 
 // update_nodes (:229-245) + |dx|^2 (:273).  The step of a failed factorisation (non-positive pivot) is NOT
 // applied: the reference returns Err from solve() at :271 before update_nodes(), its state stays intact.
+// one node's update; returns its |dx|^2 term
+template <typename TO, typename T>
+__device__ __forceinline__ double update_node(const UpdArgs<TO, T> &a, int node) {
+  double nrm = 0.0;
+  const int nd = a.node_dim[node];
+  T d[3] = {0, 0, 0};
+  const TO *src = a.dx_ref_in ? a.dx_ref_in + a.node_offset[node] : a.x + a.node_pcol[node];
+  for (int t = 0; t < nd; t++) d[t] = (T)src[t];
+  auto p = a.pose[node];
+  const bool regauge = a.gauge_anchor >= 0 && !a.dx_ref_in;
+  if (regauge) {
+    // dx = y - V c, c = y_anchor, rotation field about the anchor's position (see "gauge transfer")
+    const TO *ya = a.x + a.node_pcol[a.gauge_anchor];
+    const T c0 = (T)ya[0], c1 = (T)ya[1], c2 = (T)ya[2];
+    const auto pa = a.pose[a.gauge_anchor];
+    d[0] = d[0] - c0 + c2 * (p.y - pa.y);
+    d[1] = d[1] - c1 - c2 * (p.x - pa.x);
+    if (nd == 3) d[2] -= c2;
+    if (node == a.gauge_anchor) { d[0] = 0; d[1] = 0; d[2] = 0; }
+  }
+  if (a.dx_ref_out) {
+    TO *dst = a.dx_ref_out + a.node_offset[node];
+    for (int t = 0; t < nd; t++) dst[t] = (TO)d[t];
+  }
+  if (!a.export_only && !(regauge && node == a.gauge_anchor)) {
+    if (!a.norm_counts || a.norm_counts[node])
+      for (int t = 0; t < nd; t++) nrm += (double)d[t] * (double)d[t];
+    p.x += a.sign * d[0];
+    p.y += a.sign * d[1];
+    if (nd == 3) {  // rotation *= UnitComplex::from_angle(dtheta), no renormalisation (:236)
+      const T c = cos(a.sign * d[2]), s = sin(a.sign * d[2]);
+      const T re = p.z * c - p.w * s, im = p.z * s + p.w * c;
+      p.z = re;
+      p.w = im;
+    }
+    a.pose[node] = p;
+  }
+  return nrm;
+}
+
 template <typename TO, typename T>
 __global__ void __launch_bounds__(UPD_THREADS) k_update(UpdArgs<TO, T> a) {
   __shared__ double red[UPD_THREADS / 64];
@@ -3722,41 +3762,7 @@ __global__ void __launch_bounds__(UPD_THREADS) k_update(UpdArgs<TO, T> a) {
   if (a.gate && *a.gate == 0) return;
   // a failed factorisation, or a launch enqueued behind the iteration that met the stop rule (:298-300): the state stays
   const bool failed = a.err && (a.err[0] != 0 || a.err[1] != 0);
-  if (node >= 0 && !failed) {
-    const int nd = a.node_dim[node];
-    T d[3] = {0, 0, 0};
-    const TO *src = a.dx_ref_in ? a.dx_ref_in + a.node_offset[node] : a.x + a.node_pcol[node];
-    for (int t = 0; t < nd; t++) d[t] = (T)src[t];
-    auto p = a.pose[node];
-    const bool regauge = a.gauge_anchor >= 0 && !a.dx_ref_in;
-    if (regauge) {
-      // dx = y - V c, c = y_anchor, rotation field about the anchor's position (see "gauge transfer")
-      const TO *ya = a.x + a.node_pcol[a.gauge_anchor];
-      const T c0 = (T)ya[0], c1 = (T)ya[1], c2 = (T)ya[2];
-      const auto pa = a.pose[a.gauge_anchor];
-      d[0] = d[0] - c0 + c2 * (p.y - pa.y);
-      d[1] = d[1] - c1 - c2 * (p.x - pa.x);
-      if (nd == 3) d[2] -= c2;
-      if (node == a.gauge_anchor) { d[0] = 0; d[1] = 0; d[2] = 0; }
-    }
-    if (a.dx_ref_out) {
-      TO *dst = a.dx_ref_out + a.node_offset[node];
-      for (int t = 0; t < nd; t++) dst[t] = (TO)d[t];
-    }
-    if (!a.export_only && !(regauge && node == a.gauge_anchor)) {
-      if (!a.norm_counts || a.norm_counts[node])
-        for (int t = 0; t < nd; t++) nrm += (double)d[t] * (double)d[t];
-      p.x += a.sign * d[0];
-      p.y += a.sign * d[1];
-      if (nd == 3) {  // rotation *= UnitComplex::from_angle(dtheta), no renormalisation (:236)
-        const T c = cos(a.sign * d[2]), s = sin(a.sign * d[2]);
-        const T re = p.z * c - p.w * s, im = p.z * s + p.w * c;
-        p.z = re;
-        p.w = im;
-      }
-      a.pose[node] = p;
-    }
-  }
+  if (node >= 0 && !failed) nrm = update_node(a, node);
   if (a.export_only) return;
   double tot = block_sum<double, UPD_THREADS>(nrm, red);
   if (threadIdx.x == 0) a.norm_partial[blockIdx.x] = tot;

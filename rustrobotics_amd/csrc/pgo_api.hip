@@ -319,16 +319,16 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<T> xch_own_;               // exchange buffer 0 (boundary update matrices) unless the caller binds one
   T *xch_ = nullptr, *x_ptr_ = nullptr;
   int solve_threads_max_ = 512;     // RR_PGO_SOLVE_THREADS=<n>: cap of the back-substitution workgroup size
-  int factor_threads_max_ = 1024;   // 16-wave workgroups for steps whose fronts exceed 128 rows (RR_PGO_FACTOR_512=1: 8 waves)
+  static constexpr int factor_threads_max_ = 1024;   // 16-wave workgroups for steps whose fronts exceed 128 rows (8 waves: intel 4134 against 4318 it/s, r04)
   struct UpdMap { int64_t offset; int n_tiles; };
   std::vector<std::vector<UpdMap>> upd_maps_;   // [step][super-panel]: slice of upd_map_buf_ (k_big_update's tile list)
   std::vector<UpdMap> schur_maps_;              // [step]: k_big_schur's tile list
   static constexpr int schur_tile_ = 64;        // k_big_schur's tile edge (128 x 128 tiles, k_big_schur<T, 4>: measured 13 % slower, r03)
   bool schur_split_ = true;                     // RR_PGO_SCHUR_SPLIT=0: every super-panel's update reaches through the Schur complement (r02)
   DevBuf<int32_t> upd_map_buf_;
-  bool xcd_remap_ = true;           // RR_PGO_XCD_REMAP=0: k_big_update's tiles in dispatch order instead of one contiguous eighth of the launch per XCD
+  static constexpr bool xcd_remap_ = true;   // k_big_update / k_big_schur: one contiguous eighth of the tile list per XCD (dispatch order: FETCH_SIZE 96 against 37 MB per launch, r02)
   int sp_solve_min_nc_ = 256;       // back substitution: levels whose widest pivot block has at least this many columns run k_big_solve_sp (RR_PGO_SP_SOLVE_MIN)
-  bool gather_update_ = true;       // big fronts: k_big_build builds the pivot columns only, a front's first trailing update gathers its tiles from the children (RR_PGO_NO_GATHER_UPDATE=1: whole fronts are built)
+  static constexpr bool gather_update_ = true;   // big fronts: k_big_build builds the pivot columns only, a front's first trailing update gathers its tiles from the children
   // k_big_flow (flow.hip.h): levels of at most flow_max_nf_ big fronts run as ONE launch of ticket-ordered tile tasks
   struct FlowLevel {
     DevBuf<FlowRec> tasks;     // every task with a copy of its front's records (one 128-byte load per task)
@@ -362,8 +362,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<int2> xl_child_done_;
   DevBuf<unsigned long long> xl_trace_;   // diagnostic builds only
   int64_t xl_ticket_word_ = 0;
-  bool fused_assembly_ = true;      // RR_PGO_SPLIT_ASSEMBLY=1: H entries and rhs of the fronts beyond LDS by a k_big_assemble launch per level
-  bool flow_deep_ = true;           // RR_PGO_FLOW_DEEP=0: no look-back over the previous super-panel (fast mode; see build_flow_levels)
+  static constexpr bool fused_assembly_ = true;   // H entries and rhs of the fronts beyond LDS by k_big_build's own waves when its launch is a single round of workgroups (else a k_big_assemble launch)
+  static constexpr bool flow_deep_ = true;   // fast mode: panel steps of blocks 0 and 1 look back over the previous super-panel (see build_flow_levels)
   bool flow_exact_ = false;         // RR_PGO_FLOW_EXACT=1: bit-identical to the launch sequence (tile (0, 0) forms the next super-panel's first block)
   struct SolveFlowLevel { DevBuf<SolveFlowFront> fronts; DevBuf<SolveFlowTask> tasks; int n_tasks = 0; int64_t ticket_word = 0; };
   std::vector<std::unique_ptr<SolveFlowLevel>> solve_flow_;   // per step: k_big_solve_flow's tasks and counters (null: k_big_solve_sp launches)
@@ -585,20 +585,13 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       for (const Step &st : sym.steps) any_big = any_big || st.kind != STEP_TASKS;
       gemv_part_.alloc(any_big ? (size_t)kGemvSlices * g.dim : 4);
     }
-    // LDS fronts: 16-wave workgroups for fronts of more than 128 rows (RR_PGO_FACTOR_512=1: 8 waves;
-    // intel.g2o r04: 4318 / 4134 it/s with 16 / 8 waves)
-    factor_threads_max_ = getenv("RR_PGO_FACTOR_512") ? 512 : 1024;
     if (const char *e = getenv("RR_PGO_SOLVE_THREADS")) solve_threads_max_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_SP_SOLVE_MIN")) sp_solve_min_nc_ = std::atoi(e);
-    if (const char *e = getenv("RR_PGO_XCD_REMAP")) xcd_remap_ = std::atoi(e) != 0;
     if (const char *e = getenv("RR_PGO_SCHUR_SPLIT")) schur_split_ = std::atoi(e) != 0;
-    gather_update_ = getenv("RR_PGO_NO_GATHER_UPDATE") == nullptr;
     no_graph_ = getenv("RR_PGO_NO_GRAPH") != nullptr;
     force_graph_ = getenv("RR_PGO_FORCE_GRAPH") != nullptr && !no_graph_;
-    fused_assembly_ = getenv("RR_PGO_SPLIT_ASSEMBLY") == nullptr;
     if (const char *e = getenv("RR_PGO_FLOW")) flow_max_nf_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_FLOW_EXACT")) flow_exact_ = std::atoi(e) != 0;
-    if (const char *e = getenv("RR_PGO_FLOW_DEEP")) flow_deep_ = std::atoi(e) != 0;
     if (const char *e = getenv("RR_PGO_FLOW_TASKS")) flow_max_tasks_ = std::atoi(e);
     if (const char *e = getenv("RR_PGO_SOLVE_FLOW")) solve_flow_on_ = std::atoi(e) != 0;
     if (const char *e = getenv("RR_PGO_FLOW_SCHUR_MIN")) flow_schur_min_ = std::atoi(e);
@@ -1035,7 +1028,6 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         // half the launch's workgroups: the model's tiles are cheaper than loaded ones, and a chain step drawn a little
         // early only waits, while one drawn late stalls its front (measured: 128 ... 256 slots equal, 512 1 % slower)
         int P = std::max(1, flow_grid_ / 2);
-        if (const char *e = getenv("RR_PGO_FLOW_SLOTS")) P = std::max(1, std::atoi(e));   // experiments: a large value = order of earliest starts
         std::vector<float> ftime(n_flags, 0.f);
         std::vector<int> pending(n_gen, 0);
         for (int i = 0; i < n_gen; i++) for_each_need(i, [&](int f, float) { if (producer[f] >= 0) pending[i]++; });

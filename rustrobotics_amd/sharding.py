@@ -152,6 +152,43 @@ class HostStagedCollectives:
         self.torch.cuda.synchronize()
 
 
+class HostStagedShardDriver:
+    """One rank of a torch.distributed group WITHOUT RCCL between the ranks (backend gloo): TorchShardDriver's interface over
+    HostStagedCollectives.  `bench.py --collectives host-staged` runs its N > 1 plan through this when several ranks share one
+    GPU -- the rehearsal of the multi-GPU run a one-GPU box allows: same handles (opt.world_size = N), same stages, same
+    buffers, same record; only the transport of the two collectives differs (and synchronises with the host)."""
+
+    def __init__(self, arrays, precision, device, rank, world, dist):
+        import torch
+        self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
+        self.graph = PoseGraph.from_arrays(*arrays, precision=precision, device=device, rank=rank, world_size=world, sharded=True)
+        self.coll = HostStagedCollectives(torch, dist, self.graph)
+        self.use_dist = True
+
+    def run_steps(self, k):
+        g, c = self.graph, self.coll
+        for _ in range(k):
+            g.stage(0)
+            c.all_gather_boundary()
+            g.stage(1)
+            c.all_reduce_scalars()
+
+    def optimize(self, num_iterations, tolerance=1e-4):
+        return gauss_newton([self.graph], num_iterations, self.coll, tolerance)
+
+    def global_error(self):
+        return global_error([self.graph], self.coll)
+
+    def exchange_bytes_per_step(self):
+        x = self.coll.xch
+        return {"all_gather_bytes_total": int(x.numel() * x.element_size()),
+                "all_gather_bytes_contributed_per_rank": int(self.coll.chunk * x.element_size()), "all_reduce_bytes": 16}
+
+    def collectives_description(self):
+        return ("per iteration: all-gather of the boundary update matrices + all-reduce(sum) of two doubles, STAGED THROUGH HOST MEMORY "
+                "over gloo (ranks that share one GPU: a rehearsal of the protocol, not a transport to time)")
+
+
 def emulate(arrays, P, precision="f64", device=-1):
     """P sharded handles of the same graph in this process + their emulated collectives."""
     import torch

@@ -652,21 +652,18 @@ def test_levenberg_marquardt_through_the_big_front_path(api, oracle):
     assert _state_diff_se2(g.state(), o.state()) <= 1e-6
 
 
-@pytest.mark.parametrize("env", ["RR_PGO_FLOW=0", "RR_PGO_FLOW_TASKS=100000000", "RR_PGO_FLOW_EXACT", "RR_PGO_NO_GATHER_UPDATE",
-                                 "RR_PGO_SCHUR_SPLIT=0", "RR_PGO_XCD_REMAP=0", "RR_PGO_SOLVE_FLOW=0", "RR_PGO_EDGE_LINEARIZE",
-                                 "RR_PGO_FLOW_DEEP=0", "RR_PGO_FLOW_SCHUR_MIN=100000000", "RR_PGO_FLOW_SLOTS=1000000",
-                                 "RR_PGO_SPLIT_ASSEMBLY", "RR_PGO_FLOW_GRID=1", "RR_PGO_FLOW_GRID=7", "RR_PGO_SP_SOLVE_MIN=100000",
+@pytest.mark.parametrize("env", ["RR_PGO_FLOW=0", "RR_PGO_FLOW_TASKS=100000000", "RR_PGO_FLOW_EXACT",
+                                 "RR_PGO_SCHUR_SPLIT=0", "RR_PGO_SOLVE_FLOW=0", "RR_PGO_EDGE_LINEARIZE",
+                                 "RR_PGO_FLOW_SCHUR_MIN=100000000",
+                                 "RR_PGO_FLOW_GRID=1", "RR_PGO_FLOW_GRID=7", "RR_PGO_SP_SOLVE_MIN=100000",
                                  "RR_PGO_SP_SOLVE_MIN=1", "RR_PGO_NO_GRAPH", "RR_PGO_FORCE_GRAPH"])
 def test_alternate_big_front_launch_sequences_agree(api, env, monkeypatch):
     """The switches read when a handle is created that change WHICH kernels run: the launch-per-step sequence for every
     level (RR_PGO_FLOW=0) or the dataflow launch for every level of at most 64 fronts (RR_PGO_FLOW_TASKS), its exact mode,
-    whole fronts built by k_big_build instead of gathered by the first trailing update, every super-panel's update
-    reaching through the Schur complement instead of ONE k_big_schur pass per level, tiles in dispatch order instead of
-    one contiguous eighth per XCD, one k_big_solve_sp launch per 128 columns instead of ONE k_big_solve_flow launch per
-    level in the back substitution, the edge-parallel linearisation, and three switches of the dataflow launch (panel
-    steps that never look back over the previous super-panel, Schur complements always inside the launch, tickets in
-    the order of earliest starts instead of the list schedule's), and the H entries of the fronts beyond LDS added by a
-    k_big_assemble launch per level instead of by k_big_build's own waves; and the dataflow launches with ONE workgroup or
+    every super-panel's update reaching through the Schur complement instead of ONE k_big_schur pass per level,
+    one k_big_solve_sp launch per 128 columns instead of ONE k_big_solve_flow launch per
+    level in the back substitution, the edge-parallel linearisation, the Schur complements always inside the dataflow
+    launch; and the dataflow launches with ONE workgroup or
     seven instead of two per CU -- tasks wait only for smaller tickets, so any grid must finish, with the same bits; the back
     substitution of the fronts beyond LDS by k_solve_mid everywhere / by k_big_solve_flow everywhere (RR_PGO_SP_SOLVE_MIN); and
     the iteration as plain launches / as replays of one captured hipGraph (optimize() picks by the launch count otherwise).
@@ -683,8 +680,7 @@ def test_alternate_big_front_launch_sequences_agree(api, env, monkeypatch):
     monkeypatch.delenv(env)
     ealt = alt.optimize(3)
     np.testing.assert_allclose(ealt, eref, rtol=1e-9)
-    if env in ("RR_PGO_SCHUR_SPLIT", "RR_PGO_XCD_REMAP", "RR_PGO_NO_GATHER_UPDATE", "RR_PGO_SOLVE_FLOW", "RR_PGO_SPLIT_ASSEMBLY", "RR_PGO_FLOW_GRID",
-               "RR_PGO_NO_GRAPH", "RR_PGO_FORCE_GRAPH"):
+    if env in ("RR_PGO_SCHUR_SPLIT", "RR_PGO_SOLVE_FLOW", "RR_PGO_FLOW_GRID", "RR_PGO_NO_GRAPH", "RR_PGO_FORCE_GRAPH"):
         # placement, one pass or one per super-panel, gathered or built: the same chunks in the same order -- the same bits
         assert np.array_equal(ealt, eref) and np.array_equal(np.array(alt.state()), np.array(ref.state()))
     assert _state_diff_se2(alt.state(), ref.state()) <= 1e-8
@@ -814,10 +810,10 @@ def test_lds_dataflow_launches_are_bit_identical_to_the_level_schedule(api, name
     ref = api[0].new(g2o_path(name))
     eref, sref = np.array(ref.optimize(4)), np.array(ref.state())
     # (RR_PGO_FORCE_GRAPH: the iterations as replays of the captured hipGraph instead of plain launches)
-    # (RR_PGO_FACTOR_512 / RR_PGO_SOLVE_THREADS: smaller workgroups for the same fronts -- the sums of a front do not depend on the
+    # (RR_PGO_SOLVE_THREADS: smaller workgroups for the same fronts -- the sums of a front do not depend on the
     # workgroup size, kernels.hip.h, solve_front)
     for env, val in (("RR_PGO_LDS_FLOW", "0"), ("RR_PGO_LDS_FLOW_GRID", "1"), ("RR_PGO_LDS_FLOW_GRID", "7"), ("RR_PGO_TASK_US", "60"), ("RR_PGO_FORCE_GRAPH", "1"),
-                     ("RR_PGO_NO_GRAPH", "1"), ("RR_PGO_FACTOR_512", "1"), ("RR_PGO_SOLVE_THREADS", "256")):
+                     ("RR_PGO_NO_GRAPH", "1"), ("RR_PGO_SOLVE_THREADS", "256")):
         monkeypatch.setenv(env, val)
         alt = api[0].new(g2o_path(name))
         monkeypatch.delenv(env)
@@ -1562,3 +1558,39 @@ def test_optimize_with_log_and_plot_steps_like_the_reference(api, solver, tmp_pa
     assert svg.count("<circle") == len(pd["poses"]) and svg.count(">*</text>") == len(pd["landmarks"]) and "<polyline" in svg
     with pytest.raises(api[2]):   # SE(3): todo!() in the reference (:398-399)
         api[0].new(g2o_path("sphere2500")).plot()
+
+
+def test_bench_py_runs_its_multi_rank_plan_under_torchrun_on_one_gpu(tmp_path):
+    """bench.py's world > 1 branch -- the replicas headline, then ONE lattice and ONE sphere2500 sharded over the ranks, the
+    set-up agreement (Ctx.all_ok), the watchdog, the JSON assembly -- launched exactly as the driver launches it
+    (python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2), on the one GPU this box has:
+    --collectives host-staged puts both ranks on device 0 and carries the collectives over gloo through host memory
+    (sharding.HostStagedShardDriver).  First contact with two real ranks must not be the driver's 8-GPU run.  The child
+    is started from a process that never execs; torchrun starts before anything of ITS process touches the GPU."""
+    import json
+    import subprocess
+    import sys
+    port = str(29300 + os.getpid() % 500)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RR_PGO_BENCH_SECONDARY_LIMIT="400")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2",
+           "--collectives", "host-staged", "--lattice", "grid:120x80"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["scaling"] == "weak" and "rehearsal" in d
+    assert d["config"]["parallelism"] == "replicas (no communication)"
+    assert abs(d["value"] - 2 * 12 / (d["ms_per_step"] * 12e-3)) <= 1e-6 * d["value"]   # whole-job aggregate over both ranks
+    assert d["roofline"]["frac"] > 0 and abs(d["errors"][-1] - 359.996111514) < 1e-6
+    sec = d["secondary"]
+    assert [s["parallelism"] for s in sec] == ["sharded2", "sharded2", "sharded2"], sec
+    for s in sec:
+        assert "error" not in s and s["scaling"] == "strong" and s["n_gpus"] == 2, s
+        assert s["exchange_bytes_per_step"]["all_gather_bytes_total"] > 0 and "HOST MEMORY" in s["collectives"]
+    # the sharded lattice (f64 state in mixed) converges to the unsharded answer; sphere2500 to the oracle's minimum
+    from rustrobotics_amd import PoseGraph
+    ref = PoseGraph.synthetic_grid(120, 80, precision="mixed").optimize(10)
+    assert abs(sec[0]["chi2_final"] - ref[-1]) <= 1e-9 * ref[-1] and sec[0]["stopped_by_reference_rule"]
+    assert abs(sec[2]["chi2_final"] - 727.149667) <= 1e-5
