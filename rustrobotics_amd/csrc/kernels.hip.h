@@ -158,7 +158,9 @@ template <typename T, typename TC = T> struct LinArgs {
   const typename VecT<TC>::V4 *e_info_a; // i11 i12 i13 i22
   const typename VecT<TC>::V2 *e_info_b; // i23 i33
   const int64_t *e_slot;                 // (offset into hvals << 1) | transposed
-  const int32_t *inc_ptr, *inc_list;     // entry = edge << 4 | offdiag << 3 | owns << 2 | kind << 1 | role (sharded runs: see Engine)
+  const int32_t *inc_ptr;
+  const int2 *inc_list;                  // per incidence: (edge << 4 | offdiag << 3 | owns << 2 | kind << 1 | role, the OTHER endpoint's node) --
+                                         // the far pose is requested together with the edge record, not after it (sharded runs: see Engine)
   const int32_t *node_list;              // sharded runs: the nodes this rank linearises (own + shared), else null;
                                          // n_nodes is then the length of the list
   const uint8_t *node_dim;               // 3 (SE2) or 2 (XY)
@@ -402,7 +404,8 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<TO, T> a) {
     const V4 self = a.pose[node];
     const int q1 = a.inc_ptr[node + 1];
     for (int q = a.inc_ptr[node] + sub; q < q1; q += LIN_GROUP) {
-      const int ent = a.inc_list[q];
+      const int2 inc = a.inc_list[q];
+      const int ent = inc.x;
       // sharded runs: an edge contributes to diagonal blocks, right-hand side and chi2 on ONE rank (bit 2, its
       // owner -- the other ranks' copies of a far endpoint are stale); the off-diagonal block of an edge between
       // two shared nodes is written by every rank (bit 3)
@@ -410,8 +413,7 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize(LinArgs<TO, T> a) {
       const bool owns = ent & 4;
       const int k = ent >> 4, kind = (ent >> 1) & 1, role = ent & 1;
       const EdgeRec<T> rec = a.e_rec[k];
-      const int2 ft = int2{rec.from, rec.to};
-      const V4 other = a.pose[role ? ft.x : ft.y];
+      const V4 other = a.pose[inc.y];
       const V4 z = rec.meas;
       const V4 wa = rec.info_a;
       const V2 wb = rec.info_b;
@@ -648,7 +650,8 @@ template <typename T, typename TC = T> struct LinArgs3 {
   const typename VecT<TC>::V4 *e_meas;  // 2 per edge, same packing
   const TC *e_info;                     // 21 per edge, row-major upper triangle
   const int64_t *e_slot;
-  const int32_t *inc_ptr, *inc_list;    // entry = edge << 4 | offdiag << 3 | owns << 2 | role
+  const int32_t *inc_ptr;
+  const int2 *inc_list;                 // as LinArgs::inc_list: (edge << 4 | offdiag << 3 | owns << 2 | role, the other endpoint's node)
   const int32_t *node_list;             // sharded runs: the nodes this rank linearises, else null
   const int32_t *node_offset;
   const int64_t *diag_off;
@@ -771,12 +774,12 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize_se3(LinArgs3<TO, T> a
     const T ts[3] = {st.x, st.y, st.z}, qs[4] = {sq.x, sq.y, sq.z, sq.w};
     const int q1 = a.inc_ptr[node + 1];
     for (int q = a.inc_ptr[node] + sub; q < q1; q += LIN_GROUP) {
-      const int ent = a.inc_list[q];
+      const int2 inc = a.inc_list[q];
+      const int ent = inc.x;
       if (!(ent & 12)) continue;   // sharded runs: see k_linearize
       const bool owns = ent & 4;
       const int k = ent >> 4, role = ent & 1;
-      const int2 ft = a.e_idx[k];
-      const int other = role ? ft.x : ft.y;
+      const int other = inc.y;
       const V4 ot = a.pose[2 * other], oq = a.pose[2 * other + 1];
       const T to[3] = {ot.x, ot.y, ot.z}, qo[4] = {oq.x, oq.y, oq.z, oq.w};
       const V4 zt = a.e_meas[2 * k], zq = a.e_meas[2 * k + 1];

@@ -300,7 +300,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<int2> e_idx_;
   DevBuf<EdgeRec<S>> e_rec_;   // SE(2): every edge's from / to / slot / measurement / information as one record (k_linearize)
   DevBuf<int64_t> e_slot_, diag_off_;
-  DevBuf<int32_t> inc_ptr_, inc_list_, node_offset_, node_pcol_;
+  DevBuf<int32_t> inc_ptr_, node_offset_, node_pcol_;
+  DevBuf<int2> inc_list_;
   DevBuf<uint8_t> node_dim_;
   DevBuf<S> e_info3_;   // SE(3): 21 information entries per edge
   bool is3d_ = false;
@@ -509,7 +510,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       e_meas_.upload(emeas);
       e_info3_.upload(einfo);
     }
-    std::vector<int32_t> inc(sym.inc_list.size());
+    std::vector<int2> inc(sym.inc_list.size());
     if (E >= (1 << 27)) throw ApiError(RR_PGO_EUNSUPPORTED, "more than 2^27 edges");
     for (size_t q = 0; q < inc.size(); q++) {
       int k = sym.inc_list[q] >> 1, role = sym.inc_list[q] & 1;
@@ -520,7 +521,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       const int pf = world_ > 1 ? sym.node_part[g.edge_from[k]] : 0, pt = world_ > 1 ? sym.node_part[g.edge_to[k]] : 0;
       const int owns = (pf >= 0 ? pf : pt >= 0 ? pt : 0) == rank_ ? 1 : 0;
       const int offd = role == 0 && (owns || (pf < 0 && pt < 0)) ? 1 : 0;
-      inc[q] = (k << 4) | (offd << 3) | (owns << 2) | ((g.edge_kind[k] == EDGE_SE2_XY ? 1 : 0) << 1) | role;
+      inc[q] = int2{(k << 4) | (offd << 3) | (owns << 2) | ((g.edge_kind[k] == EDGE_SE2_XY ? 1 : 0) << 1) | role,
+                    role ? g.edge_from[k] : g.edge_to[k]};
     }
     inc_ptr_.upload(sym.inc_ptr);
     inc_list_.upload(inc);

@@ -508,12 +508,20 @@ def test_offline_pmc_traffic_names_kernels_of_the_newest_kernel_stats():
     tags = sorted({re.match(r"(r\d+z)_kernel_stats_", os.path.basename(f)).group(1) for f in glob.glob(os.path.join(prof, "r*z_kernel_stats_*.csv"))})
     newest = tags[-1]
     assert doc["_tag"] == newest, "pmc_traffic.json is from %s, the newest kernel statistics from %s: re-take the PMC passes (scripts/gpu_pmc.sh)" % (doc["_tag"], newest)
-    stats = {"intel": "intel_f64", "grid": "grid_f32"}
+    stats = {"intel": "intel_f64", "grid": "grid_f32", "m3500": "m3500_f64", "sphere2500": "sphere2500_f64"}
+    assert {"intel:f64", "m3500:f64", "sphere2500:f64", "grid:400x250:1000000:f32"} <= set(doc)   # no BASELINE config without traffic
     for key, e in doc.items():
         if key.startswith("_"):
             continue
         rows = list(csv.DictReader(open(os.path.join(prof, "%s_kernel_stats_%s.csv" % (newest, stats[key.split(":")[0]])))))
         names = {re.sub(r"<.*", "", r["Name"].replace("void ", "").replace("rrpgo::", "")) for r in rows}
+        if key.endswith(":classes"):
+            # the attribution of a whole iteration's traffic: every kernel it names ran, and the shares add up
+            kernels = {k: v for k, v in e.items() if not k.startswith("_")}
+            # (k_copy_words16: the restart of the profiling script's repetitions, not part of an iteration of the bench's statistics)
+            assert set(kernels) - {"k_copy_words16"} <= names, (key, sorted(set(kernels) - names))
+            assert e["_total_bytes_per_step"] == sum(v["traffic_bytes_per_step"] for v in kernels.values())
+            continue
         ran = [k for k in e["kernel"].split("+") if k in names]
         assert ran, (key, e["kernel"], sorted(names))
         # the counters' view of the dominant kernel agrees with the byte model to within what a cache hierarchy can do
