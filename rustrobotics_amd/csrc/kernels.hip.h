@@ -1840,6 +1840,7 @@ __device__ void process_front(const FactorArgs<T> &a, int s, const SnMeta &m, T 
 // the other, entirely out of LDS.
 template <typename T, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_factor_tasks(FactorArgs<T> a) {
+  if (opt_stopped(a.err)) return;   // rr_pgo_optimize: enqueued behind the iteration that met the stop rule
   extern __shared__ __align__(16) unsigned char smem_raw[];
   __shared__ T dinv[W16_SCR];   // inverse of the current 16 x 16 diagonal block + an identity (diag16_factor_invert_full)
   T *smem = reinterpret_cast<T *>(smem_raw);
@@ -3214,6 +3215,7 @@ __device__ void solve_front(const FactorArgs<T> &a, int s, const SnMeta &m, T *w
 
 template <typename T, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_solve_tasks(FactorArgs<T> a) {
+  if (opt_stopped(a.err)) return;   // rr_pgo_optimize: enqueued behind the iteration that met the stop rule
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
   const int task = a.task_begin + blockIdx.x;

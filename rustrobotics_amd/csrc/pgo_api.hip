@@ -419,7 +419,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   double opt_lambda0_ = 0.01;
   bool stop_dirty_ = false;          // the stop word err_[1] may be set: cleared before the next launch outside such a call
   bool sync_optimize_ = false;       // RR_PGO_SYNC_OPTIMIZE=1: rr_pgo_optimize with one host round trip per iteration (the r01 - r05
-                                     // form, bit-identical: the parity alternative; handles without the LDS dataflow launches always)
+                                     // form, bit-identical: the parity alternative; always with the edge-parallel linearisation)
   int n_lin_blocks_ = 0, n_upd_blocks_ = 0;
   bool no_graph_ = false, force_graph_ = false;   // RR_PGO_NO_GRAPH=1 / RR_PGO_FORCE_GRAPH=1 (read when the handle is created): plain launches / replays of the captured hipGraph everywhere
   bool edge_lin_ = false;           // RR_PGO_EDGE_LINEARIZE=1: k_linearize_edges (one thread per edge, atomics) instead of the pull form
@@ -2000,7 +2000,10 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   // optimize(), pose_graph_optimization.rs:247-303
   void optimize(int solver, int iters, double *errors, int *n_errors, double *norms) override {
     if (sharded_) throw ApiError(RR_PGO_EUNSUPPORTED, "sharded handle: drive it with rr_pgo_stage + the two collectives");
-    if (lds_flow_ && !edge_lin_ && !sync_optimize_ && !prof_.on) {
+    // (an iteration of dozens of launches -- the 1M-edge lattice: 67, 4.4 ms -- gains nothing from the loop on the device: a host
+    // round trip is 0.5 % of its iteration, and the item behind the stop would be dozens of empty launches.  Built and measured, r06:
+    // 4.55 against 4.50 ms per iteration through optimize(), also with only the next linearisation enqueued ahead.)
+    if (!edge_lin_ && !sync_optimize_ && !prof_.on && n_launches_per_iter < 48) {
       optimize_pipelined(solver, iters, errors, n_errors, norms);
       return;
     }
@@ -2062,8 +2065,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     *n_errors = ne;
   }
 
-  // ---- rr_pgo_optimize without a host round trip per iteration (graphs on the LDS dataflow launches: an iteration is a few
-  // launches of 0.1 - 0.6 ms altogether, and a stream synchronisation + two copies per iteration were ~25 us of idle device).
+  // ---- rr_pgo_optimize without a host round trip per iteration (on the small graphs an iteration is a few launches of
+  // 0.1 - 0.6 ms altogether, and a stream synchronisation + two copies per iteration were ~25 us of idle device; handles of
+  // fewer than 48 launches per iteration).
   // The loop of :247-303 is cut into ITEMS, each a fixed sequence of launches whose last kernel publishes (chi2, |dx|, flags)
   // in the host-coherent ring and -- on the device -- takes the decisions the reference takes on the host: the stop rule
   // (:298-300, the stop word err[1]: every later launch of the call is empty or leaves the state alone), Levenberg-
@@ -2134,7 +2138,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       ~Scope() { e->opt_active_ = false; e->opt_first_ = false; e->stop_dirty_ = true; }
     } scope{this};
     opt_active_ = true; opt_first_ = true; opt_lambda_dev_ = lm; opt_lambda0_ = 0.01;   // :254
-    long enq = 0, seen = 0;
+    // TWO whole items in the queue: the device never waits for the host, and the item behind the stop is a handful of empty
+    // launches behind its linearisation (which publishes the final chi2)
+    long enq = 0, seen = 0;   // items enqueued / consumed
     int ne = 0, dev_err = 0;
     bool stop_seen = false;
     while (true) {

@@ -1171,6 +1171,28 @@ def test_optimize_with_the_stop_rule_on_the_device_is_bit_identical_to_the_host_
     assert fast.global_error() == slow.global_error()
 
 
+@pytest.mark.parametrize("precision,solver", [("f64", "GaussNewton"), ("mixed", "GaussNewton"), ("f32", "GaussNewton"), ("f64", "LevenbergMarquardt")])
+def test_device_side_loop_on_a_graph_with_fronts_beyond_lds_on_the_level_schedule(api, precision, solver, monkeypatch):
+    """The same bit-identity for a graph with fronts beyond LDS and the LDS fronts on the level schedule (k_factor_tasks /
+    k_solve_tasks per level, k_big_* launches: 40 launches per iteration, under the 48 from which rr_pgo_optimize keeps the host
+    loop): Gauss-Newton in the three precisions (fp32: the gauge transfer; the stop rule is met in fp64 / mixed, not in fp32) and
+    Levenberg-Marquardt."""
+    from rustrobotics_amd import synthetic_grid_arrays
+    arrays = synthetic_grid_arrays(100, 100)
+    Solver = getattr(api[1], solver)
+    fast = api[0].from_arrays(*arrays, precision=precision, solver=Solver)
+    assert 8 < fast.stats()["n_launches_per_iter"] < 48 and fast.stats()["n_big_fronts"] > 0
+    monkeypatch.setenv("RR_PGO_SYNC_OPTIMIZE", "1")
+    slow = api[0].from_arrays(*arrays, precision=precision, solver=Solver)
+    monkeypatch.delenv("RR_PGO_SYNC_OPTIMIZE")
+    for iters in (0, 2, 10, 3):
+        ef, nf = fast.optimize(iters, return_norms=True)
+        es, ns = slow.optimize(iters, return_norms=True)
+        assert np.array_equal(ef, es) and np.array_equal(nf, ns), (precision, solver, iters, ef, es)
+        assert np.array_equal(np.array(fast.state()), np.array(slow.state()))
+    assert fast.global_error() == slow.global_error()
+
+
 def test_optimize_stops_enqueueing_when_the_device_reports_the_stop(api):
     """optimize(100000) on intel converges in six iterations: the call must return after those (one skipped item behind
     them), not after a hundred thousand empty launches."""
