@@ -201,6 +201,9 @@ def roofline_of(g, workload, precision, prof_iters=20):
                     "avg_launch_us": dom_us / max(n_launch, 1),
                     "algorithmic_bytes_per_launch": nbytes / max(n_launch, 1),
                     "per_step_us_by_kernel_class": per_iter_us}
+    roofline["timing"] = ("HIP events around every launch of rr_pgo_profile's eager iterations (launches that do work).  A rocprofv3 --stats "
+                          "average over a whole bench.py run also counts the EMPTY launches of the iteration enqueued behind each optimize() "
+                          "call's stop (a few us each: scripts/kernel_stats_real.py separates them, profiles/*_kernel_working_launches_*.txt)")
     mfma_kernel = None
     if per_iter_us.get("big_update", 0) > 0:
         tf = stats["big_update_flops"] / (per_iter_us["big_update"] * 1e-6) / 1e12

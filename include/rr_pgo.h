@@ -153,14 +153,22 @@ int rr_pgo_update(rr_pgo *h, const double *dx, double sign);
  * flow incl. the LM accept/reject quirks (:275-286) and the |dx| < 1e-4 break
  * (:298-300).  errors_out needs num_iterations+1 slots; *n_errors = 1 +
  * iterations executed (the length of the reference's returned Vec<f64>).
- * norms_out (may be NULL): |dx| per executed iteration. */
+ * norms_out (may be NULL): |dx| per executed iteration.
+ * The loop runs on the device: the stop rule, Levenberg-Marquardt's accept / reject and lambda are decided by the kernel
+ * that finishes an iteration, which publishes (chi2, |dx|) in host-coherent memory; the host enqueues one iteration ahead
+ * and polls -- no stream synchronisation inside the call (handles of 48+ launches per iteration, i.e. graphs of tens of
+ * thousands of poses, keep one host round trip per iteration: 0.5 % of theirs).  Same bits either way.
+ * With log or plot the reference prints / plots BETWEEN iterations (:258-268, :288-296): a shim steps through
+ * rr_pgo_linearize_solve / rr_pgo_update / rr_pgo_chi2 instead. */
 int rr_pgo_optimize(rr_pgo *h, int32_t num_iterations, double *errors_out,
                     int32_t *n_errors, double *norms_out);
 
 /* State read-back: SE2 -> x, y, atan2(im,re) ; XY -> x, y ; SE3 -> x,y,z,qx,qy,qz,qw,
  * node order.  (Field access on PoseGraph.nodes in the reference.) */
 int rr_pgo_get_state(rr_pgo *h, double *out);
-/* Overwrite the state (same packing); used to restart a benchmark run. */
+/* Overwrite the state (same packing); used to restart a benchmark run.  Returns once the copy is enqueued on the handle's
+ * stream (everything else the handle does is ordered behind it); setting the state of the previous call again costs a
+ * comparison and one device-side copy. */
 int rr_pgo_set_state(rr_pgo *h, const double *state);
 
 /* ---- inspection of the assembled system (parity tests) ------------------- */

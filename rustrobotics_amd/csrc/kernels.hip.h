@@ -1150,7 +1150,7 @@ template <typename T> __device__ __forceinline__ T pin(T v) {
 // atomics = global_load / global_store ... sc1 -- the store is written through to memory, the load bypasses this
 // CU's L1 and is served coherently by L2; no release / acquire fence is needed around them (MI355X_MICROARCH.md,
 // inter-workgroup visibility; measured for this path with lines shared by two producers: scripts/handoff_probe.hip,
-// profiles/r03_handoff_probe.txt).
+// profiles/archive/r03_handoff_probe.txt).
 template <bool SC1, typename T> __device__ __forceinline__ T mem_ld(const T *p) {
   if constexpr (SC1) return __hip_atomic_load(const_cast<T *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else return *p;

@@ -18,6 +18,7 @@ for W in intel:f64 m3500:f64 dlr:f64 sphere2500:f64 intel:mixed; do
   rm -rf /tmp/prof_$WL
   ( cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$WL -- python3 $GRAFT_REPO_ROOT/bench.py --workload $WL --precision $PR --no-cpu-baseline --no-secondary > /tmp/prof_$WL.log 2>&1 )
   cp $(find /tmp/prof_$WL -name "*kernel_stats.csv" | head -1) gpurun_out/kernel_stats_${WL}_${PR}_$TAG.csv
+  python3 scripts/kernel_stats_real.py $(find /tmp/prof_$WL -name "*kernel_trace.csv" | head -1) > gpurun_out/kernel_working_launches_${WL}_${PR}_$TAG.txt
   echo "$WL $PR done"
 done
 # the kernel timeline of optimize(10) calls from the initial state (what the headline times)

@@ -63,7 +63,7 @@ doc["sphere2500:f64:classes"] = by_class("sphere2500", g2o_iters)
 doc["grid:400x250:1000000:f32"] = entry("grid", ["k_big_flow"], "k_big_flow", grid_iters)
 doc["grid:400x250:1000000:f32:k_big_update"] = entry("grid", ["k_big_update", "k_big_schur"], "k_big_update+k_big_schur", grid_iters)
 doc["grid:400x250:1000000:f32:k_big_update"]["note"] = (
-    "r02 (profiles/r02z_grid_*_SIZE.txt): k_big_update 48 launches per step x 160.6 MB = 7.7 GB per step, plus 177 k_big_panel32 launches x 14.7 MB "
+    "r02 (profiles/archive/r02z_grid_*_SIZE.txt): k_big_update 48 launches per step x 160.6 MB = 7.7 GB per step, plus 177 k_big_panel32 launches x 14.7 MB "
     "= 2.6 GB. r03: the panel steps and per-super-panel updates of every level are tasks of k_big_flow (entry above), the Schur "
     "complements one k_big_schur pass per level")
 doc["grid:400x250:1000000:f32:classes"] = by_class("grid", grid_iters)
