@@ -192,7 +192,7 @@ template <typename U> struct PinnedBuf {
   // coherent (fine-grained): a kernel's system-scope stores are visible to the polling host while the kernel runs
   void alloc(size_t n, bool coherent = true) {
     if (p) { (void)hipHostFree(p); p = nullptr; }
-    HIPCHK(hipHostMalloc((void **)&p, n * sizeof(U), coherent ? (hipHostMallocMapped | hipHostMallocCoherent) : hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&p, n * sizeof(U), coherent ? (hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) : hipHostMallocDefault));
   }
   U &operator[](size_t i) const { return p[i]; }
   operator U *() const { return p; }

@@ -1193,6 +1193,43 @@ def test_device_side_loop_on_a_graph_with_fronts_beyond_lds_on_the_level_schedul
     assert fast.global_error() == slow.global_error()
 
 
+def test_optimize_calls_on_several_host_threads_at_once(api):
+    """Handles are independent (include/rr_pgo.h, threading): four host threads run rr_pgo_optimize on four handles at the same time
+    -- four polling loops, four rings, the dataflow launches of four graphs sharing the chip (ctypes releases the GIL for the call).
+    Every thread must get the result its handle gives alone, to the last bit, call after call."""
+    import threading
+    names = ["intel", "input_M3500_g2o", "dlr", "sphere2500"]
+    alone = {}
+    handles = {n: api[0].new(g2o_path(n)) for n in names}
+    s0 = {n: np.array(h.state()) for n, h in handles.items()}
+    for n in names:   # (from the state as rr_pgo_get_state / rr_pgo_set_state round-trip it: theta -> cos, sin is not the file's last bit)
+        g = api[0].new(g2o_path(n))
+        g.set_state(s0[n])
+        alone[n] = (g.optimize(10, return_norms=True), np.array(g.state()))
+    out, errs = {}, []
+
+    def work(n):
+        try:
+            h = handles[n]
+            for _ in range(8):
+                h.set_state(s0[n])
+                res = h.optimize(10, return_norms=True)
+            out[n] = (res, np.array(h.state()))
+        except Exception as e:   # noqa: BLE001
+            errs.append((n, e))
+
+    threads = [threading.Thread(target=work, args=(n,)) for n in names]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errs, errs
+    for n in names:
+        (e, nr), st = out[n]
+        (e0, nr0), st0 = alone[n]
+        assert np.array_equal(e, e0) and np.array_equal(nr, nr0) and np.array_equal(st, st0), n
+
+
 def test_optimize_stops_enqueueing_when_the_device_reports_the_stop(api):
     """optimize(100000) on intel converges in six iterations: the call must return after those (one skipped item behind
     them), not after a hundred thousand empty launches."""
