@@ -149,3 +149,34 @@ def test_sharded_driver_world2_gloo():
     assert log0[:4] == [("stage", 0), ("stage", 1), ("stage", 0), ("stage", 1)]
     assert x0 == [0.0, 1.0, 2.0, 3.0, 0.0, 0.0, 0.0, 0.0] and x1 == [0.0, 0.0, 0.0, 0.0, 4.0, 5.0, 6.0, 7.0]   # owned parts only
     assert s0 == [22.0, 0.0] and s1 == [6.0, 0.0]   # stage 1 saw the OTHER rank's chunk: the all-gather ran before it
+
+
+def test_optimize_steps_runs_exactly_k_iterations_through_optimize_calls():
+    """bench.py's timed region is whole rr_pgo_optimize calls (optimize(10) from the initial state, again and again): whatever the
+    stop rule does, EXACTLY K iterations run -- the last call asks for what is left -- and every call starts from the initial state."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class Stub:
+        def __init__(self, stops_after):
+            self.stops_after, self.calls, self.restarts = stops_after, [], 0
+
+        def restarter(self, state):
+            def restart():
+                self.restarts += 1
+            return restart
+
+        def optimize_count(self, n):
+            done = min(n, self.stops_after)
+            self.calls.append((n, done))
+            return done
+
+    for stops_after, steps in ((6, 200), (6, 20), (7, 5), (100, 25), (1, 3)):
+        g = Stub(stops_after)
+        bench.optimize_steps(g, object(), steps)
+        assert sum(d for _, d in g.calls) == steps, (stops_after, steps, g.calls)
+        assert all(n <= bench.OPTIMIZE_CALL for n, _ in g.calls) and g.restarts == len(g.calls)
+        left = steps
+        for n, d in g.calls:   # every call asks for optimize(10), or for what is left of K
+            assert n == min(left, bench.OPTIMIZE_CALL)
+            left -= d
