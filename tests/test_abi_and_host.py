@@ -195,6 +195,13 @@ def test_loader_parses_large_files_in_parts_like_a_sequential_pass(lib, tmp_path
     assert rc == _lib.EPARSE and msg == f"line 21:{tail}", msg
 
 
+def test_trim_needs_no_device_and_no_handles(lib):
+    """rr_pgo_trim gives back what the library keeps between handles (include/rr_pgo.h): callable at any time, also before the
+    first handle and on a host without a GPU."""
+    lib.rr_pgo_trim.restype = C.c_int
+    assert lib.rr_pgo_trim() == 0 and lib.rr_pgo_trim() == 0
+
+
 def test_integration_md_shim_keeps_the_reference_public_surface():
     """SURVEY 8(b): the four public items of robotics::mapping on this path -- PoseGraphSolver, PoseGraph::new,
     PoseGraph::optimize(num_iterations, log, plot), PoseGraph::plot -- with the reference's signatures

@@ -1230,6 +1230,22 @@ def test_optimize_calls_on_several_host_threads_at_once(api):
         assert np.array_equal(e, e0) and np.array_equal(nr, nr0) and np.array_equal(st, st0), n
 
 
+def test_trim_between_handles(api):
+    """rr_pgo_trim(): pooled device chunks, pooled streams and cached analyses of destroyed handles are released; a live handle is
+    untouched, and the next constructor (which allocates and analyses afresh) gives the same bits."""
+    from rustrobotics_amd import _lib
+    L = _lib.load()
+    L.rr_pgo_trim.restype = C_int = __import__("ctypes").c_int
+    live = api[0].new(g2o_path("intel"))
+    first = api[0].new(g2o_path("dlr"))
+    e1 = first.optimize(10)
+    del first
+    assert L.rr_pgo_trim() == 0
+    second = api[0].new(g2o_path("dlr"))
+    assert np.array_equal(second.optimize(10), e1)
+    assert abs(live.optimize(10)[-1] - 359.996111514) < 1e-6
+
+
 def test_optimize_stops_enqueueing_when_the_device_reports_the_stop(api):
     """optimize(100000) on intel converges in six iterations: the call must return after those (one skipped item behind
     them), not after a hundred thousand empty launches."""
