@@ -3238,15 +3238,14 @@ __global__ void __launch_bounds__(THREADS) k_solve_tasks(FactorArgs<T> a) {
 // of a level, spread over the whole chip: workgroup (bx, by, front) takes 64 columns and the by-th of
 // R row slices, lanes along the rows (coalesced), a wave 4 columns at a time.  Partial sums go to
 // part[by][col0 + j] (fixed slots, summed in order by the solve kernels: deterministic).
-template <typename T> __global__ void __launch_bounds__(256) k_big_gemv_partial(FactorArgs<T> a, T *part, int64_t N, int R) {
-  if (opt_stopped(a.err)) return;   // rr_pgo_optimize: enqueued behind the iteration that met the stop rule
-  __shared__ T xs[1024];
-  const SnMeta m = a.task_meta[a.task_begin + blockIdx.z];
+// FLOW: a GEMV task of k_solve_flow (lds_flow.hip.h) -- the entries of x are waited for in place (x_wait), the partial sums are
+// written through; waves beyond the fourth of a larger workgroup only take part in the barriers.  Same sums either way.
+template <typename T, bool FLOW>
+__device__ __forceinline__ void big_gemv_unit(const FactorArgs<T> &a, const SnMeta &m, T *part, int64_t N, int R, int bx, int by, T *xs /* 1024 */) {
   const int nc = m.nc, nr = m.nr, M = nc + nr + 1;
-  const int j0 = blockIdx.x * 64;
-  if (j0 >= nc) return;
+  const int j0 = bx * 64;
   const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63;
-  const int by = blockIdx.y;
+  const int nthreads = blockDim.x;
   const int i_begin = (int)((int64_t)nr * by / R), i_end = (int)((int64_t)nr * (by + 1) / R);
   const T *Lg = a.lvals + m.loff;
   const int32_t *rows = a.sn_rows + m.rows_ptr;
@@ -3258,8 +3257,12 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_gemv_partial(
   for (int ib = i_begin; ib < i_end; ib += 1024) {
     const int cnt = min(1024, i_end - ib);
     __syncthreads();
-    for (int t = tid; t < cnt; t += 256) xs[t] = a.x[rows[ib + t]];
+    for (int t = tid; t < cnt; t += nthreads) {
+      if constexpr (FLOW) xs[t] = x_wait(a.x + rows[ib + t], a.err, a.wait_ticks);
+      else xs[t] = a.x[rows[ib + t]];
+    }
     __syncthreads();
+    if (wave < 4) {
 #pragma unroll
     for (int p = 0; p < 4; p++) {
       const int jc = j0 + 16 * wave + 4 * p;   // this wave's 4 columns of the pass (clamped: no branch per load)
@@ -3285,15 +3288,25 @@ template <typename T> __global__ void __launch_bounds__(256) k_big_gemv_partial(
         acc[p][0] += c0[i] * xv; acc[p][1] += c1[i] * xv; acc[p][2] += c2[i] * xv; acc[p][3] += c3[i] * xv;
       }
     }
+    }
   }
+  if (wave < 4) {
 #pragma unroll
   for (int p = 0; p < 4; p++)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const T sum = wave_sum63<T>(acc[p][q]);
       const int j = j0 + 16 * wave + 4 * p + q;
-      if (lane == 63 && j < nc) part[(int64_t)by * N + m.col0 + j] = sum;
+      if (lane == 63 && j < nc) mem_st<FLOW>(part + (int64_t)by * N + m.col0 + j, sum);
     }
+  }
+}
+template <typename T> __global__ void __launch_bounds__(256) k_big_gemv_partial(FactorArgs<T> a, T *part, int64_t N, int R) {
+  if (opt_stopped(a.err)) return;   // rr_pgo_optimize: enqueued behind the iteration that met the stop rule
+  __shared__ T xs[1024];
+  const SnMeta m = a.task_meta[a.task_begin + blockIdx.z];
+  if ((int)blockIdx.x * 64 >= m.nc) return;
+  big_gemv_unit<T, false>(a, m, part, N, R, blockIdx.x, blockIdx.y, xs);
 }
 
 template <typename T> __device__ __forceinline__ T half_wave_sum(T v) {   // sums of lanes 0..31 / 32..63 in lanes 31 / 63
@@ -3304,7 +3317,7 @@ template <typename T> __device__ __forceinline__ T half_wave_sum(T v) {   // sum
   v += dpp_get<0x142, 0xa>(v);
   return v;
 }
-template <typename T, int THREADS>
+template <typename T, int THREADS, bool FLOW = false>   // FLOW: a task of k_solve_flow -- the partial sums read past L1, x written through (its entries are their own flags)
 __device__ void solve_big_front(const FactorArgs<T> &a, const SnMeta &m, T *work, const T *part, int64_t N, int R) {
   constexpr int NW = THREADS / 64;
   constexpr int NQ = 32;                // column pairs per wave and pass
@@ -3324,7 +3337,7 @@ __device__ void solve_big_front(const FactorArgs<T> &a, const SnMeta &m, T *work
       for (int r0 = 0; r0 < R; r0 += 8) {   // eight slices requested together, subtracted in slice order
         T p[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) p[u] = part[(int64_t)min(r0 + u, R - 1) * N + m.col0 + j];
+        for (int u = 0; u < 8; u++) p[u] = mem_ld<FLOW>(part + (int64_t)min(r0 + u, R - 1) * N + m.col0 + j);
 #pragma unroll
         for (int u = 0; u < 8; u++)
           if (r0 + u < R) t -= p[u];
@@ -3332,9 +3345,9 @@ __device__ void solve_big_front(const FactorArgs<T> &a, const SnMeta &m, T *work
     xf[j] = t;
   }
   auto stage_w = [&](int b) {   // Wt[c * 32 + j] = W_b(j, c)  ->  Ws[j * 33 + c]
-    if (tid < 1024) {
-      const int c = tid >> 5, j = tid & 31;
-      Ws[(b & 1) * (32 * 33) + j * 33 + c] = Wb[(int64_t)b * 1024 + tid];
+    for (int e = tid; e < 1024; e += THREADS) {   // (k_solve_mid: 1024 threads, one entry each; a task of k_solve_flow: 256 or 512)
+      const int c = e >> 5, j = e & 31;
+      Ws[(b & 1) * (32 * 33) + j * 33 + c] = Wb[(int64_t)b * 1024 + e];
     }
   };
   stage_w(nblk - 1);
@@ -3447,7 +3460,7 @@ __device__ void solve_big_front(const FactorArgs<T> &a, const SnMeta &m, T *work
     __syncthreads();
   }
   }
-  for (int j = tid; j < nc; j += THREADS) a.x[m.col0 + j] = xf[j];
+  for (int j = tid; j < nc; j += THREADS) mem_st<FLOW>(a.x + m.col0 + j, xf[j]);
   __syncthreads();
 }
 

@@ -33,7 +33,12 @@ struct alignas(128) LdsFlowTask {   // what a workgroup loads per ticket: ONE 12
   SnMeta m;                         // record of the task's first front (factorisation) / last front (back substitution)
   int32_t sn;                       // that front
   int32_t sn_begin, sn_end;         // the task's fronts: task_sn[sn_begin .. sn_end)
-  int32_t pad[13];
+  // k_solve_flow only -- a front beyond LDS with a narrow pivot block (kind > 0; the task is that ONE front):
+  int32_t kind;                     //   0: LDS fronts (solve_front); 1: GEMV unit (64 columns x one row slice of L21^T x[rows]); 2: the front's L11
+  int32_t slices;                   //   row slices of the level's k_big_gemv_partial launch (the sums are formed slice by slice: the same bits)
+  int32_t bx, by;                   //   GEMV unit: column block, slice
+  int32_t n_units;                  //   kind 2: the GEMV units to wait for (the front's solve flag word counts them)
+  int32_t pad[8];
 };
 static_assert(sizeof(LdsFlowTask) == 128, "LdsFlowTask is one 128-byte line");
 
@@ -73,8 +78,35 @@ __global__ void __launch_bounds__(THREADS) k_factor_flow(FactorArgs<T> a, const 
   }
 }
 
+// a counter of finished units behind a front's solve flag word: bounded like dep_wait
+__device__ __forceinline__ bool dep_wait_count(const unsigned *p, unsigned need, int *err, unsigned long long max_ticks) {
+  bool ok = true;
+  if (dep_flag_ld(p) < need) {
+    const unsigned long long t0 = wall_clock64();
+    for (unsigned spins = 1;; spins++) {
+      __builtin_amdgcn_s_sleep(1);
+      if (dep_flag_ld(p) >= need) break;
+      if ((spins & 31u) == 0u) {
+        const int e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e != 0 || wall_clock64() - t0 > max_ticks) {
+          if (e == 0 && (threadIdx.x & 63) == 0) atomicOr(err, DEVERR_FLOW_TIMEOUT);
+          ok = false;
+          break;
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  return ok;
+}
+
+// Fronts beyond LDS with narrow pivot blocks (sphere2500: five of six levels) are tasks of this launch too, in place of a
+// k_big_gemv_partial + k_solve_mid launch pair per level (~24 us per level): per front its GEMV units (k_big_gemv_partial's
+// decomposition and sums: 64 columns x one row slice, spread over the workgroups of the launch; x[rows] waited for entry by entry)
+// count themselves in the front's solve flag word, the front's L11 task waits for the count and solves (solve_big_front).
+// `part`: the partial sums, [slice][N] (N = dim).
 template <typename T, int THREADS>
-__global__ void __launch_bounds__(THREADS) k_solve_flow(FactorArgs<T> a, const LdsFlowTask *tasks, int n_tasks, unsigned *ticket) {
+__global__ void __launch_bounds__(THREADS) k_solve_flow(FactorArgs<T> a, const LdsFlowTask *tasks, int n_tasks, unsigned *ticket, T *part, int64_t N) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   __shared__ int ticket_slot[2];
   T *smem = reinterpret_cast<T *>(smem_raw);
@@ -83,6 +115,18 @@ __global__ void __launch_bounds__(THREADS) k_solve_flow(FactorArgs<T> a, const L
     const int tk = lds_flow_ticket(ticket, &ticket_slot[round & 1]);
     if (tk >= n_tasks || stopped) break;
     const LdsFlowTask tr = tasks[tk];
+    if (tr.kind == 1) {
+      big_gemv_unit<T, true>(a, tr.m, part, N, tr.slices, tr.bx, tr.by, smem);
+      dep_drain();
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(a.dep_flags + a.parent_dep_self + tr.sn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
+    if (tr.kind == 2) {
+      dep_wait_count(a.dep_flags + a.parent_dep_self + tr.sn, (unsigned)tr.n_units, a.err, a.wait_ticks);
+      solve_big_front<T, THREADS, true>(a, tr.m, smem, part, N, tr.slices);
+      continue;
+    }
     int snext = tr.sn;
     SnMeta mnext = tr.m;
     for (int si = tr.sn_end - 1; si >= tr.sn_begin; si--) {

@@ -343,6 +343,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   };
   std::vector<std::unique_ptr<FlowLevel>> flow_levels_;   // per step of sym_.steps (null: launch sequence)
   std::vector<SnMeta> host_task_meta_;   // host copy of task_meta_ (one record per task = per front of a big level)
+  std::vector<SnMeta> host_sn_meta_;     // host copy of sn_meta_
   DevBuf<int64_t> flow_wfill_;      // per four W blocks of a front of a flow level: offset and count of scalars in winv (k_flow_reset marks them)
   DevBuf<unsigned> flow_flags_;     // tickets + completion flags of every flow level, zeroed at the start of a factorisation
   int flow_max_nf_ = 1 << 20;       // RR_PGO_FLOW=<n> (0: never): levels of at most n fronts ...
@@ -378,6 +379,9 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   DevBuf<unsigned> dep_flags_;      // [0, S) factor flags, [S, 2 S) solve flags, then the two tickets on lines of their own, then a word nobody sets
   DevBuf<LdsFlowTask> lds_ftasks_, lds_stasks_;
   int lds_n_tasks_ = 0, lds_flow_cus_ = 256;
+  std::vector<LdsFlowTask> host_stasks_;   // k_solve_flow's tickets: [per narrow level of fronts beyond LDS, top level first: GEMV units, L11 tasks] + the LDS tasks
+  int lds_n_stasks_ = 0;
+  std::vector<char> mid_in_flow_;    // per step: the level's back substitution runs as tasks of k_solve_flow, not as launches
   unsigned long long wait_ticks_ = 200000000ull;   // bound of one in-launch wait: 2 s of the 100 MHz wall clock (RR_PGO_FLOW_TIMEOUT_MS)
   // failure injection (rr_pgo_debug_withhold): what was changed, to put it back
   int withheld_child_ = -1, withheld_parent_ = -1, withheld_level_ = -1, withheld_task_ = -1;
@@ -659,6 +663,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         }
       }
       sn_meta_.upload(meta);
+      host_sn_meta_ = meta;
       {
         std::vector<SnMeta> tm(sym.task_ptr.size() - 1);
         for (size_t t = 0; t + 1 < sym.task_ptr.size(); t++) tm[t] = meta[sym.task_sn[sym.task_ptr[t]]];
@@ -731,7 +736,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
           stk[k] = r;
         }
         lds_ftasks_.upload(ft);
-        lds_stasks_.upload(stk);
+        host_stasks_ = std::move(stk);   // uploaded by plan_mid_solve_tasks (fronts beyond LDS may join the list)
         lds_n_tasks_ = nt;
         int dev = 0;
         HIPCHK(hipGetDevice(&dev));
@@ -780,6 +785,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     stamps_.alloc((size_t)sym.S * 12 + 400000);   // per-front phase stamps | launch trace
     stamps_.zero();
 #endif
+    plan_mid_solve_tasks();
     cmark("index tables");
     configure_kernels();
     cmark("kernel attrs");
@@ -788,7 +794,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       n_launches_per_iter += st.kind == STEP_BIG ? count_big_launches(st) + count_big_solve_launches(st) : 2;
     if (lds_flow_) {   // linearise, k_factor_flow, the levels of fronts beyond LDS, k_solve_flow, update
       n_launches_per_iter = 4 + (xl_ ? 1 : 0);
-      for (size_t si = 1; si < sym.steps.size(); si++) n_launches_per_iter += (xl_ ? 0 : count_big_launches(sym.steps[si])) + count_big_solve_launches(sym.steps[si]);
+      for (size_t si = 1; si < sym.steps.size(); si++)
+        n_launches_per_iter += (xl_ ? 0 : count_big_launches(sym.steps[si])) + (mid_in_flow_[si] ? 0 : count_big_solve_launches(sym.steps[si]));
     }
   }
 
@@ -1390,6 +1397,67 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     HIPCHK(hipFuncSetAttribute((const void *)k_factor_tasks<T, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
     HIPCHK(hipFuncSetAttribute((const void *)k_solve_tasks<T, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
   }
+  int level_max_nc(const Step &st) const {
+    int max_nc = 1;
+    for (int t = st.task_begin; t < st.task_end; t++) max_nc = std::max(max_nc, sym_.sn_ncols[sym_.task_sn[sym_.task_ptr[t]]]);
+    return max_nc;
+  }
+  // row slices of a level's k_big_gemv_partial launch: enough workgroups to fill the chip, but never thinner than 128 rows
+  // (every slice is a partial sum the solve has to fetch and add per column)
+  int gemv_slices(const Step &st) const {
+    const int nf = st.task_end - st.task_begin, cb = (level_max_nc(st) + 63) / 64;
+    int max_nr = 1;
+    for (int t = st.task_begin; t < st.task_end; t++) max_nr = std::max(max_nr, sym_.sn_nrows[sym_.task_sn[sym_.task_ptr[t]]]);
+    return std::max(1, std::min(std::min(kGemvSlices, (max_nr + 127) / 128), (768 + nf * cb - 1) / (nf * cb)));
+  }
+  // Graphs on the dataflow schedule with fronts beyond LDS (sphere2500: 46, six levels): the levels whose pivot blocks are
+  // narrower than RR_PGO_SP_SOLVE_MIN columns -- all but the top one or two -- are back-substituted as TASKS of k_solve_flow
+  // (lds_flow.hip.h: GEMV units + one L11 task per front) instead of a k_big_gemv_partial + k_solve_mid launch pair per level.
+  // The wide top levels stay launches in front of k_solve_flow.  RR_PGO_SOLVE_MID_FLOW=0: every level as launches (the
+  // r03 - r05 form; the same sums in the same order: bit-identical).
+  void plan_mid_solve_tasks() {
+    mid_in_flow_.assign(sym_.steps.size(), 0);
+    if (!lds_flow_) return;
+    bool on = true;
+    if (const char *e = getenv("RR_PGO_SOLVE_MID_FLOW")) on = std::atoi(e) != 0;
+    int top = (int)sym_.steps.size() - 1;
+    while (on && top >= 1 && level_max_nc(sym_.steps[top]) >= sp_solve_min_nc_) top--;   // the wide top levels
+    std::vector<LdsFlowTask> mid;
+    int need = 1024;   // a GEMV unit's x[rows] chunk
+    for (int i = top; on && i >= 1; i--) {
+      const Step &st = sym_.steps[i];
+      if (level_max_nc(st) >= sp_solve_min_nc_) { on = false; break; }   // a wide level under a narrow one: keep every level a launch
+      const int R = gemv_slices(st);
+      for (int pass = 1; pass <= 2; pass++)   // the level's GEMV units first, then its L11 tasks
+        for (int t = st.task_begin; t < st.task_end; t++) {
+          LdsFlowTask r{};
+          r.sn_begin = sym_.task_ptr[t];
+          r.sn_end = r.sn_begin + 1;
+          r.sn = sym_.task_sn[r.sn_begin];
+          r.m = host_sn_meta_[r.sn];
+          r.kind = pass;
+          r.slices = R;
+          const int nc = sym_.sn_ncols[r.sn], nr = sym_.sn_nrows[r.sn];
+          const int units = nr > 0 ? (nc + 63) / 64 * R : 0;
+          if (pass == 2) {
+            r.n_units = units;
+            mid.push_back(r);
+            need = std::max(need, ((nc + 3) & ~3) + 2 * 32 * 33 + 64);
+          } else {
+            for (int u = 0; u < units; u++) { r.bx = u / R; r.by = u % R; mid.push_back(r); }
+          }
+        }
+    }
+    if (on && !mid.empty() && (size_t)need * sizeof(T) <= (size_t)kMaxLds) {
+      for (int i = top; i >= 1; i--) mid_in_flow_[i] = 1;
+      step_solve_lds_[0] = std::max(step_solve_lds_[0], need);
+      mid.insert(mid.end(), host_stasks_.begin(), host_stasks_.end());
+      host_stasks_.swap(mid);
+    }
+    lds_n_stasks_ = (int)host_stasks_.size();
+    lds_stasks_.upload(host_stasks_);
+  }
+
   void configure_kernels() {
     // opt in to > 64 KiB of dynamic LDS
     set_lds_attr<64>();
@@ -1771,12 +1839,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       FactorArgs<T> a = factor_args(0);
       a.solve_lds = step_solve_lds_[0];
       const int sth = std::min(st.threads, solve_threads_max_);
-      const int grid = std::min(lds_n_tasks_, lds_flow_cus_ * (sth <= 256 ? 4 : 2));
+      const int grid = std::min(lds_n_stasks_, lds_flow_cus_ * (sth <= 256 ? 4 : 2));
       unsigned *ticket = dep_flags_.p + 2 * sym_.S + 32;
       if (sth <= 256)
-        hipLaunchKernelGGL((k_solve_flow<T, 256>), dim3(grid), dim3(256), lds, stream_, a, (const LdsFlowTask *)lds_stasks_.p, lds_n_tasks_, ticket);
+        hipLaunchKernelGGL((k_solve_flow<T, 256>), dim3(grid), dim3(256), lds, stream_, a, (const LdsFlowTask *)lds_stasks_.p, lds_n_stasks_, ticket, gemv_part_.p, (int64_t)g_.dim);
       else
-        hipLaunchKernelGGL((k_solve_flow<T, 512>), dim3(grid), dim3(512), lds, stream_, a, (const LdsFlowTask *)lds_stasks_.p, lds_n_tasks_, ticket);
+        hipLaunchKernelGGL((k_solve_flow<T, 512>), dim3(grid), dim3(512), lds, stream_, a, (const LdsFlowTask *)lds_stasks_.p, lds_n_stasks_, ticket, gemv_part_.p, (int64_t)g_.dim);
       check_launch("k_solve_flow");
       pend(RR_PGO_K_SOLVE);
     }
@@ -1784,6 +1852,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   void launch_solve_steps(int first_step) {
     for (int i = (int)sym_.steps.size() - 1; i >= first_step; i--) {   // shared top fronts first, then this rank's subtrees
       const Step &st = sym_.steps[i];
+      if (mid_in_flow_[(size_t)i]) continue;   // its fronts are tasks of k_solve_flow
       const size_t lds = (size_t)step_solve_lds_[i] * sizeof(T);
       pbegin();
       if (st.kind == STEP_TASKS) {
@@ -1806,7 +1875,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         for (int z = 0; z < nf; z++) max_nr = std::max(max_nr, sym_.sn_nrows[sym_.task_sn[sym_.task_ptr[st.task_begin + z]]]);
         // row slices: enough workgroups to fill the chip, but never thinner than 128 rows (every slice is a
         // partial sum k_solve_mid has to fetch and add per column)
-        const int R = std::max(1, std::min(std::min(kGemvSlices, (max_nr + 127) / 128), (768 + nf * cb - 1) / (nf * cb)));
+        const int R = gemv_slices(st);
+        (void)max_nr;
         const FactorArgs<T> fa = factor_args(st.task_begin);
         hipLaunchKernelGGL(k_big_gemv_partial<T>, dim3(cb, R, nf), dim3(256), 0, stream_, fa, gemv_part_.p, (int64_t)g_.dim, R);
         check_launch("k_big_gemv_partial");

@@ -917,6 +917,23 @@ def test_cross_level_flow_launch_is_bit_identical_to_one_launch_per_level(api, n
         assert np.array_equal(np.array(alt.state()), s2), env
 
 
+@pytest.mark.parametrize("name,prec", [("sphere2500", "f64"), ("torus3D", "f64"), ("sphere2500", "mixed")])
+def test_fronts_beyond_lds_solved_as_tasks_of_the_dataflow_launch_give_the_same_bits(api, name, prec, monkeypatch):
+    """On the dataflow schedule the fronts beyond LDS with narrow pivot blocks are back-substituted as tasks of k_solve_flow
+    (per front its GEMV units -- k_big_gemv_partial's decomposition and sums, x[rows] waited for entry by entry -- and one L11
+    task that waits for their count) instead of a k_big_gemv_partial + k_solve_mid launch pair per level:
+    RR_PGO_SOLVE_MID_FLOW=0 keeps the launches and must give the same bits; the default has fewer launches per iteration."""
+    new = api[0].new(g2o_path(name), precision=prec)
+    monkeypatch.setenv("RR_PGO_SOLVE_MID_FLOW", "0")
+    old = api[0].new(g2o_path(name), precision=prec)
+    monkeypatch.delenv("RR_PGO_SOLVE_MID_FLOW")
+    assert new.stats()["n_big_fronts"] > 0 and new.stats()["n_launches_per_iter"] < old.stats()["n_launches_per_iter"]
+    assert np.array_equal(new.linearize_and_solve(), old.linearize_and_solve())
+    en, eo = new.optimize(6, return_norms=True), old.optimize(6, return_norms=True)
+    assert np.array_equal(en[0], eo[0]) and np.array_equal(en[1], eo[1])
+    assert np.array_equal(np.array(new.state()), np.array(old.state()))
+
+
 @pytest.mark.parametrize("name", ["sphere2500", "torus3D"])
 def test_cross_level_plan_that_exceeds_the_task_limit_falls_back_to_one_launch_per_level(api, name, monkeypatch):
     """The cross-level form turns every Schur tile into an UPDATE task, so a level can exceed the task limit that its per-level
