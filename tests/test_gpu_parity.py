@@ -917,16 +917,24 @@ def test_cross_level_flow_launch_is_bit_identical_to_one_launch_per_level(api, n
         assert np.array_equal(np.array(alt.state()), s2), env
 
 
-@pytest.mark.parametrize("name,prec", [("sphere2500", "f64"), ("torus3D", "f64"), ("sphere2500", "mixed")])
+@pytest.mark.parametrize("name,prec", [("sphere2500", "f64"), ("torus3D", "f64"), ("sphere2500", "mixed"), ("lattice100", "f64"), ("lattice100", "f32"),
+                                       ("lattice120x80", "mixed")])
 def test_fronts_beyond_lds_solved_as_tasks_of_the_dataflow_launch_give_the_same_bits(api, name, prec, monkeypatch):
     """On the dataflow schedule the fronts beyond LDS with narrow pivot blocks are back-substituted as tasks of k_solve_flow
     (per front its GEMV units -- k_big_gemv_partial's decomposition and sums, x[rows] waited for entry by entry -- and one L11
     task that waits for their count) instead of a k_big_gemv_partial + k_solve_mid launch pair per level:
     RR_PGO_SOLVE_MID_FLOW=0 keeps the launches and must give the same bits; the default has fewer launches per iteration."""
-    new = api[0].new(g2o_path(name), precision=prec)
+    if name.startswith("lattice"):   # SE(2) lattices of ~10 k poses: hundreds of fronts beyond LDS above an LDS dataflow schedule (fp32: the gauge transfer)
+        from rustrobotics_amd import synthetic_grid_arrays
+        arrays = synthetic_grid_arrays(*((100, 100) if name == "lattice100" else (120, 80)))
+        make = lambda: api[0].from_arrays(*arrays, precision=prec)   # noqa: E731
+    else:
+        make = lambda: api[0].new(g2o_path(name), precision=prec)    # noqa: E731
+    new = make()
     monkeypatch.setenv("RR_PGO_SOLVE_MID_FLOW", "0")
-    old = api[0].new(g2o_path(name), precision=prec)
+    old = make()
     monkeypatch.delenv("RR_PGO_SOLVE_MID_FLOW")
+    assert new.stats()["lds_dataflow"] == 1
     assert new.stats()["n_big_fronts"] > 0 and new.stats()["n_launches_per_iter"] < old.stats()["n_launches_per_iter"]
     assert np.array_equal(new.linearize_and_solve(), old.linearize_and_solve())
     en, eo = new.optimize(6, return_norms=True), old.optimize(6, return_norms=True)
