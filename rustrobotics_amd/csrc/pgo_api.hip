@@ -2205,7 +2205,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     for (int i = 0; i < OPT_RING; i++) opt_ring_[i].seq = 0ull;   // (nothing of an earlier call is in flight: every call consumes what it enqueued)
     struct Scope {   // whatever happens, the launches behind this call are plain ones again and know about the stop word
       Engine *e;
-      ~Scope() { e->opt_active_ = false; e->opt_first_ = false; e->stop_dirty_ = true; }
+      bool done = false;
+      ~Scope() {
+        e->opt_active_ = false; e->opt_first_ = false; e->stop_dirty_ = true;
+        // left by an exception (a failed launch, a lost item): what is still enqueued must not publish into the next call's ring
+        if (!done) (void)hipStreamSynchronize(e->stream_);
+      }
     } scope{this};
     opt_active_ = true; opt_first_ = true; opt_lambda_dev_ = lm; opt_lambda0_ = 0.01;   // :254
     // TWO whole items in the queue: the device never waits for the host, and the item behind the stop is a handful of empty
@@ -2236,6 +2241,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
       }
       if (sl.flags & OPT_STOP) stop_seen = true;
     }
+    scope.done = true;   // every item that was enqueued has been consumed
     if (dev_err) throw_on_flag(dev_err);
     *n_errors = ne;
   }
