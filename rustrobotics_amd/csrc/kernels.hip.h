@@ -635,6 +635,132 @@ __global__ void __launch_bounds__(LIN_THREADS) k_linearize_edges(LinArgs<TO, T> 
   if (threadIdx.x == 0) a.chi2_partial[blockIdx.x] = tot;
 }
 
+// ---- the edge-parallel form exactly as the north star words it (RR_PGO_EDGE_LINEARIZE=2): ONE WAVEFRONT PER EDGE.
+// The wave reads the edge's record (one 64 / 128-byte line) and its two endpoint poses with wave-uniform loads, evaluates error
+// and Jacobians once, STAGES A, B, the information matrix and the error in LDS, and then lane l forms output scalar l out of the
+// staged operands (dynamic indices are LDS addresses, not register selects):
+//   lanes 0-5 / 6-8     lower triangle of A^T W A / -A^T W e      -> the from-node's accumulator
+//   lanes 9-14 / 15-17  lower triangle of B^T W B / -B^T W e      -> the to-node's accumulator
+//   lanes 18-26         A^T W B, the off-diagonal block            -> stored (one writer per block)
+//   lane 27             e^T W e
+// The scatter-add is LDS-REDUCED: a workgroup takes 64 consecutive edges (file order: runs of one from-node), keeps one
+// accumulator of 9 scalars per node it meets in an LDS table (open addressing, ds atomics), and flushes every occupied entry
+// with ONE set of global atomic adds at the end.  k_lin_init / k_lin_finish as for k_linearize_edges; floating-point atomics
+// make the last bits vary from run to run (the pull form is bit-reproducible and is the product).
+constexpr int WE_EDGES = 64, WE_SLOTS = 128;
+template <typename T> __device__ __forceinline__ void lds_atomic_add(T *p, T v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <typename TO, typename T>
+__global__ void __launch_bounds__(256) k_linearize_wave_edges(LinArgs<TO, T> a, int n_edges) {
+  using V4 = typename VecT<T>::V4;
+  using V2 = typename VecT<T>::V2;
+  __shared__ int slot_node[WE_SLOTS];
+  __shared__ T slot_acc[WE_SLOTS][9];     // 00 10 11 20 21 22 of J^T W J, then -J^T W e
+  __shared__ T stage[4][40];              // per wave: A (9) | B (9) | W (9) | e (3) | W e (3)
+  __shared__ double red[4];
+  const int tid = threadIdx.x, wave = wave_index(), lane = tid & 63;
+  for (int s = tid; s < WE_SLOTS; s += 256) {
+    slot_node[s] = -1;
+#pragma unroll
+    for (int q = 0; q < 9; q++) slot_acc[s][q] = 0;
+  }
+  __syncthreads();
+  T *st = stage[wave];
+  double chi = 0.0;
+  const int e0 = blockIdx.x * WE_EDGES;
+  for (int t = 0; t < WE_EDGES / 4; t++) {
+    const int k = e0 + 4 * t + wave;      // wave-uniform
+    if (k >= n_edges) break;
+    const EdgeRec<T> rec = a.e_rec[k];
+    const int kind = a.node_dim[rec.to] == 2 ? 1 : 0;
+    const V4 x1 = a.pose[rec.from], x2 = a.pose[rec.to];
+    const V4 wa = rec.info_a;
+    const V2 wb = rec.info_b;
+    const T W[3][3] = {{wa.x, wa.y, wa.z}, {wa.y, wa.w, wb.x}, {wa.z, wb.x, wb.y}};
+    T e[3], A[3][3], B[3][3];
+    edge_linearize_2d<T>(kind, x1, x2, rec.meas, e, A, B);
+    // stage the operands (every lane holds the same values: lane q of the first 39 writes entry q)
+    T mine = 0;
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+      mine = lane == q ? A[q / 3][q % 3] : mine;
+      mine = lane == 9 + q ? B[q / 3][q % 3] : mine;
+      mine = lane == 18 + q ? W[q / 3][q % 3] : mine;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      mine = lane == 27 + q ? e[q] : mine;
+      mine = lane == 30 + q ? W[q][0] * e[0] + W[q][1] * e[1] + W[q][2] * e[2] : mine;
+    }
+    if (lane < 33) st[lane] = mine;
+    // the two accumulators of this edge: lane 0 finds (or claims) the from-node's entry, lane 1 the to-node's
+    int slot = 0;
+    if (lane < 2 && a.write_system) {
+      const int node = lane == 0 ? rec.from : rec.to;
+      int h = (int)((unsigned)node * 2654435761u >> 25) & (WE_SLOTS - 1);
+      for (;;) {
+        const int prev = atomicCAS(&slot_node[h], -1, node);
+        if (prev == -1 || prev == node) break;
+        h = (h + 1) & (WE_SLOTS - 1);   // (at most 2 x WE_EDGES distinct nodes per workgroup: the table never fills)
+      }
+      slot = h;
+    }
+    const int slot_f = __shfl(slot, 0), slot_t = __shfl(slot, 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const T *As = st, *Bs = st + 9, *Ws = st + 18, *es = st + 27, *wes = st + 30;
+    // lane -> (i, j) of a lower triangle: 0:(0,0) 1:(1,0) 2:(1,1) 3:(2,0) 4:(2,1) 5:(2,2)
+    auto tri_i = [](int q) { return q < 1 ? 0 : q < 3 ? 1 : 2; };
+    auto tri_j = [](int q) { return q < 1 ? 0 : q < 3 ? q - 1 : q - 3; };
+    auto jwj = [&](const T *J, const T *K, int i, int j) {   // (J^T W K)(i, j)
+      T sum = 0;
+      for (int r = 0; r < 3; r++) {
+        T jw = 0;
+        for (int c = 0; c < 3; c++) jw += J[c * 3 + i] * Ws[c * 3 + r];
+        sum += jw * K[r * 3 + j];
+      }
+      return sum;
+    };
+    auto jwe = [&](const T *J, int i) { return -(J[0 * 3 + i] * wes[0] + J[1 * 3 + i] * wes[1] + J[2 * 3 + i] * wes[2]); };
+    if (a.write_system) {
+      if (lane < 6) lds_atomic_add(&slot_acc[slot_f][lane], jwj(As, As, tri_i(lane), tri_j(lane)));
+      else if (lane < 9) lds_atomic_add(&slot_acc[slot_f][lane], jwe(As, lane - 6));
+      else if (lane < 15) lds_atomic_add(&slot_acc[slot_t][lane - 9], jwj(Bs, Bs, tri_i(lane - 9), tri_j(lane - 9)));
+      else if (lane < 18) lds_atomic_add(&slot_acc[slot_t][lane - 9], jwe(Bs, lane - 15));
+      else if (lane < 27) {
+        const int q = lane - 18, i = q / 3, j = q % 3, d2 = kind ? 2 : 3;
+        if (j < d2) {
+          const int64_t so = rec.slot;
+          TO *dst = a.hvals + (so >> 1);
+          dst[(so & 1) ? j * 3 + i : i * d2 + j] = (TO)jwj(As, Bs, i, j);
+        }
+      }
+    }
+    if (lane == 27) chi += (double)(es[0] * wes[0] + es[1] * wes[1] + es[2] * wes[2]);
+    __builtin_amdgcn_wave_barrier();   // the stage is rewritten by the next edge
+  }
+  __syncthreads();
+  if (a.write_system)
+    for (int s = tid; s < WE_SLOTS; s += 256) {
+      const int node = slot_node[s];
+      if (node < 0) continue;
+      const T *f = slot_acc[s];
+      const int nd = a.node_dim[node];
+      TO *d = a.hvals + a.diag_off[node];
+      TO *bo = a.b + a.node_offset[node];
+      if (nd == 3) {
+        unsafeAtomicAdd(d + 0, (TO)f[0]); unsafeAtomicAdd(d + 3, (TO)f[1]); unsafeAtomicAdd(d + 4, (TO)f[2]);
+        unsafeAtomicAdd(d + 6, (TO)f[3]); unsafeAtomicAdd(d + 7, (TO)f[4]); unsafeAtomicAdd(d + 8, (TO)f[5]);
+        unsafeAtomicAdd(bo + 0, (TO)f[6]); unsafeAtomicAdd(bo + 1, (TO)f[7]); unsafeAtomicAdd(bo + 2, (TO)f[8]);
+      } else {
+        unsafeAtomicAdd(d + 0, (TO)f[0]); unsafeAtomicAdd(d + 2, (TO)f[1]); unsafeAtomicAdd(d + 3, (TO)f[2]);
+        unsafeAtomicAdd(bo + 0, (TO)f[6]); unsafeAtomicAdd(bo + 1, (TO)f[7]);
+      }
+    }
+  const double tot = block_sum<double, 256>(chi, red);
+  if (threadIdx.x == 0) a.chi2_partial[blockIdx.x] = tot;
+}
+
 // ------------------------------------------------------------------ SE(3)
 // NOT reference behaviour: the reference's SE(3) path is todo!() (pose_graph_optimization.rs:241,
 // 357,570).  Build-defined, g2o file convention, identical to the oracle's definition:

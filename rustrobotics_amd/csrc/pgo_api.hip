@@ -427,6 +427,7 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
   int n_lin_blocks_ = 0, n_upd_blocks_ = 0;
   bool no_graph_ = false, force_graph_ = false;   // RR_PGO_NO_GRAPH=1 / RR_PGO_FORCE_GRAPH=1 (read when the handle is created): plain launches / replays of the captured hipGraph everywhere
   bool edge_lin_ = false;           // RR_PGO_EDGE_LINEARIZE=1: k_linearize_edges (one thread per edge, atomics) instead of the pull form
+  bool edge_lin_wave_ = false;      // RR_PGO_EDGE_LINEARIZE=2: k_linearize_wave_edges (one WAVEFRONT per edge, operands staged in LDS, LDS-reduced scatter-add)
   int host_counter_ = 0;             // mirrors the device slot counter
 
  public:
@@ -603,7 +604,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     if (const char *e = getenv("RR_PGO_FLOW_SCHUR_MIN")) flow_schur_min_ = std::atoi(e);
     n_lin_blocks_ = (int)(((int64_t)n_list_ * LIN_GROUP + LIN_THREADS - 1) / LIN_THREADS);
     edge_lin_ = getenv("RR_PGO_EDGE_LINEARIZE") != nullptr && !is3d_ && !sharded_ && g_.n_edges() > 0;
-    if (edge_lin_) n_lin_blocks_ = std::max(1, (g_.n_edges() + LIN_THREADS - 1) / LIN_THREADS);
+    edge_lin_wave_ = edge_lin_ && std::atoi(getenv("RR_PGO_EDGE_LINEARIZE")) == 2;
+    if (edge_lin_) n_lin_blocks_ = std::max(1, (g_.n_edges() + (edge_lin_wave_ ? WE_EDGES : LIN_THREADS) - 1) / (edge_lin_wave_ ? WE_EDGES : LIN_THREADS));
     n_upd_blocks_ = (n_list_ + UPD_THREADS - 1) / UPD_THREADS;
     chi_partial_.alloc((size_t)n_lin_blocks_);
     norm_partial_.alloc((size_t)n_upd_blocks_);
@@ -1607,7 +1609,8 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         hipLaunchKernelGGL(k_fill_words, dim3(16), dim3(256), 0, stream_, reinterpret_cast<unsigned *>(x_ptr_), (int)((size_t)g_.dim * sizeof(T) / 4), X_PENDING_WORD);
       }
       if (write_system) hipLaunchKernelGGL((k_lin_init<T, S>), dim3(nb), dim3(256), 0, stream_, la);
-      hipLaunchKernelGGL((k_linearize_edges<T, S>), dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_, la, g_.n_edges());
+      if (edge_lin_wave_) hipLaunchKernelGGL((k_linearize_wave_edges<T, S>), dim3(n_lin_blocks_), dim3(256), 0, stream_, la, g_.n_edges());
+      else hipLaunchKernelGGL((k_linearize_edges<T, S>), dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_, la, g_.n_edges());
       if (write_system) hipLaunchKernelGGL((k_lin_finish<T, S>), dim3(nb), dim3(256), 0, stream_, la);
     } else if (!is3d_) {
       hipLaunchKernelGGL((k_linearize<T, S>), dim3(n_lin_blocks_), dim3(LIN_THREADS), 0, stream_,

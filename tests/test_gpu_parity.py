@@ -98,13 +98,16 @@ def test_assembled_system_matches_oracle(api, oracle, name, lm):
     _assert_system_matches_oracle(g, o, name, lm, 1e-12, 1e-11)
 
 
+@pytest.mark.parametrize("form", ["1", "2"])
 @pytest.mark.parametrize("name", SE2_FILES)
-def test_edge_parallel_linearisation_matches_the_oracle(api, oracle, name, monkeypatch):
-    """The kernel form north_star words (RR_PGO_EDGE_LINEARIZE=1: k_lin_init + k_linearize_edges + k_lin_finish, one thread
-    per edge, wave-reduced scatter-add with floating-point atomics) against the ORACLE, not against the pull form: chi2
+def test_edge_parallel_linearisation_matches_the_oracle(api, oracle, name, form, monkeypatch):
+    """The kernel forms north_star words -- RR_PGO_EDGE_LINEARIZE=1: k_lin_init + k_linearize_edges + k_lin_finish, one THREAD
+    per edge, wave-reduced scatter-add with floating-point atomics; =2: k_linearize_wave_edges, one WAVEFRONT per edge, the
+    Jacobians, the information matrix and the error staged in LDS, lane l forming output scalar l, the scatter-add reduced in
+    an LDS table per 64 edges before one set of global atomics per node -- against the ORACLE, not against the pull form: chi2
     (pose_graph_optimization.rs:537-574) at 1e-12, every block of H and b (:434-486, :165-192, :305-369) at 1e-11 -- the
     order of the atomic sums moves the last bits, nothing more."""
-    monkeypatch.setenv("RR_PGO_EDGE_LINEARIZE", "1")
+    monkeypatch.setenv("RR_PGO_EDGE_LINEARIZE", form)
     g = api[0].new(g2o_path(name))
     monkeypatch.delenv("RR_PGO_EDGE_LINEARIZE")
     o = oracle.load(g2o_path(name))
@@ -653,7 +656,7 @@ def test_levenberg_marquardt_through_the_big_front_path(api, oracle):
 
 
 @pytest.mark.parametrize("env", ["RR_PGO_FLOW=0", "RR_PGO_FLOW_TASKS=100000000", "RR_PGO_FLOW_EXACT",
-                                 "RR_PGO_SCHUR_SPLIT=0", "RR_PGO_SOLVE_FLOW=0", "RR_PGO_EDGE_LINEARIZE",
+                                 "RR_PGO_SCHUR_SPLIT=0", "RR_PGO_SOLVE_FLOW=0", "RR_PGO_EDGE_LINEARIZE", "RR_PGO_EDGE_LINEARIZE=2",
                                  "RR_PGO_FLOW_SCHUR_MIN=100000000",
                                  "RR_PGO_FLOW_GRID=1", "RR_PGO_FLOW_GRID=7", "RR_PGO_SP_SOLVE_MIN=100000",
                                  "RR_PGO_SP_SOLVE_MIN=1", "RR_PGO_NO_GRAPH", "RR_PGO_FORCE_GRAPH"])
@@ -746,13 +749,15 @@ def test_results_are_bit_reproducible(api, case):
     assert np.array_equal(s1, s2)
 
 
+@pytest.mark.parametrize("form", ["1", "2"])
 @pytest.mark.parametrize("name", ["intel", "dlr", "simulation-pose-landmark"])
-def test_edge_parallel_linearisation_agrees_with_the_pull_form(api, name, monkeypatch):
-    """RR_PGO_EDGE_LINEARIZE=1 swaps k_linearize (pull form, bit-reproducible) for k_linearize_edges (one thread per
-    edge, floating-point atomics): same H, b and chi2 up to the order of the sums, on pose-pose and pose-landmark
-    factors (reference maths: pose_graph_optimization.rs:434-486,516-535)."""
+def test_edge_parallel_linearisation_agrees_with_the_pull_form(api, name, form, monkeypatch):
+    """RR_PGO_EDGE_LINEARIZE=1 / 2 swap k_linearize (pull form, bit-reproducible) for k_linearize_edges (one thread per
+    edge) / k_linearize_wave_edges (one wavefront per edge, LDS-staged, LDS-reduced), both with floating-point atomics: same
+    H, b and chi2 up to the order of the sums, on pose-pose and pose-landmark factors (reference maths:
+    pose_graph_optimization.rs:434-486,516-535)."""
     ref = api[0].new(g2o_path(name))
-    monkeypatch.setenv("RR_PGO_EDGE_LINEARIZE", "1")
+    monkeypatch.setenv("RR_PGO_EDGE_LINEARIZE", form)
     alt = api[0].new(g2o_path(name))
     monkeypatch.delenv("RR_PGO_EDGE_LINEARIZE")
     assert alt.global_error() == pytest.approx(ref.global_error(), rel=1e-13)
