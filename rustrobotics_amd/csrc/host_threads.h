@@ -41,8 +41,6 @@ template <class F> void parallel_indices(int n, int max_threads, F &&fn) {
 // `here` on the calling thread, `other` beside it (after it when no thread can be had); both complete before an exception
 // of either is rethrown
 template <class F, class G> void run_beside(F &&other, G &&here) {
-  int which[2] = {0, 1};
-  (void)which;
   parallel_indices(2, 2, [&](int i) { if (i == 0) here(); else other(); });
 }
 
