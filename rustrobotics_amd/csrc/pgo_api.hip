@@ -2736,6 +2736,10 @@ void analyze_handle(std::unique_ptr<rr_pgo> &h, const rr_pgo_options *opt_in, do
   if (join_env) so.split_separators = std::atoi(join_env) == 0 && join_env[0] == '0';
   if (const char *e = std::getenv("RR_PGO_ND_LEAF")) so.nd_leaf = std::atoi(e);
   if (const char *e = std::getenv("RR_PGO_BALANCE_BLOCKS")) { so.balance_blocks = std::atoi(e) != 0; if (std::atoi(e) > 1) so.balance_max_rem = std::atoi(e); }
+  // the widest front the chain pass may merge into its parent (when the cost model says the parent finishes earlier): 80 pivot
+  // columns for 2D graphs, 48 for 6 x 6 blocks -- re-measured on the r05 / r06 trees (profiles/r06_chain_cap_sweep.txt: intel + 3.1 %,
+  // M3500 - 0.3 %, dlr + 0.0 % at 80; the SE(3) graphs lose 0.4 - 2 % beyond 48, where the model's error grows with the front)
+  if (!h->g.has_se3) so.merge_chain_nc = 80;
   if (const char *e = std::getenv("RR_PGO_MERGE_CHAIN")) { so.merge_chain_nc = std::atoi(e); if (const char *c = std::strchr(e, ',')) so.merge_chain_gain_us = std::atof(c + 1); }
   if (const char *e = std::getenv("RR_PGO_AMALG_NP")) so.amalg_np = std::atoi(e);
   double t0 = now_ms();

@@ -17,6 +17,7 @@ big = arrays is not None and len(arrays[0]) > 50000
 ref = None
 for cfg in configs:
     env = dict(kv.split("=", 1) for kv in cfg.split(",")) if cfg != "-" else {}
+    env = {k: v.replace("/", ",") for k, v in env.items()}   # a comma inside a value is written "/" (RR_PGO_MERGE_CHAIN=96/1)
     for k, v in env.items():
         os.environ[k] = v
     g = PoseGraph.from_arrays(*arrays, precision=prec) if arrays is not None else PoseGraph.new(os.path.join(ROOT, "tests", "golden", "g2o", wl + ".g2o"), precision=prec)
