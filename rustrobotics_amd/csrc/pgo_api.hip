@@ -1823,14 +1823,20 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
     return 1;
   }
   int count_big_launches(const Step &st) { return launch_big_level(st, false); }
+  bool level_has_rows(const Step &st) const {
+    for (int t = st.task_begin; t < st.task_end; t++)
+      if (sym_.sn_nrows[sym_.task_sn[sym_.task_ptr[t]]] > 0) return true;
+    return false;
+  }
   int count_big_solve_launches(const Step &st) const {
     int max_nc = 1;
     for (int t = st.task_begin; t < st.task_end; t++) max_nc = std::max(max_nc, sym_.sn_ncols[sym_.task_sn[sym_.task_ptr[t]]]);
+    const int gemv = level_has_rows(st) ? 1 : 0;
     if (max_nc >= sp_solve_min_nc_) {
       const size_t si = (size_t)(&st - sym_.steps.data());
-      return si < solve_flow_.size() && solve_flow_[si] ? 2 : 1 + (max_nc + BIG_SUPER - 1) / BIG_SUPER;
+      return si < solve_flow_.size() && solve_flow_[si] ? gemv + 1 : gemv + (max_nc + BIG_SUPER - 1) / BIG_SUPER;
     }
-    return 2;
+    return gemv + 1;
   }
 
   void launch_solve() {
@@ -1874,15 +1880,12 @@ template <typename T, typename S = T> class Engine final : public EngineBase {
         int max_nc = 1;
         for (int z = 0; z < nf; z++) max_nc = std::max(max_nc, sym_.sn_ncols[sym_.task_sn[sym_.task_ptr[st.task_begin + z]]]);
         const int cb = (max_nc + 63) / 64;
-        int max_nr = 1;
-        for (int z = 0; z < nf; z++) max_nr = std::max(max_nr, sym_.sn_nrows[sym_.task_sn[sym_.task_ptr[st.task_begin + z]]]);
-        // row slices: enough workgroups to fill the chip, but never thinner than 128 rows (every slice is a
-        // partial sum k_solve_mid has to fetch and add per column)
         const int R = gemv_slices(st);
-        (void)max_nr;
         const FactorArgs<T> fa = factor_args(st.task_begin);
-        hipLaunchKernelGGL(k_big_gemv_partial<T>, dim3(cb, R, nf), dim3(256), 0, stream_, fa, gemv_part_.p, (int64_t)g_.dim, R);
-        check_launch("k_big_gemv_partial");
+        if (level_has_rows(st)) {   // (a level of root fronts -- no rows below the pivot block -- has no L21^T x to form: the solves read no partial sums)
+          hipLaunchKernelGGL(k_big_gemv_partial<T>, dim3(cb, R, nf), dim3(256), 0, stream_, fa, gemv_part_.p, (int64_t)g_.dim, R);
+          check_launch("k_big_gemv_partial");
+        }
         if (max_nc >= sp_solve_min_nc_) {
           if (solve_flow_[(size_t)i]) {
             // wide pivot blocks, the whole level's chain steps and folds as ONE launch of ticketed tasks (flow.hip.h)
